@@ -1,0 +1,90 @@
+"""ctypes binding of include/fluid_hip.h (one function per C entry point; no logic here)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfluid_hip.so")
+if not os.path.exists(_SO):
+    raise ImportError(
+        f"{_SO} is missing: build it with `make -C {_HERE}` (hipcc --offload-arch=gfx950). "
+        "This package has no CPU path.")
+lib = C.CDLL(_SO)
+
+
+class FluidError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfluid_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """fluid_params_t (include/fluid_hip.h); defaults = the reference's literals (fluid.cc:1357-1367)."""
+    _fields_ = [("n", C.c_int32), ("device", C.c_int32), ("dx", C.c_double), ("rho", C.c_double),
+                ("gravity", C.c_double * 3), ("max_dt", C.c_double), ("outer_tol", C.c_double),
+                ("update_frac", C.c_double), ("cg_tol", C.c_double), ("cg_max_iters", C.c_int32),
+                ("max_outer_passes", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32)]
+
+
+class StepStats(C.Structure):
+    """fluid_step_stats_t."""
+    _fields_ = [("dt_in", C.c_double), ("dt_out", C.c_double), ("error", C.c_double), ("max_speed", C.c_double),
+                ("relres", C.c_double), ("num_active", C.c_int64), ("outer_passes", C.c_int32),
+                ("cg_iters", C.c_int32), ("cg_iters_last", C.c_int32), ("box_lo", C.c_int32 * 3),
+                ("box_hi", C.c_int32 * 3), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {"dt_in": self.dt_in, "dt_out": self.dt_out, "error": self.error, "max_speed": self.max_speed,
+                "relres": self.relres, "num_active": self.num_active, "outer_passes": self.outer_passes,
+                "cg_iters": self.cg_iters, "cg_iters_last": self.cg_iters_last,
+                "box_lo": list(self.box_lo), "box_hi": list(self.box_hi)}
+
+
+class FIELD:
+    CONTAINER, WEIGHTS, VEL, VEL_BEFORE, INDICES, RHS, DIVER, PRESSURE, OUTPUT, SOLID = range(10)
+    DIVER2, SEARCH, Q, FLAGS = 14, 15, 16, 17
+
+
+class PROF:
+    PCG_SQ, PCG_XR, P2G, G2P, SORT, SOLVE = range(6)
+
+
+# every symbol include/fluid_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("fluid_default_params", C.c_int, [C.POINTER(Params)]),
+    ("fluid_create", C.c_int, [C.POINTER(Params), C.POINTER(_P)]),
+    ("fluid_destroy", C.c_int, [_P]),
+    ("fluid_last_error", C.c_char_p, []),
+    ("fluid_version", C.c_char_p, []),
+    ("fluid_set_solid", C.c_int, [_P, _P]),
+    ("fluid_upload_particles", C.c_int, [_P, C.c_int64, _P, _P]),
+    ("fluid_download_particles", C.c_int, [_P, _P, _P]),
+    ("fluid_num_particles", C.c_int64, [_P]),
+    ("fluid_set_dt", C.c_int, [_P, C.c_double]),
+    ("fluid_get_dt", C.c_int, [_P, C.POINTER(C.c_double)]),
+    ("fluid_scene_water_cube_drop", C.c_int64, [C.c_int32, C.c_int32, C.c_uint64, _P]),
+    ("fluid_step", C.c_int, [_P, C.POINTER(StepStats)]),
+    ("fluid_p2g", C.c_int, [_P]),
+    ("fluid_flags_index", C.c_int, [_P]),
+    ("fluid_rhs_div", C.c_int, [_P, C.c_int]),
+    ("fluid_solve", C.c_int, [_P]),
+    ("fluid_vel_update", C.c_int, [_P]),
+    ("fluid_pressure_pass", C.c_int, [_P, C.POINTER(C.c_double)]),
+    ("fluid_flip_advect", C.c_int, [_P]),
+    ("fluid_get_stats", C.c_int, [_P, C.POINTER(StepStats)]),
+    ("fluid_download_field", C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    ("fluid_upload_field", C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    ("fluid_stencil_apply", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    ("fluid_profile_enable", C.c_int, [_P, C.c_int]),
+    ("fluid_profile_read", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("fluid_profile_reset", C.c_int, [_P]),
+]
+for _name, _res, _args in SYMBOLS:
+    _f = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(rc):
+    if rc != 0:
+        raise FluidError(rc, lib.fluid_last_error().decode())

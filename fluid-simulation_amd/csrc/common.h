@@ -1,0 +1,182 @@
+// Internal declarations shared by the HIP translation units of libfluid_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fl {
+
+// ---- cell flag byte ---------------------------------------------------------------------
+// bit0 solid (static), bit1 fluid (per step: container>0 && !solid, fluid.cc:326,445,579,
+// 1423-1425), bits 2..4 = number of non-solid 6-neighbours (the multiplicity of `scale` in
+// Adiag, fluid.cc:326-407; valid on fluid cells).
+constexpr uint8_t F_SOLID = 1;
+constexpr uint8_t F_FLUID = 2;
+constexpr int F_CNT_SHIFT = 2;
+
+struct Grid {
+    int N;    // cells per axis
+    int lo;   // coordinate of index 0
+    int hi;   // coordinate of index N-1
+    __host__ __device__ inline size_t idx(int ix, int iy, int iz) const
+    {
+        return ((size_t)ix * N + (size_t)iy) * N + (size_t)iz;
+    }
+};
+
+// inclusive box in index space
+struct Box {
+    int x0, y0, z0, x1, y1, z1;
+    __host__ __device__ inline int nx() const { return x1 - x0 + 1; }
+    __host__ __device__ inline int ny() const { return y1 - y0 + 1; }
+    __host__ __device__ inline int nz() const { return z1 - z0 + 1; }
+    __host__ __device__ inline long long cells() const { return (long long)nx() * ny() * nz(); }
+};
+
+// Coefficients of the reference matrix (setA, fluid.cc:304-412): diag[k] is the float32
+// value reached after k accumulations `Adiag = float(Adiag + scale)`; off = float(-scale).
+template <typename T>
+struct Coef {
+    T diag[7];
+    T off;
+};
+
+// Scalars of one PCG solve, device resident.
+struct PcgState {
+    double bb;        // |b|^2
+    double thr;       // tol^2 |b|^2
+    double rr;        // last |r|^2 seen by the SQ kernel
+    int done;         // 1 once |r|^2 < thr (or b == 0)
+    int iters;        // Eigen's `i` (ConjugateGradient.h:70-88)
+    int breakdown;    // p.Ap <= 0 or non-finite
+    int pad;
+};
+
+// Per-step device scalars
+struct StepState {
+    int bbox_min[3];          // particle base-cell bounding box (index space)
+    int bbox_max[3];
+    int num_active;
+    int n_out;                // particles whose base cell is outside the grid
+    unsigned long long max_speed_bits;  // max |v_p| as non-negative double bits
+    double dt;                // fluid.cc:1367 / 992-999
+    double err_num;           // |b-b2|^2
+    double err_den;           // |b|^2
+};
+
+constexpr int MAX_PARTIALS = 8192;
+
+// fluid.cc:22-37
+__device__ __forceinline__ double spline(double x)
+{
+    if (x < 0) x *= -1.0;
+    if (x < 0.5) return 1.5 * (4.0 * x * x * x - 4.0 * x * x + 2.0 / 3.0);
+    if (x < 1.0) return 1.5 * ((-8.0 * (x * x * x) / 6.0) + 4.0 * x * x - 4.0 * x + 4.0 / 3.0);
+    return 0;
+}
+
+// ---- wave64 / block reductions ------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T w = __shfl_down(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+// Sum over a block of NW waves; result valid in thread 0.  `sm` needs NW entries.
+template <typename T, int NW>
+__device__ __forceinline__ T block_sum(T v, T* sm)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    T r = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += sm[i];
+    }
+    return r;
+}
+// Sum of n doubles (n <= MAX_PARTIALS) by the whole block, in a fixed order; result
+// broadcast to every thread.  `sm` needs NW+1 entries.
+template <int NW>
+__device__ __forceinline__ double block_sum_array(const double* __restrict__ a, int n, double* sm)
+{
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += NW * 64) v += a[i];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += sm[i];
+        sm[NW] = r;
+    }
+    __syncthreads();
+    return sm[NW];
+}
+
+// ---- launchers (defined in kernels_*.hip) --------------------------------------------------
+struct Particles {
+    double *px, *py, *pz, *vx, *vy, *vz;
+    uint32_t* pid;
+};
+
+// particles
+void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, StepState* ss);
+void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot, const int* cell_start, int* order);
+void launch_bin_fix(hipStream_t st, Grid g, Box box, const int* cell_start, const uint32_t* pid, int* order);
+void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst);
+void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const int* cell_start, const uint8_t* flags,
+                float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
+void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss);
+void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss);
+void launch_pack_particles(hipStream_t st, long n, Particles p, double* pos_aos, double* vel_aos);
+void launch_unpack_particles(hipStream_t st, long n, const double* pos_aos, const double* vel_aos, Particles p);
+
+// grid
+void launch_exclusive_scan(hipStream_t st, const int* in, int* out, long n, int* block_sums, int* total);
+void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total);
+void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags);
+void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w,
+                    float* rhs, float* diver, double dx, double gdt0, double gdt1, double gdt2);
+void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w,
+                       double k, double g0, double g1, double g2);
+void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w,
+                       const double* ub, const double* vb, const double* wb, double* dcx, double* dcy, double* dcz);
+void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, const float* b2, double* part, StepState* ss);
+void launch_zero_step_state(hipStream_t st, StepState* ss, int N);
+
+// pcg (kernels_pcg.hip); T = double or float
+int pcg_sq_blocks(Box box);
+int pcg_xr_blocks(Box box);
+template <typename T>
+void launch_pcg_init(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, T* x, T* r, Coef<T> cf, double* part_bb,
+                     double* part_rz0, PcgState* ps);
+template <typename T>
+void launch_pcg_sq(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
+                   const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
+                   double tol);
+template <typename T>
+void launch_pcg_xr(hipStream_t st, Grid g, Box box, const uint8_t* flags, T* x, T* r, const T* s, const T* q, Coef<T> cf,
+                   const double* part_rz_cur, const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps);
+template <typename T>
+void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf);
+template <typename T>
+void launch_store_pressure(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* x, double* pressure);
+
+}  // namespace fl

@@ -1,0 +1,756 @@
+// libfluid_hip.so — C ABI (include/fluid_hip.h) and host orchestration of the step
+// fluid.cc:1378-1490 on one MI355X.  One handle = one HIP stream; all fields live in HBM.
+#include "common.h"
+#include "../../include/fluid_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fl;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
+
+struct ProfClass {
+    long launches = 0, sampled = 0;
+    double ms = 0, cells = 0;
+    std::vector<hipEvent_t> e0, e1;
+    std::vector<double> pc;
+};
+
+struct fluid_sim {
+    fluid_params_t prm;
+    Grid g;
+    size_t ncell = 0;
+    hipStream_t st = nullptr;
+    // grid fields
+    uint8_t *solid = nullptr, *flags = nullptr;
+    float *container = nullptr, *rhs = nullptr, *diver = nullptr, *diver2 = nullptr;
+    double *u = nullptr, *v = nullptr, *w = nullptr, *ub = nullptr, *vb = nullptr, *wb = nullptr;
+    double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
+    int *indices = nullptr, *scan_sums = nullptr;
+    // pcg
+    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *Xf = nullptr;
+    double *part_bb = nullptr, *part_rr = nullptr, *part_rz[2] = {nullptr, nullptr}, *part_pq = nullptr, *part_err = nullptr;
+    PcgState* ps = nullptr;
+    PcgState* h_ps = nullptr;  // pinned
+    // particles
+    long np = 0, cap = 0;
+    Particles pa{}, pb{};
+    int *key = nullptr, *slot = nullptr, *order = nullptr, *cell_count = nullptr, *cell_start = nullptr;
+    double *stage_pos = nullptr, *stage_vel = nullptr;
+    StepState* ss = nullptr;
+    StepState* h_ss = nullptr;  // pinned
+    // boxes
+    Box Pb{0, 0, 0, -1, -1, -1}, Rb{0, 0, 0, -1, -1, -1}, Sb{0, 0, 0, -1, -1, -1};
+    int dirty_x0 = 0, dirty_x1 = -1;  // x-slab range holding non-zero field data
+    bool sorted = false, have_p2g = false, have_flags = false;
+    double dt = 0.1;
+    fluid_step_stats_t stats{};
+    // profiling
+    int prof_every = 0;
+    ProfClass prof[FLUID_PROF_COUNT];
+};
+
+static Box clip_dilate(const Box& b, int d, int N)
+{
+    Box r;
+    r.x0 = b.x0 - d < 0 ? 0 : b.x0 - d;
+    r.y0 = b.y0 - d < 0 ? 0 : b.y0 - d;
+    r.z0 = b.z0 - d < 0 ? 0 : b.z0 - d;
+    r.x1 = b.x1 + d > N - 1 ? N - 1 : b.x1 + d;
+    r.y1 = b.y1 + d > N - 1 ? N - 1 : b.y1 + d;
+    r.z1 = b.z1 + d > N - 1 ? N - 1 : b.z1 + d;
+    return r;
+}
+static bool box_empty(const Box& b) { return b.x1 < b.x0 || b.y1 < b.y0 || b.z1 < b.z0; }
+
+// ---- profiling helpers ----------------------------------------------------------------------
+static int prof_begin(fluid_sim* s, int k, double cells)
+{
+    ProfClass& p = s->prof[k];
+    p.launches++;
+    if (s->prof_every <= 0 || (p.launches - 1) % s->prof_every) return -1;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    hipEventRecord(a, s->st);
+    p.e0.push_back(a);
+    p.e1.push_back(b);
+    p.pc.push_back(cells);
+    return (int)p.e1.size() - 1;
+}
+static void prof_end(fluid_sim* s, int k, int tok)
+{
+    if (tok >= 0) hipEventRecord(s->prof[k].e1[tok], s->st);
+}
+static void prof_resolve(fluid_sim* s)
+{
+    for (int k = 0; k < FLUID_PROF_COUNT; ++k) {
+        ProfClass& p = s->prof[k];
+        for (size_t i = 0; i < p.e0.size(); ++i) {
+            float ms = 0;
+            hipEventSynchronize(p.e1[i]);
+            if (hipEventElapsedTime(&ms, p.e0[i], p.e1[i]) == hipSuccess) {
+                p.sampled++;
+                p.ms += ms;
+                p.cells += p.pc[i];
+            }
+            hipEventDestroy(p.e0[i]);
+            hipEventDestroy(p.e1[i]);
+        }
+        p.e0.clear();
+        p.e1.clear();
+        p.pc.clear();
+    }
+}
+
+// ---- memory ------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t dalloc(T** p, size_t n)
+{
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
+    return e;
+}
+
+static size_t solver_elem(const fluid_sim* s) { return s->prm.precision == FLUID_PRECISION_FP32 ? 4 : 8; }
+
+static void free_particles(fluid_sim* s)
+{
+    for (Particles* p : {&s->pa, &s->pb}) {
+        hipFree(p->px); hipFree(p->py); hipFree(p->pz); hipFree(p->vx); hipFree(p->vy); hipFree(p->vz); hipFree(p->pid);
+        *p = Particles{};
+    }
+    hipFree(s->key); hipFree(s->slot); hipFree(s->order); hipFree(s->stage_pos); hipFree(s->stage_vel);
+    s->key = s->slot = s->order = nullptr;
+    s->stage_pos = s->stage_vel = nullptr;
+    s->cap = 0;
+}
+
+static int alloc_particles(fluid_sim* s, long n)
+{
+    if (n <= s->cap) return FLUID_OK;
+    free_particles(s);
+    for (Particles* p : {&s->pa, &s->pb}) {
+        HIPCHK(dalloc(&p->px, n)); HIPCHK(dalloc(&p->py, n)); HIPCHK(dalloc(&p->pz, n));
+        HIPCHK(dalloc(&p->vx, n)); HIPCHK(dalloc(&p->vy, n)); HIPCHK(dalloc(&p->vz, n));
+        HIPCHK(dalloc(&p->pid, n));
+    }
+    HIPCHK(dalloc(&s->key, n)); HIPCHK(dalloc(&s->slot, n)); HIPCHK(dalloc(&s->order, n));
+    HIPCHK(dalloc(&s->stage_pos, 3 * n)); HIPCHK(dalloc(&s->stage_vel, 3 * n));
+    HIPCHK(hipDeviceSynchronize());
+    s->cap = n;
+    return FLUID_OK;
+}
+
+extern "C" {
+
+const char* fluid_last_error(void) { return g_err.c_str(); }
+const char* fluid_version(void) { return "libfluid_hip 0.1 gfx950"; }
+
+int fluid_default_params(fluid_params_t* p)
+{
+    if (!p) return fail(FLUID_ERR_ARG, "null params");
+    memset(p, 0, sizeof(*p));
+    p->n = 121;
+    p->device = 0;
+    p->dx = 1.0;
+    p->rho = 1.0;
+    p->gravity[0] = 0; p->gravity[1] = -10; p->gravity[2] = 0;
+    p->max_dt = 0.1;
+    p->outer_tol = 0.1;
+    p->update_frac = 0.1;
+    p->cg_tol = 2.220446049250313e-16;
+    p->cg_max_iters = 0;
+    p->max_outer_passes = 0;
+    p->precision = FLUID_PRECISION_FP64;
+    return FLUID_OK;
+}
+
+int fluid_destroy(fluid_sim_t* s)
+{
+    if (!s) return FLUID_OK;
+    if (s->st) hipStreamSynchronize(s->st);
+    prof_resolve(s);
+    free_particles(s);
+    void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
+                    s->dcz, s->pressure, s->indices, s->scan_sums, s->R, s->S[0], s->S[1], s->Q, s->Xf, s->part_bb, s->part_rr,
+                    s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (s->h_ps) hipHostFree(s->h_ps);
+    if (s->h_ss) hipHostFree(s->h_ss);
+    if (s->st) hipStreamDestroy(s->st);
+    delete s;
+    return FLUID_OK;
+}
+
+int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
+{
+    if (!p || !out) return fail(FLUID_ERR_ARG, "null argument");
+    if (p->n < 8 || p->n > 1024) return fail(FLUID_ERR_ARG, "n must be in [8,1024]");
+    if (!(p->dx > 0) || !(p->rho > 0) || !(p->max_dt > 0)) return fail(FLUID_ERR_ARG, "dx, rho, max_dt must be > 0");
+    if (p->precision != FLUID_PRECISION_FP64 && p->precision != FLUID_PRECISION_FP32) return fail(FLUID_ERR_ARG, "bad precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FLUID_ERR_HIP, "no HIP device visible: libfluid_hip has no CPU path");
+    if (p->device < 0 || p->device >= ndev) return fail(FLUID_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(p->device));
+    fluid_sim* s = new fluid_sim();
+    s->prm = *p;
+    s->g.N = p->n;
+    s->g.lo = -(p->n / 2);
+    s->g.hi = s->g.lo + p->n - 1;
+    s->ncell = (size_t)p->n * p->n * p->n;
+    s->dt = p->max_dt;
+    *out = nullptr;
+    auto bail = [&](int rc) { fluid_destroy(s); return rc; };
+#define A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
+    A(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    const size_t n = s->ncell;
+    A(dalloc(&s->solid, n)); A(dalloc(&s->flags, n));
+    A(dalloc(&s->container, n)); A(dalloc(&s->rhs, n)); A(dalloc(&s->diver, n)); A(dalloc(&s->diver2, n));
+    A(dalloc(&s->u, n)); A(dalloc(&s->v, n)); A(dalloc(&s->w, n));
+    A(dalloc(&s->ub, n)); A(dalloc(&s->vb, n)); A(dalloc(&s->wb, n));
+    A(dalloc(&s->dcx, n)); A(dalloc(&s->dcy, n)); A(dalloc(&s->dcz, n));
+    A(dalloc(&s->pressure, n));
+    A(dalloc(&s->indices, n));
+    A(dalloc(&s->scan_sums, (n + 2) / 2048 + 16));
+    const size_t se = solver_elem(s);
+    A(dalloc((char**)&s->R, n * se)); A(dalloc((char**)&s->S[0], n * se)); A(dalloc((char**)&s->S[1], n * se)); A(dalloc((char**)&s->Q, n * se));
+    if (p->precision == FLUID_PRECISION_FP32) A(dalloc((char**)&s->Xf, n * se));
+    A(dalloc(&s->part_bb, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rr, (size_t)MAX_PARTIALS));
+    A(dalloc(&s->part_rz[0], (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rz[1], (size_t)MAX_PARTIALS));
+    A(dalloc(&s->part_pq, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_err, (size_t)2 * MAX_PARTIALS));
+    A(dalloc(&s->ps, (size_t)1)); A(dalloc(&s->ss, (size_t)1));
+    A(dalloc(&s->cell_count, n + 2)); A(dalloc(&s->cell_start, n + 2));
+    A(hipHostMalloc((void**)&s->h_ps, sizeof(PcgState)));
+    A(hipHostMalloc((void**)&s->h_ss, sizeof(StepState)));
+#undef A
+    // default solid shell: solid outside W (fluid.cc:1256-1266)
+    std::vector<uint8_t> sol(n, 0);
+    const int N = p->n;
+    for (int x = 0; x < N; ++x)
+        for (int y = 0; y < N; ++y)
+            for (int z = 0; z < N; ++z)
+                if (x < 2 || x > N - 3 || y < 2 || y > N - 3 || z < 2 || z > N - 3) sol[((size_t)x * N + y) * N + z] = 1;
+    hipError_t e = hipMemcpy(s->solid, sol.data(), n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->flags, sol.data(), n, hipMemcpyHostToDevice);  // F_SOLID == 1
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // hipMemset above ran on the null stream; s->st does not wait for it
+    if (e != hipSuccess) return bail(fail(FLUID_ERR_HIP, std::string("solid upload: ") + hipGetErrorString(e)));
+    *out = s;
+    return FLUID_OK;
+}
+
+int fluid_set_solid(fluid_sim_t* s, const uint8_t* solid)
+{
+    if (!s || !solid) return fail(FLUID_ERR_ARG, "null argument");
+    const int N = s->g.N;
+    std::vector<uint8_t> sol(s->ncell);
+    for (int x = 0; x < N; ++x)
+        for (int y = 0; y < N; ++y)
+            for (int z = 0; z < N; ++z) {
+                size_t c = ((size_t)x * N + y) * N + z;
+                bool outsideW = x < 2 || x > N - 3 || y < 2 || y > N - 3 || z < 2 || z > N - 3;
+                if (outsideW && !solid[c]) return fail(FLUID_ERR_ARG, "cells outside W=[lo+2,hi-2]^3 must be solid");
+                sol[c] = solid[c] ? 1 : 0;
+            }
+    HIPCHK(hipStreamSynchronize(s->st));
+    HIPCHK(hipMemcpy(s->solid, sol.data(), s->ncell, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->flags, sol.data(), s->ncell, hipMemcpyHostToDevice));
+    s->have_p2g = s->have_flags = false;
+    return FLUID_OK;
+}
+
+int fluid_upload_particles(fluid_sim_t* s, int64_t n, const double* pos, const double* vel)
+{
+    if (!s || n < 0 || (n > 0 && !pos)) return fail(FLUID_ERR_ARG, "bad particle arguments");
+    if (n > 0x7fffffffL) return fail(FLUID_ERR_ARG, "too many particles");
+    HIPCHK(hipSetDevice(s->prm.device));
+    int rc = alloc_particles(s, (long)n);
+    if (rc) return rc;
+    s->np = (long)n;
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(s->stage_pos, pos, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
+        if (vel) HIPCHK(hipMemcpyAsync(s->stage_vel, vel, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
+        launch_unpack_particles(s->st, s->np, s->stage_pos, vel ? s->stage_vel : nullptr, s->pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->st));
+    }
+    s->sorted = s->have_p2g = s->have_flags = false;
+    return FLUID_OK;
+}
+
+int fluid_download_particles(fluid_sim_t* s, double* pos, double* vel)
+{
+    if (!s || !pos || !vel) return fail(FLUID_ERR_ARG, "null argument");
+    if (s->np == 0) return FLUID_OK;
+    HIPCHK(hipSetDevice(s->prm.device));
+    launch_pack_particles(s->st, s->np, s->pa, s->stage_pos, s->stage_vel);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(pos, s->stage_pos, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipMemcpyAsync(vel, s->stage_vel, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    return FLUID_OK;
+}
+
+int64_t fluid_num_particles(fluid_sim_t* s) { return s ? s->np : -1; }
+int fluid_set_dt(fluid_sim_t* s, double dt)
+{
+    if (!s || !(dt > 0)) return fail(FLUID_ERR_ARG, "dt must be > 0");
+    s->dt = dt;
+    return FLUID_OK;
+}
+int fluid_get_dt(fluid_sim_t* s, double* dt)
+{
+    if (!s || !dt) return fail(FLUID_ERR_ARG, "null argument");
+    *dt = s->dt;
+    return FLUID_OK;
+}
+
+// counter-based RNG (splitmix64 finaliser) -> U[0,1)
+static inline double u01(uint64_t seed, uint64_t ctr)
+{
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + ctr * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+int64_t fluid_scene_water_cube_drop(int32_t n, int32_t ppc, uint64_t seed, double* pos)
+{
+    if (n < 8 || ppc < 1) return -1;
+    const int m = (int)std::lround((double)n * 41.0 / 121.0);  // 41 of 121 in the reference (fluid.cc:1176)
+    const int c0 = -(m / 2), c1 = c0 + m - 1;
+    const int lo = -(n / 2), hi = lo + n - 1;
+    int64_t cnt = 0;
+    uint64_t ctr = 0;
+    for (int x = c0; x <= c1; ++x)
+        for (int y = c0; y <= c1; ++y)
+            for (int z = c0; z <= c1; ++z)
+                for (int k = 0; k < ppc; ++k) {
+                    // PointScatter.h:421-429: jitter around coord - 0.5
+                    const double px = x - 0.5 + u01(seed, ctr), py = y - 0.5 + u01(seed, ctr + 1), pz = z - 0.5 + u01(seed, ctr + 2);
+                    ctr += 3;
+                    // PointList::add, fluid.cc:841 (|p| < boundary-2, generalised to lo+2 < p < hi-2)
+                    if (px > lo + 2 && px < hi - 2 && py > lo + 2 && py < hi - 2 && pz > lo + 2 && pz < hi - 2) {
+                        if (pos) { pos[3 * cnt] = px; pos[3 * cnt + 1] = py; pos[3 * cnt + 2] = pz; }
+                        cnt++;
+                    }
+                }
+    return cnt;
+}
+
+}  // extern "C"
+
+// ---- phases ---------------------------------------------------------------------------------------
+static int read_ss(fluid_sim* s)
+{
+    HIPCHK(hipMemcpyAsync(s->h_ss, s->ss, sizeof(StepState), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    return FLUID_OK;
+}
+
+static int clear_dirty(fluid_sim* s)
+{
+    if (s->dirty_x1 < s->dirty_x0) return FLUID_OK;
+    const size_t N2 = (size_t)s->g.N * s->g.N;
+    const size_t off = (size_t)s->dirty_x0 * N2, cnt = (size_t)(s->dirty_x1 - s->dirty_x0 + 1) * N2;
+    float* f4[] = {s->container, s->rhs, s->diver, s->diver2};
+    double* f8[] = {s->u, s->v, s->w, s->ub, s->vb, s->wb, s->pressure};
+    for (float* p : f4) HIPCHK(hipMemsetAsync(p + off, 0, cnt * sizeof(float), s->st));
+    for (double* p : f8) HIPCHK(hipMemsetAsync(p + off, 0, cnt * sizeof(double), s->st));
+    s->dirty_x0 = 0;
+    s->dirty_x1 = -1;
+    return FLUID_OK;
+}
+
+static int phase_sort(fluid_sim* s)
+{
+    const Grid g = s->g;
+    const long ncell = (long)s->ncell;
+    int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
+    launch_zero_step_state(s->st, s->ss, g.N);
+    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 2) * sizeof(int), s->st));
+    launch_bin_count(s->st, g, s->np, s->pa, s->key, s->slot, s->cell_count, s->ss);
+    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 1, s->scan_sums, s->cell_start + ncell + 1);
+    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->order);
+    HIPCHK(hipGetLastError());
+    int rc = read_ss(s);
+    if (rc) return rc;
+    const StepState& h = *s->h_ss;
+    if (h.bbox_max[0] < 0) {
+        s->Pb = Box{0, 0, 0, -1, -1, -1};
+    } else {
+        s->Pb = Box{h.bbox_min[0], h.bbox_min[1], h.bbox_min[2], h.bbox_max[0], h.bbox_max[1], h.bbox_max[2]};
+    }
+    if (!box_empty(s->Pb)) {
+        launch_bin_fix(s->st, g, s->Pb, s->cell_start, s->pa.pid, s->order);
+        s->Rb = clip_dilate(s->Pb, 1, g.N);
+        s->Sb = clip_dilate(s->Pb, 2, g.N);
+    } else {
+        s->Rb = s->Sb = s->Pb;
+    }
+    launch_reorder(s->st, s->np, s->order, s->pa, s->pb);
+    HIPCHK(hipGetLastError());
+    std::swap(s->pa, s->pb);
+    prof_end(s, FLUID_PROF_SORT, tok);
+    s->sorted = true;
+    return FLUID_OK;
+}
+
+static int phase_p2g(fluid_sim* s)
+{
+    HIPCHK(hipSetDevice(s->prm.device));
+    int rc = phase_sort(s);
+    if (rc) return rc;
+    rc = clear_dirty(s);
+    if (rc) return rc;
+    memset(&s->stats, 0, sizeof(s->stats));
+    s->stats.dt_in = s->dt;
+    s->stats.dt_out = s->dt;
+    for (int a = 0; a < 3; ++a) {
+        s->stats.box_lo[a] = (&s->Rb.x0)[a];
+        s->stats.box_hi[a] = (&s->Rb.x1)[a];
+    }
+    if (!box_empty(s->Rb)) {
+        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rb.cells());
+        launch_p2g(s->st, s->g, s->Rb, s->pa, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        prof_end(s, FLUID_PROF_P2G, tok);
+        HIPCHK(hipGetLastError());
+        s->dirty_x0 = s->Sb.x0;
+        s->dirty_x1 = s->Sb.x1;
+    }
+    s->have_p2g = true;
+    s->have_flags = false;
+    return FLUID_OK;
+}
+
+static int phase_flags(fluid_sim* s)
+{
+    HIPCHK(hipSetDevice(s->prm.device));
+    launch_flags(s->st, s->g, s->solid, s->container, s->flags);
+    launch_index_scan(s->st, s->g, s->flags, s->indices, s->scan_sums, &s->ss->num_active);
+    HIPCHK(hipGetLastError());
+    int rc = read_ss(s);
+    if (rc) return rc;
+    s->stats.num_active = s->h_ss->num_active;
+    s->have_flags = true;
+    return FLUID_OK;
+}
+
+static int phase_rhs_div(fluid_sim* s, int which)
+{
+    if (!s->have_flags) return fail(FLUID_ERR_STATE, "rhs_div before flags_index");
+    if (box_empty(s->Rb)) return FLUID_OK;
+    const double dt = s->dt;
+    launch_rhs_div(s->st, s->g, s->Rb, s->flags, s->u, s->v, s->w, s->rhs, which ? s->diver2 : s->diver, s->prm.dx,
+                   s->prm.gravity[0] * dt, s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);  // gravity*dt, fluid.cc:420
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+
+template <typename T>
+static Coef<T> make_coef(const fluid_sim* s)
+{
+    // setA, fluid.cc:306: scale = dt/(rho dx dx); Adiag accumulates float(Adiag + scale); Aplus = float(-1*scale)
+    const double scale = s->dt / (s->prm.rho * s->prm.dx * s->prm.dx);
+    Coef<T> c;
+    float acc = 0.0f;
+    c.diag[0] = 0;
+    for (int k = 1; k <= 6; ++k) {
+        acc = (float)((double)acc + scale);
+        c.diag[k] = (T)acc;
+    }
+    c.off = (T)(float)(-1 * scale);
+    return c;
+}
+
+template <typename T>
+static int solve_impl(fluid_sim* s)
+{
+    const Grid g = s->g;
+    const Box box = s->Rb;
+    T* X = sizeof(T) == 8 ? (T*)s->pressure : (T*)s->Xf;
+    T* R = (T*)s->R;
+    T* S0 = (T*)s->S[0];
+    T* S1 = (T*)s->S[1];
+    T* Q = (T*)s->Q;
+    T* Sx[2] = {S0, S1};
+    const Coef<T> cf = make_coef<T>(s);
+    const double tol = s->prm.cg_tol;
+    long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;  // IterativeSolverBase.h:362
+    if (max_it < 1) max_it = 1;
+    const double cells = (double)box.cells();
+    int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
+    launch_pcg_init<T>(s->st, g, box, s->flags, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
+    // body 0
+    int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
+    launch_pcg_sq<T>(s->st, g, box, s->flags, R, (const T*)nullptr, Sx[0], Q, cf, s->part_bb, nullptr, nullptr, s->part_pq, s->ps, 1, tol);
+    prof_end(s, FLUID_PROF_PCG_SQ, tok);
+    tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
+    launch_pcg_xr<T>(s->st, g, box, s->flags, X, R, Sx[0], Q, cf, s->part_rz[0], s->part_pq, s->part_rr, s->part_rz[1], s->ps);
+    prof_end(s, FLUID_PROF_PCG_XR, tok);
+    long it = 1;
+    const int CHECK = 16;
+    bool done = false;
+    while (!done) {
+        for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
+            const int cur = (int)(it & 1), prv = cur ^ 1;
+            tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
+            launch_pcg_sq<T>(s->st, g, box, s->flags, R, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[cur], s->part_rz[prv], s->part_pq,
+                             s->ps, 0, tol);
+            prof_end(s, FLUID_PROF_PCG_SQ, tok);
+            tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
+            launch_pcg_xr<T>(s->st, g, box, s->flags, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_rz[prv], s->ps);
+            prof_end(s, FLUID_PROF_PCG_XR, tok);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        done = s->h_ps->done || it >= max_it;
+    }
+    int iters = s->h_ps->iters;
+    double rr = s->h_ps->rr;
+    if (!s->h_ps->done) {
+        // cap reached without the break: Eigen leaves the loop with i == maxIters (ConjugateGradient.h:66)
+        iters = (int)max_it;
+    }
+    if (sizeof(T) == 4) launch_store_pressure<T>(s->st, g, box, s->flags, X, s->pressure);
+    prof_end(s, FLUID_PROF_SOLVE, tsolve);
+    s->stats.cg_iters_last = iters;
+    s->stats.cg_iters += iters;
+    s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
+    if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN (matrix not SPD for these flags)");
+    return FLUID_OK;
+}
+
+static int phase_solve(fluid_sim* s)
+{
+    if (!s->have_flags) return fail(FLUID_ERR_STATE, "solve before flags_index");
+    if (box_empty(s->Rb)) return FLUID_OK;
+    return s->prm.precision == FLUID_PRECISION_FP32 ? solve_impl<float>(s) : solve_impl<double>(s);
+}
+
+static int phase_vel_update(fluid_sim* s)
+{
+    if (!s->have_flags) return fail(FLUID_ERR_STATE, "vel_update before flags_index");
+    if (box_empty(s->Sb)) return FLUID_OK;
+    const double dtp = s->dt * s->prm.update_frac;      // dt/10, fluid.cc:1475
+    const double k = dtp / (s->prm.rho * s->prm.dx);    // :614
+    launch_vel_update(s->st, s->g, s->Sb, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,
+                      s->prm.gravity[2] * dtp);         // gravity*dt, :638
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+
+static int phase_pressure_pass(fluid_sim* s, double* error)
+{
+    int rc;
+    if ((rc = phase_rhs_div(s, 0))) return rc;
+    if ((rc = phase_solve(s))) return rc;
+    if ((rc = phase_vel_update(s))) return rc;
+    if ((rc = phase_rhs_div(s, 1))) return rc;
+    double err = NAN;
+    if (!box_empty(s->Rb)) {
+        launch_err_norm(s->st, s->g, s->Rb, s->flags, s->diver, s->diver2, s->part_err, s->ss);
+        HIPCHK(hipGetLastError());
+        if ((rc = read_ss(s))) return rc;
+        err = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);  // fluid.cc:1483
+    }
+    s->stats.error = err;
+    s->stats.outer_passes++;
+    if (error) *error = err;
+    return FLUID_OK;
+}
+
+static int phase_flip_advect(fluid_sim* s)
+{
+    if (!s->have_p2g) return fail(FLUID_ERR_STATE, "flip_advect before p2g");
+    HIPCHK(hipSetDevice(s->prm.device));
+    if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz);
+    int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
+    launch_g2p(s->st, s->g, s->np, s->pa, s->dcx, s->dcy, s->dcz, s->ss);
+    prof_end(s, FLUID_PROF_G2P, tok);
+    launch_advect(s->st, s->g, s->np, s->pa, s->flags, s->prm.max_dt, s->prm.dx, s->ss);
+    HIPCHK(hipGetLastError());
+    int rc = read_ss(s);
+    if (rc) return rc;
+    s->dt = s->h_ss->dt;
+    double ms;
+    memcpy(&ms, &s->h_ss->max_speed_bits, sizeof(double));
+    s->stats.max_speed = ms;
+    s->stats.dt_out = s->dt;
+    s->sorted = false;
+    s->have_p2g = false;  // particles moved: fields are stale for a new gather
+    return FLUID_OK;
+}
+
+extern "C" {
+
+int fluid_p2g(fluid_sim_t* s) { return s ? phase_p2g(s) : fail(FLUID_ERR_ARG, "null handle"); }
+int fluid_flags_index(fluid_sim_t* s) { return s ? phase_flags(s) : fail(FLUID_ERR_ARG, "null handle"); }
+int fluid_rhs_div(fluid_sim_t* s, int which) { return s ? phase_rhs_div(s, which) : fail(FLUID_ERR_ARG, "null handle"); }
+int fluid_solve(fluid_sim_t* s) { return s ? phase_solve(s) : fail(FLUID_ERR_ARG, "null handle"); }
+int fluid_vel_update(fluid_sim_t* s) { return s ? phase_vel_update(s) : fail(FLUID_ERR_ARG, "null handle"); }
+int fluid_pressure_pass(fluid_sim_t* s, double* error) { return s ? phase_pressure_pass(s, error) : fail(FLUID_ERR_ARG, "null handle"); }
+int fluid_flip_advect(fluid_sim_t* s) { return s ? phase_flip_advect(s) : fail(FLUID_ERR_ARG, "null handle"); }
+
+int fluid_get_stats(fluid_sim_t* s, fluid_step_stats_t* st)
+{
+    if (!s || !st) return fail(FLUID_ERR_ARG, "null argument");
+    *st = s->stats;
+    return FLUID_OK;
+}
+
+int fluid_step(fluid_sim_t* s, fluid_step_stats_t* stats)
+{
+    if (!s) return fail(FLUID_ERR_ARG, "null handle");
+    int rc;
+    if ((rc = phase_p2g(s))) return rc;             // fluid.cc:1378-1413
+    if ((rc = phase_flags(s))) return rc;           // :1416-1455
+    double error = NAN;
+    do {                                            // :1457
+        if ((rc = phase_pressure_pass(s, &error))) return rc;
+        if (s->prm.max_outer_passes > 0 && s->stats.outer_passes >= s->prm.max_outer_passes) break;
+    } while (error > s->prm.outer_tol);             // :1484 (NaN ends the loop, inf continues)
+    if ((rc = phase_flip_advect(s))) return rc;     // :1490
+    if (stats) *stats = s->stats;
+    return FLUID_OK;
+}
+
+static int field_info(fluid_sim* s, int field, void** ptr, size_t* bytes)
+{
+    const size_t n = s->ncell, se = solver_elem(s);
+    switch (field) {
+    case FLUID_FIELD_CONTAINER: case FLUID_FIELD_WEIGHTS: case FLUID_FIELD_OUTPUT: *ptr = s->container; *bytes = n * 4; return 0;
+    case FLUID_FIELD_INDICES: *ptr = s->indices; *bytes = n * 4; return 0;
+    case FLUID_FIELD_RHS: *ptr = s->rhs; *bytes = n * 4; return 0;
+    case FLUID_FIELD_DIVER: *ptr = s->diver; *bytes = n * 4; return 0;
+    case FLUID_FIELD_DIVER2: *ptr = s->diver2; *bytes = n * 4; return 0;
+    case FLUID_FIELD_PRESSURE: *ptr = s->pressure; *bytes = n * 8; return 0;
+    case FLUID_FIELD_SOLID: *ptr = s->solid; *bytes = n; return 0;
+    case FLUID_FIELD_FLAGS: *ptr = s->flags; *bytes = n; return 0;
+    case FLUID_FIELD_SEARCH: *ptr = s->S[0]; *bytes = n * se; return 0;
+    case FLUID_FIELD_Q: *ptr = s->Q; *bytes = n * se; return 0;
+    case FLUID_FIELD_VEL: case FLUID_FIELD_VEL_BEFORE: *ptr = nullptr; *bytes = 3 * n * 8; return 0;
+    }
+    return -1;
+}
+
+int fluid_download_field(fluid_sim_t* s, int field, void* dst, size_t bytes)
+{
+    if (!s || !dst) return fail(FLUID_ERR_ARG, "null argument");
+    void* p;
+    size_t nb;
+    if (field_info(s, field, &p, &nb)) return fail(FLUID_ERR_ARG, "unknown field id");
+    if (bytes != nb) return fail(FLUID_ERR_ARG, "byte count does not match the field size");
+    HIPCHK(hipSetDevice(s->prm.device));
+    HIPCHK(hipStreamSynchronize(s->st));
+    if (field == FLUID_FIELD_VEL || field == FLUID_FIELD_VEL_BEFORE) {
+        double* src[3] = {field == FLUID_FIELD_VEL ? s->u : s->ub, field == FLUID_FIELD_VEL ? s->v : s->vb, field == FLUID_FIELD_VEL ? s->w : s->wb};
+        for (int a = 0; a < 3; ++a) HIPCHK(hipMemcpy((char*)dst + a * s->ncell * 8, src[a], s->ncell * 8, hipMemcpyDeviceToHost));
+        return FLUID_OK;
+    }
+    HIPCHK(hipMemcpy(dst, p, nb, hipMemcpyDeviceToHost));
+    return FLUID_OK;
+}
+
+int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
+{
+    if (!s || !src) return fail(FLUID_ERR_ARG, "null argument");
+    void* p;
+    size_t nb;
+    if (field_info(s, field, &p, &nb)) return fail(FLUID_ERR_ARG, "unknown field id");
+    if (bytes != nb) return fail(FLUID_ERR_ARG, "byte count does not match the field size");
+    if (field == FLUID_FIELD_SOLID || field == FLUID_FIELD_FLAGS || field == FLUID_FIELD_INDICES || field == FLUID_FIELD_Q)
+        return fail(FLUID_ERR_ARG, "field is not uploadable (use fluid_set_solid / fluid_flags_index)");
+    HIPCHK(hipSetDevice(s->prm.device));
+    HIPCHK(hipStreamSynchronize(s->st));
+    if (field == FLUID_FIELD_VEL || field == FLUID_FIELD_VEL_BEFORE) {
+        double* d[3] = {field == FLUID_FIELD_VEL ? s->u : s->ub, field == FLUID_FIELD_VEL ? s->v : s->vb, field == FLUID_FIELD_VEL ? s->w : s->wb};
+        for (int a = 0; a < 3; ++a) HIPCHK(hipMemcpy(d[a], (const char*)src + a * s->ncell * 8, s->ncell * 8, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(p, src, nb, hipMemcpyHostToDevice));
+    }
+    // an uploaded field may be non-zero anywhere: widen every box to the whole grid
+    const int N = s->g.N;
+    s->Rb = s->Sb = Box{0, 0, 0, N - 1, N - 1, N - 1};
+    s->dirty_x0 = 0;
+    s->dirty_x1 = N - 1;
+    if (field == FLUID_FIELD_CONTAINER) { s->have_p2g = true; s->have_flags = false; }
+    return FLUID_OK;
+}
+
+int fluid_stencil_apply(fluid_sim_t* s, int reps, int box_mode, float* avg_ms)
+{
+    if (!s || reps < 1) return fail(FLUID_ERR_ARG, "bad argument");
+    if (!s->have_flags) return fail(FLUID_ERR_STATE, "stencil_apply before flags_index");
+    HIPCHK(hipSetDevice(s->prm.device));
+    const int N = s->g.N;
+    const Box box = box_mode ? s->Rb : Box{0, 0, 0, N - 1, N - 1, N - 1};
+    if (box_empty(box)) return fail(FLUID_ERR_STATE, "empty active box");
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, s->st));
+    for (int i = 0; i < reps; ++i) {
+        if (s->prm.precision == FLUID_PRECISION_FP32)
+            launch_stencil_apply<float>(s->st, s->g, box, s->flags, (const float*)s->S[0], (float*)s->Q, make_coef<float>(s));
+        else
+            launch_stencil_apply<double>(s->st, s->g, box, s->flags, (const double*)s->S[0], (double*)s->Q, make_coef<double>(s));
+    }
+    HIPCHK(hipEventRecord(e1, s->st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (avg_ms) *avg_ms = ms / reps;
+    return FLUID_OK;
+}
+
+int fluid_profile_enable(fluid_sim_t* s, int sample_every)
+{
+    if (!s || sample_every < 0) return fail(FLUID_ERR_ARG, "bad argument");
+    s->prof_every = sample_every;
+    return FLUID_OK;
+}
+int fluid_profile_read(fluid_sim_t* s, int klass, int64_t* n_launches, int64_t* n_sampled, double* total_ms, double* cells)
+{
+    if (!s || klass < 0 || klass >= FLUID_PROF_COUNT) return fail(FLUID_ERR_ARG, "bad argument");
+    prof_resolve(s);
+    const ProfClass& p = s->prof[klass];
+    if (n_launches) *n_launches = p.launches;
+    if (n_sampled) *n_sampled = p.sampled;
+    if (total_ms) *total_ms = p.ms;
+    if (cells) *cells = p.cells;
+    return FLUID_OK;
+}
+int fluid_profile_reset(fluid_sim_t* s)
+{
+    if (!s) return fail(FLUID_ERR_ARG, "null handle");
+    prof_resolve(s);
+    for (int k = 0; k < FLUID_PROF_COUNT; ++k) {
+        s->prof[k].launches = s->prof[k].sampled = 0;
+        s->prof[k].ms = s->prof[k].cells = 0;
+    }
+    return FLUID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// Grid-side kernels of the PIC/FLIP step for gfx950: cell flags + unknown numbering
+// (integer, bit-exact), RHS/divergence, velocity update (gather form), FLIP delta field.
+#include "common.h"
+
+namespace fl {
+
+// ---- exclusive prefix sum over ints ---------------------------------------------------------
+// Three launches: chunk sums, one-block scan of the chunk sums, per-chunk scan + offset.
+// MODE 0: in = int array, out = exclusive sums.
+// MODE 1: in = flag bytes (1 where F_FLUID), out = the reference's `indices` grid: running
+//         count on fluid cells in x-major / z-fastest order, -1 elsewhere (fluid.cc:1388,1416-1433).
+constexpr int SCAN_T = 256;
+constexpr int SCAN_E = 8;
+constexpr int SCAN_CHUNK = SCAN_T * SCAN_E;
+
+template <int MODE>
+__device__ __forceinline__ int scan_load(const void* in, long i)
+{
+    if (MODE == 0) return ((const int*)in)[i];
+    return (((const uint8_t*)in)[i] & F_FLUID) ? 1 : 0;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(const void* __restrict__ in, long n, int* __restrict__ block_sums)
+{
+    __shared__ int sm[4];
+    long base = (long)blockIdx.x * SCAN_CHUNK + (long)threadIdx.x * SCAN_E;
+    int s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e)
+        if (base + e < n) s += scan_load<MODE>(in, base + e);
+    s = block_sum<int, 4>(s, sm);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+}
+
+// exclusive scan of block_sums[0..nb) in place by ONE block of 1024 threads; total -> *total
+__global__ __launch_bounds__(1024) void k_scan_block_sums(int* __restrict__ block_sums, int nb, int* __restrict__ total)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = i < nb ? block_sums[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        int carry = carry_s;
+        if (i < nb) block_sums[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SCAN_T) void k_scan_final(const void* __restrict__ in, long n, const int* __restrict__ block_sums,
+                                                       int* __restrict__ out)
+{
+    __shared__ int wsum[4];
+    long base = (long)blockIdx.x * SCAN_CHUNK + (long)threadIdx.x * SCAN_E;
+    int v[SCAN_E];
+    int s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e) {
+        v[e] = (base + e < n) ? scan_load<MODE>(in, base + e) : 0;
+        s += v[e];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int off = block_sums[blockIdx.x] + inc - s;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e) {
+        if (base + e < n) {
+            if (MODE == 0) out[base + e] = off;
+            else out[base + e] = v[e] ? off : -1;
+        }
+        off += v[e];
+    }
+}
+
+template <int MODE>
+static void scan_impl(hipStream_t st, const void* in, int* out, long n, int* block_sums, int* total)
+{
+    int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(k_scan_sums<MODE>, dim3(nb), dim3(SCAN_T), 0, st, in, n, block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, st, block_sums, nb, total);
+    hipLaunchKernelGGL(k_scan_final<MODE>, dim3(nb), dim3(SCAN_T), 0, st, in, n, (const int*)block_sums, out);
+}
+
+void launch_exclusive_scan(hipStream_t st, const int* in, int* out, long n, int* block_sums, int* total)
+{
+    scan_impl<0>(st, in, out, n, block_sums, total);
+}
+void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total)
+{
+    scan_impl<1>(st, flags, indices, (long)g.N * g.N * g.N, block_sums, total);
+}
+
+// ---- flags -----------------------------------------------------------------------------------
+// fluid(c) = container(c) > 0 && !solid(c)            (fluid.cc:326,445,579,1423-1425)
+// cnt(c)   = #{6-neighbours that are not solid}       (multiplicity of `scale` in Adiag(c),
+//            fluid.cc:328-372 for the + side, 378-405 and 334/349/365 for the - side; an
+//            off-grid neighbour reads background 0 = not solid)
+__global__ __launch_bounds__(256) void k_flags(Grid g, const uint8_t* __restrict__ solid, const float* __restrict__ container,
+                                               uint8_t* __restrict__ flags)
+{
+    const long ncell = (long)g.N * g.N * g.N;
+    long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncell) return;
+    const int N = g.N;
+    const int iz = (int)(c % N), iy = (int)((c / N) % N), ix = (int)(c / ((long)N * N));
+    const uint8_t sol = solid[c] ? F_SOLID : 0;
+    uint8_t f = sol;
+    if (!sol && container[c] > 0) {
+        int cnt = 0;
+        cnt += (ix > 0) ? !solid[c - (long)N * N] : 1;
+        cnt += (ix < N - 1) ? !solid[c + (long)N * N] : 1;
+        cnt += (iy > 0) ? !solid[c - N] : 1;
+        cnt += (iy < N - 1) ? !solid[c + N] : 1;
+        cnt += (iz > 0) ? !solid[c - 1] : 1;
+        cnt += (iz < N - 1) ? !solid[c + 1] : 1;
+        f = (uint8_t)(F_FLUID | (cnt << F_CNT_SHIFT));
+    }
+    flags[c] = f;
+}
+
+void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags)
+{
+    const long ncell = (long)g.N * g.N * g.N;
+    hipLaunchKernelGGL(k_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, g, solid, container, flags);
+}
+
+// ---- box helpers -----------------------------------------------------------------------------
+struct CellIt {
+    int ix, iy, iz;
+    size_t c;
+    bool ok;
+};
+__device__ __forceinline__ CellIt box_cell(const Grid& g, const Box& box)
+{
+    CellIt r;
+    const int nz = box.nz(), ny = box.ny();
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    r.ok = t < box.cells();
+    if (!r.ok) { r.ix = r.iy = r.iz = 0; r.c = 0; return r; }
+    r.iz = (int)(t % nz) + box.z0;
+    r.iy = (int)((t / nz) % ny) + box.y0;
+    r.ix = (int)(t / ((long)nz * ny)) + box.x0;
+    r.c = g.idx(r.ix, r.iy, r.iz);
+    return r;
+}
+
+// ---- setRHS + setDiver -------------------------------------------------------------------------
+// fluid.cc:414-479 then 566-610, per fluid cell, with the reference's float32 grid
+// narrowing after every accumulation and its term order (-x,+x,-y,+y,-z,+z).
+__global__ __launch_bounds__(256) void k_rhs_div(Grid g, Box box, const uint8_t* __restrict__ flags, const double* __restrict__ u,
+                                                 const double* __restrict__ v, const double* __restrict__ w, float* __restrict__ rhs,
+                                                 float* __restrict__ diver, double dx, double g0, double g1, double g2)
+{
+    CellIt it = box_cell(g, box);
+    if (!it.ok) return;
+    const size_t c = it.c;
+    const int N = g.N;
+    const uint8_t f = flags[c];
+    float r = 0.0f, d = 0.0f;
+    if (f & F_FLUID) {
+        const double scale = 1.0 / dx;
+        const long sx = (long)N * N, sy = N;
+        const bool hxm = it.ix > 0, hxp = it.ix < N - 1, hym = it.iy > 0, hyp = it.iy < N - 1, hzm = it.iz > 0, hzp = it.iz < N - 1;
+        const double uc = u[c], vc = v[c], wc = w[c];
+        const double ui = hxp ? u[c + sx] : 0.0, vj = hyp ? v[c + sy] : 0.0, wk = hzp ? w[c + 1] : 0.0;
+        const bool sxm = hxm && (flags[c - sx] & F_SOLID), sxp = hxp && (flags[c + sx] & F_SOLID);
+        const bool sym = hym && (flags[c - sy] & F_SOLID), syp = hyp && (flags[c + sy] & F_SOLID);
+        const bool szm = hzm && (flags[c - 1] & F_SOLID), szp = hzp && (flags[c + 1] & F_SOLID);
+        if (sxm) r = (float)((double)r - (scale * (uc + g0)));
+        if (sxp) r = (float)((double)r + (scale * (ui + g0)));
+        if (sym) r = (float)((double)r - (scale * (vc + g1)));
+        if (syp) r = (float)((double)r + (scale * (vj + g1)));
+        if (szm) r = (float)((double)r - (scale * (wc + g2)));
+        if (szp) r = (float)((double)r + (scale * (wk + g2)));
+        double du = 0, dv = 0, dw = 0;
+        if (!sxp) du = (ui - uc) / dx;
+        if (!syp) dv = (vj - vc) / dx;
+        if (!szp) dw = (wk - wc) / dx;
+        d = (float)(((double)r) - du - dv - dw);
+    }
+    rhs[c] = r;
+    diver[c] = d;
+}
+
+void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w, float* rhs,
+                    float* diver, double dx, double gdt0, double gdt1, double gdt2)
+{
+    hipLaunchKernelGGL(k_rhs_div, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, flags, u, v, w, rhs, diver, dx,
+                       gdt0, gdt1, gdt2);
+}
+
+// ---- velUpdate, gather form ------------------------------------------------------------------
+// fluid.cc:612-703.  The reference sweeps cells in x-major order and, at fluid cell c, adds
+// -k p(c)+g' to all three stored components of c and +k p(c) to component a of c+e_a.  Every
+// cell therefore sees, in this order: the +k p(c-e_a) of its three lower neighbours (they are
+// visited first), then its own term.  The second sweep zeroes v(c) and v(c+e_a).a for every
+// solid c.  Gathered per cell the result is bit-identical and needs no atomics.
+__global__ __launch_bounds__(256) void k_vel_update(Grid g, Box box, const uint8_t* __restrict__ flags, const double* __restrict__ p,
+                                                    double* __restrict__ u, double* __restrict__ v, double* __restrict__ w, double k,
+                                                    double g0, double g1, double g2)
+{
+    CellIt it = box_cell(g, box);
+    if (!it.ok) return;
+    const size_t c = it.c;
+    const int N = g.N;
+    const long sx = (long)N * N, sy = N;
+    const uint8_t f = flags[c];
+    const uint8_t fxm = it.ix > 0 ? flags[c - sx] : 0, fym = it.iy > 0 ? flags[c - sy] : 0, fzm = it.iz > 0 ? flags[c - 1] : 0;
+    double uc = u[c], vc = v[c], wc = w[c];
+    if (fxm & F_FLUID) uc = uc + k * p[c - sx];   // :646
+    if (fym & F_FLUID) vc = vc + k * p[c - sy];   // :653
+    if (fzm & F_FLUID) wc = wc + k * p[c - 1];    // :660
+    if (f & F_FLUID) {
+        const double pre = p[c];
+        uc = uc - k * pre + g0;                   // :639
+        vc = vc - k * pre + g1;                   // :640
+        wc = wc - k * pre + g2;                   // :641
+    }
+    if (f & F_SOLID) { uc = 0; vc = 0; wc = 0; }  // :682
+    if (fxm & F_SOLID) uc = 0;                    // :686
+    if (fym & F_SOLID) vc = 0;                    // :691
+    if (fzm & F_SOLID) wc = 0;                    // :696
+    u[c] = uc; v[c] = vc; w[c] = wc;
+}
+
+void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w, double k,
+                       double g0, double g1, double g2)
+{
+    hipLaunchKernelGGL(k_vel_update, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, flags, p, u, v, w, k, g0, g1,
+                       g2);
+}
+
+// ---- FLIP delta field ------------------------------------------------------------------------
+// dc(c) = getVelocity(c, vels) - getVelocity(c, velBeforeUpdate)  (fluid.cc:59-70, 239-240, 252)
+__global__ __launch_bounds__(256) void k_flip_delta(Grid g, Box box, const double* __restrict__ u, const double* __restrict__ v,
+                                                    const double* __restrict__ w, const double* __restrict__ ub,
+                                                    const double* __restrict__ vb, const double* __restrict__ wb,
+                                                    double* __restrict__ dcx, double* __restrict__ dcy, double* __restrict__ dcz)
+{
+    CellIt it = box_cell(g, box);
+    if (!it.ok) return;
+    const size_t c = it.c;
+    const int N = g.N;
+    const long sx = (long)N * N, sy = N;
+    const bool hxp = it.ix < N - 1, hyp = it.iy < N - 1, hzp = it.iz < N - 1;
+    const double cu = (u[c] + (hxp ? u[c + sx] : 0.0)) / 2.0, pu = (ub[c] + (hxp ? ub[c + sx] : 0.0)) / 2.0;
+    const double cv = (v[c] + (hyp ? v[c + sy] : 0.0)) / 2.0, pv = (vb[c] + (hyp ? vb[c + sy] : 0.0)) / 2.0;
+    const double cw = (w[c] + (hzp ? w[c + 1] : 0.0)) / 2.0, pw = (wb[c] + (hzp ? wb[c + 1] : 0.0)) / 2.0;
+    dcx[c] = cu - pu;
+    dcy[c] = cv - pv;
+    dcz[c] = cw - pw;
+}
+
+void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w, const double* ub,
+                       const double* vb, const double* wb, double* dcx, double* dcy, double* dcz)
+{
+    hipLaunchKernelGGL(k_flip_delta, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, u, v, w, ub, vb, wb, dcx, dcy,
+                       dcz);
+}
+
+// ---- error = |b-b2| / |b| --------------------------------------------------------------------
+// fluid.cc:1483 over the unknowns that setA2/setOnlyB fill (Adiag != 0, :498,556).
+__global__ __launch_bounds__(256) void k_err_partial(Grid g, Box box, const uint8_t* __restrict__ flags, const float* __restrict__ b,
+                                                     const float* __restrict__ b2, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    const long ncells = box.cells();
+    const int nz = box.nz(), ny = box.ny();
+    double num = 0, den = 0;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < ncells; t += (long)gridDim.x * 256) {
+        int iz = (int)(t % nz) + box.z0, iy = (int)((t / nz) % ny) + box.y0, ix = (int)(t / ((long)nz * ny)) + box.x0;
+        size_t c = g.idx(ix, iy, iz);
+        uint8_t f = flags[c];
+        if ((f & F_FLUID) && (f >> F_CNT_SHIFT)) {
+            double bb = (double)b[c], d = bb - (double)b2[c];
+            num += d * d;
+            den += bb * bb;
+        }
+    }
+    num = block_sum<double, 4>(num, sm);
+    den = block_sum<double, 4>(den, sm);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = num; part[2 * blockIdx.x + 1] = den; }
+}
+__global__ __launch_bounds__(256) void k_err_final(const double* __restrict__ part, int nb, StepState* ss)
+{
+    __shared__ double sm[4];
+    double num = 0, den = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) { num += part[2 * i]; den += part[2 * i + 1]; }
+    num = block_sum<double, 4>(num, sm);
+    den = block_sum<double, 4>(den, sm);
+    if (threadIdx.x == 0) { ss->err_num = num; ss->err_den = den; }
+}
+
+void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, const float* b2, double* part, StepState* ss)
+{
+    long nb = (box.cells() + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_err_partial, dim3((unsigned)nb), dim3(256), 0, st, g, box, flags, b, b2, part);
+    hipLaunchKernelGGL(k_err_final, dim3(1), dim3(256), 0, st, (const double*)part, (int)nb, ss);
+}
+
+__global__ void k_zero_step_state(StepState* ss, int N)
+{
+    ss->bbox_min[0] = ss->bbox_min[1] = ss->bbox_min[2] = N;
+    ss->bbox_max[0] = ss->bbox_max[1] = ss->bbox_max[2] = -1;
+    ss->num_active = 0;
+    ss->n_out = 0;
+    ss->max_speed_bits = 0ull;
+    ss->err_num = 0;
+    ss->err_den = 0;
+}
+void launch_zero_step_state(hipStream_t st, StepState* ss, int N)
+{
+    hipLaunchKernelGGL(k_zero_step_state, dim3(1), dim3(1), 0, st, ss, N);
+}
+
+}  // namespace fl

@@ -1,0 +1,298 @@
+// Particle-side kernels of the PIC/FLIP step for gfx950 (wave64).
+//
+// The reference scatters from particles to cells under one std::mutex per cell
+// (fluid.cc:265-299, 843-882).  Here particles are counting-sorted by base cell every step and
+// the transfer is a GATHER per cell over the 27 neighbouring cell lists: no atomics on the
+// fields, and the summation order is a pure function of the input (bitwise reproducible).
+#include "common.h"
+
+namespace fl {
+
+// ---- counting sort by base cell ----------------------------------------------------------
+// key = linear index of round(pos) (C round(): half away from zero, fluid.cc:267-269), or
+// NCELL for a particle whose base cell is off the grid (it can reach no cell:
+// its clamped support lies in the solid shell, fluid.cc:271-276,288).
+__global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, int* __restrict__ key, int* __restrict__ slot,
+                                                   int* __restrict__ cell_count, StepState* ss)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+    int nout = 0;
+    if (i < n) {
+        int bx = (int)round(p.px[i]) - g.lo, by = (int)round(p.py[i]) - g.lo, bz = (int)round(p.pz[i]) - g.lo;
+        bool in = bx >= 0 && bx < g.N && by >= 0 && by < g.N && bz >= 0 && bz < g.N;
+        long ncell = (long)g.N * g.N * g.N;
+        int k = in ? (int)g.idx(bx, by, bz) : (int)ncell;
+        key[i] = k;
+        slot[i] = atomicAdd(&cell_count[k], 1);
+        if (in) {
+            mn[0] = mx[0] = bx; mn[1] = mx[1] = by; mn[2] = mx[2] = bz;
+        } else {
+            nout = 1;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (hi >= 0) {
+                atomicMin(&ss->bbox_min[a], lo);
+                atomicMax(&ss->bbox_max[a], hi);
+            }
+        }
+    }
+    nout = wave_sum(nout);
+    if ((threadIdx.x & 63) == 0 && nout) atomicAdd(&ss->n_out, nout);
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(long n, const int* __restrict__ key, const int* __restrict__ slot,
+                                                     const int* __restrict__ cell_start, int* __restrict__ order)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) order[cell_start[key[i]] + slot[i]] = (int)i;
+}
+
+// Slots were handed out by atomics in arrival order; put every cell's short list into
+// ascending original-id order so that all later sums have a fixed order.
+__global__ __launch_bounds__(256) void k_bin_fix(Grid g, Box box, const int* __restrict__ cell_start, const uint32_t* __restrict__ pid,
+                                                 int* __restrict__ order)
+{
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int nz = box.nz(), ny = box.ny();
+    if (t >= box.cells()) return;
+    int iz = (int)(t % nz) + box.z0;
+    int iy = (int)((t / nz) % ny) + box.y0;
+    int ix = (int)(t / ((long)nz * ny)) + box.x0;
+    size_t c = g.idx(ix, iy, iz);
+    int a = cell_start[c], b = cell_start[c + 1];
+    for (int i = a + 1; i < b; ++i) {
+        int oi = order[i];
+        uint32_t ki = pid[oi];
+        int j = i - 1;
+        while (j >= a && pid[order[j]] > ki) {
+            order[j + 1] = order[j];
+            --j;
+        }
+        order[j + 1] = oi;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__ order, Particles s, Particles d)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int i = order[j];
+    d.px[j] = s.px[i]; d.py[j] = s.py[i]; d.pz[j] = s.pz[i];
+    d.vx[j] = s.vx[i]; d.vy[j] = s.vy[i]; d.vz[j] = s.vz[i];
+    d.pid[j] = s.pid[i];
+}
+
+// ---- particle -> grid (gather form) --------------------------------------------------------
+// fluid.cc:1106-1148 (P2Gtransfer) + 265-299 (p2gCatmullRom) + 843-882 (interpolate).
+// Cell c receives w*v from every particle whose base cell b satisfies |b-c|<=1 per axis
+// (support base-1..base+1 clamped to the grid, fluid.cc:271-276), unless c is solid
+// (:288; "within W" is implied by non-solid, see fluid_set_solid).  weights is a float32
+// accumulator updated as float(weights + w) (:292); the velocity sum is fp64 (:293) and is
+// divided by double(weights) where weights>0 (:1138-1142).  container (:873) accumulates the
+// same w under "w>0", i.e. the same float sequence, so one array serves both.
+// The post-P2G velocity is also stored as velBeforeUpdate (fluid.cc:1455).
+__global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const int* __restrict__ cell_start,
+                                             const uint8_t* __restrict__ flags, float* __restrict__ container,
+                                             double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
+                                             double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
+{
+    const int nz = box.nz(), ny = box.ny();
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= box.cells()) return;
+    const int iz = (int)(t % nz) + box.z0;
+    const int iy = (int)((t / nz) % ny) + box.y0;
+    const int ix = (int)(t / ((long)nz * ny)) + box.x0;
+    const size_t c = g.idx(ix, iy, iz);
+    if (flags[c] & F_SOLID) return;  // fields stay 0
+    const double cx = (double)(ix + g.lo), cy = (double)(iy + g.lo), cz = (double)(iz + g.lo);
+    float wf = 0.0f;
+    double su = 0, sv = 0, sw = 0;
+    const int x0 = ix > 0 ? ix - 1 : 0, x1 = ix < g.N - 1 ? ix + 1 : g.N - 1;
+    const int y0 = iy > 0 ? iy - 1 : 0, y1 = iy < g.N - 1 ? iy + 1 : g.N - 1;
+    const int z0 = iz > 0 ? iz - 1 : 0, z1 = iz < g.N - 1 ? iz + 1 : g.N - 1;
+    for (int nx = x0; nx <= x1; ++nx)
+        for (int nyy = y0; nyy <= y1; ++nyy) {
+            const int j0 = cell_start[g.idx(nx, nyy, z0)];
+            const int j1 = cell_start[g.idx(nx, nyy, z1) + 1];
+            for (int j = j0; j < j1; ++j) {
+                const double cw = spline(p.px[j] - cx) * spline(p.py[j] - cy) * spline(p.pz[j] - cz);
+                wf = (float)((double)wf + cw);
+                su = su + cw * p.vx[j];
+                sv = sv + cw * p.vy[j];
+                sw = sw + cw * p.vz[j];
+            }
+        }
+    if (wf > 0) {
+        const double wd = (double)wf;
+        su /= wd; sv /= wd; sw /= wd;
+    }
+    container[c] = wf;
+    u[c] = su; v[c] = sv; w[c] = sw;
+    ub[c] = su; vb[c] = sv; wb[c] = sw;
+}
+
+// ---- grid -> particle, FLIP -----------------------------------------------------------------
+// fluid.cc:978-991 + CatmullRomFLIP 210-263.  dc* holds getVelocity(new) - getVelocity(old)
+// per cell (k_flip_delta), i.e. the (velc - velp) term of :252.
+__global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const double* __restrict__ dcx, const double* __restrict__ dcy,
+                                             const double* __restrict__ dcz, StepState* ss)
+{
+    __shared__ double sm[4];
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    double len = 0;
+    if (i < n) {
+        const double cx = p.px[i], cy = p.py[i], cz = p.pz[i];
+        const int lo = g.lo, hi = g.hi, wlo = g.lo + 2, whi = g.hi - 2;
+        int fcx = (int)round(cx), fcy = (int)round(cy), fcz = (int)round(cz);
+        int minx = fcx - 1 > lo ? fcx - 1 : lo, maxx = fcx + 1 < hi ? fcx + 1 : hi;
+        int miny = fcy - 1 > lo ? fcy - 1 : lo, maxy = fcy + 1 < hi ? fcy + 1 : hi;
+        int minz = fcz - 1 > lo ? fcz - 1 : lo, maxz = fcz + 1 < hi ? fcz + 1 : hi;
+        double weight = 0, d0 = 0, d1 = 0, d2 = 0;
+        for (int x = minx; x <= maxx; ++x)
+            for (int y = miny; y <= maxy; ++y)
+                for (int z = minz; z <= maxz; ++z) {
+                    if (x >= wlo && x <= whi && y >= wlo && y <= whi && z >= wlo && z <= whi) {  // :237
+                        const size_t c = g.idx(x - lo, y - lo, z - lo);
+                        const double cw = spline(cx - x) * spline(cy - y) * spline(cz - z);
+                        weight += cw;
+                        d0 += dcx[c] * cw;
+                        d1 += dcy[c] * cw;
+                        d2 += dcz[c] * cw;
+                    }
+                }
+        double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
+        if (weight != 0) {  // :258-262
+            vx += d0 / weight;
+            vy += d1 / weight;
+            vz += d2 / weight;
+            p.vx[i] = vx; p.vy[i] = vy; p.vz[i] = vz;
+        }
+        len = sqrt(vx * vx + vy * vy + vz * vz);  // Vec3::length, math/Vec3.h:224-230
+        if (!(len == len)) len = 0;               // NaN never raises the max (maxSpeed < NaN is false, :982)
+    }
+    len = wave_max(len);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = sm[0];
+        for (int k = 1; k < 4; ++k) m = sm[k] > m ? sm[k] : m;
+        if (m > 0) atomicMax(&ss->max_speed_bits, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+__device__ __forceinline__ bool is_solid(const Grid& g, const uint8_t* flags, int x, int y, int z)
+{
+    // saccessor.getValue outside the filled box -> background 0 -> not solid (fluid.cc:46-57)
+    if (x < g.lo || x > g.hi || y < g.lo || y > g.hi || z < g.lo || z > g.hi) return false;
+    return flags[g.idx(x - g.lo, y - g.lo, z - g.lo)] & F_SOLID;
+}
+
+// fluid.cc:992-1036: new dt from maxSpeed, move, stuck-particle handling with e = 0.
+__global__ __launch_bounds__(256) void k_advect(Grid g, long n, Particles p, const uint8_t* __restrict__ flags, double max_dt, double dx,
+                                                StepState* ss)
+{
+    const double maxSpeed = __longlong_as_double((long long)ss->max_speed_bits);
+    double timestep;
+    if (maxSpeed != 0) timestep = max_dt < dx / maxSpeed ? max_dt : dx / maxSpeed;
+    else timestep = max_dt;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const double e = 0;
+        double P0 = p.px[i], P1 = p.py[i], P2 = p.pz[i];
+        double V0 = p.vx[i], V1 = p.vy[i], V2 = p.vz[i];
+        const double q0 = P0 + timestep * V0, q1 = P1 + timestep * V1, q2 = P2 + timestep * V2;
+        if (is_solid(g, flags, (int)round(q0), (int)round(q1), (int)round(q2))) {
+            const double vx = V0 * timestep, vy = V1 * timestep, vz = V2 * timestep;
+            // Coord(double,double,double): the two untouched axes truncate toward zero (:1017-1025)
+            if (is_solid(g, flags, (int)round(P0 + vx), (int)P1, (int)P2)) V0 *= -1.0 * e;
+            if (is_solid(g, flags, (int)P0, (int)round(P1 + vy), (int)P2)) V1 *= -1.0 * e;
+            if (is_solid(g, flags, (int)P0, (int)P1, (int)round(P2 + vz))) V2 *= -1.0 * e;
+            P0 += V0 * timestep; P1 += V1 * timestep; P2 += V2 * timestep;
+            p.vx[i] = V0; p.vy[i] = V1; p.vz[i] = V2;
+        } else {
+            P0 = q0; P1 = q1; P2 = q2;
+        }
+        p.px[i] = P0; p.py[i] = P1; p.pz[i] = P2;
+    }
+}
+
+// dt is published by its own 1-thread launch AFTER k_advect so that no block of k_advect can
+// read a max_speed/dt pair from two different steps.
+__global__ void k_publish_dt(double max_dt, double dx, StepState* ss)
+{
+    const double maxSpeed = __longlong_as_double((long long)ss->max_speed_bits);
+    ss->dt = (maxSpeed != 0) ? (max_dt < dx / maxSpeed ? max_dt : dx / maxSpeed) : max_dt;
+}
+
+// ---- host <-> device particle layout -------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(long n, Particles p, double* __restrict__ pos, double* __restrict__ vel)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const size_t o = 3 * (size_t)p.pid[j];
+    pos[o] = p.px[j]; pos[o + 1] = p.py[j]; pos[o + 2] = p.pz[j];
+    vel[o] = p.vx[j]; vel[o + 1] = p.vy[j]; vel[o + 2] = p.vz[j];
+}
+__global__ __launch_bounds__(256) void k_unpack(long n, const double* __restrict__ pos, const double* __restrict__ vel, Particles p)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    p.px[j] = pos[3 * j]; p.py[j] = pos[3 * j + 1]; p.pz[j] = pos[3 * j + 2];
+    if (vel) { p.vx[j] = vel[3 * j]; p.vy[j] = vel[3 * j + 1]; p.vz[j] = vel[3 * j + 2]; }
+    else { p.vx[j] = 0; p.vy[j] = 0; p.vz[j] = 0; }
+    p.pid[j] = (uint32_t)j;
+}
+
+static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
+
+void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, StepState* ss)
+{
+    if (n > 0) hipLaunchKernelGGL(k_bin_count, dim3(nblk(n)), dim3(256), 0, st, g, n, p, key, slot, cell_count, ss);
+}
+void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot, const int* cell_start, int* order)
+{
+    if (n > 0) hipLaunchKernelGGL(k_bin_scatter, dim3(nblk(n)), dim3(256), 0, st, n, key, slot, cell_start, order);
+}
+void launch_bin_fix(hipStream_t st, Grid g, Box box, const int* cell_start, const uint32_t* pid, int* order)
+{
+    hipLaunchKernelGGL(k_bin_fix, dim3(nblk(box.cells())), dim3(256), 0, st, g, box, cell_start, pid, order);
+}
+void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst)
+{
+    if (n > 0) hipLaunchKernelGGL(k_reorder, dim3(nblk(n)), dim3(256), 0, st, n, order, src, dst);
+}
+void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const int* cell_start, const uint8_t* flags, float* container,
+                double* u, double* v, double* w, double* ub, double* vb, double* wb)
+{
+    hipLaunchKernelGGL(k_p2g, dim3(nblk(box.cells())), dim3(256), 0, st, g, box, p, cell_start, flags, container, u, v, w, ub, vb, wb);
+}
+void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss)
+{
+    if (n > 0) hipLaunchKernelGGL(k_g2p, dim3(nblk(n)), dim3(256), 0, st, g, n, p, dcx, dcy, dcz, ss);
+}
+void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss)
+{
+    if (n > 0) hipLaunchKernelGGL(k_advect, dim3(nblk(n)), dim3(256), 0, st, g, n, p, flags, max_dt, dx, ss);
+    hipLaunchKernelGGL(k_publish_dt, dim3(1), dim3(1), 0, st, max_dt, dx, ss);
+}
+void launch_pack_particles(hipStream_t st, long n, Particles p, double* pos_aos, double* vel_aos)
+{
+    if (n > 0) hipLaunchKernelGGL(k_pack, dim3(nblk(n)), dim3(256), 0, st, n, p, pos_aos, vel_aos);
+}
+void launch_unpack_particles(hipStream_t st, long n, const double* pos_aos, const double* vel_aos, Particles p)
+{
+    if (n > 0) hipLaunchKernelGGL(k_unpack, dim3(nblk(n)), dim3(256), 0, st, n, pos_aos, vel_aos, p);
+}
+
+}  // namespace fl

@@ -1,0 +1,168 @@
+/*
+ * fluid_hip.h — C ABI of the MI355X-native PIC/FLIP step (libfluid_hip.so).
+ *
+ * The reference (Aakash1312/Fluid-Simulation) has no plugin/FFI interface: the hot path is
+ * the body of the step loop in main() (fluid.cc:1368-1507).  This header is the boundary a
+ * maintainer would bind instead of that loop body; every entry point names the reference
+ * lines it replaces.  Plain pointers and sizes only; no C++ or torch types; no exceptions
+ * cross the boundary (int status, fluid_last_error() for the text).
+ *
+ * Conventions
+ *   grid      N cells per axis, cell coordinate c in [lo,hi], lo = -(N/2), hi = lo+N-1
+ *             (N=121 -> the reference's -60..60, fluid.cc:1159).  "W" = [lo+2,hi-2]
+ *             (the reference's literal 58, fluid.cc:1264).  Dense layout, z fastest:
+ *             linear = ((x-lo)*N + (y-lo))*N + (z-lo)  — the order of the reference's
+ *             index numbering sweep (fluid.cc:1416-1433).
+ *   particles host side AoS xyz doubles, like std::vector<openvdb::Vec3d> (fluid.cc:806-807).
+ *   ownership device memory belongs to the handle; host buffers belong to the caller.
+ *   threading one handle = one host thread = one HIP stream; calls are sequential.
+ */
+#ifndef FLUID_HIP_H
+#define FLUID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fluid_sim fluid_sim_t;
+
+/* status codes */
+#define FLUID_OK 0
+#define FLUID_ERR_ARG 1      /* bad argument                                   */
+#define FLUID_ERR_HIP 2      /* HIP runtime error (no device, OOM, launch)     */
+#define FLUID_ERR_STATE 3    /* call order (e.g. step before upload_particles) */
+#define FLUID_ERR_SOLVER 4   /* PCG hit the iteration cap / broke down         */
+
+/* field ids for fluid_download_field / fluid_upload_field */
+#define FLUID_FIELD_CONTAINER 0   /* float32 N^3  particle weight density (fluid.cc:1157,1413)        */
+#define FLUID_FIELD_WEIGHTS 1     /* float32 N^3  P2G weights (fluid.cc:809,1108); == container here  */
+#define FLUID_FIELD_VEL 2         /* float64 3*N^3, SoA planes [u|v|w] (Vec3dGrid vels, :1240)        */
+#define FLUID_FIELD_VEL_BEFORE 3  /* float64 3*N^3  velBeforeUpdate (:1455)                           */
+#define FLUID_FIELD_INDICES 4     /* int32   N^3   unknown numbering, -1 elsewhere (:1388,1416-1433)  */
+#define FLUID_FIELD_RHS 5         /* float32 N^3   rhs grid of the last setRHS (:1234,414-479)        */
+#define FLUID_FIELD_DIVER 6       /* float32 N^3   b of the last pass = diver grid (:1231,566-610)    */
+#define FLUID_FIELD_PRESSURE 7    /* float64 N^3   p scattered back to cells (VectorXd p, :1474)      */
+#define FLUID_FIELD_OUTPUT 8      /* float32 N^3   outputGrid written to .vdb (:1434-1448)            */
+#define FLUID_FIELD_SOLID 9       /* uint8   N^3   1 = solid (:1166,1266)                             */
+#define FLUID_FIELD_DIVER2 14     /* float32 N^3   b2, divergence after the update (:1477-1481)       */
+#define FLUID_FIELD_SEARCH 15     /* solver dtype N^3  PCG search vector s (stencil input)            */
+#define FLUID_FIELD_Q 16          /* solver dtype N^3  q = A s (stencil output)                       */
+#define FLUID_FIELD_FLAGS 17      /* uint8   N^3   bit0 solid, bit1 fluid, bits2-4 diag count         */
+
+/* solver precision */
+#define FLUID_PRECISION_FP64 0    /* fp64 PCG vectors (reference arithmetic: Eigen VectorXd)          */
+#define FLUID_PRECISION_FP32 1    /* fp32 PCG vectors (stencil micro-benchmark / experiments only)    */
+
+typedef struct fluid_params {
+    int32_t n;                /* cells per axis                         fluid.cc:1159 (121)      */
+    int32_t device;           /* HIP device ordinal                                             */
+    double dx;                /* cell size                              fluid.cc:1358 (1.0)      */
+    double rho;               /* density                                fluid.cc:1471,1475 (1)   */
+    double gravity[3];        /*                                        fluid.cc:1357 (0,-10,0)  */
+    double max_dt;            /* maxTimeStep of FLIPadvect              fluid.cc:1490 (0.1)      */
+    double outer_tol;         /* do..while(error > 0.1)                 fluid.cc:1484            */
+    double update_frac;       /* velUpdate(dt/10)                       fluid.cc:1475 (0.1)      */
+    double cg_tol;            /* Eigen default epsilon                  IterativeSolverBase.h:283 */
+    int32_t cg_max_iters;     /* 0 = 2*numActive                        IterativeSolverBase.h:362 */
+    int32_t max_outer_passes; /* 0 = unlimited (reference)                                       */
+    int32_t precision;        /* FLUID_PRECISION_*                                               */
+    int32_t reserved;
+} fluid_params_t;
+
+typedef struct fluid_step_stats {
+    double dt_in;             /* dt used by this step's pressure block  fluid.cc:1469-1475       */
+    double dt_out;            /* dt written by FLIPadvect               fluid.cc:992-999         */
+    double error;             /* last ||b-b2||/||b||                    fluid.cc:1483            */
+    double max_speed;         /*                                        fluid.cc:976-991         */
+    double relres;            /* last solve: sqrt(|r|^2/|b|^2)          ConjugateGradient.h:87   */
+    int64_t num_active;       /* numActive                              fluid.cc:1395-1433       */
+    int32_t outer_passes;     /* passes of the do..while                fluid.cc:1457-1484       */
+    int32_t cg_iters;         /* PCG iterations summed over the passes                           */
+    int32_t cg_iters_last;    /* iterations of the last solve                                    */
+    int32_t box_lo[3];        /* active box of this step (index space, inclusive)                */
+    int32_t box_hi[3];
+    int32_t reserved;
+} fluid_step_stats_t;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* Reference defaults (N=121, g=(0,-10,0), dx=1, rho=1, max_dt=0.1, outer_tol=0.1,
+ * update_frac=0.1, cg_tol=2.2e-16, fp64).  fluid.cc:1357-1367. */
+int fluid_default_params(fluid_params_t* p);
+/* Allocates all device fields, sets the default solid shell (solid outside W,
+ * fluid.cc:1256-1266).  Replaces the grid/PointList set-up of fluid.cc:1157-1347. */
+int fluid_create(const fluid_params_t* p, fluid_sim_t** out);
+int fluid_destroy(fluid_sim_t* s);
+/* Text of the last error on the calling thread ("" if none). */
+const char* fluid_last_error(void);
+/* "libfluid_hip <version> gfx950" */
+const char* fluid_version(void);
+
+/* ---- scene ---------------------------------------------------------------------------- */
+/* solid[N^3] uint8, 1 = solid (saccessor.setValue(xyz,1), fluid.cc:1266,1341).  Cells outside
+ * W must be solid (the reference reads pressure(-1) otherwise) -> FLUID_ERR_ARG. */
+int fluid_set_solid(fluid_sim_t* s, const uint8_t* solid);
+/* PointList contents (fluid.cc:806-807,841): n particles, pos/vel = 3n doubles AoS.
+ * vel may be NULL (zeros, like PointList::add). */
+int fluid_upload_particles(fluid_sim_t* s, int64_t n, const double* pos, const double* vel);
+/* Back to the caller in the ORIGINAL upload order. */
+int fluid_download_particles(fluid_sim_t* s, double* pos, double* vel);
+int64_t fluid_num_particles(fluid_sim_t* s);
+/* dt carried between steps (double dt, fluid.cc:1367; written by FLIPadvect :1490). */
+int fluid_set_dt(fluid_sim_t* s, double dt);
+int fluid_get_dt(fluid_sim_t* s, double* dt);
+/* Host-only synthetic input "water_cube_drop" (generalises fluid.cc:1176,1349 +
+ * PointScatter.h:421-429): centred cube of side round(N*41/121) cells, ppc particles per cube
+ * voxel at c - 0.5 + U[0,1)^3 (counter-based RNG).  pos==NULL -> returns the count only.
+ * Needs no GPU. */
+int64_t fluid_scene_water_cube_drop(int32_t n, int32_t ppc, uint64_t seed, double* pos);
+
+/* ---- the step ------------------------------------------------------------------------- */
+/* One iteration of the loop body fluid.cc:1378-1490 (everything except the .vdb write). */
+int fluid_step(fluid_sim_t* s, fluid_step_stats_t* stats);
+
+/* Per-phase entry points (parity tests drive these one by one). */
+int fluid_p2g(fluid_sim_t* s);                 /* fluid.cc:1378,1384 (P2Gtransfer 1106-1148) + 1388-1413 (interpolate 843-882) */
+int fluid_flags_index(fluid_sim_t* s);         /* fluid.cc:1416-1455 index sweep, output copy, velBeforeUpdate */
+int fluid_rhs_div(fluid_sim_t* s, int which);  /* setRHS+setDiver: which=0 -> b (1469-1470), 1 -> b2 (1477-1480) */
+int fluid_solve(fluid_sim_t* s);               /* setA,setA2,compute,solve fluid.cc:1471-1474 (matrix-free PCG) */
+int fluid_vel_update(fluid_sim_t* s);          /* velUpdate(dt/10) fluid.cc:1475 */
+int fluid_pressure_pass(fluid_sim_t* s, double* error); /* one do..while body fluid.cc:1457-1483 */
+int fluid_flip_advect(fluid_sim_t* s);         /* FLIPadvect fluid.cc:1490 (972-1038) */
+/* Stats of the phases run since the last fluid_step / fluid_p2g. */
+int fluid_get_stats(fluid_sim_t* s, fluid_step_stats_t* stats);
+
+/* ---- fields --------------------------------------------------------------------------- */
+/* bytes must equal the field's size (see FLUID_FIELD_*). */
+int fluid_download_field(fluid_sim_t* s, int field, void* dst, size_t bytes);
+/* Upload CONTAINER (then call fluid_flags_index), VEL, VEL_BEFORE, DIVER, PRESSURE, SEARCH. */
+int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes);
+
+/* ---- stencil operator alone (micro-benchmark + parity of the 7-point apply) ------------ */
+/* q = A s with the matrix of fluid.cc:304-412 for the current flags and dt; `reps` launches
+ * timed with HIP events on the handle's stream; avg_ms = mean duration of one launch.
+ * box: 0 = dense sweep over all N^3 cells, 1 = active box only. */
+int fluid_stencil_apply(fluid_sim_t* s, int reps, int box, float* avg_ms);
+
+/* ---- profiling ------------------------------------------------------------------------- */
+/* Kernel classes timed with hipEvent pairs on the handle's stream. */
+#define FLUID_PROF_PCG_SQ 0      /* fused p-update + 7-point apply + dot     */
+#define FLUID_PROF_PCG_XR 1      /* fused x,r update + dots                  */
+#define FLUID_PROF_P2G 2
+#define FLUID_PROF_G2P 3
+#define FLUID_PROF_SORT 4
+#define FLUID_PROF_SOLVE 5       /* whole solve                              */
+#define FLUID_PROF_COUNT 6
+/* every `sample_every`-th launch of each class is bracketed by an event pair (0 = off). */
+int fluid_profile_enable(fluid_sim_t* s, int sample_every);
+/* Resolves pending events; n_launches = launches seen, n_sampled = launches timed,
+ * total_ms = sum over the timed ones, cells = sum of cells swept by the timed ones. */
+int fluid_profile_read(fluid_sim_t* s, int klass, int64_t* n_launches, int64_t* n_sampled, double* total_ms, double* cells);
+int fluid_profile_reset(fluid_sim_t* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUID_HIP_H */
