@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — substeps/s of the PIC/FLIP step (fluid.cc:1378-1490) on MI355X.
+
+One "step" = one fluid_step(): sort + P2G, flags/index, the pressure do..while (RHS/divergence,
+matrix-free PCG, velocity update, error), FLIP gather + advect, on the synthetic
+water_cube_drop scene, particles and fields resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the timed region (the
+fused PCG search-update + 7-point apply, FLUID_PROF_PCG_SQ), measured live with hipEvent pairs on
+the solver's stream; `cpu_baseline` is the oracle (CPU restatement, 1 thread) timed on one step
+from the same state.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6300
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=256, help="cells per axis (BASELINE configs: 128, 256)")
+    ap.add_argument("--ppc", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cg-tol", type=float, default=2.220446049250313e-16, help="PCG relative tolerance (reference: Eigen epsilon)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-micro", action="store_true", help="skip the dense stencil micro-benchmark")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="keep timing oracle steps until this much CPU time is spent")
+    ap.add_argument("--sample-every", type=int, default=8, help="bracket every k-th PCG launch with hipEvents")
+    return ap.parse_args()
+
+
+def stencil_microbench(fs, n, device):
+    """Dense sweep q = A s over all n^3 cells, all-fluid interior (SURVEY.md 8d micro-benchmark)."""
+    out = {}
+    for prec, T in (("fp64", 8), ("fp32", 4)):
+        sim = fs.FluidSim(n=n, precision=prec, device=device)
+        F = fs.FIELD
+        solid = sim.field(F.SOLID)
+        sim.upload_field(F.CONTAINER, (solid == 0).astype(np.float32))
+        sim.flags_index()
+        rng = np.random.default_rng(1)
+        s = rng.uniform(-1, 1, size=(n, n, n)) * (solid == 0)
+        sim.upload_field(F.SEARCH, s)
+        sim.stencil_apply(reps=5, box=0)
+        ms = sim.stencil_apply(reps=50, box=0)
+        algo = n ** 3 * (2 * T + 1)
+        out[prec] = {"ms": ms, "bytes_per_cell": 2 * T + 1, "achieved_GBs": algo / (ms * 1e-3) / 1e9,
+                     "frac_of_peak": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        sim.close()
+    return out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    fs = entry.load_package()
+
+    n, ppc = a.n, a.ppc
+    pos0 = fs.water_cube_drop(n, ppc, seed=a.seed)
+    sim = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol)
+    sim.upload_particles(pos0)
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sim.step()
+    # state at the start of the timed region, for the CPU leg
+    cpu_state = None
+    if rank == 0 and not a.no_cpu:
+        p, v = sim.download_particles()
+        cpu_state = (p, v, sim.dt)
+
+    sim.profile_reset()
+    sim.profile_enable(a.sample_every)
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(a.steps):
+        stats.append(sim.step())   # fluid_step() synchronises its stream before returning
+    barrier()
+    t1 = time.perf_counter()
+    sim.profile_enable(0)
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / a.steps * 1e3
+    # N>1: every rank advances its own replica of the scene (see DESIGN.md "Multi-GPU")
+    value = world * a.steps / elapsed
+
+    T = 8
+    sq = sim.profile_read(fs.PROF.PCG_SQ)
+    xr = sim.profile_read(fs.PROF.PCG_XR)
+    solve = sim.profile_read(fs.PROF.SOLVE)
+    p2g = sim.profile_read(fs.PROF.P2G)
+    g2p = sim.profile_read(fs.PROF.G2P)
+    srt = sim.profile_read(fs.PROF.SORT)
+    roof = None
+    if sq["sampled"]:
+        avg_ms = sq["total_ms"] / sq["sampled"]
+        cells = sq["cells"] / sq["sampled"]
+        algo = cells * (4 * T + 1)
+        ach = algo / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_stencil<double,true> (PCG search update + 7-point apply + dot)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_cell": 4 * T + 1, "cells_per_launch": cells, "avg_launch_us": avg_ms * 1e3,
+                "launches": sq["launches"], "sampled": sq["sampled"]}
+
+    def per(d):
+        return None if not d["sampled"] else d["total_ms"] / d["sampled"]
+
+    out = {
+        "metric": "simulated substeps/sec", "value": value, "unit": "substeps/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"water_cube_drop {n}^3 grid, {ppc} particles/cell, {len(pos0)} particles, pure FLIP",
+                   "grid": n, "ppc": ppc, "particles": int(len(pos0)), "cg_tol": a.cg_tol,
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (one per GPU)"},
+        "roofline": roof,
+        "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),
+                       "cg_iters_total": sum(s["cg_iters"] for s in stats), "relres_last": stats[-1]["relres"],
+                       "box_last": [stats[-1]["box_lo"], stats[-1]["box_hi"]]},
+        "kernel_ms": {"pcg_sq_avg": per(sq), "pcg_xr_avg": per(xr), "solve_avg": per(solve), "p2g_avg": per(p2g),
+                      "g2p_avg": per(g2p), "sort_avg": per(srt)},
+    }
+
+    if not a.no_micro:
+        out["stencil_microbench"] = {"workload": f"dense {n}^3 all-fluid interior, q=A s", **stencil_microbench(fs, n, local_rank)}
+
+    if cpu_state is not None:
+        oracle = entry.load_oracle()
+        orc = oracle.Oracle(n=n)
+        orc.set_cg_tol(a.cg_tol)
+        orc.set_particles(cpu_state[0], cpu_state[1])
+        orc.dt = cpu_state[2]
+        csteps, csec = 0, 0.0
+        while csec < a.cpu_seconds and csteps < a.steps:
+            c0 = time.perf_counter()
+            orc.step()
+            csec += time.perf_counter() - c0
+            csteps += 1
+        out["cpu_baseline"] = {"value": csteps / csec, "unit": "substeps/s", "cores": 1, "kind": "port",
+                               "sample": f"{csteps} oracle step(s) of the same {n}^3 workload from the state at the start of the timed region ({csec:.1f} s)"}
+        # full-size parity readout: GPU vs oracle after the same number of steps from the same state
+        sim2 = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol)
+        sim2.upload_particles(cpu_state[0], cpu_state[1])
+        sim2.dt = cpu_state[2]
+        for _ in range(csteps):
+            sim2.step()
+        pg, vg = sim2.download_particles()
+        po, vo = orc.particles()
+        out["parity_at_size"] = {"steps": csteps, "pos_rel_l2": float(np.linalg.norm(pg - po) / np.linalg.norm(po)),
+                                 "vel_rel_l2": float(np.linalg.norm(vg - vo) / max(np.linalg.norm(vo), 1e-300)),
+                                 "indices_equal": bool(np.array_equal(sim2.field(fs.FIELD.INDICES), orc.field(4)))}
+        sim2.close()
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
