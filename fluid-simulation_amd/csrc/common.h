@@ -37,7 +37,16 @@ struct Box {
 template <typename T>
 struct Coef {
     T diag[7];
+    T inv[7];   // 1/diag, as Eigen's DiagonalPreconditioner stores it (BasicPreconditioners.h:73)
     T off;
+};
+
+// Box-local solver layout: local (i,j,k) <-> global index (x0+i-1, y0+j-1, z0+k-LBOX_K0);
+// interior 1..nx, 1..ny, K0..K0+nz-1; everything else is zero padding (never an unknown).
+constexpr int LBOX_K0 = 16;
+struct LBox {
+    int x0, y0, z0, nx, ny, nz, Lx, Ly, Lz;
+    __host__ __device__ inline size_t cells() const { return (size_t)Lx * Ly * Lz; }
 };
 
 // Scalars of one PCG solve, device resident.
@@ -137,7 +146,7 @@ struct Particles {
 };
 
 // particles
-void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, StepState* ss);
+void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, int* part, StepState* ss);
 void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot, const int* cell_start, int* order);
 void launch_bin_fix(hipStream_t st, Grid g, Box box, const int* cell_start, const uint32_t* pid, int* order);
 void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst);
@@ -162,21 +171,24 @@ void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, cons
 void launch_zero_step_state(hipStream_t st, StepState* ss, int N);
 
 // pcg (kernels_pcg.hip); T = double or float
-int pcg_sq_blocks(Box box);
-int pcg_xr_blocks(Box box);
+LBox make_lbox(const Box& b);
+size_t lbox_max_cells(int N);
+int pcg_sq_blocks(const LBox& L);
+int pcg_xr_blocks(const LBox& L);
+void launch_cnt_local(hipStream_t st, Grid g, LBox L, const uint8_t* flags, uint8_t* cnt);
 template <typename T>
-void launch_pcg_init(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, T* x, T* r, Coef<T> cf, double* part_bb,
+void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, T* x, T* r, Coef<T> cf, double* part_bb,
                      double* part_rz0, PcgState* ps);
 template <typename T>
-void launch_pcg_sq(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
+void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
                    double tol);
 template <typename T>
-void launch_pcg_xr(hipStream_t st, Grid g, Box box, const uint8_t* flags, T* x, T* r, const T* s, const T* q, Coef<T> cf,
-                   const double* part_rz_cur, const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps);
+void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
+                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps);
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf);
 template <typename T>
-void launch_store_pressure(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* x, double* pressure);
+void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure);
 
 }  // namespace fl

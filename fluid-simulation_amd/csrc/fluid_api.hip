@@ -42,9 +42,12 @@ struct fluid_sim {
     float *container = nullptr, *rhs = nullptr, *diver = nullptr, *diver2 = nullptr;
     double *u = nullptr, *v = nullptr, *w = nullptr, *ub = nullptr, *vb = nullptr, *wb = nullptr;
     double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
-    int *indices = nullptr, *scan_sums = nullptr;
+    int *indices = nullptr, *scan_sums = nullptr, *ipart = nullptr;
     // pcg
-    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *Xf = nullptr;
+    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr;  // box-local layout (LBox)
+    uint8_t* cntL = nullptr;
+    LBox L{};
+    size_t lmax = 0;
     double *part_bb = nullptr, *part_rr = nullptr, *part_rz[2] = {nullptr, nullptr}, *part_pq = nullptr, *part_err = nullptr;
     PcgState* ps = nullptr;
     PcgState* h_ps = nullptr;  // pinned
@@ -188,7 +191,7 @@ int fluid_destroy(fluid_sim_t* s)
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
-                    s->dcz, s->pressure, s->indices, s->scan_sums, s->R, s->S[0], s->S[1], s->Q, s->Xf, s->part_bb, s->part_rr,
+                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
@@ -229,9 +232,12 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     A(dalloc(&s->pressure, n));
     A(dalloc(&s->indices, n));
     A(dalloc(&s->scan_sums, (n + 2) / 2048 + 16));
+    A(dalloc(&s->ipart, (size_t)1024 * 8));
     const size_t se = solver_elem(s);
-    A(dalloc((char**)&s->R, n * se)); A(dalloc((char**)&s->S[0], n * se)); A(dalloc((char**)&s->S[1], n * se)); A(dalloc((char**)&s->Q, n * se));
-    if (p->precision == FLUID_PRECISION_FP32) A(dalloc((char**)&s->Xf, n * se));
+    s->lmax = lbox_max_cells(p->n);  // >= n: the arrays double as N^3 scratch for fluid_stencil_apply
+    const size_t ln = s->lmax;
+    A(dalloc((char**)&s->R, ln * se)); A(dalloc((char**)&s->S[0], ln * se)); A(dalloc((char**)&s->S[1], ln * se));
+    A(dalloc((char**)&s->Q, ln * se)); A(dalloc((char**)&s->X, ln * se)); A(dalloc(&s->cntL, ln));
     A(dalloc(&s->part_bb, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rr, (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_rz[0], (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rz[1], (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_pq, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_err, (size_t)2 * MAX_PARTIALS));
@@ -386,7 +392,7 @@ static int phase_sort(fluid_sim* s)
     int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
     launch_zero_step_state(s->st, s->ss, g.N);
     HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 2) * sizeof(int), s->st));
-    launch_bin_count(s->st, g, s->np, s->pa, s->key, s->slot, s->cell_count, s->ss);
+    launch_bin_count(s->st, g, s->np, s->pa, s->key, s->slot, s->cell_count, s->ipart, s->ss);
     launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 1, s->scan_sums, s->cell_start + ncell + 1);
     launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->order);
     HIPCHK(hipGetLastError());
@@ -449,6 +455,15 @@ static int phase_flags(fluid_sim* s)
     int rc = read_ss(s);
     if (rc) return rc;
     s->stats.num_active = s->h_ss->num_active;
+    if (!box_empty(s->Rb)) {
+        // box-local solver layout of this step: diag counts + zeroed search vectors (padding must read 0)
+        s->L = make_lbox(s->Rb);
+        launch_cnt_local(s->st, s->g, s->L, s->flags, s->cntL);
+        const size_t lb = s->L.cells() * solver_elem(s);
+        HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
+        HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
+        HIPCHK(hipGetLastError());
+    }
     s->have_flags = true;
     return FLUID_OK;
 }
@@ -472,9 +487,11 @@ static Coef<T> make_coef(const fluid_sim* s)
     Coef<T> c;
     float acc = 0.0f;
     c.diag[0] = 0;
+    c.inv[0] = 0;
     for (int k = 1; k <= 6; ++k) {
         acc = (float)((double)acc + scale);
         c.diag[k] = (T)acc;
+        c.inv[k] = (T)1 / c.diag[k];
     }
     c.off = (T)(float)(-1 * scale);
     return c;
@@ -484,26 +501,25 @@ template <typename T>
 static int solve_impl(fluid_sim* s)
 {
     const Grid g = s->g;
-    const Box box = s->Rb;
-    T* X = sizeof(T) == 8 ? (T*)s->pressure : (T*)s->Xf;
+    const LBox L = s->L;
+    T* X = (T*)s->X;
     T* R = (T*)s->R;
-    T* S0 = (T*)s->S[0];
-    T* S1 = (T*)s->S[1];
     T* Q = (T*)s->Q;
-    T* Sx[2] = {S0, S1};
+    T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
+    const uint8_t* cnt = s->cntL;
     const Coef<T> cf = make_coef<T>(s);
     const double tol = s->prm.cg_tol;
     long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;  // IterativeSolverBase.h:362
     if (max_it < 1) max_it = 1;
-    const double cells = (double)box.cells();
+    const double cells = (double)L.cells();
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
-    launch_pcg_init<T>(s->st, g, box, s->flags, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
+    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
     // body 0
     int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-    launch_pcg_sq<T>(s->st, g, box, s->flags, R, (const T*)nullptr, Sx[0], Q, cf, s->part_bb, nullptr, nullptr, s->part_pq, s->ps, 1, tol);
+    launch_pcg_sq<T>(s->st, L, cnt, R, (const T*)nullptr, Sx[0], Q, cf, s->part_bb, nullptr, nullptr, s->part_pq, s->ps, 1, tol);
     prof_end(s, FLUID_PROF_PCG_SQ, tok);
     tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-    launch_pcg_xr<T>(s->st, g, box, s->flags, X, R, Sx[0], Q, cf, s->part_rz[0], s->part_pq, s->part_rr, s->part_rz[1], s->ps);
+    launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[0], Q, cf, s->part_rz[0], s->part_pq, s->part_rr, s->part_rz[1], s->ps);
     prof_end(s, FLUID_PROF_PCG_XR, tok);
     long it = 1;
     const int CHECK = 16;
@@ -512,11 +528,10 @@ static int solve_impl(fluid_sim* s)
         for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
             tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-            launch_pcg_sq<T>(s->st, g, box, s->flags, R, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[cur], s->part_rz[prv], s->part_pq,
-                             s->ps, 0, tol);
+            launch_pcg_sq<T>(s->st, L, cnt, R, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[cur], s->part_rz[prv], s->part_pq, s->ps, 0, tol);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            launch_pcg_xr<T>(s->st, g, box, s->flags, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_rz[prv], s->ps);
+            launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_rz[prv], s->ps);
             prof_end(s, FLUID_PROF_PCG_XR, tok);
         }
         HIPCHK(hipGetLastError());
@@ -525,12 +540,13 @@ static int solve_impl(fluid_sim* s)
         done = s->h_ps->done || it >= max_it;
     }
     int iters = s->h_ps->iters;
-    double rr = s->h_ps->rr;
+    const double rr = s->h_ps->rr;
     if (!s->h_ps->done) {
         // cap reached without the break: Eigen leaves the loop with i == maxIters (ConjugateGradient.h:66)
         iters = (int)max_it;
     }
-    if (sizeof(T) == 4) launch_store_pressure<T>(s->st, g, box, s->flags, X, s->pressure);
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
     s->stats.cg_iters += iters;

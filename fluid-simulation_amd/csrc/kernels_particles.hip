@@ -13,24 +13,28 @@ namespace fl {
 // NCELL for a particle whose base cell is off the grid (it can reach no cell:
 // its clamped support lies in the solid shell, fluid.cc:271-276,288).
 __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, int* __restrict__ key, int* __restrict__ slot,
-                                                   int* __restrict__ cell_count, StepState* ss)
+                                                   int* __restrict__ cell_count, int* __restrict__ part)
 {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // per-block bbox partials (no same-address atomics: 80k waves hammering 6 words cost 5.6 ms)
+    __shared__ int sm[4][7];
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
     int nout = 0;
-    if (i < n) {
+    const long ncell = (long)g.N * g.N * g.N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         int bx = (int)round(p.px[i]) - g.lo, by = (int)round(p.py[i]) - g.lo, bz = (int)round(p.pz[i]) - g.lo;
         bool in = bx >= 0 && bx < g.N && by >= 0 && by < g.N && bz >= 0 && bz < g.N;
-        long ncell = (long)g.N * g.N * g.N;
         int k = in ? (int)g.idx(bx, by, bz) : (int)ncell;
         key[i] = k;
         slot[i] = atomicAdd(&cell_count[k], 1);
         if (in) {
-            mn[0] = mx[0] = bx; mn[1] = mx[1] = by; mn[2] = mx[2] = bz;
+            mn[0] = bx < mn[0] ? bx : mn[0]; mx[0] = bx > mx[0] ? bx : mx[0];
+            mn[1] = by < mn[1] ? by : mn[1]; mx[1] = by > mx[1] ? by : mx[1];
+            mn[2] = bz < mn[2] ? bz : mn[2]; mx[2] = bz > mx[2] ? bz : mx[2];
         } else {
-            nout = 1;
+            nout++;
         }
     }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         int lo = mn[a], hi = mx[a];
@@ -40,15 +44,62 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
             lo = l2 < lo ? l2 : lo;
             hi = h2 > hi ? h2 : hi;
         }
-        if ((threadIdx.x & 63) == 0) {
-            if (hi >= 0) {
-                atomicMin(&ss->bbox_min[a], lo);
-                atomicMax(&ss->bbox_max[a], hi);
-            }
-        }
+        if (lane == 0) { sm[w][a] = lo; sm[w][3 + a] = hi; }
     }
     nout = wave_sum(nout);
-    if ((threadIdx.x & 63) == 0 && nout) atomicAdd(&ss->n_out, nout);
+    if (lane == 0) sm[w][6] = nout;
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int a = threadIdx.x;
+        int v = sm[0][a];
+        for (int k = 1; k < 4; ++k) {
+            int t = sm[k][a];
+            v = a < 3 ? (t < v ? t : v) : (a < 6 ? (t > v ? t : v) : v + t);
+        }
+        part[blockIdx.x * 8 + a] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_bbox(const int* __restrict__ part, int nb, StepState* ss)
+{
+    __shared__ int sm[4][7];
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1}, nout = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int l = part[b * 8 + a], h = part[b * 8 + 3 + a];
+            mn[a] = l < mn[a] ? l : mn[a];
+            mx[a] = h > mx[a] ? h : mx[a];
+        }
+        nout += part[b * 8 + 6];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane == 0) { sm[w][a] = lo; sm[w][3 + a] = hi; }
+    }
+    nout = wave_sum(nout);
+    if (lane == 0) sm[w][6] = nout;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; ++a) {
+            int lo = sm[0][a], hi = sm[0][3 + a];
+            for (int k = 1; k < 4; ++k) {
+                lo = sm[k][a] < lo ? sm[k][a] : lo;
+                hi = sm[k][3 + a] > hi ? sm[k][3 + a] : hi;
+            }
+            ss->bbox_min[a] = lo;
+            ss->bbox_max[a] = hi;
+        }
+        ss->n_out = sm[0][6] + sm[1][6] + sm[2][6] + sm[3][6];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bin_scatter(long n, const int* __restrict__ key, const int* __restrict__ slot,
@@ -256,9 +307,13 @@ __global__ __launch_bounds__(256) void k_unpack(long n, const double* __restrict
 
 static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 
-void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, StepState* ss)
+void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, int* part, StepState* ss)
 {
-    if (n > 0) hipLaunchKernelGGL(k_bin_count, dim3(nblk(n)), dim3(256), 0, st, g, n, p, key, slot, cell_count, ss);
+    if (n <= 0) return;
+    unsigned nb = nblk(n);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, g, n, p, key, slot, cell_count, part);
+    hipLaunchKernelGGL(k_bin_bbox, dim3(1), dim3(256), 0, st, (const int*)part, (int)nb, ss);
 }
 void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot, const int* cell_start, int* order)
 {

@@ -3,30 +3,40 @@
 // SparseMatrix + IncompleteCholesky PCG (fluid.cc:1352,1473-1474) becomes a PCG whose SpMV is
 // an LDS-tiled 7-point stencil.  Loop structure and stopping rule follow
 // Eigen/src/IterativeLinearSolvers/ConjugateGradient.h:28-90 with the diagonal (Jacobi)
-// preconditioner; two launches per iteration, all scalars stay on the device:
+// preconditioner (BasicPreconditioners.h:73,91: multiply by the stored reciprocal diagonal);
+// two launches per iteration, all scalars stay on the device:
 //
-//   SQ: [beta from the previous launch's partial sums]  s' = r/diag + beta s ;  q = A s' ;
+//   SQ: [beta from the previous launch's partial sums]  s' = invdiag r + beta s ;  q = A s' ;
 //       partial s'.q                                           (4T+1 bytes per cell)
-//   XR: [alpha = r.z / s.q]  x += alpha s ; r -= alpha q ; partial r.r, r.(r/diag)
+//   XR: [alpha = r.z / s.q]  x += alpha s ; r -= alpha q ; partial r.r, r.(invdiag r)
 //                                                               (6T+1 bytes per cell)
 //
 // Every block of a launch re-sums the previous launch's per-block partials in a fixed order
-// (<= 2048 doubles from L2) instead of a grid-wide atomic or an extra reduction launch, so all
+// (<= 1024 doubles from L2) instead of a grid-wide atomic or an extra reduction launch, so all
 // blocks take the same branch and results are run-to-run reproducible.
 //
-// Bandwidth-bound integer/fp work: no MFMA.  Tile = 4 x 4 x 64 cells (x,y,z; z fastest ->
-// one 64-lane wave per 512-byte row), halo staged in LDS, x/y/z neighbours read from LDS.
+// The solver works on a BOX-LOCAL copy of the unknowns: the active box of the step (particle
+// bounding box + 1) is laid out densely with a zero ring and padded, 128-byte aligned z rows,
+// so tiles need no bounds checks, XR is a flat 16-byte-vector stream, and the working set of
+// the drop scene (~1M cells) stays in L2/Infinity Cache.
+//
+// Bandwidth/latency-bound fp64 work: no MFMA.
 #include "common.h"
 
 namespace fl {
 
-constexpr int TX = 4, TY = 4, TZ = 64;
-constexpr int LY = TY + 2, LZ = TZ + 2;
-constexpr int LDS_CELLS = (TX + 2) * LY * LZ;
-constexpr int SQ_MAX_BLOCKS = 2048;
-constexpr int XR_MAX_BLOCKS = 1024;
-
-__device__ __forceinline__ bool active(uint8_t f) { return (f & F_FLUID) && (f >> F_CNT_SHIFT); }
+// static indices only: a runtime index into a by-value kernel argument would go through scratch
+template <typename T>
+__device__ __forceinline__ void load_coef(T* sdiag, T* sinv, const Coef<T>& cf)
+{
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            sdiag[i] = cf.diag[i];
+            sinv[i] = cf.inv[i];
+        }
+    }
+}
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD (b % 8) a contiguous range of
 // virtual block ids so that neighbouring tiles share one L2 (speed only, never correctness).
@@ -36,15 +46,361 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-// static indices only: a runtime index into a by-value kernel argument would go through scratch
-template <typename T>
-__device__ __forceinline__ void load_diag(T* sdiag, const Coef<T>& cf)
+// ================================================================================================
+// Box-local PCG
+// ================================================================================================
+constexpr int TX = 4, TY = 8, TZ = 32;       // tile of the SQ kernel (x,y,z), 256 threads
+constexpr int PY = TY + 2, PZ = TZ + 2;      // LDS plane with y/z halo
+constexpr int SQ_MAX_BLOCKS = 1024;
+constexpr int XR_MAX_BLOCKS = 512;
+
+LBox make_lbox(const Box& b)
 {
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) sdiag[i] = cf.diag[i];
-    }
+    LBox L;
+    L.x0 = b.x0; L.y0 = b.y0; L.z0 = b.z0;
+    L.nx = b.nx(); L.ny = b.ny(); L.nz = b.nz();
+    L.Lx = (L.nx + TX - 1) / TX * TX + 2;
+    L.Ly = (L.ny + TY - 1) / TY * TY + 2;
+    L.Lz = LBOX_K0 + (L.nz + TZ - 1) / TZ * TZ + 16;
+    return L;
 }
+size_t lbox_max_cells(int N)
+{
+    Box b{0, 0, 0, N - 1, N - 1, N - 1};
+    return make_lbox(b).cells();
+}
+static inline int sq_tiles(const LBox& L) { return ((L.nx + TX - 1) / TX) * ((L.ny + TY - 1) / TY) * ((L.nz + TZ - 1) / TZ); }
+int pcg_sq_blocks(const LBox& L)
+{
+    int n = sq_tiles(L);
+    return n < SQ_MAX_BLOCKS ? (n < 1 ? 1 : n) : SQ_MAX_BLOCKS;
+}
+int pcg_xr_blocks(const LBox& L)
+{
+    long n = ((long)L.cells() / 2 + 256 * 4 - 1) / (256 * 4);
+    return (int)(n < XR_MAX_BLOCKS ? (n < 1 ? 1 : n) : XR_MAX_BLOCKS);
+}
+
+// local cell -> diag count (0 = not an unknown).  One launch per step.
+__global__ __launch_bounds__(256) void k_cnt_local(Grid g, LBox L, const uint8_t* __restrict__ flags, uint8_t* __restrict__ cnt)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)L.cells()) return;
+    const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
+    uint8_t c = 0;
+    if (i >= 1 && i <= L.nx && j >= 1 && j <= L.ny && k >= LBOX_K0 && k < LBOX_K0 + L.nz) {
+        const uint8_t f = flags[g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0)];
+        if (f & F_FLUID) c = f >> F_CNT_SHIFT;  // Adiag == 0 rows are not unknowns (fluid.cc:498)
+    }
+    cnt[t] = c;
+}
+
+// Sum three partial arrays in one pass; results broadcast to all threads.  sm: 12 doubles.
+__device__ __forceinline__ void block_sum3(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
+                                           const double* __restrict__ c, int nc, double* sm, double& ra, double& rb, double& rc)
+{
+    double va = 0, vb = 0, vc = 0;
+    for (int i = threadIdx.x; i < na; i += 256) va += a[i];
+    for (int i = threadIdx.x; i < nb; i += 256) vb += b[i];
+    for (int i = threadIdx.x; i < nc; i += 256) vc += c[i];
+    va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[w] = va; sm[4 + w] = vb; sm[8 + w] = vc; }
+    __syncthreads();
+    ra = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    rb = ((sm[4] + sm[5]) + sm[6]) + sm[7];
+    rc = ((sm[8] + sm[9]) + sm[10]) + sm[11];
+}
+
+// x = 0, r = b (ConjugateGradient.h:41), partial |b|^2 and r.(invdiag r) (:62-65)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const float* __restrict__ b,
+                                                    T* __restrict__ x, T* __restrict__ r, Coef<T> cf, double* __restrict__ part_bb,
+                                                    double* __restrict__ part_rz0, PcgState* ps)
+{
+    __shared__ double red[4];
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ps->done = 0; ps->iters = 0; ps->breakdown = 0; ps->bb = 0; ps->thr = 0; ps->rr = 0; }
+    const long n = (long)L.cells();
+    double abb = 0, arz = 0;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+        const uint8_t c = cnt[t];
+        T rv = 0;
+        if (c) {
+            const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
+            rv = (T)b[g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0)];
+            const T z = rv * sinv[c];
+            abb += (double)rv * (double)rv;
+            arz += (double)rv * (double)z;
+        }
+        x[t] = 0;
+        r[t] = rv;
+    }
+    abb = block_sum<double, 4>(abb, red);
+    arz = block_sum<double, 4>(arz, red);
+    if (threadIdx.x == 0) { part_bb[blockIdx.x] = abb; part_rz0[blockIdx.x] = arz; }
+}
+
+// SQ: s' = invdiag r + beta s ; q = A s' ; partial s'.q
+// Thread (ly = tid>>5, kz = tid&31) owns the x-column lx = -1..TX of its (y,z): the x
+// neighbours stay in registers, y/z neighbours go through LDS.  All global loads of the tile
+// are issued BEFORE the partial-sum reduction that yields beta, so both latencies overlap.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
+                                                  const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
+                                                  const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
+                                                  const double* __restrict__ part_rz_old, double* __restrict__ part_pq, int n_prev,
+                                                  PcgState* ps, int first, double tol)
+{
+    __shared__ T sT[TX * PY * PZ];
+    __shared__ double red[16];
+    __shared__ int s_done;
+    __shared__ T sdiag[8], sinv[8];
+    const int tid = threadIdx.x;
+    load_coef(sdiag, sinv, cf);
+    // one read per block, broadcast: block 0 of THIS launch may set done while we start
+    if (tid == 0) s_done = ps->done;
+
+    const int nty = (L.ny + TY - 1) / TY, ntz = (L.nz + TZ - 1) / TZ;
+    const int ntiles = ((L.nx + TX - 1) / TX) * nty * ntz;
+    const long sx = (long)L.Ly * L.Lz;
+    const int ly = tid >> 5, kz = tid & 31;
+
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // ---- issue the first tile's loads -------------------------------------------------------
+    uint8_t fc[TX + 2], fy = 0, fz = 0;
+    T rv[TX + 2], sv[TX + 2], ry = 0, sy = 0, rz = 0, sz = 0;
+    long c0 = 0;
+    auto issue = [&](int tl) {
+        const int tz = tl % ntz, ty = (tl / ntz) % nty, tx = tl / (ntz * nty);
+        const int i0 = 1 + tx * TX, j0 = 1 + ty * TY, k0 = LBOX_K0 + tz * TZ;
+        c0 = ((long)(i0 - 1) * L.Ly + (j0 + ly)) * L.Lz + k0 + kz;
+#pragma unroll
+        for (int m = 0; m < TX + 2; ++m) {
+            fc[m] = cnt[c0 + m * sx];
+            rv[m] = r[c0 + m * sx];
+            sv[m] = first ? (T)0 : s_in[c0 + m * sx];
+        }
+        {   // y halo: one cell per thread
+            const int pl = tid >> 6, side = (tid >> 5) & 1;
+            const long cy = ((long)(i0 + pl) * L.Ly + (side ? j0 + TY : j0 - 1)) * L.Lz + k0 + kz;
+            fy = cnt[cy]; ry = r[cy]; sy = first ? (T)0 : s_in[cy];
+        }
+        if (tid < 64) {  // z halo: 64 cells
+            const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
+            const long cz = ((long)(i0 + lx) * L.Ly + (j0 + l2)) * L.Lz + (side ? k0 + TZ : k0 - 1);
+            fz = cnt[cz]; rz = r[cz]; sz = first ? (T)0 : s_in[cz];
+        }
+    };
+    if (tile < ntiles) issue(tile);
+
+    // ---- scalars ------------------------------------------------------------------------------
+    T beta = 0;
+    __syncthreads();  // s_done, coef tables
+    if (s_done) return;
+    if (first) {
+        // ConjugateGradient.h:45-60: b == 0 -> x = 0, done.
+        double bb, d1, d2;
+        block_sum3(part_rr, n_prev, part_rr, 0, part_rr, 0, red, bb, d1, d2);
+        if (blockIdx.x == 0 && tid == 0) {
+            ps->bb = bb;
+            ps->thr = tol * tol * bb;
+            ps->rr = bb;
+            if (!(bb > 0)) ps->done = 1;
+        }
+        if (!(bb > 0)) return;
+    } else {
+        double rr, rzn, rzo;
+        block_sum3(part_rr, n_prev, part_rz_new, n_prev, part_rz_old, n_prev, red, rr, rzn, rzo);
+        if (rr < ps->thr) {  // ConjugateGradient.h:75-77: break before i++
+            if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->done = 1; }
+            return;
+        }
+        beta = (T)(rzn / rzo);  // :82-83
+        if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->iters += 1; }  // :85
+    }
+
+    double acc = 0;
+    while (tile < ntiles) {
+        // ---- combine -> LDS ---------------------------------------------------------------------
+        T val[TX + 2];
+#pragma unroll
+        for (int m = 0; m < TX + 2; ++m) val[m] = fc[m] ? rv[m] * sinv[fc[m]] + beta * sv[m] : (T)0;
+#pragma unroll
+        for (int lx = 0; lx < TX; ++lx) sT[(lx * PY + ly + 1) * PZ + kz + 1] = val[lx + 1];
+        {
+            const int pl = tid >> 6, side = (tid >> 5) & 1;
+            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = fy ? ry * sinv[fy] + beta * sy : (T)0;
+        }
+        if (tid < 64) {
+            const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
+            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = fz ? rz * sinv[fz] + beta * sz : (T)0;
+        }
+        __syncthreads();
+        const long cc = c0;
+        uint8_t fcc[TX];
+        T nbv[TX], cen[TX];
+#pragma unroll
+        for (int lx = 0; lx < TX; ++lx) {
+            const int o = (lx * PY + ly + 1) * PZ + kz + 1;
+            fcc[lx] = fc[lx + 1];
+            cen[lx] = val[lx + 1];
+            nbv[lx] = val[lx] + val[lx + 2] + sT[o - PZ] + sT[o + PZ] + sT[o - 1] + sT[o + 1];
+        }
+        const int next = tile + gridDim.x;
+        __syncthreads();  // LDS free for the next tile
+        if (next < ntiles) issue(next);  // next tile's loads fly while this tile finishes
+#pragma unroll
+        for (int lx = 0; lx < TX; ++lx) {
+            const long c = cc + (lx + 1) * sx;
+            T qv = 0;
+            if (fcc[lx]) {
+                qv = sdiag[fcc[lx]] * cen[lx] + cf.off * nbv[lx];
+                acc += (double)cen[lx] * (double)qv;
+            }
+            s_out[c] = cen[lx];
+            q[c] = qv;
+        }
+        tile = next;
+    }
+    acc = block_sum<double, 4>(acc, red);
+    if (tid == 0) part_pq[blockIdx.x] = acc;
+}
+
+// XR: alpha, x += alpha s, r -= alpha q, partial |r|^2 and r.(invdiag r)   (ConjugateGradient.h:70-74,79-81)
+// Flat stream over the local box, two cells (16 bytes) per lane per access, 4 accesses in flight.
+template <typename T>
+struct alignas(2 * sizeof(T)) Vec2 {
+    T a, b;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r,
+                                                  const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
+                                                  const double* __restrict__ part_rz_cur, int n_xr, const double* __restrict__ part_pq,
+                                                  int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps)
+{
+    __shared__ double red[16];
+    __shared__ int s_done;
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    if (threadIdx.x == 0) s_done = ps->done;
+    typedef Vec2<T> V2;
+    const V2* x2 = (const V2*)x;
+    const V2* r2 = (const V2*)r;
+    const V2* s2 = (const V2*)s;
+    const V2* q2 = (const V2*)q;
+    const uint16_t* c2 = (const uint16_t*)cnt;
+    const long nth = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    constexpr int U = 4;
+    V2 xv[U], rv[U], sv[U], qv[U];
+    uint16_t cv[U];
+    auto issue = [&](long base) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long e = base + u * nth;
+            if (e < n2) { cv[u] = c2[e]; xv[u] = x2[e]; rv[u] = r2[e]; sv[u] = s2[e]; qv[u] = q2[e]; }
+            else cv[u] = 0;
+        }
+    };
+    issue(i);
+    __syncthreads();
+    if (s_done) return;
+    double rz, pq, d3;
+    block_sum3(part_rz_cur, n_xr, part_pq, n_sq, part_pq, 0, red, rz, pq, d3);
+    if (!(pq > 0) || !(rz == rz)) {  // not SPD / NaN: stop instead of spreading NaNs
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ps->breakdown = 1; ps->done = 1; }
+        return;
+    }
+    const T alpha = (T)(rz / pq);
+    double arr = 0, arz = 0;
+    for (; i < n2; i += U * nth) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long e = i + u * nth;
+            if (cv[u]) {
+                const int ca = cv[u] & 0xff, cb = cv[u] >> 8;
+                V2 xo = xv[u], ro = rv[u];
+                if (ca) {
+                    xo.a = xo.a + alpha * sv[u].a;
+                    ro.a = ro.a - alpha * qv[u].a;
+                    const T z = ro.a * sinv[ca];
+                    arr += (double)ro.a * (double)ro.a;
+                    arz += (double)ro.a * (double)z;
+                }
+                if (cb) {
+                    xo.b = xo.b + alpha * sv[u].b;
+                    ro.b = ro.b - alpha * qv[u].b;
+                    const T z = ro.b * sinv[cb];
+                    arr += (double)ro.b * (double)ro.b;
+                    arz += (double)ro.b * (double)z;
+                }
+                ((V2*)x)[e] = xo;
+                ((V2*)r)[e] = ro;
+            }
+        }
+        if (i + U * nth < n2) issue(i + U * nth);
+    }
+    arr = block_sum<double, 4>(arr, red);
+    arz = block_sum<double, 4>(arz, red);
+    if (threadIdx.x == 0) { part_rr[blockIdx.x] = arr; part_rz_next[blockIdx.x] = arz; }
+}
+
+// local x -> global pressure field (VectorXd p scattered back to cells, fluid.cc:637)
+template <typename T>
+__global__ __launch_bounds__(256) void k_store_pressure_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ x,
+                                                          double* __restrict__ pressure)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)L.cells()) return;
+    const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
+    if (i >= 1 && i <= L.nx && j >= 1 && j <= L.ny && k >= LBOX_K0 && k < LBOX_K0 + L.nz)
+        pressure[g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0)] = cnt[t] ? (double)x[t] : 0.0;
+}
+
+void launch_cnt_local(hipStream_t st, Grid g, LBox L, const uint8_t* flags, uint8_t* cnt)
+{
+    hipLaunchKernelGGL(k_cnt_local, dim3((unsigned)((L.cells() + 255) / 256)), dim3(256), 0, st, g, L, flags, cnt);
+}
+template <typename T>
+void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, T* x, T* r, Coef<T> cf, double* part_bb,
+                     double* part_rz0, PcgState* ps)
+{
+    hipLaunchKernelGGL((k_pcg_init_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, x, r, cf, part_bb, part_rz0, ps);
+}
+template <typename T>
+void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
+                   const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
+                   double tol)
+{
+    hipLaunchKernelGGL((k_pcg_sq_l<T>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr, part_rz_new,
+                       part_rz_old, part_pq, pcg_xr_blocks(L), ps, first, tol);
+}
+template <typename T>
+void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
+                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps)
+{
+    hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
+                       pcg_xr_blocks(L), part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps);
+}
+template <typename T>
+void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure)
+{
+    hipLaunchKernelGGL((k_store_pressure_l<T>), dim3((unsigned)((L.cells() + 255) / 256)), dim3(256), 0, st, g, L, cnt, x, pressure);
+}
+
+// ================================================================================================
+// q = A s on the GLOBAL dense layout (fluid_stencil_apply: operator parity + dense micro-benchmark)
+// Tile = 4 x 4 x 64 cells, one 64-lane wave per 512-byte row, halo staged in LDS.
+// ================================================================================================
+constexpr int GX = 4, GY = 4, GZ = 64;
+constexpr int GLY = GY + 2, GLZ = GZ + 2;
+constexpr int G_MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ bool active(uint8_t f) { return (f & F_FLUID) && (f >> F_CNT_SHIFT); }
 
 struct Tiles {
     int ntx, nty, ntz;
@@ -53,69 +409,34 @@ struct Tiles {
 static inline Tiles make_tiles(const Box& b)
 {
     Tiles t;
-    t.ntx = (b.nx() + TX - 1) / TX;
-    t.nty = (b.ny() + TY - 1) / TY;
-    t.ntz = (b.nz() + TZ - 1) / TZ;
+    t.ntx = (b.nx() + GX - 1) / GX;
+    t.nty = (b.ny() + GY - 1) / GY;
+    t.ntz = (b.nz() + GZ - 1) / GZ;
     return t;
 }
 
-// FUSED = true : the SQ kernel of the PCG.   FUSED = false : q = A s only (s read from s_in).
-template <typename T, bool FUSED>
-__global__ __launch_bounds__(256) void k_stencil(Grid g, Box box, Tiles tl, const uint8_t* __restrict__ flags, const T* __restrict__ r,
-                                                 const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
-                                                 const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
-                                                 const double* __restrict__ part_rz_old, double* __restrict__ part_pq, int n_prev,
-                                                 PcgState* ps, int first, double tol)
+template <typename T>
+__global__ __launch_bounds__(256) void k_stencil_g(Grid g, Box box, Tiles tl, const uint8_t* __restrict__ flags, const T* __restrict__ s_in,
+                                                   T* __restrict__ q, Coef<T> cf)
 {
-    __shared__ T sT[LDS_CELLS];
-    __shared__ double red[8];
-    __shared__ int s_done;
-    __shared__ T sdiag[8];  // dynamic index by diag count: LDS, not a kernarg select chain
+    __shared__ T sT[(GX + 2) * GLY * GLZ];
+    __shared__ T sdiag[8], sinv[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    load_diag(sdiag, cf);
-    T beta = 0;
-    if (FUSED) {
-        // one read per block, broadcast: block 0 of THIS launch may set done while we start
-        if (tid == 0) s_done = ps->done;
-        __syncthreads();
-        if (s_done) return;
-        if (first) {
-            // ConjugateGradient.h:45-60: b == 0 -> x = 0, done.
-            const double bb = block_sum_array<4>(part_rr, n_prev, red);
-            if (blockIdx.x == 0 && tid == 0) {
-                ps->bb = bb;
-                ps->thr = tol * tol * bb;
-                ps->rr = bb;
-                if (!(bb > 0)) ps->done = 1;
-            }
-            if (!(bb > 0)) return;
-        } else {
-            const double rr = block_sum_array<4>(part_rr, n_prev, red);
-            if (rr < ps->thr) {  // ConjugateGradient.h:75-77: break before i++
-                if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->done = 1; }
-                return;
-            }
-            const double rzn = block_sum_array<4>(part_rz_new, n_prev, red);
-            const double rzo = block_sum_array<4>(part_rz_old, n_prev, red);
-            beta = (T)(rzn / rzo);  // :82-83
-            if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->iters += 1; }  // :85
-        }
-    }
+    load_coef(sdiag, sinv, cf);
     const int N = g.N;
     const long sxl = (long)N * N;
-    double acc = 0;
     const int ntiles = tl.count();
     for (int tile = xcd_remap(blockIdx.x, gridDim.x); tile < ntiles; tile += gridDim.x) {
         const int tz = tile % tl.ntz, ty = (tile / tl.ntz) % tl.nty, tx = tile / (tl.ntz * tl.nty);
-        const int x0 = box.x0 + tx * TX, y0 = box.y0 + ty * TY, z0 = box.z0 + tz * TZ;
+        const int x0 = box.x0 + tx * GX, y0 = box.y0 + ty * GY, z0 = box.z0 + tz * GZ;
         __syncthreads();  // LDS reuse across tiles
         T sc[4];
         uint8_t fc[4];
         unsigned inb = 0;
-        // interior rows: wave wv owns rows wv, wv+4, wv+8, wv+12 (row = lx*TY + ly)
+        // interior rows: wave wv owns rows wv, wv+4, wv+8, wv+12 (row = lx*GY + ly)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int row = wv + 4 * k, lx = row / TY, ly = row % TY;
+            const int row = wv + 4 * k, lx = row / GY, ly = row % GY;
             const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lane;
             const bool in = gx <= box.x1 && gy <= box.y1 && gz <= box.z1;
             T val = 0;
@@ -123,228 +444,75 @@ __global__ __launch_bounds__(256) void k_stencil(Grid g, Box box, Tiles tl, cons
             if (in) {
                 const size_t c = (size_t)gx * sxl + (size_t)gy * N + gz;
                 f = flags[c];
-                if (active(f)) {
-                    if (FUSED) {
-                        val = r[c] / sdiag[f >> F_CNT_SHIFT];
-                        if (!first) val = val + beta * s_in[c];
-                    } else {
-                        val = s_in[c];
-                    }
-                }
-                if (FUSED) s_out[c] = val;
+                if (active(f)) val = s_in[c];
                 inb |= 1u << k;
             }
             sc[k] = val;
             fc[k] = f;
-            sT[((lx + 1) * LY + (ly + 1)) * LZ + lane + 1] = val;
+            sT[((lx + 1) * GLY + (ly + 1)) * GLZ + lane + 1] = val;
         }
         // x/y face halo rows: 16 rows, 4 per wave
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int h = wv * 4 + k, face = h >> 2, j = h & 3;
-            const int lx = face == 0 ? -1 : (face == 1 ? TX : j);
-            const int ly = face == 2 ? -1 : (face == 3 ? TY : j);
+            const int lx = face == 0 ? -1 : (face == 1 ? GX : j);
+            const int ly = face == 2 ? -1 : (face == 3 ? GY : j);
             const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lane;
             T val = 0;
             if (gx >= 0 && gx < N && gy >= 0 && gy < N && gz < N) {
                 const size_t c = (size_t)gx * sxl + (size_t)gy * N + gz;
-                const uint8_t f = flags[c];
-                if (active(f)) {
-                    if (FUSED) {
-                        val = r[c] / sdiag[f >> F_CNT_SHIFT];
-                        if (!first) val = val + beta * s_in[c];
-                    } else {
-                        val = s_in[c];
-                    }
-                }
+                if (active(flags[c])) val = s_in[c];
             }
-            sT[((lx + 1) * LY + (ly + 1)) * LZ + lane + 1] = val;
+            sT[((lx + 1) * GLY + (ly + 1)) * GLZ + lane + 1] = val;
         }
         // z halo of the 16 interior rows: 32 cells
         if (tid < 32) {
-            const int row = tid >> 1, side = tid & 1, lx = row / TY, ly = row % TY;
-            const int gx = x0 + lx, gy = y0 + ly, gz = side ? z0 + TZ : z0 - 1;
+            const int row = tid >> 1, side = tid & 1, lx = row / GY, ly = row % GY;
+            const int gx = x0 + lx, gy = y0 + ly, gz = side ? z0 + GZ : z0 - 1;
             T val = 0;
             if (gx < N && gy < N && gz >= 0 && gz < N) {
                 const size_t c = (size_t)gx * sxl + (size_t)gy * N + gz;
-                const uint8_t f = flags[c];
-                if (active(f)) {
-                    if (FUSED) {
-                        val = r[c] / sdiag[f >> F_CNT_SHIFT];
-                        if (!first) val = val + beta * s_in[c];
-                    } else {
-                        val = s_in[c];
-                    }
-                }
+                if (active(flags[c])) val = s_in[c];
             }
-            sT[((lx + 1) * LY + (ly + 1)) * LZ + (side ? TZ + 1 : 0)] = val;
+            sT[((lx + 1) * GLY + (ly + 1)) * GLZ + (side ? GZ + 1 : 0)] = val;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (inb & (1u << k)) {
-                const int row = wv + 4 * k, lx = row / TY, ly = row % TY;
+                const int row = wv + 4 * k, lx = row / GY, ly = row % GY;
                 const size_t c = (size_t)(x0 + lx) * sxl + (size_t)(y0 + ly) * N + (z0 + lane);
                 T qv = 0;
                 if (active(fc[k])) {
-                    const int o = ((lx + 1) * LY + (ly + 1)) * LZ + lane + 1;
-                    const T nb = sT[o - LY * LZ] + sT[o + LY * LZ] + sT[o - LZ] + sT[o + LZ] + sT[o - 1] + sT[o + 1];
+                    const int o = ((lx + 1) * GLY + (ly + 1)) * GLZ + lane + 1;
+                    const T nb = sT[o - GLY * GLZ] + sT[o + GLY * GLZ] + sT[o - GLZ] + sT[o + GLZ] + sT[o - 1] + sT[o + 1];
                     qv = sdiag[fc[k] >> F_CNT_SHIFT] * sc[k] + cf.off * nb;
-                    acc += (double)sc[k] * (double)qv;
                 }
                 q[c] = qv;
             }
         }
     }
-    if (FUSED) {
-        acc = block_sum<double, 4>(acc, red);
-        if (tid == 0) part_pq[blockIdx.x] = acc;
-    }
 }
 
-// XR kernel: alpha, x += alpha s, r -= alpha q, partial |r|^2 and r.(r/diag)
-// ConjugateGradient.h:70-74,79-81.
-template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_xr(Grid g, Box box, const uint8_t* __restrict__ flags, T* __restrict__ x, T* __restrict__ r,
-                                                const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
-                                                const double* __restrict__ part_rz_cur, int n_xr, const double* __restrict__ part_pq,
-                                                int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps)
-{
-    __shared__ double red[8];
-    __shared__ int s_done;
-    __shared__ T sdiag[8];
-    load_diag(sdiag, cf);
-    if (threadIdx.x == 0) s_done = ps->done;
-    __syncthreads();
-    if (s_done) return;
-    const double rz = block_sum_array<4>(part_rz_cur, n_xr, red);
-    const double pq = block_sum_array<4>(part_pq, n_sq, red);
-    if (!(pq > 0) || !(rz == rz)) {  // not SPD / NaN: stop instead of spreading NaNs
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ps->breakdown = 1; ps->done = 1; }
-        return;
-    }
-    const T alpha = (T)(rz / pq);
-    const long ncells = box.cells();
-    const int nz = box.nz(), ny = box.ny();
-    double arr = 0, arz = 0;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < ncells; t += (long)gridDim.x * 256) {
-        const int iz = (int)(t % nz) + box.z0, iy = (int)((t / nz) % ny) + box.y0, ix = (int)(t / ((long)nz * ny)) + box.x0;
-        const size_t c = g.idx(ix, iy, iz);
-        const uint8_t f = flags[c];
-        if (active(f)) {
-            const T xn = x[c] + alpha * s[c];
-            const T rn = r[c] - alpha * q[c];
-            x[c] = xn;
-            r[c] = rn;
-            const T z = rn / sdiag[f >> F_CNT_SHIFT];
-            arr += (double)rn * (double)rn;
-            arz += (double)rn * (double)z;
-        }
-    }
-    arr = block_sum<double, 4>(arr, red);
-    arz = block_sum<double, 4>(arz, red);
-    if (threadIdx.x == 0) { part_rr[blockIdx.x] = arr; part_rz_next[blockIdx.x] = arz; }
-}
-
-// x = 0, r = b (ConjugateGradient.h:41: residual = rhs - A*0), partial |b|^2 and r.(r/diag) (:62-65)
-template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_init(Grid g, Box box, const uint8_t* __restrict__ flags, const float* __restrict__ b,
-                                                  T* __restrict__ x, T* __restrict__ r, Coef<T> cf, double* __restrict__ part_bb,
-                                                  double* __restrict__ part_rz0, PcgState* ps)
-{
-    __shared__ double red[8];
-    __shared__ T sdiag[8];
-    load_diag(sdiag, cf);
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ps->done = 0; ps->iters = 0; ps->breakdown = 0; ps->bb = 0; ps->thr = 0; ps->rr = 0; }
-    const long ncells = box.cells();
-    const int nz = box.nz(), ny = box.ny();
-    double abb = 0, arz = 0;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < ncells; t += (long)gridDim.x * 256) {
-        const int iz = (int)(t % nz) + box.z0, iy = (int)((t / nz) % ny) + box.y0, ix = (int)(t / ((long)nz * ny)) + box.x0;
-        const size_t c = g.idx(ix, iy, iz);
-        const uint8_t f = flags[c];
-        T rv = 0;
-        if (active(f)) {
-            rv = (T)b[c];
-            const T z = rv / sdiag[f >> F_CNT_SHIFT];
-            abb += (double)rv * (double)rv;
-            arz += (double)rv * (double)z;
-        }
-        x[c] = 0;
-        r[c] = rv;
-    }
-    abb = block_sum<double, 4>(abb, red);
-    arz = block_sum<double, 4>(arz, red);
-    if (threadIdx.x == 0) { part_bb[blockIdx.x] = abb; part_rz0[blockIdx.x] = arz; }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_store_pressure(Grid g, Box box, const uint8_t* __restrict__ flags, const T* __restrict__ x,
-                                                        double* __restrict__ pressure)
-{
-    const long ncells = box.cells();
-    const int nz = box.nz(), ny = box.ny();
-    long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ncells) return;
-    const int iz = (int)(t % nz) + box.z0, iy = (int)((t / nz) % ny) + box.y0, ix = (int)(t / ((long)nz * ny)) + box.x0;
-    const size_t c = g.idx(ix, iy, iz);
-    pressure[c] = active(flags[c]) ? (double)x[c] : 0.0;
-}
-
-int pcg_sq_blocks(Box box)
-{
-    int n = make_tiles(box).count();
-    return n < SQ_MAX_BLOCKS ? (n < 1 ? 1 : n) : SQ_MAX_BLOCKS;
-}
-int pcg_xr_blocks(Box box)
-{
-    long n = (box.cells() + 255) / 256;
-    return (int)(n < XR_MAX_BLOCKS ? (n < 1 ? 1 : n) : XR_MAX_BLOCKS);
-}
-
-template <typename T>
-void launch_pcg_init(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, T* x, T* r, Coef<T> cf, double* part_bb,
-                     double* part_rz0, PcgState* ps)
-{
-    hipLaunchKernelGGL((k_pcg_init<T>), dim3(pcg_xr_blocks(box)), dim3(256), 0, st, g, box, flags, b, x, r, cf, part_bb, part_rz0, ps);
-}
-template <typename T>
-void launch_pcg_sq(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
-                   const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol)
-{
-    hipLaunchKernelGGL((k_stencil<T, true>), dim3(pcg_sq_blocks(box)), dim3(256), 0, st, g, box, make_tiles(box), flags, r, s_in, s_out, q,
-                       cf, part_rr, part_rz_new, part_rz_old, part_pq, pcg_xr_blocks(box), ps, first, tol);
-}
-template <typename T>
-void launch_pcg_xr(hipStream_t st, Grid g, Box box, const uint8_t* flags, T* x, T* r, const T* s, const T* q, Coef<T> cf,
-                   const double* part_rz_cur, const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps)
-{
-    hipLaunchKernelGGL((k_pcg_xr<T>), dim3(pcg_xr_blocks(box)), dim3(256), 0, st, g, box, flags, x, r, s, q, cf, part_rz_cur,
-                       pcg_xr_blocks(box), part_pq, pcg_sq_blocks(box), part_rr, part_rz_next, ps);
-}
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
 {
-    hipLaunchKernelGGL((k_stencil<T, false>), dim3(pcg_sq_blocks(box)), dim3(256), 0, st, g, box, make_tiles(box), flags, (const T*)nullptr,
-                       s, (T*)nullptr, q, cf, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, 0,
-                       (PcgState*)nullptr, 0, 0.0);
-}
-template <typename T>
-void launch_store_pressure(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* x, double* pressure)
-{
-    hipLaunchKernelGGL((k_store_pressure<T>), dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, flags, x, pressure);
+    const Tiles tl = make_tiles(box);
+    int nb = tl.count();
+    if (nb > G_MAX_BLOCKS) nb = G_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL((k_stencil_g<T>), dim3(nb), dim3(256), 0, st, g, box, tl, flags, s, q, cf);
 }
 
-#define INST(T)                                                                                                                          \
-    template void launch_pcg_init<T>(hipStream_t, Grid, Box, const uint8_t*, const float*, T*, T*, Coef<T>, double*, double*, PcgState*); \
-    template void launch_pcg_sq<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*,           \
-                                   const double*, const double*, double*, PcgState*, int, double);                                       \
-    template void launch_pcg_xr<T>(hipStream_t, Grid, Box, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,           \
-                                   const double*, double*, double*, PcgState*);                                                          \
-    template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                                \
-    template void launch_store_pressure<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, double*);
+#define INST(T)                                                                                                                        \
+    template void launch_pcg_init<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, T*, T*, Coef<T>, double*, double*,          \
+                                     PcgState*);                                                                                       \
+    template void launch_pcg_sq<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
+                                   const double*, double*, PcgState*, int, double);                                                    \
+    template void launch_pcg_xr<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, const double*, \
+                                   double*, double*, PcgState*);                                                                       \
+    template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
+    template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);
 INST(double)
 INST(float)
 

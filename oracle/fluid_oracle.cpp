@@ -354,22 +354,24 @@ inline void spmv(const StencilA& A, const std::vector<double>& x, std::vector<do
     }
 }
 
-// Eigen/src/IterativeLinearSolvers/ConjugateGradient.h:28-90 restated with the
-// DiagonalPreconditioner (Jacobi) in place of IncompleteCholesky; same start (x=0),
+// Eigen/src/IterativeLinearSolvers/ConjugateGradient.h:28-90 restated with Eigen's
+// DiagonalPreconditioner (Jacobi: multiply by the stored 1/diag, BasicPreconditioners.h:73,91)
+// in place of IncompleteCholesky; same start (x=0),
 // same stopping rule (|r|^2 < tol^2 |b|^2 on the recursively updated residual),
 // same iteration cap 2n (IterativeSolverBase.h:362-363), same b=0 early-out.
 void cg_jacobi(const StencilA& A, const std::vector<double>& rhs, std::vector<double>& x, double tol, int& iters, double& relres)
 {
     const int n = A.n;
     x.assign(n, 0.0);
-    std::vector<double> residual(rhs), p(n), z(n), tmp(n);
+    std::vector<double> residual(rhs), p(n), z(n), tmp(n), invdiag(n);
+    for (int i = 0; i < n; ++i) invdiag[i] = 1.0 / A.diag[i];
     double rhsNorm2 = 0;
     for (int i = 0; i < n; ++i) rhsNorm2 += rhs[i] * rhs[i];
     if (rhsNorm2 == 0) { iters = 0; relres = 0; return; }
     double threshold = tol * tol * rhsNorm2;
     double residualNorm2 = rhsNorm2;
     if (residualNorm2 < threshold) { iters = 0; relres = sqrt(residualNorm2 / rhsNorm2); return; }
-    for (int i = 0; i < n; ++i) p[i] = residual[i] / A.diag[i];
+    for (int i = 0; i < n; ++i) p[i] = invdiag[i] * residual[i];
     double absNew = 0;
     for (int i = 0; i < n; ++i) absNew += residual[i] * p[i];
     int maxIters = 2 * n, i = 0;
@@ -387,7 +389,7 @@ void cg_jacobi(const StencilA& A, const std::vector<double>& rhs, std::vector<do
         if (residualNorm2 < threshold) break;
         double absOld = absNew;
         absNew = 0;
-        for (int k = 0; k < n; ++k) { z[k] = residual[k] / A.diag[k]; absNew += residual[k] * z[k]; }
+        for (int k = 0; k < n; ++k) { z[k] = invdiag[k] * residual[k]; absNew += residual[k] * z[k]; }
         double beta = absNew / absOld;
         for (int k = 0; k < n; ++k) p[k] = z[k] + beta * p[k];
         i++;
