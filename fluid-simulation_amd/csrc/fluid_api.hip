@@ -511,7 +511,7 @@ static int solve_impl(fluid_sim* s)
     const double tol = s->prm.cg_tol;
     long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;  // IterativeSolverBase.h:362
     if (max_it < 1) max_it = 1;
-    const double cells = (double)L.cells();
+    const double cells = (double)s->Rb.cells();  // units one launch processes = cells of the active box
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
     // body 0

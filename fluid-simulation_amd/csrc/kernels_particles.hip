@@ -153,37 +153,74 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
 // divided by double(weights) where weights>0 (:1138-1142).  container (:873) accumulates the
 // same w under "w>0", i.e. the same float sequence, so one array serves both.
 // The post-P2G velocity is also stored as velBeforeUpdate (fluid.cc:1455).
+//
+// Work decomposition: one block = 2 x 2 cell columns (x,y) x 64 cells in z; wave = one column,
+// lane = z.  The particles of a grid row (fixed x,y; z-1..z+64) are CONTIGUOUS in the sorted
+// arrays, so the block stages each of the 4 x 4 neighbouring rows into LDS with coalesced loads
+// and every lane then walks its own 3-cell window inside LDS.  (A lane-per-cell loop straight
+// from global memory makes each wave load touch ~32 cache lines and thrashes the 32 KB L1:
+// 7.4 ms at 256^3 against 0.3 ms for the compute.)  Rows are visited in ascending (x,y) and
+// particles in ascending sorted order: the sum order per cell is fixed.
+constexpr int P2G_CH = 640;  // particles staged per chunk: 6 x 8 B x 640 = 30 KB of LDS
+
 __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const int* __restrict__ cell_start,
                                              const uint8_t* __restrict__ flags, float* __restrict__ container,
                                              double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
                                              double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
 {
-    const int nz = box.nz(), ny = box.ny();
-    long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= box.cells()) return;
-    const int iz = (int)(t % nz) + box.z0;
-    const int iy = (int)((t / nz) % ny) + box.y0;
-    const int ix = (int)(t / ((long)nz * ny)) + box.x0;
-    const size_t c = g.idx(ix, iy, iz);
-    if (flags[c] & F_SOLID) return;  // fields stay 0
+    __shared__ double spx[P2G_CH], spy[P2G_CH], spz[P2G_CH], svx[P2G_CH], svy[P2G_CH], svz[P2G_CH];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int N = g.N;
+    const int ntz = (box.nz() + 63) / 64, nty = (box.ny() + 1) / 2;
+    const int tile = blockIdx.x;
+    const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
+    const int tx0 = box.x0 + tx * 2, ty0 = box.y0 + ty * 2, tz0 = box.z0 + tz * 64;
+    const int ix = tx0 + (wv >> 1), iy = ty0 + (wv & 1), iz = tz0 + lane;
+    const bool valid = ix <= box.x1 && iy <= box.y1 && iz <= box.z1;
+    const size_t c = valid ? g.idx(ix, iy, iz) : 0;
+    const bool live = valid && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
     const double cx = (double)(ix + g.lo), cy = (double)(iy + g.lo), cz = (double)(iz + g.lo);
+    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + 64 < N - 1 ? tz0 + 64 : N - 1;
+    const int wz0 = iz > 0 ? iz - 1 : 0, wz1 = iz < N - 1 ? iz + 1 : N - 1;
     float wf = 0.0f;
     double su = 0, sv = 0, sw = 0;
-    const int x0 = ix > 0 ? ix - 1 : 0, x1 = ix < g.N - 1 ? ix + 1 : g.N - 1;
-    const int y0 = iy > 0 ? iy - 1 : 0, y1 = iy < g.N - 1 ? iy + 1 : g.N - 1;
-    const int z0 = iz > 0 ? iz - 1 : 0, z1 = iz < g.N - 1 ? iz + 1 : g.N - 1;
-    for (int nx = x0; nx <= x1; ++nx)
-        for (int nyy = y0; nyy <= y1; ++nyy) {
-            const int j0 = cell_start[g.idx(nx, nyy, z0)];
-            const int j1 = cell_start[g.idx(nx, nyy, z1) + 1];
-            for (int j = j0; j < j1; ++j) {
-                const double cw = spline(p.px[j] - cx) * spline(p.py[j] - cy) * spline(p.pz[j] - cz);
-                wf = (float)((double)wf + cw);
-                su = su + cw * p.vx[j];
-                sv = sv + cw * p.vy[j];
-                sw = sw + cw * p.vz[j];
+    for (int rx = tx0 - 1; rx <= tx0 + 2; ++rx) {
+        if (rx < 0 || rx >= N) continue;
+        for (int ry = ty0 - 1; ry <= ty0 + 2; ++ry) {
+            if (ry < 0 || ry >= N) continue;
+            const int jb = cell_start[g.idx(rx, ry, zlo)];
+            const int je = cell_start[g.idx(rx, ry, zhi) + 1];
+            if (je == jb) continue;  // block-uniform
+            const bool mine = live && rx >= ix - 1 && rx <= ix + 1 && ry >= iy - 1 && ry <= iy + 1;
+            int a = 0, b = 0;
+            if (mine) {
+                a = cell_start[g.idx(rx, ry, wz0)];
+                b = cell_start[g.idx(rx, ry, wz1) + 1];
+            }
+            for (int cb = jb; cb < je; cb += P2G_CH) {
+                const int ce = cb + P2G_CH < je ? cb + P2G_CH : je;
+                __syncthreads();  // the previous chunk has been consumed
+                for (int j = cb + tid; j < ce; j += 256) {
+                    const int k = j - cb;
+                    spx[k] = p.px[j]; spy[k] = p.py[j]; spz[k] = p.pz[j];
+                    svx[k] = p.vx[j]; svy[k] = p.vy[j]; svz[k] = p.vz[j];
+                }
+                __syncthreads();
+                if (mine) {
+                    const int lo = a > cb ? a : cb, hi = b < ce ? b : ce;
+                    for (int j = lo; j < hi; ++j) {
+                        const int k = j - cb;
+                        const double cw = spline(spx[k] - cx) * spline(spy[k] - cy) * spline(spz[k] - cz);
+                        wf = (float)((double)wf + cw);
+                        su = su + cw * svx[k];
+                        sv = sv + cw * svy[k];
+                        sw = sw + cw * svz[k];
+                    }
+                }
             }
         }
+    }
+    if (!live) return;  // fields stay 0
     if (wf > 0) {
         const double wd = (double)wf;
         su /= wd; sv /= wd; sw /= wd;
@@ -330,7 +367,8 @@ void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Par
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const int* cell_start, const uint8_t* flags, float* container,
                 double* u, double* v, double* w, double* ub, double* vb, double* wb)
 {
-    hipLaunchKernelGGL(k_p2g, dim3(nblk(box.cells())), dim3(256), 0, st, g, box, p, cell_start, flags, container, u, v, w, ub, vb, wb);
+    const unsigned nt = (unsigned)(((box.nx() + 1) / 2) * ((box.ny() + 1) / 2) * ((box.nz() + 63) / 64));
+    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(256), 0, st, g, box, p, cell_start, flags, container, u, v, w, ub, vb, wb);
 }
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss)
 {
