@@ -189,6 +189,8 @@ void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf);
 template <typename T>
+void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen);
+template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure);
 
 }  // namespace fl

@@ -718,17 +718,26 @@ int fluid_stencil_apply(fluid_sim_t* s, int reps, int box_mode, float* avg_ms)
     if (!s->have_flags) return fail(FLUID_ERR_STATE, "stencil_apply before flags_index");
     HIPCHK(hipSetDevice(s->prm.device));
     const int N = s->g.N;
-    const Box box = box_mode ? s->Rb : Box{0, 0, 0, N - 1, N - 1, N - 1};
+    const Box box = box_mode == 1 ? s->Rb : Box{0, 0, 0, N - 1, N - 1, N - 1};
     if (box_empty(box)) return fail(FLUID_ERR_STATE, "empty active box");
+    // tuning knobs of the marching kernel (developer use): FLUID_MARCH_VARIANT=MY*100+MD, FLUID_MARCH_CX=planes/chunk
+    const char* ev = getenv("FLUID_MARCH_VARIANT");
+    const char* ec = getenv("FLUID_MARCH_CX");
+    const int mv = ev ? atoi(ev) : 0, mc = ec ? atoi(ec) : 0;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, s->st));
     for (int i = 0; i < reps; ++i) {
-        if (s->prm.precision == FLUID_PRECISION_FP32)
-            launch_stencil_apply<float>(s->st, s->g, box, s->flags, (const float*)s->S[0], (float*)s->Q, make_coef<float>(s));
-        else
-            launch_stencil_apply<double>(s->st, s->g, box, s->flags, (const double*)s->S[0], (double*)s->Q, make_coef<double>(s));
+        // box_mode 0: dense sweep (x-marching kernel; grids under 192^3 cannot fill 256 CUs with 32-plane chunks -> tiled);
+        // 1: active box, tiled kernel; 2: dense sweep, tiled kernel
+        if (s->prm.precision == FLUID_PRECISION_FP32) {
+            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<float>(s->st, s->g, s->flags, (const float*)s->S[0], (float*)s->Q, make_coef<float>(s), mv, mc);
+            else launch_stencil_apply<float>(s->st, s->g, box, s->flags, (const float*)s->S[0], (float*)s->Q, make_coef<float>(s));
+        } else {
+            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<double>(s->st, s->g, s->flags, (const double*)s->S[0], (double*)s->Q, make_coef<double>(s), mv, mc);
+            else launch_stencil_apply<double>(s->st, s->g, box, s->flags, (const double*)s->S[0], (double*)s->Q, make_coef<double>(s));
+        }
     }
     HIPCHK(hipEventRecord(e1, s->st));
     HIPCHK(hipGetLastError());

@@ -494,6 +494,125 @@ __global__ __launch_bounds__(256) void k_stencil_g(Grid g, Box box, Tiles tl, co
     }
 }
 
+// ---- dense sweep, x-marching ("2.5D") ------------------------------------------------------------
+// One block = footprint MY x MZ in (y,z), marched through a chunk of x planes.  The x
+// neighbours of a cell stay in the thread's registers (s at x-1, x, x+1), the y/z neighbours
+// come from ONE double-buffered LDS plane, so each s value is fetched once per block (+ the
+// 1-cell y/z rim, served by L2 when neighbouring footprints share an XCD) and there is one
+// barrier per plane.  Loads run D planes ahead of use to keep ~64 KB per CU in flight.
+constexpr int MZ = 64;
+
+template <typename T, int MY, int MD>
+__global__ __launch_bounds__(MY * 64) void k_stencil_march(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
+                                                       const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
+{
+    __shared__ T pl[2][MY + 2][MZ + 2];
+    __shared__ T sdiag[8], sinv[8];
+    const int tid = threadIdx.x, wy = tid >> 6, lz = tid & 63;
+    load_coef(sdiag, sinv, cf);
+    const int N = g.N;
+    const long sx = (long)N * N;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tz = vb % ntz, ty = (vb / ntz) % nty, cx = vb / (ntz * nty);
+    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
+    const int y = ty * MY + wy, z = tz * MZ + lz;
+    const bool cv = y < N && z < N;
+    const long col = (long)y * N + z;
+    // rim duty: threads 0..127 the two y rows, 128..143 the 2 x MY z cells
+    int hy = -1, hz = -1, hly = 0, hlz = 0;
+    if (tid < 128) {
+        const int r = tid >> 6;
+        hy = r ? ty * MY + MY : ty * MY - 1;
+        hz = tz * MZ + (tid & 63);
+        hly = r ? MY + 1 : 0;
+        hlz = (tid & 63) + 1;
+    } else if (tid < 128 + 2 * MY) {
+        const int k = tid - 128, r = k >> 1, side = k & 1;
+        hy = ty * MY + r;
+        hz = side ? tz * MZ + MZ : tz * MZ - 1;
+        hly = r + 1;
+        hlz = side ? MZ + 1 : 0;
+    }
+    const bool hduty = tid < 128 + 2 * MY;
+    const bool hv = hduty && hy >= 0 && hy < N && hz >= 0 && hz < N;
+    const long hcol = (long)hy * N + hz;
+    auto ld = [&](int x, long colx, bool ok, T& val, uint8_t& f) {
+        if (ok && x >= 0 && x < N) {
+            const long c = (long)x * sx + colx;
+            f = flags[c];
+            val = s[c];
+        } else {
+            f = 0;
+            val = 0;
+        }
+    };
+    auto mk = [](T v, uint8_t f) { return ((f & F_FLUID) && (f >> F_CNT_SHIFT)) ? v : (T)0; };
+    T vm1, v0, hv0;
+    uint8_t fm1, f0, hf0;
+    ld(xa - 1, col, cv, vm1, fm1);
+    ld(xa, col, cv, v0, f0);
+    ld(xa, hcol, hv, hv0, hf0);
+    T qv[MD], hq[MD];
+    uint8_t qf[MD], hqf[MD];
+#pragma unroll
+    for (int d = 0; d < MD; ++d) {
+        ld(xa + 1 + d, col, cv, qv[d], qf[d]);
+        ld(xa + 1 + d, hcol, hv, hq[d], hqf[d]);
+    }
+    T sm1 = mk(vm1, fm1), s0 = mk(v0, f0), h0 = mk(hv0, hf0);
+    __syncthreads();  // coef tables
+    for (int xb = xa; xb < xe; xb += MD) {
+#pragma unroll
+        for (int d = 0; d < MD; ++d) {
+            const int x = xb + d;
+            if (x < xe) {  // block-uniform
+                const int buf = x & 1;
+                pl[buf][wy + 1][lz + 1] = s0;
+                if (hduty) pl[buf][hly][hlz] = h0;
+                __syncthreads();
+                const T sp1 = mk(qv[d], qf[d]);
+                if (cv) {
+                    T out = 0;
+                    if ((f0 & F_FLUID) && (f0 >> F_CNT_SHIFT)) {
+                        const T nb = sm1 + sp1 + pl[buf][wy][lz + 1] + pl[buf][wy + 2][lz + 1] + pl[buf][wy + 1][lz] + pl[buf][wy + 1][lz + 2];
+                        out = sdiag[f0 >> F_CNT_SHIFT] * s0 + cf.off * nb;
+                    }
+                    __builtin_nontemporal_store(out, &q[(long)x * sx + col]);  // streamed once: keep s, not q, in cache
+                }
+                sm1 = s0;
+                s0 = sp1;
+                f0 = qf[d];
+                h0 = mk(hq[d], hqf[d]);
+                ld(x + 1 + MD, col, cv, qv[d], qf[d]);
+                ld(x + 1 + MD, hcol, hv, hq[d], hqf[d]);
+            }
+        }
+    }
+}
+
+template <typename T, int MY, int MD>
+static void march_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
+{
+    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZ - 1) / MZ, ncx = (g.N + cxlen - 1) / cxlen;
+    hipLaunchKernelGGL((k_stencil_march<T, MY, MD>), dim3(nty * ntz * ncx), dim3(MY * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
+}
+
+// variant = MY*100 + MD (0 = default); cxlen = planes per chunk (0 = default)
+template <typename T>
+void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen)
+{
+    if (cxlen <= 0) cxlen = 32;
+    switch (variant) {
+    case 804: march_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
+    case 808: march_launch<T, 8, 8>(st, g, cxlen, flags, s, q, cf); break;
+    case 1604: march_launch<T, 16, 4>(st, g, cxlen, flags, s, q, cf); break;
+    case 1608: march_launch<T, 16, 8>(st, g, cxlen, flags, s, q, cf); break;
+    case 404: march_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
+    case 408: march_launch<T, 4, 8>(st, g, cxlen, flags, s, q, cf); break;
+    default: march_launch<T, 16, 4>(st, g, cxlen, flags, s, q, cf); break;  // best of the sweep at 256^3 (profiles/r01/stencil_sweep.txt)
+    }
+}
+
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
 {
@@ -512,6 +631,7 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_pcg_xr<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, const double*, \
                                    double*, double*, PcgState*);                                                                       \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
+    template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);
 INST(double)
 INST(float)

@@ -190,8 +190,11 @@ def test_stencil_apply_dense(fs, oracle):
         dt_np = np.float64 if prec == "fp64" else np.float32
         s = (rng.uniform(-1, 1, size=(n, n, n)) * (solid == 0)).astype(dt_np)
         sim.upload_field(F.SEARCH, s)
-        sim.stencil_apply(reps=1, box=0)
+        sim.stencil_apply(reps=1, box=2)      # tiled kernel, dense box
+        q_tiled = sim.field(F.Q)
+        sim.stencil_apply(reps=1, box=0)      # x-marching kernel
         q = sim.field(F.Q)
+        assert np.array_equal(q, q_tiled), "marching and tiled stencil kernels disagree"
         # numpy reference: diag count = non-solid neighbours, off = float32(-scale)
         scale = np.float64(sim.dt)
         acc = np.float32(0); table = [np.float32(0)]

@@ -1,0 +1,8 @@
+#!/usr/bin/env python3
+"""Dense stencil micro-benchmark only: python tools_micro.py [n]"""
+import json, sys
+import __graft_entry__ as entry
+import bench
+fs = entry.load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+print(json.dumps(bench.stencil_microbench(fs, n, 0)))

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Developer sweep of the marching-stencil knobs: python tools_sweep.py [n]"""
+import os, sys, json
+import numpy as np
+import __graft_entry__ as entry
+fs = entry.load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+for prec, T in (("fp64", 8), ("fp32", 4)):
+    sim = fs.FluidSim(n=n, precision=prec)
+    F = fs.FIELD
+    solid = sim.field(F.SOLID)
+    sim.upload_field(F.CONTAINER, (solid == 0).astype(np.float32))
+    sim.flags_index()
+    s = np.random.default_rng(1).uniform(-1, 1, size=(n, n, n)) * (solid == 0)
+    sim.upload_field(F.SEARCH, s)
+    algo = n ** 3 * (2 * T + 1)
+    for var in (404, 804, 1604):
+        for cx in (16, 32, 64):
+            os.environ["FLUID_MARCH_VARIANT"] = str(var); os.environ["FLUID_MARCH_CX"] = str(cx)
+            sim.stencil_apply(reps=3, box=0)
+            ms = min(sim.stencil_apply(reps=30, box=0) for _ in range(3))
+            print(prec, var, cx, f"{ms*1e3:.1f}us {algo/ms/1e6:.0f} GB/s", flush=True)
+    sim.close()
