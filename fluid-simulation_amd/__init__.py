@@ -9,4 +9,10 @@ import fails; if no GPU is visible, ``FluidSim(...)`` raises.
 from ._lib import lib, FluidError, Params, StepStats, FIELD, PROF  # noqa: F401
 from .sim import FluidSim, water_cube_drop, grid_bounds  # noqa: F401
 
-__all__ = ["FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "grid_bounds", "lib"]
+def load_dist():
+    """torch is imported only when the multi-GPU path is used."""
+    from . import dist
+    return dist
+
+
+__all__ = ["load_dist", "FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "grid_bounds", "lib"]

@@ -143,7 +143,14 @@ __device__ __forceinline__ double block_sum_array(const double* __restrict__ a, 
 struct Particles {
     double *px, *py, *pz, *vx, *vy, *vz;
     uint32_t* pid;
+    __host__ __device__ inline Particles shifted(long o) const
+    {
+        Particles q = *this;
+        q.px += o; q.py += o; q.pz += o; q.vx += o; q.vy += o; q.vz += o; q.pid += o;
+        return q;
+    }
 };
+constexpr uint32_t PID_DEAD = 0xFFFFFFFFu;  // multi-GPU: particle handed to a neighbour rank
 
 // particles
 void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, int* part, StepState* ss);
@@ -155,12 +162,20 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const int* cell_st
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss);
 void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss);
 void launch_pack_particles(hipStream_t st, long n, Particles p, double* pos_aos, double* vel_aos);
+void launch_classify_migrate(hipStream_t st, Grid g, long n, Particles p, int xs, int xe, int has_lo, int has_hi, double* send_lo,
+                             double* send_hi, int cap, int* counters);
+void launch_unpack_records(hipStream_t st, long n, const double* rec, Particles p, long off);
+void launch_pack_records(hipStream_t st, long n, Particles p, long off, double* rec);
+void launch_unpack_ids(hipStream_t st, long n, const double* pos, const double* vel, const uint32_t* ids, Particles p);
+void launch_pack_ids(hipStream_t st, long n, Particles p, long off, double* pos, double* vel, uint32_t* ids);
 void launch_unpack_particles(hipStream_t st, long n, const double* pos_aos, const double* vel_aos, Particles p);
 
 // grid
 void launch_exclusive_scan(hipStream_t st, const int* in, int* out, long n, int* block_sums, int* total);
 void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total);
-void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags);
+void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags, int x0, int x1);
+void launch_index_scan_range(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total, int x0, int x1);
+void launch_add_offset(hipStream_t st, int* idx, long n, int off);
 void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w,
                     float* rhs, float* diver, double dx, double gdt0, double gdt1, double gdt2);
 void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w,
@@ -186,6 +201,15 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps);
+template <typename T>
+void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
+                  const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol);
+template <typename T>
+void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps);
+template <typename T>
+void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
+                     const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps);
+void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b);
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf);
 template <typename T>

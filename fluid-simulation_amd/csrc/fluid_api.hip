@@ -64,6 +64,20 @@ struct fluid_sim {
     bool sorted = false, have_p2g = false, have_flags = false;
     double dt = 0.1;
     fluid_step_stats_t stats{};
+    // multi-GPU (x-slab decomposition)
+    bool dist = false;
+    fluid_comm_t comm{};
+    std::vector<int> bounds;
+    int xs = 0, xe = 0;          // owned x planes [xs, xe)
+    long p_off = 0;              // my live particles are pa[p_off .. p_off+np)
+    long n_dropped = 0;          // particles that left the grid on this rank (inert)
+    double *mig_lo = nullptr, *mig_hi = nullptr, *mig_rlo = nullptr, *mig_rhi = nullptr;  // 7-double records
+    long mig_cap = 0;
+    int* d_small = nullptr;      // device scratch ints: [0..1] migrate counters, [2..3] received counts, [4..19] misc
+    int* h_small = nullptr;      // pinned mirror
+    double *gstage[2] = {nullptr, nullptr}, *gpq = nullptr;  // all-reduced PCG scalars
+    void *zplane = nullptr, *splane = nullptr;               // zero / scratch ring planes for an empty local box
+    Box Rr{0, 0, 0, -1, -1, -1}, Sr{0, 0, 0, -1, -1, -1};    // local parts of Rb / Sb
     // profiling
     int prof_every = 0;
     ProfClass prof[FLUID_PROF_COUNT];
@@ -192,10 +206,12 @@ int fluid_destroy(fluid_sim_t* s)
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->cntL, s->part_bb, s->part_rr,
-                    s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss};
+                    s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
+                    s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     if (s->h_ss) hipHostFree(s->h_ss);
+    if (s->h_small) hipHostFree(s->h_small);
     if (s->st) hipStreamDestroy(s->st);
     delete s;
     return FLUID_OK;
@@ -219,6 +235,8 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     s->g.hi = s->g.lo + p->n - 1;
     s->ncell = (size_t)p->n * p->n * p->n;
     s->dt = p->max_dt;
+    s->xs = 0;
+    s->xe = p->n;
     *out = nullptr;
     auto bail = [&](int rc) { fluid_destroy(s); return rc; };
 #define A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
@@ -242,7 +260,9 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     A(dalloc(&s->part_rz[0], (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rz[1], (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_pq, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_err, (size_t)2 * MAX_PARTIALS));
     A(dalloc(&s->ps, (size_t)1)); A(dalloc(&s->ss, (size_t)1));
-    A(dalloc(&s->cell_count, n + 2)); A(dalloc(&s->cell_start, n + 2));
+    A(dalloc(&s->cell_count, n + 4)); A(dalloc(&s->cell_start, n + 4));
+    A(dalloc(&s->d_small, (size_t)32));
+    A(hipHostMalloc((void**)&s->h_small, 32 * sizeof(int)));
     A(hipHostMalloc((void**)&s->h_ps, sizeof(PcgState)));
     A(hipHostMalloc((void**)&s->h_ss, sizeof(StepState)));
 #undef A
@@ -289,6 +309,7 @@ int fluid_upload_particles(fluid_sim_t* s, int64_t n, const double* pos, const d
     int rc = alloc_particles(s, (long)n);
     if (rc) return rc;
     s->np = (long)n;
+    s->p_off = 0;
     if (n > 0) {
         HIPCHK(hipMemcpyAsync(s->stage_pos, pos, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
         if (vel) HIPCHK(hipMemcpyAsync(s->stage_vel, vel, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
@@ -305,7 +326,7 @@ int fluid_download_particles(fluid_sim_t* s, double* pos, double* vel)
     if (!s || !pos || !vel) return fail(FLUID_ERR_ARG, "null argument");
     if (s->np == 0) return FLUID_OK;
     HIPCHK(hipSetDevice(s->prm.device));
-    launch_pack_particles(s->st, s->np, s->pa, s->stage_pos, s->stage_vel);
+    launch_pack_particles(s->st, s->np, s->pa.shifted(s->p_off), s->stage_pos, s->stage_vel);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(pos, s->stage_pos, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipMemcpyAsync(vel, s->stage_vel, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st));
@@ -391,9 +412,10 @@ static int phase_sort(fluid_sim* s)
     const long ncell = (long)s->ncell;
     int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
     launch_zero_step_state(s->st, s->ss, g.N);
-    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 2) * sizeof(int), s->st));
-    launch_bin_count(s->st, g, s->np, s->pa, s->key, s->slot, s->cell_count, s->ipart, s->ss);
-    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 1, s->scan_sums, s->cell_start + ncell + 1);
+    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 4) * sizeof(int), s->st));
+    launch_bin_count(s->st, g, s->np, s->pa.shifted(s->p_off), s->key, s->slot, s->cell_count, s->ipart, s->ss);
+    // buckets: the N^3 cells, then "off the grid", then "dead" (multi-GPU migrants)
+    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
     launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->order);
     HIPCHK(hipGetLastError());
     int rc = read_ss(s);
@@ -405,15 +427,16 @@ static int phase_sort(fluid_sim* s)
         s->Pb = Box{h.bbox_min[0], h.bbox_min[1], h.bbox_min[2], h.bbox_max[0], h.bbox_max[1], h.bbox_max[2]};
     }
     if (!box_empty(s->Pb)) {
-        launch_bin_fix(s->st, g, s->Pb, s->cell_start, s->pa.pid, s->order);
+        launch_bin_fix(s->st, g, s->Pb, s->cell_start, s->pa.shifted(s->p_off).pid, s->order);
         s->Rb = clip_dilate(s->Pb, 1, g.N);
         s->Sb = clip_dilate(s->Pb, 2, g.N);
     } else {
         s->Rb = s->Sb = s->Pb;
     }
-    launch_reorder(s->st, s->np, s->order, s->pa, s->pb);
+    launch_reorder(s->st, s->np, s->order, s->pa.shifted(s->p_off), s->pb);
     HIPCHK(hipGetLastError());
     std::swap(s->pa, s->pb);
+    s->p_off = 0;
     prof_end(s, FLUID_PROF_SORT, tok);
     s->sorted = true;
     return FLUID_OK;
@@ -449,7 +472,7 @@ static int phase_p2g(fluid_sim* s)
 static int phase_flags(fluid_sim* s)
 {
     HIPCHK(hipSetDevice(s->prm.device));
-    launch_flags(s->st, s->g, s->solid, s->container, s->flags);
+    launch_flags(s->st, s->g, s->solid, s->container, s->flags, 0, s->g.N - 1);
     launch_index_scan(s->st, s->g, s->flags, s->indices, s->scan_sums, &s->ss->num_active);
     HIPCHK(hipGetLastError());
     int rc = read_ss(s);
@@ -600,9 +623,9 @@ static int phase_flip_advect(fluid_sim* s)
     HIPCHK(hipSetDevice(s->prm.device));
     if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz);
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    launch_g2p(s->st, s->g, s->np, s->pa, s->dcx, s->dcy, s->dcz, s->ss);
+    launch_g2p(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->ss);
     prof_end(s, FLUID_PROF_G2P, tok);
-    launch_advect(s->st, s->g, s->np, s->pa, s->flags, s->prm.max_dt, s->prm.dx, s->ss);
+    launch_advect(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->flags, s->prm.max_dt, s->prm.dx, s->ss);
     HIPCHK(hipGetLastError());
     int rc = read_ss(s);
     if (rc) return rc;
@@ -633,9 +656,12 @@ int fluid_get_stats(fluid_sim_t* s, fluid_step_stats_t* st)
     return FLUID_OK;
 }
 
+static int dist_step(fluid_sim* s, fluid_step_stats_t* stats);
+
 int fluid_step(fluid_sim_t* s, fluid_step_stats_t* stats)
 {
     if (!s) return fail(FLUID_ERR_ARG, "null handle");
+    if (s->dist) return dist_step(s, stats);
     int rc;
     if ((rc = phase_p2g(s))) return rc;             // fluid.cc:1378-1413
     if ((rc = phase_flags(s))) return rc;           // :1416-1455
@@ -775,6 +801,444 @@ int fluid_profile_reset(fluid_sim_t* s)
         s->prof[k].launches = s->prof[k].sampled = 0;
         s->prof[k].ms = s->prof[k].cells = 0;
     }
+    return FLUID_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Multi-GPU: x-slab domain decomposition.  Every rank holds full-size field arrays
+// and computes its slab [xs,xe) only; halo planes live at their global index.  All communication
+// goes through the caller's fluid_comm_t (RCCL via torch.distributed in bench.py, gloo in tests).
+// =====================================================================================================
+#define COMMCHK(expr)                                                                              \
+    do {                                                                                           \
+        if ((expr) != 0) return fail(FLUID_ERR_HIP, std::string("comm callback failed: ") + #expr); \
+    } while (0)
+
+static int comm_sendrecv(fluid_sim* s, const void* send_lo, size_t nlo_s, void* recv_lo, size_t nlo_r, const void* send_hi, size_t nhi_s,
+                         void* recv_hi, size_t nhi_r)
+{
+    const bool has_lo = s->comm.rank > 0, has_hi = s->comm.rank < s->comm.size - 1;
+    if (!has_lo) nlo_s = nlo_r = 0;
+    if (!has_hi) nhi_s = nhi_r = 0;
+    COMMCHK(s->comm.sendrecv(s->comm.ctx, send_lo, nlo_s, recv_lo, nlo_r, send_hi, nhi_s, recv_hi, nhi_r, (void*)s->st));
+    return FLUID_OK;
+}
+static int comm_allreduce(fluid_sim* s, void* buf, int count, int dtype, int op)
+{
+    COMMCHK(s->comm.allreduce(s->comm.ctx, buf, count, dtype, op, (void*)s->st));
+    return FLUID_OK;
+}
+// boundary planes of a global-layout field: my first/last owned plane -> the neighbours' halo planes
+static int exchange_planes(fluid_sim* s, void* field, size_t elem)
+{
+    const size_t n2 = (size_t)s->g.N * s->g.N, pb = n2 * elem;
+    char* f = (char*)field;
+    return comm_sendrecv(s, f + (size_t)s->xs * pb, pb, s->xs > 0 ? f + (size_t)(s->xs - 1) * pb : nullptr, pb,
+                         f + (size_t)(s->xe - 1) * pb, pb, s->xe < s->g.N ? f + (size_t)s->xe * pb : nullptr, pb);
+}
+static int read_ints(fluid_sim* s, const int* dev, int n, int* host_slot)
+{
+    HIPCHK(hipMemcpyAsync(host_slot, dev, n * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    return FLUID_OK;
+}
+static Box clip_x(const Box& b, int xs, int xe)
+{
+    Box r = b;
+    if (r.x0 < xs) r.x0 = xs;
+    if (r.x1 > xe - 1) r.x1 = xe - 1;
+    if (r.x1 < r.x0) { r.x0 = xs; r.x1 = xs - 1; }  // empty in x, still a valid (y,z) extent
+    return r;
+}
+
+static int dist_sort(fluid_sim* s)
+{
+    const Grid g = s->g;
+    const int N = g.N;
+    const long ncell = (long)s->ncell, n2 = (long)N * N;
+    const bool has_lo = s->comm.rank > 0, has_hi = s->comm.rank < s->comm.size - 1;
+    int rc;
+    int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
+    // ---- A. hand particles that left the slab to the neighbours -------------------------------------
+    HIPCHK(hipMemsetAsync(s->d_small, 0, 32 * sizeof(int), s->st));
+    launch_classify_migrate(s->st, g, s->np, s->pa.shifted(s->p_off), s->xs, s->xe, has_lo, has_hi, s->mig_lo, s->mig_hi, (int)s->mig_cap,
+                            s->d_small);
+    HIPCHK(hipGetLastError());
+    if ((rc = comm_sendrecv(s, s->d_small + 0, sizeof(int), s->d_small + 2, sizeof(int), s->d_small + 1, sizeof(int), s->d_small + 3, sizeof(int)))) return rc;
+    if ((rc = read_ints(s, s->d_small, 4, s->h_small))) return rc;
+    HIPCHK(hipStreamSynchronize(s->st));
+    const long nl = s->h_small[0], nr = s->h_small[1], ml = s->h_small[2], mr = s->h_small[3];
+    if (nl > s->mig_cap || nr > s->mig_cap || ml > s->mig_cap || mr > s->mig_cap)
+        return fail(FLUID_ERR_STATE, "particle migration buffer overflow");
+    if ((rc = comm_sendrecv(s, s->mig_lo, (size_t)nl * 56, s->mig_rlo, (size_t)ml * 56, s->mig_hi, (size_t)nr * 56, s->mig_rhi, (size_t)mr * 56))) return rc;
+    if (s->p_off + s->np + ml + mr > s->cap) return fail(FLUID_ERR_STATE, "particle capacity exceeded on this rank");
+    launch_unpack_records(s->st, ml, s->mig_rlo, s->pa, s->p_off + s->np);
+    launch_unpack_records(s->st, mr, s->mig_rhi, s->pa, s->p_off + s->np + ml);
+    s->np += ml + mr;
+    // ---- B. count per cell (dead -> last bucket) ------------------------------------------------------
+    launch_zero_step_state(s->st, s->ss, N);
+    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 4) * sizeof(int), s->st));
+    launch_bin_count(s->st, g, s->np, s->pa.shifted(s->p_off), s->key, s->slot, s->cell_count, s->ipart, s->ss);
+    HIPCHK(hipGetLastError());
+    // ---- C. neighbours' boundary-plane counts become my ghost planes xs-1 and xe ------------------------
+    if ((rc = comm_sendrecv(s, s->cell_count + (long)s->xs * n2, n2 * sizeof(int), s->xs > 0 ? s->cell_count + (long)(s->xs - 1) * n2 : nullptr,
+                            n2 * sizeof(int), s->cell_count + (long)(s->xe - 1) * n2, n2 * sizeof(int),
+                            s->xe < N ? s->cell_count + (long)s->xe * n2 : nullptr, n2 * sizeof(int)))) return rc;
+    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
+    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->order);
+    HIPCHK(hipGetLastError());
+    // offsets: [4] start of plane xs, [5] start of plane xs+1, [6] start of plane xe-1, [7] start of plane xe,
+    //          [8] start of plane xe+1 (or of the off-grid bucket), [9] off-grid bucket, [10] dead bucket, [11] total
+    const long o_xs = (long)s->xs * n2, o_xe = (long)s->xe * n2;
+    if ((rc = read_ints(s, s->cell_start + o_xs, 1, s->h_small + 4))) return rc;
+    if ((rc = read_ints(s, s->cell_start + o_xs + n2, 1, s->h_small + 5))) return rc;
+    if ((rc = read_ints(s, s->cell_start + o_xe - n2, 1, s->h_small + 6))) return rc;
+    if ((rc = read_ints(s, s->cell_start + o_xe, 1, s->h_small + 7))) return rc;
+    if ((rc = read_ints(s, s->cell_start + (s->xe < N ? o_xe + n2 : ncell), 1, s->h_small + 8))) return rc;
+    if ((rc = read_ints(s, s->cell_start + ncell, 3, s->h_small + 9))) return rc;
+    // global particle bounding box: MIN over [min3, -max3]
+    if ((rc = read_ss(s))) return rc;
+    {
+        const StepState& h = *s->h_ss;
+        int* v = s->h_small + 16;
+        for (int a = 0; a < 3; ++a) {
+            v[a] = h.bbox_max[a] < 0 ? 0x7fffffff : h.bbox_min[a];
+            v[3 + a] = h.bbox_max[a] < 0 ? 0x7fffffff : -h.bbox_max[a];
+        }
+        HIPCHK(hipMemcpyAsync(s->d_small + 16, v, 6 * sizeof(int), hipMemcpyHostToDevice, s->st));
+        if ((rc = comm_allreduce(s, s->d_small + 16, 6, FLUID_DT_I32, FLUID_OP_MIN))) return rc;
+        if ((rc = read_ints(s, s->d_small + 16, 6, s->h_small + 16))) return rc;
+        HIPCHK(hipStreamSynchronize(s->st));
+        if (v[0] == 0x7fffffff) s->Pb = Box{0, 0, 0, -1, -1, -1};
+        else s->Pb = Box{v[0], v[1], v[2], -v[3], -v[4], -v[5]};
+    }
+    const long gl = s->h_small[4];                         // left ghosts precede my first plane
+    const long gr = s->h_small[8] - s->h_small[7];         // right ghosts = plane xe
+    const long n_slab = s->h_small[7] - s->h_small[4];     // my particles inside the slab
+    const long n_oog = s->h_small[10] - s->h_small[9];     // off the grid on an outer rank: inert, dropped
+    s->n_dropped += n_oog;
+    if (!box_empty(s->Pb)) {
+        s->Rb = clip_dilate(s->Pb, 1, N);
+        s->Sb = clip_dilate(s->Pb, 2, N);
+        const Box mine = clip_x(s->Pb, s->xs, s->xe);
+        if (!box_empty(mine)) launch_bin_fix(s->st, g, mine, s->cell_start, s->pa.shifted(s->p_off).pid, s->order);
+    } else {
+        s->Rb = s->Sb = s->Pb;
+    }
+    s->Rr = box_empty(s->Rb) ? s->Rb : clip_x(s->Rb, s->xs, s->xe);
+    s->Sr = box_empty(s->Sb) ? s->Sb : clip_x(s->Sb, s->xs, s->xe);
+    if (gl + s->np + gr > s->cap) return fail(FLUID_ERR_STATE, "particle capacity exceeded on this rank (ghosts)");
+    // order[] is indexed by DESTINATION position; only [gl, gl+n_slab) is mine (ghost gaps are filled below,
+    // the off-grid and dead tails are dropped)
+    launch_reorder(s->st, n_slab, s->order + gl, s->pa.shifted(s->p_off), s->pb.shifted(gl));
+    HIPCHK(hipGetLastError());
+    std::swap(s->pa, s->pb);
+    s->p_off = gl;
+    s->np = n_slab;
+    // ---- D. ghost particles: my first/last plane -> neighbours; theirs into the gaps the scan left ------
+    const long n_slo = s->h_small[5] - s->h_small[4], n_shi = s->h_small[7] - s->h_small[6];
+    if (n_slo > s->mig_cap || n_shi > s->mig_cap || gl > s->mig_cap || gr > s->mig_cap)
+        return fail(FLUID_ERR_STATE, "ghost particle buffer overflow");
+    launch_pack_records(s->st, n_slo, s->pa, s->h_small[4], s->mig_lo);
+    launch_pack_records(s->st, n_shi, s->pa, s->h_small[6], s->mig_hi);
+    HIPCHK(hipGetLastError());
+    if ((rc = comm_sendrecv(s, s->mig_lo, (size_t)n_slo * 56, s->mig_rlo, (size_t)gl * 56, s->mig_hi, (size_t)n_shi * 56, s->mig_rhi, (size_t)gr * 56))) return rc;
+    launch_unpack_records(s->st, gl, s->mig_rlo, s->pa, 0);
+    launch_unpack_records(s->st, gr, s->mig_rhi, s->pa, s->h_small[7]);
+    HIPCHK(hipGetLastError());
+    prof_end(s, FLUID_PROF_SORT, tok);
+    s->sorted = true;
+    return FLUID_OK;
+}
+
+template <typename T>
+static int dist_solve_impl(fluid_sim* s)
+{
+    const Grid g = s->g;
+    const LBox L = s->L;
+    T* X = (T*)s->X;
+    T* R = (T*)s->R;
+    T* Q = (T*)s->Q;
+    T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
+    const uint8_t* cnt = s->cntL;
+    const Coef<T> cf = make_coef<T>(s);
+    const double tol = s->prm.cg_tol;
+    long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
+    if (max_it < 1) max_it = 1;
+    const size_t plane = (size_t)L.Ly * L.Lz * sizeof(T);
+    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L);
+    int rc;
+    auto ring = [&](T* S) -> int {
+        char* b = (char*)S;
+        if (L.nx > 0) return comm_sendrecv(s, b + plane, plane, b, plane, b + (size_t)L.nx * plane, plane, b + (size_t)(L.nx + 1) * plane, plane);
+        return comm_sendrecv(s, s->zplane, plane, s->splane, plane, s->zplane, plane, (char*)s->splane + plane, plane);
+    };
+    const double cells = (double)s->Rr.cells();
+    int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
+    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
+    launch_sum2(s->st, s->part_bb, nxr, s->part_rz[0], nxr, s->gstage[1], s->gstage[1] + 1);
+    if ((rc = comm_allreduce(s, s->gstage[1], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+    long it = 0;
+    const int CHECK = 16;
+    bool done = false;
+    while (!done) {
+        for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
+            const int cur = (int)(it & 1), prv = cur ^ 1;
+            // stage[prv] = [|r|^2, r.z] of the previous body (or of the start); stage[cur][1] = the r.z before that
+            int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
+            launch_pcg_s<T>(s->st, L, cnt, R, Sx[prv], Sx[cur], cf, s->gstage[prv], s->gstage[prv] + 1, s->gstage[cur] + 1, s->ps, it == 0, tol);
+            if ((rc = ring(Sx[cur]))) return rc;
+            launch_pcg_q<T>(s->st, L, cnt, Sx[cur], Q, cf, s->part_pq, s->ps);
+            prof_end(s, FLUID_PROF_PCG_SQ, tok);
+            launch_sum2(s->st, s->part_pq, nsq, s->part_pq, 0, s->gpq, nullptr);
+            if ((rc = comm_allreduce(s, s->gpq, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
+            launch_pcg_xr_g<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->gstage[prv] + 1, s->gpq, s->part_rr, s->part_rz[0], s->ps);
+            prof_end(s, FLUID_PROF_PCG_XR, tok);
+            launch_sum2(s->st, s->part_rr, nxr, s->part_rz[0], nxr, s->gstage[cur], s->gstage[cur] + 1);
+            if ((rc = comm_allreduce(s, s->gstage[cur], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+        }
+        HIPCHK(hipGetLastError());
+        // every rank must leave the loop at the same iteration: agree on the flag
+        if ((rc = comm_allreduce(s, &s->ps->done, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
+        HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        done = s->h_ps->done || it >= max_it;
+    }
+    int iters = s->h_ps->iters;
+    const double rr = s->h_ps->rr;
+    if (!s->h_ps->done) iters = (int)max_it;
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    HIPCHK(hipGetLastError());
+    prof_end(s, FLUID_PROF_SOLVE, tsolve);
+    s->stats.cg_iters_last = iters;
+    s->stats.cg_iters += iters;
+    s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
+    if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
+    return FLUID_OK;
+}
+
+static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
+{
+    const Grid g = s->g;
+    const int N = g.N;
+    const long n2 = (long)N * N;
+    int rc;
+    HIPCHK(hipSetDevice(s->prm.device));
+    // ---- sort + migration + ghosts; P2G on my slab (fluid.cc:1378-1413) ---------------------------------
+    if ((rc = dist_sort(s))) return rc;
+    if ((rc = clear_dirty(s))) return rc;
+    memset(&s->stats, 0, sizeof(s->stats));
+    s->stats.dt_in = s->dt;
+    s->stats.dt_out = s->dt;
+    for (int a = 0; a < 3; ++a) {
+        s->stats.box_lo[a] = (&s->Rb.x0)[a];
+        s->stats.box_hi[a] = (&s->Rb.x1)[a];
+    }
+    s->dirty_x0 = s->xs > 0 ? s->xs - 1 : 0;
+    s->dirty_x1 = s->xe < N ? s->xe : N - 1;
+    if (!box_empty(s->Rb) && !box_empty(s->Rr)) {
+        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
+        launch_p2g(s->st, g, s->Rr, s->pa, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        prof_end(s, FLUID_PROF_P2G, tok);
+        HIPCHK(hipGetLastError());
+    }
+    // halo planes of container and velocity (velBeforeUpdate = the same values)
+    if ((rc = exchange_planes(s, s->container, 4))) return rc;
+    double* vf[3] = {s->u, s->v, s->w};
+    double* vbf[3] = {s->ub, s->vb, s->wb};
+    for (int a = 0; a < 3; ++a) {
+        if ((rc = exchange_planes(s, vf[a], 8))) return rc;
+        if (s->xs > 0) HIPCHK(hipMemcpyAsync(vbf[a] + (long)(s->xs - 1) * n2, vf[a] + (long)(s->xs - 1) * n2, n2 * 8, hipMemcpyDeviceToDevice, s->st));
+        if (s->xe < N) HIPCHK(hipMemcpyAsync(vbf[a] + (long)s->xe * n2, vf[a] + (long)s->xe * n2, n2 * 8, hipMemcpyDeviceToDevice, s->st));
+    }
+    // ---- flags on my slab + halo planes; unknown numbering with the lower ranks' offset (:1416-1433) ----
+    const int fx0 = s->xs > 0 ? s->xs - 1 : 0, fx1 = s->xe < N ? s->xe : N - 1;
+    launch_flags(s->st, g, s->solid, s->container, s->flags, fx0, fx1);
+    launch_index_scan_range(s->st, g, s->flags, s->indices, s->scan_sums, &s->ss->num_active, s->xs, s->xe - 1);
+    HIPCHK(hipGetLastError());
+    {
+        // all-gather of the per-rank counts as an all-reduce of a one-hot vector
+        HIPCHK(hipMemsetAsync(s->d_small + 16, 0, 16 * sizeof(int), s->st));
+        HIPCHK(hipMemcpyAsync(s->d_small + 16 + s->comm.rank, &s->ss->num_active, sizeof(int), hipMemcpyDeviceToDevice, s->st));
+        if ((rc = comm_allreduce(s, s->d_small + 16, s->comm.size, FLUID_DT_I32, FLUID_OP_SUM))) return rc;
+        if ((rc = read_ints(s, s->d_small + 16, s->comm.size, s->h_small + 16))) return rc;
+        HIPCHK(hipStreamSynchronize(s->st));
+        long off = 0, tot = 0;
+        for (int r = 0; r < s->comm.size; ++r) {
+            if (r < s->comm.rank) off += s->h_small[16 + r];
+            tot += s->h_small[16 + r];
+        }
+        launch_add_offset(s->st, s->indices + (long)s->xs * n2, (long)(s->xe - s->xs) * n2, (int)off);
+        s->stats.num_active = tot;
+    }
+    // local solver layout: my part of the active box in x, the GLOBAL active extent in y and z
+    if (!box_empty(s->Rb)) {
+        s->L = make_lbox(s->Rr);
+        launch_cnt_local(s->st, g, s->L, s->flags, s->cntL);
+        const size_t lb = s->L.cells() * solver_elem(s);
+        HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
+        HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
+        HIPCHK(hipGetLastError());
+    }
+    s->have_p2g = s->have_flags = true;
+    // ---- pressure do..while (:1457-1484) ------------------------------------------------------------------
+    double error = NAN;
+    do {
+        const double dt = s->dt;
+        if (!box_empty(s->Rb)) {
+            if (!box_empty(s->Rr))
+                launch_rhs_div(s->st, g, s->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver, s->prm.dx, s->prm.gravity[0] * dt,
+                               s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);
+            rc = s->prm.precision == FLUID_PRECISION_FP32 ? dist_solve_impl<float>(s) : dist_solve_impl<double>(s);
+            if (rc) return rc;
+            if ((rc = exchange_planes(s, s->pressure, 8))) return rc;
+            const double dtp = dt * s->prm.update_frac, k = dtp / (s->prm.rho * s->prm.dx);
+            if (!box_empty(s->Sr))
+                launch_vel_update(s->st, g, s->Sr, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,
+                                  s->prm.gravity[2] * dtp);
+            for (int a = 0; a < 3; ++a)
+                if ((rc = exchange_planes(s, vf[a], 8))) return rc;
+            if (!box_empty(s->Rr)) {
+                launch_rhs_div(s->st, g, s->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver2, s->prm.dx, s->prm.gravity[0] * dt,
+                               s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);
+                launch_err_norm(s->st, g, s->Rr, s->flags, s->diver, s->diver2, s->part_err, s->ss);
+            } else {
+                HIPCHK(hipMemsetAsync(&s->ss->err_num, 0, 2 * sizeof(double), s->st));
+            }
+            HIPCHK(hipGetLastError());
+            if ((rc = comm_allreduce(s, &s->ss->err_num, 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            if ((rc = read_ss(s))) return rc;
+            error = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);
+        }
+        s->stats.error = error;
+        s->stats.outer_passes++;
+        if (s->prm.max_outer_passes > 0 && s->stats.outer_passes >= s->prm.max_outer_passes) break;
+    } while (error > s->prm.outer_tol);
+    // ---- FLIP gather + advect (:1490) ---------------------------------------------------------------------
+    if (!box_empty(s->Rb) && !box_empty(s->Rr))
+        launch_flip_delta(s->st, g, s->Rr, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz);
+    double* dcf[3] = {s->dcx, s->dcy, s->dcz};
+    for (int a = 0; a < 3; ++a)
+        if ((rc = exchange_planes(s, dcf[a], 8))) return rc;
+    int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
+    launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->ss);
+    prof_end(s, FLUID_PROF_G2P, tok);
+    HIPCHK(hipGetLastError());
+    // non-negative doubles order like their bit patterns: MAX over int64
+    if ((rc = comm_allreduce(s, &s->ss->max_speed_bits, 1, FLUID_DT_I64, FLUID_OP_MAX))) return rc;
+    launch_advect(s->st, g, s->np, s->pa.shifted(s->p_off), s->flags, s->prm.max_dt, s->prm.dx, s->ss);
+    HIPCHK(hipGetLastError());
+    if ((rc = read_ss(s))) return rc;
+    s->dt = s->h_ss->dt;
+    double ms;
+    memcpy(&ms, &s->h_ss->max_speed_bits, sizeof(double));
+    s->stats.max_speed = ms;
+    s->stats.dt_out = s->dt;
+    s->sorted = false;
+    s->have_p2g = false;
+    if (stats) *stats = s->stats;
+    return FLUID_OK;
+}
+
+extern "C" {
+
+int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const int32_t* bounds, fluid_sim_t** out)
+{
+    if (!p || !comm || !bounds || !out) return fail(FLUID_ERR_ARG, "null argument");
+    if (comm->size < 1 || comm->size > 16 || comm->rank < 0 || comm->rank >= comm->size) return fail(FLUID_ERR_ARG, "bad rank/size (max 16 ranks)");
+    if (!comm->sendrecv || !comm->allreduce) return fail(FLUID_ERR_ARG, "comm callbacks missing");
+    if (bounds[0] != 0 || bounds[comm->size] != p->n) return fail(FLUID_ERR_ARG, "bounds must start at 0 and end at n");
+    for (int r = 0; r < comm->size; ++r)
+        if (bounds[r + 1] <= bounds[r]) return fail(FLUID_ERR_ARG, "every rank needs at least one x plane");
+    int rc = fluid_create(p, out);
+    if (rc) return rc;
+    fluid_sim* s = *out;
+    s->dist = true;
+    s->comm = *comm;
+    s->bounds.assign(bounds, bounds + comm->size + 1);
+    s->xs = bounds[comm->rank];
+    s->xe = bounds[comm->rank + 1];
+    auto bail = [&](const std::string& m) { fluid_destroy(s); *out = nullptr; return fail(FLUID_ERR_HIP, m); };
+    if (dalloc(&s->gstage[0], (size_t)2) != hipSuccess || dalloc(&s->gstage[1], (size_t)2) != hipSuccess || dalloc(&s->gpq, (size_t)1) != hipSuccess)
+        return bail("alloc of reduction scalars failed");
+    const LBox Lm = make_lbox(Box{0, 0, 0, p->n - 1, p->n - 1, p->n - 1});
+    const size_t plane = (size_t)Lm.Ly * Lm.Lz * 8;
+    if (dalloc((char**)&s->zplane, plane) != hipSuccess || dalloc((char**)&s->splane, 2 * plane) != hipSuccess) return bail("alloc of ring planes failed");
+    if (hipDeviceSynchronize() != hipSuccess) return bail("device sync failed");
+    return FLUID_OK;
+}
+
+int fluid_upload_particles_ids(fluid_sim_t* s, int64_t n, const double* pos, const double* vel, const uint32_t* ids)
+{
+    if (!s || n < 0 || (n > 0 && (!pos || !ids))) return fail(FLUID_ERR_ARG, "bad particle arguments");
+    HIPCHK(hipSetDevice(s->prm.device));
+    // room for ghosts and for particles that migrate in later (slabs re-balance as the fluid spreads)
+    const long cap = 4 * (long)n + (1L << 20);
+    int rc = alloc_particles(s, cap);
+    if (rc) return rc;
+    if (s->dist && !s->mig_lo) {
+        s->mig_cap = cap / 4 + (1L << 16);
+        HIPCHK(dalloc(&s->mig_lo, (size_t)s->mig_cap * 7)); HIPCHK(dalloc(&s->mig_hi, (size_t)s->mig_cap * 7));
+        HIPCHK(dalloc(&s->mig_rlo, (size_t)s->mig_cap * 7)); HIPCHK(dalloc(&s->mig_rhi, (size_t)s->mig_cap * 7));
+        HIPCHK(hipDeviceSynchronize());
+    }
+    s->np = (long)n;
+    s->p_off = 0;
+    if (n > 0) {
+        uint32_t* dids = (uint32_t*)s->order;  // staging: order[] is free between steps
+        HIPCHK(hipMemcpyAsync(s->stage_pos, pos, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
+        if (vel) HIPCHK(hipMemcpyAsync(s->stage_vel, vel, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
+        HIPCHK(hipMemcpyAsync(dids, ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
+        launch_unpack_ids(s->st, s->np, s->stage_pos, vel ? s->stage_vel : nullptr, dids, s->pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->st));
+    }
+    s->sorted = s->have_p2g = s->have_flags = false;
+    return FLUID_OK;
+}
+
+int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, uint32_t* ids)
+{
+    if (!s) return -1;
+    if (!pos || !vel || !ids) return s->np;
+    if (s->np == 0) return 0;
+    if (hipSetDevice(s->prm.device) != hipSuccess) return -1;
+    uint32_t* dids = (uint32_t*)s->order;
+    launch_pack_ids(s->st, s->np, s->pa, s->p_off, s->stage_pos, s->stage_vel, dids);
+    if (hipMemcpyAsync(pos, s->stage_pos, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(vel, s->stage_vel, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(ids, dids, s->np * sizeof(uint32_t), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s->st) != hipSuccess) return -1;
+    return s->np;
+}
+
+int fluid_partition_by_count(int32_t n, int64_t np, const double* pos, int32_t size, int32_t* bounds)
+{
+    if (n < 8 || size < 1 || !bounds || (np > 0 && !pos)) return fail(FLUID_ERR_ARG, "bad argument");
+    if (size > n) return fail(FLUID_ERR_ARG, "more ranks than x planes");
+    const int lo = -(n / 2);
+    std::vector<int64_t> hist(n, 0);
+    for (int64_t i = 0; i < np; ++i) {
+        long bx = std::lround(pos[3 * i]) - lo;  // C round(): half away from zero, like the base cell (fluid.cc:267)
+        if (bx < 0) bx = 0;
+        if (bx > n - 1) bx = n - 1;
+        hist[bx]++;
+    }
+    bounds[0] = 0;
+    int64_t acc = 0;
+    int x = 0;
+    for (int r = 1; r < size; ++r) {
+        const int64_t target = np * r / size;
+        while (x < n && acc + hist[x] <= target) acc += hist[x++];
+        int b = x;
+        if (b <= bounds[r - 1]) b = bounds[r - 1] + 1;          // at least one plane per rank
+        if (b > n - (size - r)) b = n - (size - r);             // leave planes for the ranks above
+        while (x < b) acc += hist[x++];
+        bounds[r] = b;
+    }
+    bounds[size] = n;
     return FLUID_OK;
 }
 

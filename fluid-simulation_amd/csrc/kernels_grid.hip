@@ -121,11 +121,10 @@ void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indice
 //            fluid.cc:328-372 for the + side, 378-405 and 334/349/365 for the - side; an
 //            off-grid neighbour reads background 0 = not solid)
 __global__ __launch_bounds__(256) void k_flags(Grid g, const uint8_t* __restrict__ solid, const float* __restrict__ container,
-                                               uint8_t* __restrict__ flags)
+                                               uint8_t* __restrict__ flags, long c_begin, long c_end)
 {
-    const long ncell = (long)g.N * g.N * g.N;
-    long c = (long)blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncell) return;
+    long c = c_begin + (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= c_end) return;
     const int N = g.N;
     const int iz = (int)(c % N), iy = (int)((c / N) % N), ix = (int)(c / ((long)N * N));
     const uint8_t sol = solid[c] ? F_SOLID : 0;
@@ -143,10 +142,29 @@ __global__ __launch_bounds__(256) void k_flags(Grid g, const uint8_t* __restrict
     flags[c] = f;
 }
 
-void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags)
+// x planes [x0, x1] (inclusive); the whole grid for x0=0, x1=N-1
+void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags, int x0, int x1)
 {
-    const long ncell = (long)g.N * g.N * g.N;
-    hipLaunchKernelGGL(k_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, g, solid, container, flags);
+    const long n2 = (long)g.N * g.N, c0 = (long)x0 * n2, c1 = (long)(x1 + 1) * n2;
+    if (c1 <= c0) return;
+    hipLaunchKernelGGL(k_flags, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, st, g, solid, container, flags, c0, c1);
+}
+
+// multi-GPU: unknown numbering of a slab = local running count + number of unknowns on lower ranks
+__global__ __launch_bounds__(256) void k_add_offset(int* __restrict__ idx, long n, int off)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && idx[i] >= 0) idx[i] += off;
+}
+void launch_index_scan_range(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total, int x0, int x1)
+{
+    const long n2 = (long)g.N * g.N;
+    if (x1 < x0) return;
+    scan_impl<1>(st, flags + (long)x0 * n2, indices + (long)x0 * n2, (long)(x1 - x0 + 1) * n2, block_sums, total);
+}
+void launch_add_offset(hipStream_t st, int* idx, long n, int off)
+{
+    if (n > 0 && off) hipLaunchKernelGGL(k_add_offset, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, n, off);
 }
 
 // ---- box helpers -----------------------------------------------------------------------------

@@ -24,13 +24,15 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
         int bx = (int)round(p.px[i]) - g.lo, by = (int)round(p.py[i]) - g.lo, bz = (int)round(p.pz[i]) - g.lo;
         bool in = bx >= 0 && bx < g.N && by >= 0 && by < g.N && bz >= 0 && bz < g.N;
         int k = in ? (int)g.idx(bx, by, bz) : (int)ncell;
+        const bool dead = p.pid[i] == PID_DEAD;  // migrated to a neighbour rank: last bucket, dropped after the sort
+        if (dead) { k = (int)ncell + 1; in = false; }
         key[i] = k;
         slot[i] = atomicAdd(&cell_count[k], 1);
         if (in) {
             mn[0] = bx < mn[0] ? bx : mn[0]; mx[0] = bx > mx[0] ? bx : mx[0];
             mn[1] = by < mn[1] ? by : mn[1]; mx[1] = by > mx[1] ? by : mx[1];
             mn[2] = bz < mn[2] ? bz : mn[2]; mx[2] = bz > mx[2] ? bz : mx[2];
-        } else {
+        } else if (!dead) {
             nout++;
         }
     }
@@ -323,6 +325,73 @@ __global__ void k_publish_dt(double max_dt, double dx, StepState* ss)
     ss->dt = (maxSpeed != 0) ? (max_dt < dx / maxSpeed ? max_dt : dx / maxSpeed) : max_dt;
 }
 
+// ---- multi-GPU: neighbour migration and ghost particles ------------------------------------------
+// A particle whose base cell x left the slab [xs,xe) after advect is appended (7 doubles: pos,
+// vel, id) to the send buffer of that side and marked dead; CFL <= 1 cell/step keeps migrants
+// adjacent, and most waves have none, so the append atomics are rare.
+__global__ __launch_bounds__(256) void k_classify_migrate(Grid g, long n, Particles p, int xs, int xe, int has_lo, int has_hi,
+                                                          double* __restrict__ send_lo, double* __restrict__ send_hi, int cap,
+                                                          int* __restrict__ counters)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (p.pid[i] == PID_DEAD) return;
+    const int bx = (int)round(p.px[i]) - g.lo;
+    int side = -1;
+    if (bx < xs && has_lo) side = 0;
+    else if (bx >= xe && has_hi) side = 1;
+    if (side < 0) return;
+    const int k = atomicAdd(&counters[side], 1);
+    if (k < cap) {
+        double* d = (side ? send_hi : send_lo) + (size_t)k * 7;
+        d[0] = p.px[i]; d[1] = p.py[i]; d[2] = p.pz[i];
+        d[3] = p.vx[i]; d[4] = p.vy[i]; d[5] = p.vz[i];
+        d[6] = (double)p.pid[i];
+    }
+    p.pid[i] = PID_DEAD;  // (on overflow the host reports the error; the count tells)
+}
+
+// records (7 doubles) -> SoA at p[off + j]
+__global__ __launch_bounds__(256) void k_unpack_records(long n, const double* __restrict__ rec, Particles p, long off)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const double* d = rec + (size_t)j * 7;
+    p.px[off + j] = d[0]; p.py[off + j] = d[1]; p.pz[off + j] = d[2];
+    p.vx[off + j] = d[3]; p.vy[off + j] = d[4]; p.vz[off + j] = d[5];
+    p.pid[off + j] = (uint32_t)d[6];
+}
+// SoA p[off + j] -> records (7 doubles); ghosts of a boundary plane are one contiguous sorted range
+__global__ __launch_bounds__(256) void k_pack_records(long n, Particles p, long off, double* __restrict__ rec)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double* d = rec + (size_t)j * 7;
+    d[0] = p.px[off + j]; d[1] = p.py[off + j]; d[2] = p.pz[off + j];
+    d[3] = p.vx[off + j]; d[4] = p.vy[off + j]; d[5] = p.vz[off + j];
+    d[6] = (double)p.pid[off + j];
+}
+__global__ __launch_bounds__(256) void k_unpack_ids(long n, const double* __restrict__ pos, const double* __restrict__ vel,
+                                                    const uint32_t* __restrict__ ids, Particles p)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    p.px[j] = pos[3 * j]; p.py[j] = pos[3 * j + 1]; p.pz[j] = pos[3 * j + 2];
+    if (vel) { p.vx[j] = vel[3 * j]; p.vy[j] = vel[3 * j + 1]; p.vz[j] = vel[3 * j + 2]; }
+    else { p.vx[j] = 0; p.vy[j] = 0; p.vz[j] = 0; }
+    p.pid[j] = ids[j];
+}
+// device order (no unsort): pos/vel AoS + ids
+__global__ __launch_bounds__(256) void k_pack_ids(long n, Particles p, long off, double* __restrict__ pos, double* __restrict__ vel,
+                                                  uint32_t* __restrict__ ids)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    pos[3 * j] = p.px[off + j]; pos[3 * j + 1] = p.py[off + j]; pos[3 * j + 2] = p.pz[off + j];
+    vel[3 * j] = p.vx[off + j]; vel[3 * j + 1] = p.vy[off + j]; vel[3 * j + 2] = p.vz[off + j];
+    ids[j] = p.pid[off + j];
+}
+
 // ---- host <-> device particle layout -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack(long n, Particles p, double* __restrict__ pos, double* __restrict__ vel)
 {
@@ -378,6 +447,27 @@ void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* f
 {
     if (n > 0) hipLaunchKernelGGL(k_advect, dim3(nblk(n)), dim3(256), 0, st, g, n, p, flags, max_dt, dx, ss);
     hipLaunchKernelGGL(k_publish_dt, dim3(1), dim3(1), 0, st, max_dt, dx, ss);
+}
+void launch_classify_migrate(hipStream_t st, Grid g, long n, Particles p, int xs, int xe, int has_lo, int has_hi, double* send_lo,
+                             double* send_hi, int cap, int* counters)
+{
+    if (n > 0) hipLaunchKernelGGL(k_classify_migrate, dim3(nblk(n)), dim3(256), 0, st, g, n, p, xs, xe, has_lo, has_hi, send_lo, send_hi, cap, counters);
+}
+void launch_unpack_records(hipStream_t st, long n, const double* rec, Particles p, long off)
+{
+    if (n > 0) hipLaunchKernelGGL(k_unpack_records, dim3(nblk(n)), dim3(256), 0, st, n, rec, p, off);
+}
+void launch_pack_records(hipStream_t st, long n, Particles p, long off, double* rec)
+{
+    if (n > 0) hipLaunchKernelGGL(k_pack_records, dim3(nblk(n)), dim3(256), 0, st, n, p, off, rec);
+}
+void launch_unpack_ids(hipStream_t st, long n, const double* pos, const double* vel, const uint32_t* ids, Particles p)
+{
+    if (n > 0) hipLaunchKernelGGL(k_unpack_ids, dim3(nblk(n)), dim3(256), 0, st, n, pos, vel, ids, p);
+}
+void launch_pack_ids(hipStream_t st, long n, Particles p, long off, double* pos, double* vel, uint32_t* ids)
+{
+    if (n > 0) hipLaunchKernelGGL(k_pack_ids, dim3(nblk(n)), dim3(256), 0, st, n, p, off, pos, vel, ids);
 }
 void launch_pack_particles(hipStream_t st, long n, Particles p, double* pos_aos, double* vel_aos)
 {

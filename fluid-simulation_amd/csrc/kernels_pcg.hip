@@ -143,11 +143,46 @@ __global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_
     if (threadIdx.x == 0) { part_bb[blockIdx.x] = abb; part_rz0[blockIdx.x] = arz; }
 }
 
+// Start of a CG body (ConjugateGradient.h:45-60 for the first, :75-85 for the others): sums the
+// previous launch's partials (or reads the all-reduced scalars when n_prev == 1), decides
+// convergence identically in every block, returns beta.  false = this block must exit.
+template <typename T>
+__device__ __forceinline__ bool pcg_head(const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
+                                         const double* __restrict__ part_rz_old, int n_prev, PcgState* ps, int first, double tol,
+                                         double* red, T& beta)
+{
+    const int tid = threadIdx.x;
+    beta = 0;
+    if (first) {
+        // b == 0 -> x = 0, done.
+        double bb, d1, d2;
+        block_sum3(part_rr, n_prev, part_rr, 0, part_rr, 0, red, bb, d1, d2);
+        if (blockIdx.x == 0 && tid == 0) {
+            ps->bb = bb;
+            ps->thr = tol * tol * bb;
+            ps->rr = bb;
+            if (!(bb > 0)) ps->done = 1;
+        }
+        return bb > 0;
+    }
+    double rr, rzn, rzo;
+    block_sum3(part_rr, n_prev, part_rz_new, n_prev, part_rz_old, n_prev, red, rr, rzn, rzo);
+    if (rr < ps->thr) {  // break before i++
+        if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->done = 1; }
+        return false;
+    }
+    beta = (T)(rzn / rzo);  // :82-83
+    if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->iters += 1; }  // :85
+    return true;
+}
+
 // SQ: s' = invdiag r + beta s ; q = A s' ; partial s'.q
 // Thread (ly = tid>>5, kz = tid&31) owns the x-column lx = -1..TX of its (y,z): the x
 // neighbours stay in registers, y/z neighbours go through LDS.  All global loads of the tile
 // are issued BEFORE the partial-sum reduction that yields beta, so both latencies overlap.
-template <typename T>
+// FUSED = false (multi-GPU): s' was formed by k_pcg_s_l and its x ring planes were received from
+// the neighbour ranks; this kernel then only applies the stencil and forms the partial s'.q.
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
                                                   const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
@@ -180,18 +215,18 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
 #pragma unroll
         for (int m = 0; m < TX + 2; ++m) {
             fc[m] = cnt[c0 + m * sx];
-            rv[m] = r[c0 + m * sx];
-            sv[m] = first ? (T)0 : s_in[c0 + m * sx];
+            rv[m] = FUSED ? r[c0 + m * sx] : (T)0;
+            sv[m] = (FUSED && first) ? (T)0 : s_in[c0 + m * sx];
         }
         {   // y halo: one cell per thread
             const int pl = tid >> 6, side = (tid >> 5) & 1;
             const long cy = ((long)(i0 + pl) * L.Ly + (side ? j0 + TY : j0 - 1)) * L.Lz + k0 + kz;
-            fy = cnt[cy]; ry = r[cy]; sy = first ? (T)0 : s_in[cy];
+            fy = cnt[cy]; ry = FUSED ? r[cy] : (T)0; sy = (FUSED && first) ? (T)0 : s_in[cy];
         }
         if (tid < 64) {  // z halo: 64 cells
             const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
             const long cz = ((long)(i0 + lx) * L.Ly + (j0 + l2)) * L.Lz + (side ? k0 + TZ : k0 - 1);
-            fz = cnt[cz]; rz = r[cz]; sz = first ? (T)0 : s_in[cz];
+            fz = cnt[cz]; rz = FUSED ? r[cz] : (T)0; sz = (FUSED && first) ? (T)0 : s_in[cz];
         }
     };
     if (tile < ntiles) issue(tile);
@@ -200,26 +235,8 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     T beta = 0;
     __syncthreads();  // s_done, coef tables
     if (s_done) return;
-    if (first) {
-        // ConjugateGradient.h:45-60: b == 0 -> x = 0, done.
-        double bb, d1, d2;
-        block_sum3(part_rr, n_prev, part_rr, 0, part_rr, 0, red, bb, d1, d2);
-        if (blockIdx.x == 0 && tid == 0) {
-            ps->bb = bb;
-            ps->thr = tol * tol * bb;
-            ps->rr = bb;
-            if (!(bb > 0)) ps->done = 1;
-        }
-        if (!(bb > 0)) return;
-    } else {
-        double rr, rzn, rzo;
-        block_sum3(part_rr, n_prev, part_rz_new, n_prev, part_rz_old, n_prev, red, rr, rzn, rzo);
-        if (rr < ps->thr) {  // ConjugateGradient.h:75-77: break before i++
-            if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->done = 1; }
-            return;
-        }
-        beta = (T)(rzn / rzo);  // :82-83
-        if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->iters += 1; }  // :85
+    if (FUSED) {
+        if (!pcg_head<T>(part_rr, part_rz_new, part_rz_old, n_prev, ps, first, tol, red, beta)) return;
     }
 
     double acc = 0;
@@ -227,16 +244,16 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
         // ---- combine -> LDS ---------------------------------------------------------------------
         T val[TX + 2];
 #pragma unroll
-        for (int m = 0; m < TX + 2; ++m) val[m] = fc[m] ? rv[m] * sinv[fc[m]] + beta * sv[m] : (T)0;
+        for (int m = 0; m < TX + 2; ++m) val[m] = FUSED ? (fc[m] ? rv[m] * sinv[fc[m]] + beta * sv[m] : (T)0) : sv[m];
 #pragma unroll
         for (int lx = 0; lx < TX; ++lx) sT[(lx * PY + ly + 1) * PZ + kz + 1] = val[lx + 1];
         {
             const int pl = tid >> 6, side = (tid >> 5) & 1;
-            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = fy ? ry * sinv[fy] + beta * sy : (T)0;
+            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = FUSED ? (fy ? ry * sinv[fy] + beta * sy : (T)0) : sy;
         }
         if (tid < 64) {
             const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
-            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = fz ? rz * sinv[fz] + beta * sz : (T)0;
+            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = FUSED ? (fz ? rz * sinv[fz] + beta * sz : (T)0) : sz;
         }
         __syncthreads();
         const long cc = c0;
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
                 qv = sdiag[fcc[lx]] * cen[lx] + cf.off * nbv[lx];
                 acc += (double)cen[lx] * (double)qv;
             }
-            s_out[c] = cen[lx];
+            if (FUSED) s_out[c] = cen[lx];
             q[c] = qv;
         }
         tile = next;
@@ -269,13 +286,64 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     if (tid == 0) part_pq[blockIdx.x] = acc;
 }
 
-// XR: alpha, x += alpha s, r -= alpha q, partial |r|^2 and r.(invdiag r)   (ConjugateGradient.h:70-74,79-81)
-// Flat stream over the local box, two cells (16 bytes) per lane per access, 4 accesses in flight.
+// S (multi-GPU): s' = invdiag r + beta s, pointwise over the local box (flat, 16-byte vectors).
 template <typename T>
 struct alignas(2 * sizeof(T)) Vec2 {
     T a, b;
 };
 
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_s_l(long n2, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
+                                                 const T* __restrict__ s_in, T* __restrict__ s_out, Coef<T> cf,
+                                                 const double* __restrict__ g_rr, const double* __restrict__ g_rz_new,
+                                                 const double* __restrict__ g_rz_old, PcgState* ps, int first, double tol)
+{
+    __shared__ double red[16];
+    __shared__ int s_done;
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    if (threadIdx.x == 0) s_done = ps->done;
+    __syncthreads();
+    if (s_done) return;
+    T beta;
+    if (!pcg_head<T>(g_rr, g_rz_new, g_rz_old, 1, ps, first, tol, red, beta)) return;
+    typedef Vec2<T> V2;
+    const V2* r2 = (const V2*)r;
+    const V2* s2 = (const V2*)s_in;
+    const uint16_t* c2 = (const uint16_t*)cnt;
+    const long nth = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n2; e += nth) {
+        const uint16_t c = c2[e];
+        const int ca = c & 0xff, cb = c >> 8;
+        V2 o;
+        o.a = 0; o.b = 0;
+        if (c) {
+            const V2 rv = r2[e];
+            V2 sv;
+            sv.a = 0; sv.b = 0;
+            if (!first) sv = s2[e];
+            if (ca) o.a = rv.a * sinv[ca] + beta * sv.a;
+            if (cb) o.b = rv.b * sinv[cb] + beta * sv.b;
+        }
+        ((V2*)s_out)[e] = o;
+    }
+}
+
+// out_a[0] = sum a[0..na), out_b[0] = sum b[0..nb)   (one block; fixed order)
+__global__ __launch_bounds__(256) void k_sum2(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
+                                              double* __restrict__ out_a, double* __restrict__ out_b)
+{
+    __shared__ double red[16];
+    double ra, rb, rc;
+    block_sum3(a, na, b, nb, b, 0, red, ra, rb, rc);
+    if (threadIdx.x == 0) {
+        out_a[0] = ra;
+        if (out_b) out_b[0] = rb;
+    }
+}
+
+// XR: alpha, x += alpha s, r -= alpha q, partial |r|^2 and r.(invdiag r)   (ConjugateGradient.h:70-74,79-81)
+// Flat stream over the local box, two cells (16 bytes) per lane per access, 4 accesses in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r,
                                                   const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
@@ -376,8 +444,33 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
                    double tol)
 {
-    hipLaunchKernelGGL((k_pcg_sq_l<T>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr, part_rz_new,
-                       part_rz_old, part_pq, pcg_xr_blocks(L), ps, first, tol);
+    hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
+                       part_rz_new, part_rz_old, part_pq, pcg_xr_blocks(L), ps, first, tol);
+}
+// multi-GPU pieces: n_* = 1 means "already all-reduced scalar"
+template <typename T>
+void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
+                  const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol)
+{
+    hipLaunchKernelGGL((k_pcg_s_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, r, s_in, s_out, cf, g_rr,
+                       g_rz_new, g_rz_old, ps, first, tol);
+}
+template <typename T>
+void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps)
+{
+    hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, (const T*)nullptr, s, (T*)nullptr, q, cf,
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0);
+}
+template <typename T>
+void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
+                     const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps)
+{
+    hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, g_rz_cur, 1,
+                       g_pq, 1, part_rr, part_rz_next, ps);
+}
+void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b)
+{
+    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, st, a, na, b, nb, out_a, out_b);
 }
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
@@ -632,7 +725,12 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
                                    double*, double*, PcgState*);                                                                       \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
-    template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);
+    template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);                                \
+    template void launch_pcg_s<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, Coef<T>, const double*, const double*,     \
+                                  const double*, PcgState*, int, double);                                                              \
+    template void launch_pcg_q<T>(hipStream_t, LBox, const uint8_t*, const T*, T*, Coef<T>, double*, PcgState*);                        \
+    template void launch_pcg_xr_g<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,             \
+                                     const double*, double*, double*, PcgState*);
 INST(double)
 INST(float)
 

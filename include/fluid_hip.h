@@ -162,6 +162,47 @@ int fluid_profile_enable(fluid_sim_t* s, int sample_every);
 int fluid_profile_read(fluid_sim_t* s, int klass, int64_t* n_launches, int64_t* n_sampled, double* total_ms, double* cells);
 int fluid_profile_reset(fluid_sim_t* s);
 
+/* ---- multi-GPU: x-slab domain decomposition (one process per GPU) ------------------------- */
+/* The reference is single-process (no communication backend); this is new design.
+ * Rank r owns the x planes [bounds[r], bounds[r+1]); every rank keeps full-size field arrays and
+ * computes only its slab (+1-plane halos at their global index).  Exchanges per step: ghost
+ * particles and cell counts of the boundary planes (P2G), boundary planes of container/velocity/
+ * pressure/FLIP-delta, per PCG iteration one plane of the search vector each way plus two
+ * scalar all-reduces, max-speed all-reduce, neighbour particle migration.
+ *
+ * Transport is supplied by the caller (RCCL through torch.distributed in bench.py; gloo in the
+ * tests; a C++ host would pass ncclSend/ncclRecv/ncclAllReduce wrappers).  All pointers are
+ * DEVICE pointers; calls must be ordered after prior work on `stream` and complete (or be
+ * stream-ordered) before later work on it.  Return 0 on success. */
+#define FLUID_DT_F64 0
+#define FLUID_DT_I32 1
+#define FLUID_DT_I64 2
+#define FLUID_OP_SUM 0
+#define FLUID_OP_MAX 1
+#define FLUID_OP_MIN 2
+typedef struct fluid_comm {
+    int32_t rank, size;
+    void* ctx;
+    /* Send send_lo[0..nlo_send) bytes to rank-1 and send_hi to rank+1; receive nlo_recv bytes from
+     * rank-1 into recv_lo and nhi_recv bytes from rank+1 into recv_hi.  A missing neighbour
+     * (rank 0 / size-1) has its sizes passed as 0.  Sizes are known to both sides. */
+    int (*sendrecv)(void* ctx, const void* send_lo, size_t nlo_send, void* recv_lo, size_t nlo_recv,
+                    const void* send_hi, size_t nhi_send, void* recv_hi, size_t nhi_recv, void* stream);
+    /* In-place all-reduce of `count` elements of dtype FLUID_DT_* with FLUID_OP_*. */
+    int (*allreduce)(void* ctx, void* buf, int32_t count, int32_t dtype, int32_t op, void* stream);
+} fluid_comm_t;
+
+/* Like fluid_create, for rank comm->rank of comm->size.  bounds[size+1]: bounds[0]=0,
+ * bounds[size]=n, strictly increasing (every slab >= 1 plane; >= 3 recommended). */
+int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const int32_t* bounds, fluid_sim_t** out);
+/* Upload THIS rank's particles (base cell x inside its slab) with their global ids (unique
+ * across ranks; the order of fluid_download_particles_ids is the device order). */
+int fluid_upload_particles_ids(fluid_sim_t* s, int64_t n, const double* pos, const double* vel, const uint32_t* ids);
+/* This rank's current particles and ids; call with NULLs to get the count. */
+int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, uint32_t* ids);
+/* Equal-count split of the x planes for `size` ranks from a host particle set (host-only). */
+int fluid_partition_by_count(int32_t n, int64_t np, const double* pos, int32_t size, int32_t* bounds);
+
 #ifdef __cplusplus
 }
 #endif
