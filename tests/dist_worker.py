@@ -1,7 +1,7 @@
 """Worker of the multi-process tests: one rank of an x-slab decomposed run.
 
   python -m torch.distributed.run --nproc-per-node P --master-addr 127.0.0.1 --master-port PORT \
-      tests/dist_worker.py --n 32 --ppc 4 --steps 3 --mode staged --out /tmp/x.npz
+      tests/dist_worker.py --grid 32 --ppc 4 --steps 3 --mode staged --out /tmp/x.npz
 mode staged = gloo + host staging, every rank on GPU 0 (what a 1-GPU box can run);
 mode device = nccl (RCCL), one GPU per rank.
 """
@@ -20,7 +20,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=32)
+    ap.add_argument("--grid", dest="n", type=int, default=32)
     ap.add_argument("--ppc", type=int, default=4)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--mode", default="staged")

@@ -16,7 +16,7 @@ def run_dist(world, n, ppc, steps, tmp_path, extra=()):
     out = str(tmp_path / f"dist_{world}_{n}.npz")
     port = 29500 + (os.getpid() % 2000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "--n", str(n), "--ppc", str(ppc),
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "--grid", str(n), "--ppc", str(ppc),
            "--steps", str(steps), "--mode", "staged", "--out", out, *extra]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
