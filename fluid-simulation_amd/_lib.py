@@ -78,11 +78,21 @@ SYMBOLS = [
     ("fluid_profile_enable", C.c_int, [_P, C.c_int]),
     ("fluid_profile_read", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("fluid_profile_reset", C.c_int, [_P]),
+    # multi-GPU (argtypes with the comm struct are completed in dist.py)
+    ("fluid_create_dist", C.c_int, None),
+    ("fluid_upload_particles_ids", C.c_int, None),
+    ("fluid_download_particles_ids", C.c_int64, None),
+    ("fluid_partition_by_count", C.c_int, None),
+    ("fluid_rccl_unique_id", C.c_int, None),
+    ("fluid_rccl_comm_create", C.c_int, None),
+    ("fluid_rccl_comm_destroy", C.c_int, None),
+    ("fluid_rccl_last_error", C.c_char_p, None),
 ]
 for _name, _res, _args in SYMBOLS:
     _f = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
     _f.restype = _res
-    _f.argtypes = _args
+    if _args is not None:
+        _f.argtypes = _args
 
 
 def check(rc):

@@ -41,6 +41,14 @@ lib.fluid_download_particles_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
 lib.fluid_partition_by_count.restype = C.c_int
 lib.fluid_partition_by_count.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
 
+lib.fluid_rccl_unique_id.restype = C.c_int
+lib.fluid_rccl_unique_id.argtypes = [C.c_char_p, C.c_void_p]
+lib.fluid_rccl_comm_create.restype = C.c_int
+lib.fluid_rccl_comm_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(FluidComm)]
+lib.fluid_rccl_comm_destroy.restype = C.c_int
+lib.fluid_rccl_comm_destroy.argtypes = [C.POINTER(FluidComm)]
+lib.fluid_rccl_last_error.restype = C.c_char_p
+
 _DT = {0: torch.float64, 1: torch.int32, 2: torch.int64}
 _OP = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
 _ESZ = {0: 8, 1: 4, 2: 8}
@@ -160,6 +168,36 @@ class TorchComm:
         except Exception as e:
             self.error = e
             return 1
+
+
+class RcclComm:
+    """fluid_comm_t backed by RCCL inside the C++ library (no Python in the PCG loop).
+
+    The ncclUniqueId is made by rank 0 and broadcast over the existing torch.distributed group
+    (bootstrap only); RCCL itself is the librccl.so of the running PyTorch, so the process holds
+    one RCCL.  Call with the rank's GPU already current (torch.cuda.set_device)."""
+
+    def __init__(self, group=None):
+        import os
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.error = None
+        self.calls = {"sendrecv": -1, "allreduce": -1}
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.path = (path if os.path.exists(path) else "").encode()
+        idbuf = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            if lib.fluid_rccl_unique_id(self.path, idbuf) != 0:
+                raise RuntimeError("fluid_rccl_unique_id: " + lib.fluid_rccl_last_error().decode())
+        obj = [bytes(idbuf)]
+        dist.broadcast_object_list(obj, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        self.struct = FluidComm()
+        idb = (C.c_uint8 * 128).from_buffer_copy(obj[0])
+        if lib.fluid_rccl_comm_create(self.path, idb, self.rank, self.size, C.byref(self.struct)) != 0:
+            raise RuntimeError("fluid_rccl_comm_create: " + lib.fluid_rccl_last_error().decode())
+
+    def close(self):
+        lib.fluid_rccl_comm_destroy(C.byref(self.struct))
 
 
 class DistFluidSim(FluidSim):

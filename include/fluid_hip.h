@@ -192,6 +192,14 @@ typedef struct fluid_comm {
     int (*allreduce)(void* ctx, void* buf, int32_t count, int32_t dtype, int32_t op, void* stream);
 } fluid_comm_t;
 
+/* Native transport: fluid_comm_t over RCCL (ncclSend/ncclRecv/ncclAllReduce on the solver's stream).
+ * librccl_path: the librccl.so to dlopen ("" = by name); id128: ncclUniqueId made by rank 0 with
+ * fluid_rccl_unique_id and handed to the other ranks by the launcher.  Binds to the current HIP device. */
+int fluid_rccl_unique_id(const char* librccl_path, void* id128);
+int fluid_rccl_comm_create(const char* librccl_path, const void* id128, int32_t rank, int32_t size, fluid_comm_t* out);
+int fluid_rccl_comm_destroy(fluid_comm_t* comm);
+const char* fluid_rccl_last_error(void);
+
 /* Like fluid_create, for rank comm->rank of comm->size.  bounds[size+1]: bounds[0]=0,
  * bounds[size]=n, strictly increasing (every slab >= 1 plane; >= 3 recommended). */
 int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const int32_t* bounds, fluid_sim_t** out);

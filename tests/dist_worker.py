@@ -30,7 +30,7 @@ def main():
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.mode == "device":
+    if a.mode in ("device", "rccl"):
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         dev = local
@@ -47,7 +47,10 @@ def main():
         bounds = [round(a.n * r / world) for r in range(world + 1)]
     else:
         bounds = fd.partition_by_count(a.n, pos, world)
-    comm = fd.TorchComm(mode=a.mode, device=torch.device("cuda", dev))
+    if a.mode == "rccl":
+        comm = fd.RcclComm()
+    else:
+        comm = fd.TorchComm(mode=a.mode, device=torch.device("cuda", dev))
     sim = fd.DistFluidSim(a.n, bounds, comm, device=dev)
     sim.upload_global(pos, vel)
     stats = []

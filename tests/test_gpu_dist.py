@@ -12,12 +12,12 @@ from conftest import rel_l2, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def run_dist(world, n, ppc, steps, tmp_path, extra=()):
-    out = str(tmp_path / f"dist_{world}_{n}.npz")
+def run_dist(world, n, ppc, steps, tmp_path, extra=(), mode="staged"):
+    out = str(tmp_path / f"dist_{world}_{n}_{mode}.npz")
     port = 29500 + (os.getpid() % 2000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "--grid", str(n), "--ppc", str(ppc),
-           "--steps", str(steps), "--mode", "staged", "--out", out, *extra]
+           "--steps", str(steps), "--mode", mode, "--out", out, *extra]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -50,3 +50,18 @@ def test_dist_matches_single(fs, tmp_path, world, n, ppc, steps, extra):
     assert ep < 1e-9 and ev < 1e-7 and epr < 1e-8
     assert rel_l2(d["velgrid"], sim.field(F.VEL)) < 1e-8
     assert np.allclose(d["dt"], [s["dt_out"] for s in st], rtol=1e-9)
+
+
+@pytest.mark.parametrize("mode", ["rccl", "device"])
+def test_one_rank_over_rccl(fs, tmp_path, mode):
+    """World size 1 over the RCCL transports (native ncclAllReduce / torch nccl): all a 1-GPU box can run of them.
+    Exercises dlopen + ncclCommInitRank + stream-ordered all-reduces; the neighbour exchange has no peer here."""
+    n, ppc, steps = 32, 4, 3
+    d = run_dist(1, n, ppc, steps, tmp_path, mode=mode)
+    sim = fs.FluidSim(n=n)
+    sim.upload_particles(fs.water_cube_drop(n, ppc, seed=0))
+    st = [sim.step() for _ in range(steps)]
+    p, v = sim.download_particles()
+    assert list(d["num_active"]) == [s["num_active"] for s in st]
+    assert np.array_equal(d["indices"], sim.field(fs.FIELD.INDICES))
+    assert rel_l2(d["pos"], p) < 1e-9 and rel_l2(d["vel"], v) < 1e-7
