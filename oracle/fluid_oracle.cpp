@@ -685,8 +685,8 @@ int oracle_get_triplets(void* h, int* rows, int* cols, double* vals)
 {
     Oracle* o = (Oracle*)h;
     std::vector<int> tr, tc;
-    std::vector<double> tv, b;
-    setA2(*o, tr, tc, tv, b);
+    std::vector<double> tv;
+    setA2(*o, tr, tc, tv, o->b);  // also (re)fills b, as setA2 does (fluid.cc:535)
     if (rows) {
         memcpy(rows, tr.data(), tr.size() * sizeof(int));
         memcpy(cols, tc.data(), tc.size() * sizeof(int));

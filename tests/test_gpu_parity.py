@@ -223,3 +223,72 @@ def test_errors_are_loud(fs):
         sim.set_solid(bad)  # shell must stay solid
     with pytest.raises(fs.FluidError):
         fs.FluidSim(n=4)
+
+
+def test_against_committed_golden_step(fs):
+    """HIP path vs the committed fixture (made with the reference's vendored Eigen IC-PCG in the loop)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_n16.npz"))
+    sim = fs.FluidSim(n=int(gold["n"]))
+    sim.upload_particles(gold["pos0"], gold["vel0"])
+    st = sim.step()
+    F = fs.FIELD
+    assert st["num_active"] == int(gold["num_active"]) and st["outer_passes"] == int(gold["outer_passes"])
+    assert np.array_equal(sim.field(F.INDICES), gold["indices"])
+    assert rel_l2(sim.field(F.CONTAINER), gold["container"]) < TOL_W
+    assert rel_l2(sim.field(F.VEL_BEFORE), gold["vel_before"]) < 1e-6
+    assert rel_l2(sim.field(F.PRESSURE), gold["pressure"]) < TOL_F
+    assert rel_l2(sim.field(F.VEL), gold["vel_grid"]) < TOL_F
+    p, v = sim.download_particles()
+    assert rel_l2(p, gold["pos1"]) < TOL_F and rel_l2(v, gold["vel1"]) < TOL_F
+    assert abs(st["dt_out"] - float(gold["dt_out"])) <= 1e-9
+
+
+def test_against_committed_golden_trace(fs):
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trace_n24.npz"))
+    tr = gold["trace"]
+    n = int(gold["n"])
+    sim = fs.FluidSim(n=n)
+    sim.upload_particles(fs.water_cube_drop(n, int(gold["ppc"]), seed=int(gold["seed"])))
+    for i in range(len(tr)):
+        s = sim.step()
+        assert s["num_active"] == int(tr[i, 0]) and s["outer_passes"] == int(tr[i, 1]), (i, s)
+        assert abs(s["dt_out"] - tr[i, 2]) <= 1e-7 * tr[i, 2]
+    p, v = sim.download_particles()
+    ep, ev = rel_l2(p, gold["pos_final"]), rel_l2(v, gold["vel_final"])
+    print(f"40 free-running steps vs golden: pos {ep:.2e} vel {ev:.2e}")
+    assert ep < TOL_F and ev < TOL_F
+
+
+def test_round_trip_properties_at_bench_size(fs):
+    """Size-independent checks at BASELINE's 128^3 size (no oracle run): particle count and ids survive the
+    sort, the unknown numbering is a permutation-free exclusive scan, the solve meets Eigen's stopping rule,
+    and the stencil is symmetric (s.A t == t.A s) on random vectors."""
+    n = 128
+    pos = fs.water_cube_drop(n, 8, seed=0)
+    sim = fs.FluidSim(n=n)
+    sim.upload_particles(pos)
+    st = sim.step()
+    F = fs.FIELD
+    idx = sim.field(F.INDICES)
+    active = idx[idx >= 0]
+    assert st["num_active"] == active.size and np.array_equal(active, np.arange(active.size))   # x-major running count
+    assert st["relres"] < 2.3e-16 and st["outer_passes"] == 8
+    flags = sim.field(F.FLAGS)
+    assert np.array_equal((flags & 2) != 0, idx >= 0)
+    assert np.array_equal((flags & 2) != 0, (sim.field(F.CONTAINER) > 0) & ((flags & 1) == 0))
+    p, v = sim.download_particles()
+    assert p.shape == pos.shape and np.isfinite(p).all() and np.isfinite(v).all()
+    # dt rule of FLIPadvect: dt = min(0.1, dx/maxSpeed)
+    assert abs(st["dt_out"] - min(0.1, 1.0 / st["max_speed"])) < 1e-15
+    # symmetry of the operator on the active box
+    rng = np.random.default_rng(0)
+    fluid = (idx >= 0)
+    s1 = rng.standard_normal(idx.shape) * fluid
+    s2 = rng.standard_normal(idx.shape) * fluid
+    sim.upload_field(F.SEARCH, s1); sim.flags_index(); sim.upload_field(F.SEARCH, s1)
+    sim.stencil_apply(1, 2); q1 = sim.field(F.Q)
+    sim.upload_field(F.SEARCH, s2); sim.stencil_apply(1, 2); q2 = sim.field(F.Q)
+    a, b = float((s2 * q1).sum()), float((s1 * q2).sum())
+    assert abs(a - b) <= 1e-10 * max(abs(a), abs(b))
