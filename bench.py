@@ -155,8 +155,14 @@ def main():
         cells = sq["cells"] / sq["sampled"]
         algo = cells * (4 * T + 1)
         ach = algo / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+        if transport is None and n == 256 and ppc == 8 and os.path.exists(tj):
+            # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes of this same workload (see the file's "method")
+            traffic = json.load(open(tj))["kernels"]["k_pcg_sq_l<double,true>"]["bytes_per_launch"]
+            traffic_src = "profiles/r01/pmc_traffic.json"
         roof = {"bound": "hbm", "kernel": "k_pcg_sq_l<double,true> (PCG search update + 7-point apply + dot)" if transport is None else "k_pcg_s_l + ring exchange + k_pcg_sq_l<double,false>",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo,
                 "bytes_per_cell": 4 * T + 1, "cells_per_launch": cells, "avg_launch_us": avg_ms * 1e3,
                 "launches": sq["launches"], "sampled": sq["sampled"]}
 

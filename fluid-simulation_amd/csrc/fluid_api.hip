@@ -50,7 +50,8 @@ struct fluid_sim {
     size_t lmax = 0;
     double *part_bb = nullptr, *part_rr = nullptr, *part_rz[2] = {nullptr, nullptr}, *part_pq = nullptr, *part_err = nullptr;
     PcgState* ps = nullptr;
-    PcgState* h_ps = nullptr;  // pinned
+    PcgState* h_ps = nullptr;  // pinned, 2 slots
+    hipEvent_t ev_poll[2] = {nullptr, nullptr};
     // particles
     long np = 0, cap = 0;
     Particles pa{}, pb{};
@@ -210,6 +211,7 @@ int fluid_destroy(fluid_sim_t* s)
                     s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
+    for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
     if (s->h_ss) hipHostFree(s->h_ss);
     if (s->h_small) hipHostFree(s->h_small);
     if (s->st) hipStreamDestroy(s->st);
@@ -255,7 +257,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     s->lmax = lbox_max_cells(p->n);  // >= n: the arrays double as N^3 scratch for fluid_stencil_apply
     const size_t ln = s->lmax;
     A(dalloc((char**)&s->R, ln * se)); A(dalloc((char**)&s->S[0], ln * se)); A(dalloc((char**)&s->S[1], ln * se));
-    A(dalloc((char**)&s->Q, ln * se)); A(dalloc((char**)&s->X, ln * se)); A(dalloc(&s->cntL, ln));
+    A(dalloc((char**)&s->Q, ln * se)); A(dalloc((char**)&s->X, ln * se)); A(dalloc(&s->cntL, ln + 64));
     A(dalloc(&s->part_bb, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rr, (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_rz[0], (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rz[1], (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_pq, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_err, (size_t)2 * MAX_PARTIALS));
@@ -263,7 +265,9 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     A(dalloc(&s->cell_count, n + 4)); A(dalloc(&s->cell_start, n + 4));
     A(dalloc(&s->d_small, (size_t)32));
     A(hipHostMalloc((void**)&s->h_small, 32 * sizeof(int)));
-    A(hipHostMalloc((void**)&s->h_ps, sizeof(PcgState)));
+    A(hipHostMalloc((void**)&s->h_ps, 2 * sizeof(PcgState)));
+    A(hipEventCreateWithFlags(&s->ev_poll[0], hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&s->ev_poll[1], hipEventDisableTiming));
     A(hipHostMalloc((void**)&s->h_ss, sizeof(StepState)));
 #undef A
     // default solid shell: solid outside W (fluid.cc:1256-1266)
@@ -482,7 +486,7 @@ static int phase_flags(fluid_sim* s)
         // box-local solver layout of this step: diag counts + zeroed search vectors (padding must read 0)
         s->L = make_lbox(s->Rb);
         launch_cnt_local(s->st, s->g, s->L, s->flags, s->cntL);
-        const size_t lb = s->L.cells() * solver_elem(s);
+        const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
         HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
         HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
         HIPCHK(hipGetLastError());
@@ -546,7 +550,11 @@ static int solve_impl(fluid_sim* s)
     prof_end(s, FLUID_PROF_PCG_XR, tok);
     long it = 1;
     const int CHECK = 16;
+    // The done flag is polled ONE BATCH BEHIND: batch b+1 is already queued when the host waits for the
+    // state copy of batch b, so the stream never drains between batches (kernels of a finished solve
+    // exit at their first instruction).
     bool done = false;
+    int nb = 0;
     while (!done) {
         for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
@@ -558,10 +566,17 @@ static int solve_impl(fluid_sim* s)
             prof_end(s, FLUID_PROF_PCG_XR, tok);
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
-        HIPCHK(hipStreamSynchronize(s->st));
-        done = s->h_ps->done || it >= max_it;
+        HIPCHK(hipMemcpyAsync(&s->h_ps[nb & 1], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipEventRecord(s->ev_poll[nb & 1], s->st));
+        if (nb >= 1) {
+            HIPCHK(hipEventSynchronize(s->ev_poll[(nb - 1) & 1]));
+            if (s->h_ps[(nb - 1) & 1].done) done = true;
+        }
+        if (it >= max_it) done = true;
+        ++nb;
     }
+    HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
     if (!s->h_ps->done) {
@@ -1077,7 +1092,7 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
     if (!box_empty(s->Rb)) {
         s->L = make_lbox(s->Rr);
         launch_cnt_local(s->st, g, s->L, s->flags, s->cntL);
-        const size_t lb = s->L.cells() * solver_elem(s);
+        const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
         HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
         HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
         HIPCHK(hipGetLastError());

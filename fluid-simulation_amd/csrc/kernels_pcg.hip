@@ -61,13 +61,20 @@ LBox make_lbox(const Box& b)
     L.nx = b.nx(); L.ny = b.ny(); L.nz = b.nz();
     L.Lx = (L.nx + TX - 1) / TX * TX + 2;
     L.Ly = (L.ny + TY - 1) / TY * TY + 2;
-    L.Lz = LBOX_K0 + (L.nz + TZ - 1) / TZ * TZ + 16;
+    // z rows: K0 zero cells in front (128-byte aligned interior), interior, >= 1 zero cell behind, rounded to 16.
+    // The last z tile may overrun the row by up to TZ cells: it then reads/writes the NEXT row's front padding
+    // (zeros, never an unknown), which needs the row to be longer than the tiled extent.  Arrays carry one
+    // spare row at the end for the very last wrap.
+    const int tiled = (L.nz + TZ - 1) / TZ * TZ + 1;
+    const int need = LBOX_K0 + L.nz + 1 > tiled ? LBOX_K0 + L.nz + 1 : tiled;
+    L.Lz = (need + 15) / 16 * 16;
     return L;
 }
 size_t lbox_max_cells(int N)
 {
     Box b{0, 0, 0, N - 1, N - 1, N - 1};
-    return make_lbox(b).cells();
+    const LBox L = make_lbox(b);
+    return L.cells() + (size_t)2 * L.Lz;  // + spare rows for the wrap of the last tile
 }
 static inline int sq_tiles(const LBox& L) { return ((L.nx + TX - 1) / TX) * ((L.ny + TY - 1) / TY) * ((L.nz + TZ - 1) / TZ); }
 int pcg_sq_blocks(const LBox& L)
@@ -85,7 +92,7 @@ int pcg_xr_blocks(const LBox& L)
 __global__ __launch_bounds__(256) void k_cnt_local(Grid g, LBox L, const uint8_t* __restrict__ flags, uint8_t* __restrict__ cnt)
 {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)L.cells()) return;
+    if (t >= (long)L.cells() + 2 * L.Lz) return;  // + the spare rows the last tile may wrap into: never unknowns
     const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
     uint8_t c = 0;
     if (i >= 1 && i <= L.nx && j >= 1 && j <= L.ny && k >= LBOX_K0 && k < LBOX_K0 + L.nz) {
@@ -361,16 +368,20 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
     const V2* s2 = (const V2*)s;
     const V2* q2 = (const V2*)q;
     const uint16_t* c2 = (const uint16_t*)cnt;
-    const long nth = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // Block b streams ONE contiguous chunk, and chunks are handed out XCD-contiguously like the SQ tiles
+    // (x-major), so the slab an XCD wrote in SQ is the slab it reads here: its L2 still holds part of it.
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const long per = (n2 + gridDim.x - 1) / gridDim.x;
+    const long e0 = (long)vb * per, e1 = e0 + per < n2 ? e0 + per : n2;
     constexpr int U = 4;
     V2 xv[U], rv[U], sv[U], qv[U];
     uint16_t cv[U];
+    long i = e0 + threadIdx.x;
     auto issue = [&](long base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long e = base + u * nth;
-            if (e < n2) { cv[u] = c2[e]; xv[u] = x2[e]; rv[u] = r2[e]; sv[u] = s2[e]; qv[u] = q2[e]; }
+            const long e = base + u * 256;
+            if (e < e1) { cv[u] = c2[e]; xv[u] = x2[e]; rv[u] = r2[e]; sv[u] = s2[e]; qv[u] = q2[e]; }
             else cv[u] = 0;
         }
     };
@@ -385,10 +396,10 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
     }
     const T alpha = (T)(rz / pq);
     double arr = 0, arz = 0;
-    for (; i < n2; i += U * nth) {
+    for (; i < e1; i += U * 256) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long e = i + u * nth;
+            const long e = i + u * 256;
             if (cv[u]) {
                 const int ca = cv[u] & 0xff, cb = cv[u] >> 8;
                 V2 xo = xv[u], ro = rv[u];
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
                 ((V2*)r)[e] = ro;
             }
         }
-        if (i + U * nth < n2) issue(i + U * nth);
+        if (i + U * 256 < e1) issue(i + U * 256);
     }
     arr = block_sum<double, 4>(arr, red);
     arz = block_sum<double, 4>(arz, red);
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(256) void k_store_pressure_l(Grid g, LBox L, const 
 
 void launch_cnt_local(hipStream_t st, Grid g, LBox L, const uint8_t* flags, uint8_t* cnt)
 {
-    hipLaunchKernelGGL(k_cnt_local, dim3((unsigned)((L.cells() + 255) / 256)), dim3(256), 0, st, g, L, flags, cnt);
+    hipLaunchKernelGGL(k_cnt_local, dim3((unsigned)((L.cells() + 2 * L.Lz + 255) / 256)), dim3(256), 0, st, g, L, flags, cnt);
 }
 template <typename T>
 void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, T* x, T* r, Coef<T> cf, double* part_bb,

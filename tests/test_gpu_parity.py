@@ -292,3 +292,26 @@ def test_round_trip_properties_at_bench_size(fs):
     sim.upload_field(F.SEARCH, s2); sim.stencil_apply(1, 2); q2 = sim.field(F.Q)
     a, b = float((s2 * q1).sum()), float((s1 * q2).sum())
     assert abs(a - b) <= 1e-10 * max(abs(a), abs(b))
+
+
+def test_run_sh_fluid_driver(tmp_path):
+    """`./run.sh fluid` (reference contract, run.sh:1-7): builds and runs the driver; same stdout lines per step
+    (fluid.cc:1383-1386,1456,1486,1491,1499-1502) and one density grid per step."""
+    import os, subprocess
+    from conftest import ROOT
+    env = dict(os.environ, FLUID_N="32", FLUID_PPC="4", FLUID_STEPS="3", FLUID_OUT=str(tmp_path / "simulation"))
+    r = subprocess.run([os.path.join(ROOT, "run.sh"), "fluid"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    per_step = ["2", "3", "DT", "Before", "After", "DT", "Error:", "Iteration:", "Time delta:"]
+    for i in range(3):
+        blk = lines[9 * i: 9 * i + 9]
+        for got, want in zip(blk, per_step):
+            assert got.split("\t")[0].split(" ")[0] == want.split(" ")[0], (i, got, want)
+        assert blk[7] == f"Iteration:\t{i + 1}"
+    assert lines[0] == "2" and lines[2] == "DT 0.1" and lines[-1].startswith("Time Taken")
+    for i in range(3):
+        f = tmp_path / "simulation" / f"mygrids{i}.f32"
+        assert f.exists() and f.stat().st_size == 4 + 4 * 32 ** 3
+    rho = np.fromfile(tmp_path / "simulation" / "mygrids2.f32", dtype=np.float32, offset=4).reshape(32, 32, 32)
+    assert rho.max() > 0 and rho[0].max() == 0  # density inside, nothing in the solid shell
