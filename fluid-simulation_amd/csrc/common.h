@@ -49,6 +49,24 @@ struct LBox {
     __host__ __device__ inline size_t cells() const { return (size_t)Lx * Ly * Lz; }
 };
 
+// One multigrid level: a dx x dy x dz domain inside a dense array (z stride 1, zero cells around it).
+struct MLevel {
+    int dx, dy, dz;
+    long sx, sy;
+    int ox, oy, oz;
+    size_t cells;  // allocated elements
+    __host__ __device__ inline size_t at(int i, int j, int k) const
+    {
+        return (size_t)((long)(i + ox) * sx + (long)(j + oy) * sy + (k + oz));
+    }
+};
+template <typename T>
+struct MgCoef {
+    T diag[7];  // by number of non-solid neighbours
+    T inv[7];
+    T off;
+};
+
 // Scalars of one PCG solve, device resident.
 struct PcgState {
     double bb;        // |b|^2
@@ -197,10 +215,10 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol);
+                   double tol, int n_rz = -1, int zmode = 0);
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
-                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps);
+                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1);
 template <typename T>
 void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
                   const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol);
@@ -216,5 +234,23 @@ template <typename T>
 void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen);
 template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure);
+
+// multigrid preconditioner (kernels_mg.hip)
+MLevel mg_level0(const LBox& L);
+MLevel mg_coarser(const MLevel& f);
+int mg_smooth_blocks(const MLevel& m);
+void launch_mg_type0(hipStream_t st, Grid g, LBox L, MLevel m, const uint8_t* flags, const uint8_t* cnt, uint8_t* typ);
+void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, uint8_t* tc, uint8_t* cnt_c);
+template <typename T>
+void launch_mg_smooth(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u_in, T* u_out, MgCoef<T> cf, double* part_dot,
+                      const PcgState* ps);
+template <typename T>
+void launch_mg_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* r, MgCoef<T> cf, const PcgState* ps);
+template <typename T>
+void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const uint8_t* cnt_c, T* fc, const PcgState* ps);
+template <typename T>
+void launch_mg_prolong(hipStream_t st, MLevel mf, const uint8_t* cnt_f, T* u, MLevel mc, const T* ec, const PcgState* ps);
+template <typename T>
+void launch_mg_coarsest(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, MgCoef<T> cf, int sweeps, const PcgState* ps);
 
 }  // namespace fl

@@ -44,7 +44,7 @@ struct fluid_sim {
     double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
     int *indices = nullptr, *scan_sums = nullptr, *ipart = nullptr;
     // pcg
-    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr;  // box-local layout (LBox)
+    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr, *Zmg = nullptr;  // box-local layout (LBox)
     uint8_t* cntL = nullptr;
     LBox L{};
     size_t lmax = 0;
@@ -65,6 +65,13 @@ struct fluid_sim {
     bool sorted = false, have_p2g = false, have_flags = false;
     double dt = 0.1;
     fluid_step_stats_t stats{};
+    // multigrid preconditioner (single-GPU fp64 solve)
+    static constexpr int MG_MAXL = 8;
+    int mg_nl = 0;
+    MLevel mgl[MG_MAXL];
+    uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
+    double *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual
+    size_t mg_cap[MG_MAXL] = {};
     // multi-GPU (x-slab decomposition)
     bool dist = false;
     fluid_comm_t comm{};
@@ -206,10 +213,14 @@ int fluid_destroy(fluid_sim_t* s)
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
-                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->cntL, s->part_bb, s->part_rr,
+                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->Zmg, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
                     s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (int l = 0; l < fluid_sim::MG_MAXL; ++l) {
+        void* q[] = {s->mg_typ[l], s->mg_cnt[l], s->mg_u[l], s->mg_v[l], s->mg_f[l], s->mg_r[l]};
+        for (void* p : q) if (p) hipFree(p);
+    }
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
     if (s->h_ss) hipHostFree(s->h_ss);
@@ -258,6 +269,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     const size_t ln = s->lmax;
     A(dalloc((char**)&s->R, ln * se)); A(dalloc((char**)&s->S[0], ln * se)); A(dalloc((char**)&s->S[1], ln * se));
     A(dalloc((char**)&s->Q, ln * se)); A(dalloc((char**)&s->X, ln * se)); A(dalloc(&s->cntL, ln + 64));
+    A(dalloc((char**)&s->Zmg, ln * se));
     A(dalloc(&s->part_bb, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rr, (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_rz[0], (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rz[1], (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_pq, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_err, (size_t)2 * MAX_PARTIALS));
@@ -473,6 +485,183 @@ static int phase_p2g(fluid_sim* s)
     return FLUID_OK;
 }
 
+template <typename T>
+static Coef<T> make_coef(const fluid_sim* s)
+{
+    // setA, fluid.cc:306: scale = dt/(rho dx dx); Adiag accumulates float(Adiag + scale); Aplus = float(-1*scale)
+    const double scale = s->dt / (s->prm.rho * s->prm.dx * s->prm.dx);
+    Coef<T> c;
+    float acc = 0.0f;
+    c.diag[0] = 0;
+    c.inv[0] = 0;
+    for (int k = 1; k <= 6; ++k) {
+        acc = (float)((double)acc + scale);
+        c.diag[k] = (T)acc;
+        c.inv[k] = (T)1 / c.diag[k];
+    }
+    c.off = (T)(float)(-1 * scale);
+    return c;
+}
+
+// ---- multigrid-preconditioned CG (single GPU, fp64) ----------------------------------------------
+static bool use_mg(const fluid_sim* s) { return s->prm.reserved == 0 && s->prm.precision == FLUID_PRECISION_FP64 && !s->dist; }
+
+// Level hierarchy of this step: level 0 = the box-local solver layout, coarsened until <= 8^3.
+static int mg_setup(fluid_sim* s)
+{
+    s->mgl[0] = mg_level0(s->L);
+    int nl = 1;
+    while (nl < fluid_sim::MG_MAXL && (s->mgl[nl - 1].dx > 8 || s->mgl[nl - 1].dy > 8 || s->mgl[nl - 1].dz > 8)) {
+        s->mgl[nl] = mg_coarser(s->mgl[nl - 1]);
+        ++nl;
+    }
+    if (s->mgl[nl - 1].dx > 8 || s->mgl[nl - 1].dy > 8 || s->mgl[nl - 1].dz > 8) return fail(FLUID_ERR_STATE, "multigrid: too many levels");
+    s->mg_nl = nl;
+    for (int l = 0; l < nl; ++l) {
+        const size_t need = s->mgl[l].cells + 64;
+        if (need > s->mg_cap[l]) {
+            void** arrs[] = {(void**)&s->mg_typ[l], (void**)&s->mg_cnt[l], (void**)&s->mg_u[l], (void**)&s->mg_v[l], (void**)&s->mg_f[l], (void**)&s->mg_r[l]};
+            for (void** p : arrs) { if (*p) hipFree(*p); *p = nullptr; }
+            const size_t cap = need + need / 4;
+            HIPCHK(hipMalloc((void**)&s->mg_typ[l], cap));
+            if (l > 0) HIPCHK(hipMalloc((void**)&s->mg_cnt[l], cap));
+            HIPCHK(hipMalloc((void**)&s->mg_u[l], cap * 8));
+            HIPCHK(hipMalloc((void**)&s->mg_v[l], cap * 8));
+            if (l > 0) HIPCHK(hipMalloc((void**)&s->mg_f[l], cap * 8));
+            HIPCHK(hipMalloc((void**)&s->mg_r[l], cap * 8));
+            s->mg_cap[l] = cap;
+        }
+        // the layout changes with the box: everything outside the new domain must read as zero / solid
+        HIPCHK(hipMemsetAsync(s->mg_typ[l], 0, s->mgl[l].cells, s->st));
+        if (l > 0) HIPCHK(hipMemsetAsync(s->mg_cnt[l], 0, s->mgl[l].cells, s->st));
+        HIPCHK(hipMemsetAsync(s->mg_u[l], 0, s->mgl[l].cells * 8, s->st));
+        HIPCHK(hipMemsetAsync(s->mg_v[l], 0, s->mgl[l].cells * 8, s->st));
+        if (l > 0) HIPCHK(hipMemsetAsync(s->mg_f[l], 0, s->mgl[l].cells * 8, s->st));
+        HIPCHK(hipMemsetAsync(s->mg_r[l], 0, s->mgl[l].cells * 8, s->st));
+    }
+    launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
+    for (int l = 1; l < nl; ++l) launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+
+static MgCoef<double> mg_coef(const fluid_sim* s, int level)
+{
+    MgCoef<double> c;
+    if (level == 0) {
+        const Coef<double> f = make_coef<double>(s);  // level 0 smooths with the reference's own coefficients
+        for (int k = 0; k < 7; ++k) { c.diag[k] = f.diag[k]; c.inv[k] = f.inv[k]; }
+        c.off = f.off;
+        return c;
+    }
+    const double scale = s->dt / (s->prm.rho * s->prm.dx * s->prm.dx) / std::pow(4.0, level);  // h doubles per level
+    c.off = -scale;
+    c.diag[0] = 0; c.inv[0] = 0;
+    for (int k = 1; k < 7; ++k) { c.diag[k] = scale * k; c.inv[k] = 1.0 / c.diag[k]; }
+    return c;
+}
+
+// z = M^-1 r: V(2,2) cycle.  Level-0 rhs = `rhs0`; result in `z0`; part_rz gets the partials of rhs0.z0.
+static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+{
+    const int nl = s->mg_nl;
+    const PcgState* ps = s->ps;
+    for (int l = 0; l < nl - 1; ++l) {
+        const MLevel& m = s->mgl[l];
+        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
+        const double* f = l == 0 ? rhs0 : s->mg_f[l];
+        const MgCoef<double> cf = mg_coef(s, l);
+        launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_v[l], cf, nullptr, ps);   // sweep 1 from u = 0
+        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_v[l], s->mg_u[l], cf, nullptr, ps);              // sweep 2
+        launch_mg_resid<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], cf, ps);
+        launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
+    }
+    {
+        const int l = nl - 1;
+        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
+        const double* f = l == 0 ? rhs0 : s->mg_f[l];
+        launch_mg_coarsest<double>(s->st, s->mgl[l], cnt, f, l == 0 ? z0 : s->mg_u[l], mg_coef(s, l), 12, ps);
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        const MLevel& m = s->mgl[l];
+        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
+        const double* f = l == 0 ? rhs0 : s->mg_f[l];
+        const MgCoef<double> cf = mg_coef(s, l);
+        launch_mg_prolong<double>(s->st, m, cnt, s->mg_u[l], s->mgl[l + 1], s->mg_u[l + 1], ps);
+        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_v[l], cf, nullptr, ps);
+        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_v[l], l == 0 ? z0 : s->mg_u[l], cf, l == 0 ? part_rz : nullptr, ps);
+    }
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+
+// PCG loop of ConjugateGradient.h:28-90 with z = V-cycle(r); same start, stopping rule and cap as solve_impl.
+static int solve_mg(fluid_sim* s)
+{
+    typedef double T;
+    const Grid g = s->g;
+    const LBox L = s->L;
+    T* X = (T*)s->X;
+    T* R = (T*)s->R;
+    T* Q = (T*)s->Q;
+    T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
+    T* Z = s->mg_r[0] ? s->mg_v[0] : nullptr;  // placeholder, set below
+    const uint8_t* cnt = s->cntL;
+    const Coef<T> cf = make_coef<T>(s);
+    const double tol = s->prm.cg_tol;
+    long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
+    if (max_it < 1) max_it = 1;
+    const double cells = (double)s->Rb.cells();
+    const int n_rz = mg_smooth_blocks(s->mgl[0]);
+    if (n_rz > MAX_PARTIALS) return fail(FLUID_ERR_STATE, "multigrid: partial buffer too small");
+    // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
+    Z = (T*)s->Zmg;
+    int rc;
+    int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
+    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
+    long it = 0;
+    const int CHECK = 4;
+    bool done = false;
+    int nb = 0;
+    while (!done) {
+        for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
+            const int cur = (int)(it & 1), prv = cur ^ 1;
+            if ((rc = mg_vcycle(s, R, Z, s->part_rz[cur]))) return rc;
+            int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
+            launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
+                             s->part_pq, s->ps, it == 0, tol, n_rz, 1);
+            prof_end(s, FLUID_PROF_PCG_SQ, tok);
+            tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
+            launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_err, s->ps, n_rz);
+            prof_end(s, FLUID_PROF_PCG_XR, tok);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&s->h_ps[nb & 1], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipEventRecord(s->ev_poll[nb & 1], s->st));
+        if (nb >= 1) {
+            HIPCHK(hipEventSynchronize(s->ev_poll[(nb - 1) & 1]));
+            if (s->h_ps[(nb - 1) & 1].done) done = true;
+        }
+        if (it >= max_it) done = true;
+        ++nb;
+    }
+    // the break test of the last body sits at the head of the NEXT SQ launch: run one more head-only check
+    launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[0], Sx[1], Q, cf, s->part_rr, s->part_rz[0], s->part_rz[1], s->part_pq, s->ps, 0, tol, n_rz, 1);
+    HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    int iters = s->h_ps->iters;
+    const double rr = s->h_ps->rr;
+    if (!s->h_ps->done) iters = (int)max_it;
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    HIPCHK(hipGetLastError());
+    prof_end(s, FLUID_PROF_SOLVE, tsolve);
+    s->stats.cg_iters_last = iters;
+    s->stats.cg_iters += iters;
+    s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
+    if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
+    return FLUID_OK;
+}
+
 static int phase_flags(fluid_sim* s)
 {
     HIPCHK(hipSetDevice(s->prm.device));
@@ -490,6 +679,10 @@ static int phase_flags(fluid_sim* s)
         HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
         HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
         HIPCHK(hipGetLastError());
+        if (use_mg(s)) {
+            int rc2 = mg_setup(s);
+            if (rc2) return rc2;
+        }
     }
     s->have_flags = true;
     return FLUID_OK;
@@ -504,24 +697,6 @@ static int phase_rhs_div(fluid_sim* s, int which)
                    s->prm.gravity[0] * dt, s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);  // gravity*dt, fluid.cc:420
     HIPCHK(hipGetLastError());
     return FLUID_OK;
-}
-
-template <typename T>
-static Coef<T> make_coef(const fluid_sim* s)
-{
-    // setA, fluid.cc:306: scale = dt/(rho dx dx); Adiag accumulates float(Adiag + scale); Aplus = float(-1*scale)
-    const double scale = s->dt / (s->prm.rho * s->prm.dx * s->prm.dx);
-    Coef<T> c;
-    float acc = 0.0f;
-    c.diag[0] = 0;
-    c.inv[0] = 0;
-    for (int k = 1; k <= 6; ++k) {
-        acc = (float)((double)acc + scale);
-        c.diag[k] = (T)acc;
-        c.inv[k] = (T)1 / c.diag[k];
-    }
-    c.off = (T)(float)(-1 * scale);
-    return c;
 }
 
 template <typename T>
@@ -597,6 +772,7 @@ static int phase_solve(fluid_sim* s)
 {
     if (!s->have_flags) return fail(FLUID_ERR_STATE, "solve before flags_index");
     if (box_empty(s->Rb)) return FLUID_OK;
+    if (use_mg(s) && s->mg_nl >= 2) return solve_mg(s);  // a box that is already <= 8^3 has no coarser level: Jacobi
     return s->prm.precision == FLUID_PRECISION_FP32 ? solve_impl<float>(s) : solve_impl<double>(s);
 }
 

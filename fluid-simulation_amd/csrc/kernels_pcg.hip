@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_
 // convergence identically in every block, returns beta.  false = this block must exit.
 template <typename T>
 __device__ __forceinline__ bool pcg_head(const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
-                                         const double* __restrict__ part_rz_old, int n_prev, PcgState* ps, int first, double tol,
+                                         const double* __restrict__ part_rz_old, int n_prev, int n_rz, PcgState* ps, int first, double tol,
                                          double* red, T& beta)
 {
     const int tid = threadIdx.x;
@@ -173,7 +173,7 @@ __device__ __forceinline__ bool pcg_head(const double* __restrict__ part_rr, con
         return bb > 0;
     }
     double rr, rzn, rzo;
-    block_sum3(part_rr, n_prev, part_rz_new, n_prev, part_rz_old, n_prev, red, rr, rzn, rzo);
+    block_sum3(part_rr, n_prev, part_rz_new, n_rz, part_rz_old, n_rz, red, rr, rzn, rzo);
     if (rr < ps->thr) {  // break before i++
         if (blockIdx.x == 0 && tid == 0) { ps->rr = rr; ps->done = 1; }
         return false;
@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
                                                   const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
                                                   const double* __restrict__ part_rz_old, double* __restrict__ part_pq, int n_prev,
-                                                  PcgState* ps, int first, double tol)
+                                                  PcgState* ps, int first, double tol, int n_rz, int zmode)
 {
+    // zmode: `r` is already z = M^-1 r (multigrid preconditioner); otherwise z = invdiag r is formed here
     __shared__ T sT[TX * PY * PZ];
     __shared__ double red[16];
     __shared__ int s_done;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     __syncthreads();  // s_done, coef tables
     if (s_done) return;
     if (FUSED) {
-        if (!pcg_head<T>(part_rr, part_rz_new, part_rz_old, n_prev, ps, first, tol, red, beta)) return;
+        if (!pcg_head<T>(part_rr, part_rz_new, part_rz_old, n_prev, n_rz, ps, first, tol, red, beta)) return;
     }
 
     double acc = 0;
@@ -251,16 +252,16 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
         // ---- combine -> LDS ---------------------------------------------------------------------
         T val[TX + 2];
 #pragma unroll
-        for (int m = 0; m < TX + 2; ++m) val[m] = FUSED ? (fc[m] ? rv[m] * sinv[fc[m]] + beta * sv[m] : (T)0) : sv[m];
+        for (int m = 0; m < TX + 2; ++m) val[m] = FUSED ? (fc[m] ? (zmode ? rv[m] : rv[m] * sinv[fc[m]]) + beta * sv[m] : (T)0) : sv[m];
 #pragma unroll
         for (int lx = 0; lx < TX; ++lx) sT[(lx * PY + ly + 1) * PZ + kz + 1] = val[lx + 1];
         {
             const int pl = tid >> 6, side = (tid >> 5) & 1;
-            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = FUSED ? (fy ? ry * sinv[fy] + beta * sy : (T)0) : sy;
+            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = FUSED ? (fy ? (zmode ? ry : ry * sinv[fy]) + beta * sy : (T)0) : sy;
         }
         if (tid < 64) {
             const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
-            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = FUSED ? (fz ? rz * sinv[fz] + beta * sz : (T)0) : sz;
+            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = FUSED ? (fz ? (zmode ? rz : rz * sinv[fz]) + beta * sz : (T)0) : sz;
         }
         __syncthreads();
         const long cc = c0;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void k_pcg_s_l(long n2, const uint8_t* __restr
     __syncthreads();
     if (s_done) return;
     T beta;
-    if (!pcg_head<T>(g_rr, g_rz_new, g_rz_old, 1, ps, first, tol, red, beta)) return;
+    if (!pcg_head<T>(g_rr, g_rz_new, g_rz_old, 1, 1, ps, first, tol, red, beta)) return;
     typedef Vec2<T> V2;
     const V2* r2 = (const V2*)r;
     const V2* s2 = (const V2*)s_in;
@@ -453,10 +454,11 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol)
+                   double tol, int n_rz, int zmode)
 {
+    const int nx = pcg_xr_blocks(L);
     hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
-                       part_rz_new, part_rz_old, part_pq, pcg_xr_blocks(L), ps, first, tol);
+                       part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode);
 }
 // multi-GPU pieces: n_* = 1 means "already all-reduced scalar"
 template <typename T>
@@ -470,7 +472,7 @@ template <typename T>
 void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps)
 {
     hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, (const T*)nullptr, s, (T*)nullptr, q, cf,
-                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0);
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0, 0, 0);
 }
 template <typename T>
 void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
@@ -485,10 +487,10 @@ void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int n
 }
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
-                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps)
+                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz)
 {
     hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
-                       pcg_xr_blocks(L), part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps);
+                       n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps);
 }
 template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure)
@@ -731,9 +733,9 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_pcg_init<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, T*, T*, Coef<T>, double*, double*,          \
                                      PcgState*);                                                                                       \
     template void launch_pcg_sq<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
-                                   const double*, double*, PcgState*, int, double);                                                    \
+                                   const double*, double*, PcgState*, int, double, int, int);                                          \
     template void launch_pcg_xr<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, const double*, \
-                                   double*, double*, PcgState*);                                                                       \
+                                   double*, double*, PcgState*, int);                                                                  \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);                                \

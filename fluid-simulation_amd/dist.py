@@ -212,6 +212,8 @@ class DistFluidSim(FluidSim):
         for k, v in kw.items():
             if k == "gravity":
                 p.gravity[0], p.gravity[1], p.gravity[2] = v
+            elif k == "preconditioner":
+                p.reserved = {"mg": 0, "jacobi": 1}[v]
             elif hasattr(p, k):
                 setattr(p, k, v)
             else:

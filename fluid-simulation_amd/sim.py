@@ -42,6 +42,8 @@ class FluidSim:
         for k, v in kw.items():
             if k == "gravity":
                 p.gravity[0], p.gravity[1], p.gravity[2] = v
+            elif k == "preconditioner":
+                p.reserved = {"mg": 0, "jacobi": 1}[v]   # FLUID_PRECOND_*
             elif hasattr(p, k):
                 setattr(p, k, v)
             else:

@@ -56,6 +56,10 @@ typedef struct fluid_sim fluid_sim_t;
 #define FLUID_PRECISION_FP64 0    /* fp64 PCG vectors (reference arithmetic: Eigen VectorXd)          */
 #define FLUID_PRECISION_FP32 1    /* fp32 PCG vectors (stencil micro-benchmark / experiments only)    */
 
+/* preconditioner of the PCG (fluid_params.reserved); the reference uses Eigen IncompleteCholesky */
+#define FLUID_PRECOND_MG 0        /* geometric multigrid V(2,2) cycle; iteration count independent of N  */
+#define FLUID_PRECOND_JACOBI 1    /* Eigen DiagonalPreconditioner arithmetic; used by the multi-GPU path  */
+
 typedef struct fluid_params {
     int32_t n;                /* cells per axis                         fluid.cc:1159 (121)      */
     int32_t device;           /* HIP device ordinal                                             */
@@ -69,7 +73,7 @@ typedef struct fluid_params {
     int32_t cg_max_iters;     /* 0 = 2*numActive                        IterativeSolverBase.h:362 */
     int32_t max_outer_passes; /* 0 = unlimited (reference)                                       */
     int32_t precision;        /* FLUID_PRECISION_*                                               */
-    int32_t reserved;
+    int32_t reserved;         /* preconditioner: 0 = multigrid V-cycle (fp64, one GPU), 1 = Jacobi           */
 } fluid_params_t;
 
 typedef struct fluid_step_stats {
