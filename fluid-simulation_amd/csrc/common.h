@@ -250,7 +250,10 @@ template <typename T>
 void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const uint8_t* cnt_c, T* fc, const PcgState* ps);
 template <typename T>
 void launch_mg_prolong(hipStream_t st, MLevel mf, const uint8_t* cnt_f, T* u, MLevel mc, const T* ec, const PcgState* ps);
+constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel can hold
+constexpr long MG_TAIL_CELLS = 2048;    // a level this small (and all coarser ones) goes into the tail (one CU: 94 us at 12k cells)
 template <typename T>
-void launch_mg_coarsest(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, MgCoef<T> cf, int sweeps, const PcgState* ps);
+void launch_mg_tail(hipStream_t st, int nl, const MLevel* lv, uint8_t* const* cnt, T* const* u, T* const* v, T* const* f, T* const* r,
+                    const T* off, int sweeps, const PcgState* ps);
 
 }  // namespace fl

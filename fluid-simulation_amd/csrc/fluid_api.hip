@@ -67,7 +67,7 @@ struct fluid_sim {
     fluid_step_stats_t stats{};
     // multigrid preconditioner (single-GPU fp64 solve)
     static constexpr int MG_MAXL = 8;
-    int mg_nl = 0;
+    int mg_nl = 0, mg_tail = 0;   // levels; first level handled by the single-block tail kernel
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
     double *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual
@@ -517,6 +517,12 @@ static int mg_setup(fluid_sim* s)
     }
     if (s->mgl[nl - 1].dx > 8 || s->mgl[nl - 1].dy > 8 || s->mgl[nl - 1].dz > 8) return fail(FLUID_ERR_STATE, "multigrid: too many levels");
     s->mg_nl = nl;
+    // levels small enough for one block (and everything coarser) run inside the tail kernel; level 0 never does
+    int tail = nl - 1;
+    while (tail > 1 && (long)s->mgl[tail - 1].dx * s->mgl[tail - 1].dy * s->mgl[tail - 1].dz <= MG_TAIL_CELLS) --tail;
+    if (nl - tail > MG_TAIL_MAX) tail = nl - MG_TAIL_MAX;
+    if (tail < 1) tail = 1;
+    s->mg_tail = tail;
     for (int l = 0; l < nl; ++l) {
         const size_t need = s->mgl[l].cells + 64;
         if (need > s->mg_cap[l]) {
@@ -564,25 +570,24 @@ static MgCoef<double> mg_coef(const fluid_sim* s, int level)
 // z = M^-1 r: V(2,2) cycle.  Level-0 rhs = `rhs0`; result in `z0`; part_rz gets the partials of rhs0.z0.
 static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
-    const int nl = s->mg_nl;
+    const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
-    for (int l = 0; l < nl - 1; ++l) {
+    for (int l = 0; l < tail; ++l) {
         const MLevel& m = s->mgl[l];
         const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
         const double* f = l == 0 ? rhs0 : s->mg_f[l];
         const MgCoef<double> cf = mg_coef(s, l);
-        launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_v[l], cf, nullptr, ps);   // sweep 1 from u = 0
-        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_v[l], s->mg_u[l], cf, nullptr, ps);              // sweep 2
+        launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_u[l], cf, nullptr, ps);   // two sweeps from u = 0
         launch_mg_resid<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], cf, ps);
         launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
     }
     {
-        const int l = nl - 1;
-        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
-        const double* f = l == 0 ? rhs0 : s->mg_f[l];
-        launch_mg_coarsest<double>(s->st, s->mgl[l], cnt, f, l == 0 ? z0 : s->mg_u[l], mg_coef(s, l), 12, ps);
+        double off[fluid_sim::MG_MAXL];
+        for (int l = tail; l < nl; ++l) off[l] = mg_coef(s, l).off;
+        launch_mg_tail<double>(s->st, nl - tail, s->mgl + tail, s->mg_cnt + tail, s->mg_u + tail, s->mg_v + tail, s->mg_f + tail, s->mg_r + tail,
+                               off + tail, 12, ps);
     }
-    for (int l = nl - 2; l >= 0; --l) {
+    for (int l = tail - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];
         const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
         const double* f = l == 0 ? rhs0 : s->mg_f[l];

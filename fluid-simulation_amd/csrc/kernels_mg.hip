@@ -88,8 +88,131 @@ __global__ __launch_bounds__(256) void k_mg_cnt(MLevel m, const uint8_t* __restr
     cnt[c] = n;
 }
 
-// One damped-Jacobi sweep: u_out = u_in + omega D^-1 (f - A u_in); u_in == nullptr means u_in = 0.
-// Optionally the partial of f.u_out (the r.z of the PCG when this is the last sweep of level 0).
+// ---- per-cell bodies (shared by the per-level kernels and the single-block tail kernel) ---------
+// Coefficients by neighbour count n: diag = dg[n], 1/diag = iv[n] (tables in LDS), off-diagonal = off.
+
+// damped-Jacobi sweep: u_out = u_in + omega D^-1 (f - A u_in); returns f*u_out
+template <typename T>
+__device__ __forceinline__ double d_smooth(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f,
+                                           const T* __restrict__ u_in, T* __restrict__ u_out, const T* dg, const T* iv, T off, long t)
+{
+    int i, j, k;
+    if (!mg_cell(m, t, i, j, k)) return 0;
+    const size_t c = m.at(i, j, k);
+    const int n = cnt[c];
+    T out = 0;
+    double acc = 0;
+    if (n) {
+        const T fv = f[c], uc = u_in[c];
+        const T nb = u_in[c - m.sx] + u_in[c + m.sx] + u_in[c - m.sy] + u_in[c + m.sy] + u_in[c - 1] + u_in[c + 1];
+        out = uc + (T)MG_OMEGA * iv[n] * (fv - (dg[n] * uc + off * nb));
+        acc = (double)fv * (double)out;
+    }
+    u_out[c] = out;
+    return acc;
+}
+
+// two sweeps starting from u = 0 in one pass: u1 = omega D^-1 f is formed on the fly at the 7 points
+template <typename T>
+__device__ __forceinline__ void d_smooth0(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u_out,
+                                          const T* dg, const T* iv, T off, long t)
+{
+    int i, j, k;
+    if (!mg_cell(m, t, i, j, k)) return;
+    const size_t c = m.at(i, j, k);
+    const int n = cnt[c];
+    T out = 0;
+    if (n) {
+        const T w = (T)MG_OMEGA;
+        auto u1 = [&](size_t q) { return w * iv[cnt[q]] * f[q]; };  // iv[0] = 0: non-unknowns give 0
+        const T fv = f[c], uc = w * iv[n] * fv;
+        const T nb = u1(c - m.sx) + u1(c + m.sx) + u1(c - m.sy) + u1(c + m.sy) + u1(c - 1) + u1(c + 1);
+        out = uc + w * iv[n] * (fv - (dg[n] * uc + off * nb));
+    }
+    u_out[c] = out;
+}
+
+template <typename T>
+__device__ __forceinline__ void d_resid(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u,
+                                        T* __restrict__ r, const T* dg, T off, long t)
+{
+    int i, j, k;
+    if (!mg_cell(m, t, i, j, k)) return;
+    const size_t c = m.at(i, j, k);
+    const int n = cnt[c];
+    T out = 0;
+    if (n) {
+        const T nb = u[c - m.sx] + u[c + m.sx] + u[c - m.sy] + u[c + m.sy] + u[c - 1] + u[c + 1];
+        out = f[c] - (dg[n] * u[c] + off * nb);
+    }
+    r[c] = out;
+}
+
+// f_c = (1/8) P^T r_f : a coarse cell gathers its 4x4x4 fine neighbourhood, weights (1/4,3/4,3/4,1/4) per axis
+template <typename T>
+__device__ __forceinline__ void d_restrict(const MLevel& mf, const T* __restrict__ rf, const MLevel& mc, const uint8_t* __restrict__ cnt_c,
+                                           T* __restrict__ fc, long t)
+{
+    int I, J, K;
+    if (!mg_cell(mc, t, I, J, K)) return;
+    const size_t C = mc.at(I, J, K);
+    T out = 0;
+    if (cnt_c[C]) {
+        auto w = [](int a) { return (a == 0 || a == 3) ? (T)0.25 : (T)0.75; };  // no private array: no scratch
+        const int i0 = 2 * I - 1, j0 = 2 * J - 1, k0 = 2 * K - 1;
+        T acc = 0;
+        if (i0 >= 0 && i0 + 3 < mf.dx && j0 >= 0 && j0 + 3 < mf.dy && k0 >= 0 && k0 + 3 < mf.dz) {
+            const T* p = rf + mf.at(i0, j0, k0);  // fast path: all 64 inside, 16 rows of 4 contiguous values
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const T* q = p + a * mf.sx + b * mf.sy;
+                    acc += w(a) * w(b) * ((T)0.25 * (q[0] + q[3]) + (T)0.75 * (q[1] + q[2]));
+                }
+            }
+        } else {
+            for (int a = 0; a < 4; ++a) {
+                const int i = i0 + a;
+                if (i < 0 || i >= mf.dx) continue;
+                for (int b = 0; b < 4; ++b) {
+                    const int j = j0 + b;
+                    if (j < 0 || j >= mf.dy) continue;
+                    T row = 0;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int k = k0 + d;
+                        if (k >= 0 && k < mf.dz) row += w(d) * rf[mf.at(i, j, k)];
+                    }
+                    acc += w(a) * w(b) * row;
+                }
+            }
+        }
+        out = acc * (T)0.125;
+    }
+    fc[C] = out;
+}
+
+// u += P e : a fine cell interpolates from its 8 nearest coarse cells (non-unknown coarse cells hold 0)
+template <typename T>
+__device__ __forceinline__ void d_prolong(const MLevel& mf, const uint8_t* __restrict__ cnt_f, T* __restrict__ u, const MLevel& mc,
+                                          const T* __restrict__ ec, long t)
+{
+    int i, j, k;
+    if (!mg_cell(mf, t, i, j, k)) return;
+    const size_t c = mf.at(i, j, k);
+    if (!cnt_f[c]) return;
+    const int I = i >> 1, J = j >> 1, K = k >> 1;
+    const int di = (i & 1) ? 1 : -1, dj = (j & 1) ? 1 : -1, dk = (k & 1) ? 1 : -1;
+    const size_t C = mc.at(I, J, K);  // the coarse arrays carry a ring of zeros: I+di etc. are always addressable
+    const long sx = (long)di * mc.sx, sy = (long)dj * mc.sy, sz = dk;
+    const T a = (T)0.75, b = (T)0.25;
+    const T v = a * a * a * ec[C] + a * a * b * (ec[C + sx] + ec[C + sy] + ec[C + sz]) +
+                a * b * b * (ec[C + sx + sy] + ec[C + sx + sz] + ec[C + sy + sz]) + b * b * b * ec[C + sx + sy + sz];
+    u[c] += v;
+}
+
+// ---- per-level kernels (levels too large for one block) ---------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_mg_smooth(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u_in,
                                                    T* __restrict__ u_out, MgCoef<T> cf, double* __restrict__ part_dot, const PcgState* ps)
@@ -98,25 +221,10 @@ __global__ __launch_bounds__(256) void k_mg_smooth(MLevel m, const uint8_t* __re
     __shared__ T sd[8], si[8];
     if (ps && ps->done) return;  // uniform: written by an earlier launch
     mg_load_coef(sd, si, cf);
-    int i, j, k;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
-    if (mg_cell(m, (long)blockIdx.x * 256 + threadIdx.x, i, j, k)) {
-        const size_t c = m.at(i, j, k);
-        const int n = cnt[c];
-        T out = 0;
-        if (n) {
-            const T fv = f[c], inv = si[n];
-            if (u_in) {
-                const T uc = u_in[c];
-                const T nb = u_in[c - m.sx] + u_in[c + m.sx] + u_in[c - m.sy] + u_in[c + m.sy] + u_in[c - 1] + u_in[c + 1];
-                out = uc + (T)MG_OMEGA * inv * (fv - (sd[n] * uc + cf.off * nb));
-            } else {
-                out = (T)MG_OMEGA * inv * fv;
-            }
-            acc = (double)fv * (double)out;
-        }
-        u_out[c] = out;
-    }
+    if (u_in) acc = d_smooth<T>(m, cnt, f, u_in, u_out, sd, si, cf.off, t);
+    else d_smooth0<T>(m, cnt, f, u_out, sd, si, cf.off, t);
     if (part_dot) {
         acc = block_sum<double, 4>(acc, red);
         if (threadIdx.x == 0) part_dot[blockIdx.x] = acc;
@@ -130,111 +238,120 @@ __global__ __launch_bounds__(256) void k_mg_resid(MLevel m, const uint8_t* __res
     __shared__ T sd[8], si[8];
     if (ps && ps->done) return;
     mg_load_coef(sd, si, cf);
-    int i, j, k;
-    if (!mg_cell(m, (long)blockIdx.x * 256 + threadIdx.x, i, j, k)) return;
-    const size_t c = m.at(i, j, k);
-    const int n = cnt[c];
-    T out = 0;
-    if (n) {
-        const T nb = u[c - m.sx] + u[c + m.sx] + u[c - m.sy] + u[c + m.sy] + u[c - 1] + u[c + 1];
-        out = f[c] - (sd[n] * u[c] + cf.off * nb);
-    }
-    r[c] = out;
+    d_resid<T>(m, cnt, f, u, r, sd, cf.off, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
-// f_c = (1/8) P^T r_f : a coarse cell gathers its 4x4x4 fine neighbourhood, weights (1/4,3/4,3/4,1/4) per axis
 template <typename T>
 __global__ __launch_bounds__(256) void k_mg_restrict(MLevel mf, const T* __restrict__ rf, MLevel mc, const uint8_t* __restrict__ cnt_c,
                                                      T* __restrict__ fc, const PcgState* ps)
 {
     if (ps && ps->done) return;
-    int I, J, K;
-    if (!mg_cell(mc, (long)blockIdx.x * 256 + threadIdx.x, I, J, K)) return;
-    const size_t C = mc.at(I, J, K);
-    T out = 0;
-    if (cnt_c[C]) {
-        auto w = [](int a) { return (a == 0 || a == 3) ? (T)0.25 : (T)0.75; };  // no private array: no scratch
-        T acc = 0;
-        for (int a = 0; a < 4; ++a) {
-            const int i = 2 * I - 1 + a;
-            if (i < 0 || i >= mf.dx) continue;
-            for (int b = 0; b < 4; ++b) {
-                const int j = 2 * J - 1 + b;
-                if (j < 0 || j >= mf.dy) continue;
-                T row = 0;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int k = 2 * K - 1 + d;
-                    if (k >= 0 && k < mf.dz) row += w(d) * rf[mf.at(i, j, k)];
-                }
-                acc += w(a) * w(b) * row;
-            }
-        }
-        out = acc * (T)0.125;
-    }
-    fc[C] = out;
+    d_restrict<T>(mf, rf, mc, cnt_c, fc, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
-// u += P e : a fine cell interpolates from its 8 nearest coarse cells (non-unknown coarse cells hold 0)
 template <typename T>
 __global__ __launch_bounds__(256) void k_mg_prolong(MLevel mf, const uint8_t* __restrict__ cnt_f, T* __restrict__ u, MLevel mc,
                                                     const T* __restrict__ ec, const PcgState* ps)
 {
     if (ps && ps->done) return;
-    int i, j, k;
-    if (!mg_cell(mf, (long)blockIdx.x * 256 + threadIdx.x, i, j, k)) return;
-    const size_t c = mf.at(i, j, k);
-    if (!cnt_f[c]) return;
-    const int I = i >> 1, J = j >> 1, K = k >> 1;
-    const int di = (i & 1) ? 1 : -1, dj = (j & 1) ? 1 : -1, dk = (k & 1) ? 1 : -1;
-    const size_t C = mc.at(I, J, K);  // the coarse arrays carry a ring of zeros: I+di etc. are always addressable
-    const long sx = (long)di * mc.sx, sy = (long)dj * mc.sy, sz = dk;
-    const T a = (T)0.75, b = (T)0.25;
-    const T v = a * a * a * ec[C] + a * a * b * (ec[C + sx] + ec[C + sy] + ec[C + sz]) +
-                a * b * b * (ec[C + sx + sy] + ec[C + sx + sz] + ec[C + sy + sz]) + b * b * b * ec[C + sx + sy + sz];
-    u[c] += v;
+    d_prolong<T>(mf, cnt_f, u, mc, ec, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
-// Coarsest level (domain <= 8^3): symmetric red-black Gauss-Seidel in LDS, `sweeps` forward (R,B) then
-// `sweeps` reversed (B,R).  One block of 512 threads, one thread per cell.
+// ---- tail: the whole sub-V-cycle of the small levels in ONE block ---------------------------------------
+// Levels of <= ~16k cells are pure launch latency as separate kernels (7 launches x ~3 us each).  One
+// block of 1024 threads walks down and up through them with __syncthreads() between the stages; the
+// coarsest level (<= 8^3) is solved by symmetric red-black Gauss-Seidel in LDS.
 template <typename T>
-__global__ __launch_bounds__(512) void k_mg_coarsest(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u,
-                                                     MgCoef<T> cf, int sweeps, const PcgState* ps)
+struct MgTail {
+    int nl;                 // levels in the tail; the last is the coarsest
+    MLevel m[MG_TAIL_MAX];
+    const uint8_t* cnt[MG_TAIL_MAX];
+    T* u[MG_TAIL_MAX];
+    T* v[MG_TAIL_MAX];
+    T* f[MG_TAIL_MAX];      // f[0] is the rhs handed down by the caller
+    T* r[MG_TAIL_MAX];
+    T off[MG_TAIL_MAX];     // off-diagonal of each level; diag = -off * n
+    int sweeps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* ps)
 {
+    __shared__ T sd[MG_TAIL_MAX][8], si[MG_TAIL_MAX][8];
     __shared__ T su[10 * 10 * 10];
-    __shared__ T sd[8], si[8];
     if (ps && ps->done) return;
-    mg_load_coef(sd, si, cf);
-    const int t = threadIdx.x;
-    for (int q = t; q < 1000; q += 512) su[q] = 0;
-    int i, j, k;
-    const bool ok = mg_cell(m, t, i, j, k);
-    size_t c = 0;
-    int n = 0, l = 0;
-    T fv = 0, inv = 0;
-    bool red = false;
-    if (ok) {
-        c = m.at(i, j, k);
-        n = cnt[c];
-        fv = f[c];
-        inv = n ? si[n] : (T)0;
-        l = ((i + 1) * 10 + (j + 1)) * 10 + (k + 1);
-        red = ((i + j + k) & 1) == 0;
+    const int tid = threadIdx.x;
+    if (tid < a.nl * 8) {
+        const int l = tid >> 3, n = tid & 7;
+        T off = a.off[0];
+#pragma unroll
+        for (int q = 1; q < MG_TAIL_MAX; ++q) off = (l == q) ? a.off[q] : off;  // static indices into the kernarg
+        const T d = -off * (T)n;
+        sd[l][n] = d;
+        si[l][n] = n ? (T)1 / d : (T)0;
     }
     __syncthreads();
-    for (int s = 0; s < 2 * sweeps; ++s) {
-        const bool fwd = s < sweeps;
+#define TAIL_FOR(lv) for (long t = tid; t < (long)a.m[lv].dx * a.m[lv].dy * a.m[lv].dz; t += 1024)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool col = fwd ? (h == 0) : (h == 1);  // forward: red then black; reversed: black then red
-            if (ok && n && red == col) {
-                const T nb = su[l - 100] + su[l + 100] + su[l - 10] + su[l + 10] + su[l - 1] + su[l + 1];
-                su[l] = (fv - cf.off * nb) * inv;
-            }
+    for (int l = 0; l < MG_TAIL_MAX - 1; ++l) {
+        if (l < a.nl - 1) {
+            TAIL_FOR(l) d_smooth0<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], sd[l], si[l], a.off[l], t);
+            __syncthreads();
+            TAIL_FOR(l) d_resid<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], a.r[l], sd[l], a.off[l], t);
+            __syncthreads();
+            TAIL_FOR(l + 1) d_restrict<T>(a.m[l], a.r[l], a.m[l + 1], a.cnt[l + 1], a.f[l + 1], t);
             __syncthreads();
         }
     }
-    if (ok) u[c] = n ? su[l] : (T)0;
+    // coarsest: red-black Gauss-Seidel in LDS, forward sweeps then reversed (symmetric)
+#pragma unroll
+    for (int lc = 0; lc < MG_TAIL_MAX; ++lc) {
+        if (lc == a.nl - 1) {
+            const MLevel& m = a.m[lc];
+            for (int q = tid; q < 1000; q += 1024) su[q] = 0;
+            int i = 0, j = 0, k = 0;
+            const bool ok = mg_cell(m, tid, i, j, k);
+            size_t c = 0;
+            int n = 0, lidx = 0;
+            T fv = 0, inv = 0;
+            bool isred = false;
+            if (ok) {
+                c = m.at(i, j, k);
+                n = a.cnt[lc][c];
+                fv = a.f[lc][c];
+                inv = si[lc][n];
+                lidx = ((i + 1) * 10 + (j + 1)) * 10 + (k + 1);
+                isred = ((i + j + k) & 1) == 0;
+            }
+            __syncthreads();
+            for (int s = 0; s < 2 * a.sweeps; ++s) {
+                const bool fwd = s < a.sweeps;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool col = fwd ? (h == 0) : (h == 1);
+                    if (ok && n && isred == col) {
+                        const T nb = su[lidx - 100] + su[lidx + 100] + su[lidx - 10] + su[lidx + 10] + su[lidx - 1] + su[lidx + 1];
+                        su[lidx] = (fv - a.off[lc] * nb) * inv;
+                    }
+                    __syncthreads();
+                }
+            }
+            if (ok) a.u[lc][c] = n ? su[lidx] : (T)0;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int l = MG_TAIL_MAX - 2; l >= 0; --l) {
+        if (l < a.nl - 1) {
+            TAIL_FOR(l) d_prolong<T>(a.m[l], a.cnt[l], a.u[l], a.m[l + 1], a.u[l + 1], t);
+            __syncthreads();
+            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], a.v[l], sd[l], si[l], a.off[l], t);
+            __syncthreads();
+            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.v[l], a.u[l], sd[l], si[l], a.off[l], t);
+            __syncthreads();
+        }
+    }
+#undef TAIL_FOR
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -291,10 +408,19 @@ void launch_mg_prolong(hipStream_t st, MLevel mf, const uint8_t* cnt_f, T* u, ML
 {
     hipLaunchKernelGGL((k_mg_prolong<T>), dim3(mg_blocks(mf)), dim3(256), 0, st, mf, cnt_f, u, mc, ec, ps);
 }
+// levels[0..nl) of the tail; f[0] = rhs of the first tail level; result in u[0]
 template <typename T>
-void launch_mg_coarsest(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, MgCoef<T> cf, int sweeps, const PcgState* ps)
+void launch_mg_tail(hipStream_t st, int nl, const MLevel* lv, uint8_t* const* cnt, T* const* u, T* const* v, T* const* f, T* const* r,
+                    const T* off, int sweeps, const PcgState* ps)
 {
-    hipLaunchKernelGGL((k_mg_coarsest<T>), dim3(1), dim3(512), 0, st, m, cnt, f, u, cf, sweeps, ps);
+    MgTail<T> a;
+    a.nl = nl;
+    for (int l = 0; l < MG_TAIL_MAX; ++l) {
+        const int q = l < nl ? l : nl - 1;
+        a.m[l] = lv[q]; a.cnt[l] = cnt[q]; a.u[l] = u[q]; a.v[l] = v[q]; a.f[l] = f[q]; a.r[l] = r[q]; a.off[l] = off[q];
+    }
+    a.sweeps = sweeps;
+    hipLaunchKernelGGL((k_mg_tail<T>), dim3(1), dim3(1024), 0, st, a, ps);
 }
 
 #define INSTMG(T)                                                                                                                   \
@@ -302,7 +428,8 @@ void launch_mg_coarsest(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f
     template void launch_mg_resid<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, const PcgState*);        \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                  \
     template void launch_mg_prolong<T>(hipStream_t, MLevel, const uint8_t*, T*, MLevel, const T*, const PcgState*);                   \
-    template void launch_mg_coarsest<T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, MgCoef<T>, int, const PcgState*);
+    template void launch_mg_tail<T>(hipStream_t, int, const MLevel*, uint8_t* const*, T* const*, T* const*, T* const*, T* const*, const T*, int, \
+                                    const PcgState*);
 INSTMG(double)
 
 }  // namespace fl
