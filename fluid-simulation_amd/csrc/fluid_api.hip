@@ -538,12 +538,16 @@ static int mg_setup(fluid_sim* s)
             s->mg_cap[l] = cap;
         }
         // the layout changes with the box: everything outside the new domain must read as zero / solid
+        // Level 0 needs none of this for u/v/r: every cell of its domain is rewritten before it is read, and
+        // unknown cells only look at neighbours inside the domain.  Coarse levels are read through their zero ring.
         HIPCHK(hipMemsetAsync(s->mg_typ[l], 0, s->mgl[l].cells, s->st));
-        if (l > 0) HIPCHK(hipMemsetAsync(s->mg_cnt[l], 0, s->mgl[l].cells, s->st));
-        HIPCHK(hipMemsetAsync(s->mg_u[l], 0, s->mgl[l].cells * 8, s->st));
-        HIPCHK(hipMemsetAsync(s->mg_v[l], 0, s->mgl[l].cells * 8, s->st));
-        if (l > 0) HIPCHK(hipMemsetAsync(s->mg_f[l], 0, s->mgl[l].cells * 8, s->st));
-        HIPCHK(hipMemsetAsync(s->mg_r[l], 0, s->mgl[l].cells * 8, s->st));
+        if (l > 0) {
+            HIPCHK(hipMemsetAsync(s->mg_cnt[l], 0, s->mgl[l].cells, s->st));
+            HIPCHK(hipMemsetAsync(s->mg_u[l], 0, s->mgl[l].cells * 8, s->st));
+            HIPCHK(hipMemsetAsync(s->mg_v[l], 0, s->mgl[l].cells * 8, s->st));
+            HIPCHK(hipMemsetAsync(s->mg_f[l], 0, s->mgl[l].cells * 8, s->st));
+            HIPCHK(hipMemsetAsync(s->mg_r[l], 0, s->mgl[l].cells * 8, s->st));
+        }
     }
     launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
     for (int l = 1; l < nl; ++l) launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
@@ -593,7 +597,9 @@ static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_
         const double* f = l == 0 ? rhs0 : s->mg_f[l];
         const MgCoef<double> cf = mg_coef(s, l);
         launch_mg_prolong<double>(s->st, m, cnt, s->mg_u[l], s->mgl[l + 1], s->mg_u[l + 1], ps);
+        const int tok = l == 0 ? prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells()) : -1;
         launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_v[l], cf, nullptr, ps);
+        if (l == 0) prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
         launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_v[l], l == 0 ? z0 : s->mg_u[l], cf, l == 0 ? part_rz : nullptr, ps);
     }
     HIPCHK(hipGetLastError());
