@@ -83,7 +83,7 @@ struct fluid_sim {
     long mig_cap = 0;
     int* d_small = nullptr;      // device scratch ints: [0..1] migrate counters, [2..3] received counts, [4..19] misc
     int* h_small = nullptr;      // pinned mirror
-    double *gstage[2] = {nullptr, nullptr}, *gpq = nullptr;  // all-reduced PCG scalars
+    double *gstage[2] = {nullptr, nullptr}, *gpq = nullptr, *grz = nullptr;  // all-reduced PCG scalars (grz: 2 slots, multigrid r.z)
     void *zplane = nullptr, *splane = nullptr;               // zero / scratch ring planes for an empty local box
     Box Rr{0, 0, 0, -1, -1, -1}, Sr{0, 0, 0, -1, -1, -1};    // local parts of Rb / Sb
     // profiling
@@ -215,7 +215,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->Zmg, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->zplane, s->splane};
+                    s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int l = 0; l < fluid_sim::MG_MAXL; ++l) {
         void* q[] = {s->mg_typ[l], s->mg_cnt[l], s->mg_u[l], s->mg_v[l], s->mg_f[l], s->mg_r[l]};
@@ -504,7 +504,8 @@ static Coef<T> make_coef(const fluid_sim* s)
 }
 
 // ---- multigrid-preconditioned CG (single GPU, fp64) ----------------------------------------------
-static bool use_mg(const fluid_sim* s) { return s->prm.reserved == 0 && s->prm.precision == FLUID_PRECISION_FP64 && !s->dist; }
+// (multi-GPU: the same V-cycle applied per slab, neighbour-slab unknowns treated as p = 0: block preconditioner, no halo traffic)
+static bool use_mg(const fluid_sim* s) { return s->prm.reserved == 0 && s->prm.precision == FLUID_PRECISION_FP64; }
 
 // Level hierarchy of this step: level 0 = the box-local solver layout, coarsened until <= 8^3.
 static int mg_setup(fluid_sim* s)
@@ -1221,6 +1222,79 @@ static int dist_solve_impl(fluid_sim* s)
     return FLUID_OK;
 }
 
+// Distributed PCG with the per-slab V-cycle as preconditioner (block Jacobi of multigrid solves):
+// per iteration one ring exchange and three small all-reduces (r.z, s.q, |r|^2), nothing inside the V-cycle.
+static int dist_solve_mg(fluid_sim* s)
+{
+    typedef double T;
+    const Grid g = s->g;
+    const LBox L = s->L;
+    T* X = (T*)s->X;
+    T* R = (T*)s->R;
+    T* Q = (T*)s->Q;
+    T* Z = (T*)s->Zmg;
+    T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
+    const uint8_t* cnt = s->cntL;
+    const Coef<T> cf = make_coef<T>(s);
+    const double tol = s->prm.cg_tol;
+    long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
+    if (max_it < 1) max_it = 1;
+    const size_t plane = (size_t)L.Ly * L.Lz * sizeof(T);
+    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L), n_rz = mg_smooth_blocks(s->mgl[0]);
+    if (n_rz > MAX_PARTIALS) return fail(FLUID_ERR_STATE, "multigrid: partial buffer too small");
+    int rc;
+    auto ring = [&](T* S) -> int {
+        char* b = (char*)S;
+        if (L.nx > 0) return comm_sendrecv(s, b + plane, plane, b, plane, b + (size_t)L.nx * plane, plane, b + (size_t)(L.nx + 1) * plane, plane);
+        return comm_sendrecv(s, s->zplane, plane, s->splane, plane, s->zplane, plane, (char*)s->splane + plane, plane);
+    };
+    const double cells = (double)s->Rr.cells();
+    int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
+    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
+    launch_sum2(s->st, s->part_bb, nxr, s->part_rz[0], nxr, s->gstage[1], s->gstage[1] + 1);
+    if ((rc = comm_allreduce(s, s->gstage[1], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+    long it = 0;
+    const int CHECK = 8;
+    bool done = false;
+    while (!done) {
+        for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
+            const int cur = (int)(it & 1), prv = cur ^ 1;
+            if ((rc = mg_vcycle(s, R, Z, s->part_rz[0]))) return rc;
+            launch_sum2(s->st, s->part_rz[0], n_rz, s->part_rz[0], 0, s->grz + cur, nullptr);
+            if ((rc = comm_allreduce(s, s->grz + cur, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
+            launch_pcg_s<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], cf, s->gstage[prv], s->grz + cur, s->grz + prv, s->ps, it == 0, tol, 1);
+            if ((rc = ring(Sx[cur]))) return rc;
+            launch_pcg_q<T>(s->st, L, cnt, Sx[cur], Q, cf, s->part_pq, s->ps);
+            prof_end(s, FLUID_PROF_PCG_SQ, tok);
+            launch_sum2(s->st, s->part_pq, nsq, s->part_pq, 0, s->gpq, nullptr);
+            if ((rc = comm_allreduce(s, s->gpq, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
+            launch_pcg_xr_g<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->grz + cur, s->gpq, s->part_rr, s->part_err, s->ps);
+            prof_end(s, FLUID_PROF_PCG_XR, tok);
+            launch_sum2(s->st, s->part_rr, nxr, s->part_rr, 0, s->gstage[cur], nullptr);
+            if ((rc = comm_allreduce(s, s->gstage[cur], 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+        }
+        HIPCHK(hipGetLastError());
+        // convergence of the last body of a batch is seen by the first S launch of the next batch (after one spare V-cycle)
+        if ((rc = comm_allreduce(s, &s->ps->done, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
+        HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        done = s->h_ps->done || it >= max_it;
+    }
+    int iters = s->h_ps->iters;
+    const double rr = s->h_ps->rr;
+    if (!s->h_ps->done) iters = (int)max_it;
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    HIPCHK(hipGetLastError());
+    prof_end(s, FLUID_PROF_SOLVE, tsolve);
+    s->stats.cg_iters_last = iters;
+    s->stats.cg_iters += iters;
+    s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
+    if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
+    return FLUID_OK;
+}
+
 static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
 {
     const Grid g = s->g;
@@ -1283,6 +1357,7 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
         HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
         HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
         HIPCHK(hipGetLastError());
+        if (use_mg(s) && (rc = mg_setup(s))) return rc;
     }
     s->have_p2g = s->have_flags = true;
     // ---- pressure do..while (:1457-1484) ------------------------------------------------------------------
@@ -1293,7 +1368,8 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
             if (!box_empty(s->Rr))
                 launch_rhs_div(s->st, g, s->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver, s->prm.dx, s->prm.gravity[0] * dt,
                                s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);
-            rc = s->prm.precision == FLUID_PRECISION_FP32 ? dist_solve_impl<float>(s) : dist_solve_impl<double>(s);
+            if (use_mg(s)) rc = dist_solve_mg(s);
+            else rc = s->prm.precision == FLUID_PRECISION_FP32 ? dist_solve_impl<float>(s) : dist_solve_impl<double>(s);
             if (rc) return rc;
             if ((rc = exchange_planes(s, s->pressure, 8))) return rc;
             const double dtp = dt * s->prm.update_frac, k = dtp / (s->prm.rho * s->prm.dx);
@@ -1363,7 +1439,8 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const i
     s->xs = bounds[comm->rank];
     s->xe = bounds[comm->rank + 1];
     auto bail = [&](const std::string& m) { fluid_destroy(s); *out = nullptr; return fail(FLUID_ERR_HIP, m); };
-    if (dalloc(&s->gstage[0], (size_t)2) != hipSuccess || dalloc(&s->gstage[1], (size_t)2) != hipSuccess || dalloc(&s->gpq, (size_t)1) != hipSuccess)
+    if (dalloc(&s->gstage[0], (size_t)2) != hipSuccess || dalloc(&s->gstage[1], (size_t)2) != hipSuccess || dalloc(&s->gpq, (size_t)1) != hipSuccess ||
+        dalloc(&s->grz, (size_t)2) != hipSuccess)
         return bail("alloc of reduction scalars failed");
     const LBox Lm = make_lbox(Box{0, 0, 0, p->n - 1, p->n - 1, p->n - 1});
     const size_t plane = (size_t)Lm.Ly * Lm.Lz * 8;

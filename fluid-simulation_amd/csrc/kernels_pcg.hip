@@ -304,8 +304,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_pcg_s_l(long n2, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
                                                  const T* __restrict__ s_in, T* __restrict__ s_out, Coef<T> cf,
                                                  const double* __restrict__ g_rr, const double* __restrict__ g_rz_new,
-                                                 const double* __restrict__ g_rz_old, PcgState* ps, int first, double tol)
+                                                 const double* __restrict__ g_rz_old, PcgState* ps, int first, double tol, int zmode)
 {
+    // zmode: `r` already holds z = M^-1 r (per-slab multigrid preconditioner)
     __shared__ double red[16];
     __shared__ int s_done;
     __shared__ T sdiag[8], sinv[8];
@@ -330,8 +331,8 @@ __global__ __launch_bounds__(256) void k_pcg_s_l(long n2, const uint8_t* __restr
             V2 sv;
             sv.a = 0; sv.b = 0;
             if (!first) sv = s2[e];
-            if (ca) o.a = rv.a * sinv[ca] + beta * sv.a;
-            if (cb) o.b = rv.b * sinv[cb] + beta * sv.b;
+            if (ca) o.a = (zmode ? rv.a : rv.a * sinv[ca]) + beta * sv.a;
+            if (cb) o.b = (zmode ? rv.b : rv.b * sinv[cb]) + beta * sv.b;
         }
         ((V2*)s_out)[e] = o;
     }
@@ -463,10 +464,10 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
 // multi-GPU pieces: n_* = 1 means "already all-reduced scalar"
 template <typename T>
 void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
-                  const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol)
+                  const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol, int zmode)
 {
     hipLaunchKernelGGL((k_pcg_s_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, r, s_in, s_out, cf, g_rr,
-                       g_rz_new, g_rz_old, ps, first, tol);
+                       g_rz_new, g_rz_old, ps, first, tol, zmode);
 }
 template <typename T>
 void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps)
@@ -740,7 +741,7 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);                                \
     template void launch_pcg_s<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, Coef<T>, const double*, const double*,     \
-                                  const double*, PcgState*, int, double);                                                              \
+                                  const double*, PcgState*, int, double, int);                                                           \
     template void launch_pcg_q<T>(hipStream_t, LBox, const uint8_t*, const T*, T*, Coef<T>, double*, PcgState*);                        \
     template void launch_pcg_xr_g<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,             \
                                      const double*, double*, double*, PcgState*);
