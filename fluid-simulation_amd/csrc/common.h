@@ -175,7 +175,8 @@ void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int
 void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot, const int* cell_start, int* order);
 void launch_bin_fix(hipStream_t st, Grid g, Box box, const int* cell_start, const uint32_t* pid, int* order);
 void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst);
-void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const int* cell_start, const uint8_t* flags,
+void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
+void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                 float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss);
 void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss);

@@ -57,6 +57,7 @@ struct fluid_sim {
     Particles pa{}, pb{};
     int *key = nullptr, *slot = nullptr, *order = nullptr, *cell_count = nullptr, *cell_start = nullptr;
     double *stage_pos = nullptr, *stage_vel = nullptr;
+    double* pw = nullptr;  // 9 axis weights per particle, SoA with stride cap
     StepState* ss = nullptr;
     StepState* h_ss = nullptr;  // pinned
     // boxes
@@ -78,6 +79,7 @@ struct fluid_sim {
     std::vector<int> bounds;
     int xs = 0, xe = 0;          // owned x planes [xs, xe)
     long p_off = 0;              // my live particles are pa[p_off .. p_off+np)
+    long p2g_total = 0;          // left ghosts + mine + right ghosts: the range P2G may read
     long n_dropped = 0;          // particles that left the grid on this rank (inert)
     double *mig_lo = nullptr, *mig_hi = nullptr, *mig_rlo = nullptr, *mig_rhi = nullptr;  // 7-double records
     long mig_cap = 0;
@@ -160,7 +162,8 @@ static void free_particles(fluid_sim* s)
         hipFree(p->px); hipFree(p->py); hipFree(p->pz); hipFree(p->vx); hipFree(p->vy); hipFree(p->vz); hipFree(p->pid);
         *p = Particles{};
     }
-    hipFree(s->key); hipFree(s->slot); hipFree(s->order); hipFree(s->stage_pos); hipFree(s->stage_vel);
+    hipFree(s->key); hipFree(s->slot); hipFree(s->order); hipFree(s->stage_pos); hipFree(s->stage_vel); hipFree(s->pw);
+    s->pw = nullptr;
     s->key = s->slot = s->order = nullptr;
     s->stage_pos = s->stage_vel = nullptr;
     s->cap = 0;
@@ -177,6 +180,7 @@ static int alloc_particles(fluid_sim* s, long n)
     }
     HIPCHK(dalloc(&s->key, n)); HIPCHK(dalloc(&s->slot, n)); HIPCHK(dalloc(&s->order, n));
     HIPCHK(dalloc(&s->stage_pos, 3 * n)); HIPCHK(dalloc(&s->stage_vel, 3 * n));
+    HIPCHK(dalloc(&s->pw, 9 * n));
     HIPCHK(hipDeviceSynchronize());
     s->cap = n;
     return FLUID_OK;
@@ -474,7 +478,8 @@ static int phase_p2g(fluid_sim* s)
     }
     if (!box_empty(s->Rb)) {
         int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rb.cells());
-        launch_p2g(s->st, s->g, s->Rb, s->pa, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        launch_weights(s->st, s->np, s->pa, s->pw, s->cap);
+        launch_p2g(s->st, s->g, s->Rb, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         prof_end(s, FLUID_PROF_P2G, tok);
         HIPCHK(hipGetLastError());
         s->dirty_x0 = s->Sb.x0;
@@ -1149,6 +1154,7 @@ static int dist_sort(fluid_sim* s)
     if ((rc = comm_sendrecv(s, s->mig_lo, (size_t)n_slo * 56, s->mig_rlo, (size_t)gl * 56, s->mig_hi, (size_t)n_shi * 56, s->mig_rhi, (size_t)gr * 56))) return rc;
     launch_unpack_records(s->st, gl, s->mig_rlo, s->pa, 0);
     launch_unpack_records(s->st, gr, s->mig_rhi, s->pa, s->h_small[7]);
+    s->p2g_total = s->h_small[7] + gr;
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SORT, tok);
     s->sorted = true;
@@ -1316,7 +1322,8 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
     s->dirty_x1 = s->xe < N ? s->xe : N - 1;
     if (!box_empty(s->Rb) && !box_empty(s->Rr)) {
         int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
-        launch_p2g(s->st, g, s->Rr, s->pa, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
+        launch_p2g(s->st, g, s->Rr, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         prof_end(s, FLUID_PROF_P2G, tok);
         HIPCHK(hipGetLastError());
     }

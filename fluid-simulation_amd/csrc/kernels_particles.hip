@@ -156,21 +156,46 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
 // same w under "w>0", i.e. the same float sequence, so one array serves both.
 // The post-P2G velocity is also stored as velBeforeUpdate (fluid.cc:1455).
 //
+// Separable weights: w(p,c) = sx*sy*sz with s_a = spline(pos_a - c_a) (fluid.cc:291), and a particle only ever
+// meets the cells base-1, base, base+1 per axis, so 9 spline values per particle (k_weights, bit-identical to
+// evaluating spline at (pos - cell)) replace 81 evaluations; the product keeps the reference's association
+// (sx*sy)*sz.
+//
 // Work decomposition: one block = 2 x 2 cell columns (x,y) x 64 cells in z; wave = one column,
 // lane = z.  The particles of a grid row (fixed x,y; z-1..z+64) are CONTIGUOUS in the sorted
 // arrays, so the block stages each of the 4 x 4 neighbouring rows into LDS with coalesced loads
-// and every lane then walks its own 3-cell window inside LDS.  (A lane-per-cell loop straight
-// from global memory makes each wave load touch ~32 cache lines and thrashes the 32 KB L1:
-// 7.4 ms at 256^3 against 0.3 ms for the compute.)  Rows are visited in ascending (x,y) and
-// particles in ascending sorted order: the sum order per cell is fixed.
-constexpr int P2G_CH = 640;  // particles staged per chunk: 6 x 8 B x 640 = 30 KB of LDS
+// (weights + velocities) and every lane then walks its own 3-cell window inside LDS.  (A lane-per-cell
+// loop straight from global memory makes each wave load touch ~32 cache lines and thrashes the 32 KB L1:
+// 7.4 ms at 256^3.)  Rows are visited in ascending (x,y) and particles in ascending sorted order: the sum
+// order per cell is fixed.
+constexpr int P2G_CH = 320;  // particles staged per chunk: 12 arrays x 8 B x 320 = 30 KB of LDS
+// LDS slot of staged particle k: lane z reads particle a_z + t with a_z growing by ~8 (particles per cell) from
+// lane to lane; splitting by k mod 8 keeps neighbouring lanes on neighbouring slots.
+constexpr int P2G_SEG = P2G_CH / 8 + 1;
+__device__ __forceinline__ int p2g_slot(int k) { return (k & 7) * P2G_SEG + (k >> 3); }
+constexpr int P2G_LDS = 8 * P2G_SEG;
 
-__global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const int* __restrict__ cell_start,
-                                             const uint8_t* __restrict__ flags, float* __restrict__ container,
-                                             double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
-                                             double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
+// the 9 axis weights of every (sorted) particle: w[a*3+d][j] = spline(pos_a - (base_a - 1 + d))
+__global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __restrict__ w, long stride)
 {
-    __shared__ double spx[P2G_CH], spy[P2G_CH], spz[P2G_CH], svx[P2G_CH], svy[P2G_CH], svz[P2G_CH];
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const double q[3] = {p.px[j], p.py[j], p.pz[j]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int b = (int)round(q[a]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w[(a * 3 + d) * stride + j] = spline(q[a] - (double)(b - 1 + d));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
+                                             const int* __restrict__ cell_start, const uint8_t* __restrict__ flags,
+                                             float* __restrict__ container, double* __restrict__ u, double* __restrict__ v,
+                                             double* __restrict__ w, double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
+{
+    __shared__ double sw[9][P2G_LDS];   // wx0..2, wy0..2, wz0..2
+    __shared__ double sv[3][P2G_LDS];   // vx, vy, vz
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int N = g.N;
     const int ntz = (box.nz() + 63) / 64, nty = (box.ny() + 1) / 2;
@@ -181,11 +206,10 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
     const bool valid = ix <= box.x1 && iy <= box.y1 && iz <= box.z1;
     const size_t c = valid ? g.idx(ix, iy, iz) : 0;
     const bool live = valid && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
-    const double cx = (double)(ix + g.lo), cy = (double)(iy + g.lo), cz = (double)(iz + g.lo);
     const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + 64 < N - 1 ? tz0 + 64 : N - 1;
     const int wz0 = iz > 0 ? iz - 1 : 0, wz1 = iz < N - 1 ? iz + 1 : N - 1;
     float wf = 0.0f;
-    double su = 0, sv = 0, sw = 0;
+    double su = 0, sv_ = 0, sw_ = 0;
     for (int rx = tx0 - 1; rx <= tx0 + 2; ++rx) {
         if (rx < 0 || rx >= N) continue;
         for (int ry = ty0 - 1; ry <= ty0 + 2; ++ry) {
@@ -193,30 +217,44 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
             const int jb = cell_start[g.idx(rx, ry, zlo)];
             const int je = cell_start[g.idx(rx, ry, zhi) + 1];
             if (je == jb) continue;  // block-uniform
-            const bool mine = live && rx >= ix - 1 && rx <= ix + 1 && ry >= iy - 1 && ry <= iy + 1;
-            int a = 0, b = 0;
+            const int dxi = ix - rx + 1, dyi = iy - ry + 1;  // which axis weight of a particle of this row meets my column
+            const bool mine = live && dxi >= 0 && dxi <= 2 && dyi >= 0 && dyi <= 2;
+            int cs0 = 0, cs1 = 0, cs2 = 0, cs3 = 0;  // starts of the cells wz0, wz0+1, wz0+2 and the end of the window
             if (mine) {
-                a = cell_start[g.idx(rx, ry, wz0)];
-                b = cell_start[g.idx(rx, ry, wz1) + 1];
+                const size_t r0 = g.idx(rx, ry, wz0);
+                cs0 = cell_start[r0];
+                cs1 = cell_start[r0 + 1];
+                cs2 = wz0 + 1 <= wz1 ? cell_start[r0 + 2] : cs1;
+                cs3 = wz0 + 2 <= wz1 ? cell_start[r0 + 3] : cs2;
             }
+            const double* swx = sw[dxi < 0 ? 0 : (dxi > 2 ? 2 : dxi)];
+            const double* swy = sw[3 + (dyi < 0 ? 0 : (dyi > 2 ? 2 : dyi))];
             for (int cb = jb; cb < je; cb += P2G_CH) {
                 const int ce = cb + P2G_CH < je ? cb + P2G_CH : je;
                 __syncthreads();  // the previous chunk has been consumed
                 for (int j = cb + tid; j < ce; j += 256) {
-                    const int k = j - cb;
-                    spx[k] = p.px[j]; spy[k] = p.py[j]; spz[k] = p.pz[j];
-                    svx[k] = p.vx[j]; svy[k] = p.vy[j]; svz[k] = p.vz[j];
+                    const int k = p2g_slot(j - cb);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sw[q][k] = pw[q * wstride + j];
+                    sv[0][k] = p.vx[j]; sv[1][k] = p.vy[j]; sv[2][k] = p.vz[j];
                 }
                 __syncthreads();
                 if (mine) {
-                    const int lo = a > cb ? a : cb, hi = b < ce ? b : ce;
-                    for (int j = lo; j < hi; ++j) {
-                        const int k = j - cb;
-                        const double cw = spline(spx[k] - cx) * spline(spy[k] - cy) * spline(spz[k] - cz);
-                        wf = (float)((double)wf + cw);
-                        su = su + cw * svx[k];
-                        sv = sv + cw * svy[k];
-                        sw = sw + cw * svz[k];
+#pragma unroll
+                    for (int seg = 0; seg < 3; ++seg) {
+                        const int a = seg == 0 ? cs0 : (seg == 1 ? cs1 : cs2), b = seg == 0 ? cs1 : (seg == 1 ? cs2 : cs3);
+                        const int dzi = iz - (wz0 + seg) + 1;  // 2,1,0 away from the grid edge
+                        if (dzi < 0 || dzi > 2) continue;
+                        const double* swz = sw[6 + dzi];
+                        const int lo = a > cb ? a : cb, hi = b < ce ? b : ce;
+                        for (int j = lo; j < hi; ++j) {
+                            const int k = p2g_slot(j - cb);
+                            const double cw = swx[k] * swy[k] * swz[k];
+                            wf = (float)((double)wf + cw);
+                            su = su + cw * sv[0][k];
+                            sv_ = sv_ + cw * sv[1][k];
+                            sw_ = sw_ + cw * sv[2][k];
+                        }
                     }
                 }
             }
@@ -225,11 +263,11 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
     if (!live) return;  // fields stay 0
     if (wf > 0) {
         const double wd = (double)wf;
-        su /= wd; sv /= wd; sw /= wd;
+        su /= wd; sv_ /= wd; sw_ /= wd;
     }
     container[c] = wf;
-    u[c] = su; v[c] = sv; w[c] = sw;
-    ub[c] = su; vb[c] = sv; wb[c] = sw;
+    u[c] = su; v[c] = sv_; w[c] = sw_;
+    ub[c] = su; vb[c] = sv_; wb[c] = sw_;
 }
 
 // ---- grid -> particle, FLIP -----------------------------------------------------------------
@@ -248,13 +286,26 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
         int minx = fcx - 1 > lo ? fcx - 1 : lo, maxx = fcx + 1 < hi ? fcx + 1 : hi;
         int miny = fcy - 1 > lo ? fcy - 1 : lo, maxy = fcy + 1 < hi ? fcy + 1 : hi;
         int minz = fcz - 1 > lo ? fcz - 1 : lo, maxz = fcz + 1 < hi ? fcz + 1 : hi;
+        // the 27 weights are products of 3 x 3 axis values (same values and association as spline()*spline()*spline())
+        double wx[3], wy[3], wz[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            wx[d] = spline(cx - (double)(fcx - 1 + d));
+            wy[d] = spline(cy - (double)(fcy - 1 + d));
+            wz[d] = spline(cz - (double)(fcz - 1 + d));
+        }
         double weight = 0, d0 = 0, d1 = 0, d2 = 0;
-        for (int x = minx; x <= maxx; ++x)
-            for (int y = miny; y <= maxy; ++y)
-                for (int z = minz; z <= maxz; ++z) {
+#pragma unroll
+        for (int xi = 0; xi < 3; ++xi)
+#pragma unroll
+            for (int yi = 0; yi < 3; ++yi)
+#pragma unroll
+                for (int zi = 0; zi < 3; ++zi) {
+                    const int x = fcx - 1 + xi, y = fcy - 1 + yi, z = fcz - 1 + zi;
+                    if (x < minx || x > maxx || y < miny || y > maxy || z < minz || z > maxz) continue;  // clamp to the grid (:216-221)
                     if (x >= wlo && x <= whi && y >= wlo && y <= whi && z >= wlo && z <= whi) {  // :237
                         const size_t c = g.idx(x - lo, y - lo, z - lo);
-                        const double cw = spline(cx - x) * spline(cy - y) * spline(cz - z);
+                        const double cw = wx[xi] * wy[yi] * wz[zi];
                         weight += cw;
                         d0 += dcx[c] * cw;
                         d1 += dcy[c] * cw;
@@ -433,11 +484,15 @@ void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Par
 {
     if (n > 0) hipLaunchKernelGGL(k_reorder, dim3(nblk(n)), dim3(256), 0, st, n, order, src, dst);
 }
-void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const int* cell_start, const uint8_t* flags, float* container,
-                double* u, double* v, double* w, double* ub, double* vb, double* wb)
+void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
+{
+    if (n > 0) hipLaunchKernelGGL(k_weights, dim3(nblk(n)), dim3(256), 0, st, n, p, w, stride);
+}
+void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
+                float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
 {
     const unsigned nt = (unsigned)(((box.nx() + 1) / 2) * ((box.ny() + 1) / 2) * ((box.nz() + 63) / 64));
-    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(256), 0, st, g, box, p, cell_start, flags, container, u, v, w, ub, vb, wb);
+    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(256), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb);
 }
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss)
 {
