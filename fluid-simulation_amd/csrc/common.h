@@ -243,8 +243,8 @@ int mg_smooth_blocks(const MLevel& m);
 void launch_mg_type0(hipStream_t st, Grid g, LBox L, MLevel m, const uint8_t* flags, const uint8_t* cnt, uint8_t* typ);
 void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, uint8_t* tc, uint8_t* cnt_c);
 template <typename T>
-void launch_mg_smooth(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u_in, T* u_out, MgCoef<T> cf, double* part_dot,
-                      const PcgState* ps);
+void launch_mg_smooth(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u_in, T* u_out, MgCoef<T> cf, int sweep,
+                      double* part_dot, const PcgState* ps);
 template <typename T>
 void launch_mg_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* r, MgCoef<T> cf, const PcgState* ps);
 template <typename T>

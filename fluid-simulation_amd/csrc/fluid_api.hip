@@ -587,7 +587,7 @@ static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_
         const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
         const double* f = l == 0 ? rhs0 : s->mg_f[l];
         const MgCoef<double> cf = mg_coef(s, l);
-        launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_u[l], cf, nullptr, ps);   // two sweeps from u = 0
+        launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_u[l], cf, 0, nullptr, ps);   // two sweeps from u = 0
         launch_mg_resid<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], cf, ps);
         launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
     }
@@ -604,9 +604,9 @@ static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_
         const MgCoef<double> cf = mg_coef(s, l);
         launch_mg_prolong<double>(s->st, m, cnt, s->mg_u[l], s->mgl[l + 1], s->mg_u[l + 1], ps);
         const int tok = l == 0 ? prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells()) : -1;
-        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_v[l], cf, nullptr, ps);
+        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_v[l], cf, 1, nullptr, ps);
         if (l == 0) prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
-        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_v[l], l == 0 ? z0 : s->mg_u[l], cf, l == 0 ? part_rz : nullptr, ps);
+        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_v[l], l == 0 ? z0 : s->mg_u[l], cf, 2, l == 0 ? part_rz : nullptr, ps);
     }
     HIPCHK(hipGetLastError());
     return FLUID_OK;

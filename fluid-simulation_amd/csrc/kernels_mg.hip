@@ -17,7 +17,10 @@
 
 namespace fl {
 
-constexpr double MG_OMEGA = 2.0 / 3.0;
+// Damped-Jacobi weights of the two sweeps on each side of the coarse correction: (W1, W2) before, (W2, W1) after
+// (reversed, so M stays symmetric).  (2/3, 1.2) instead of (2/3, 2/3) takes ~15 % fewer PCG iterations in the
+// prototype; |(1 - W1 x)(1 - W2 x)| < 1 on the spectrum (0,2) of D^-1 A, so the smoother still converges.
+constexpr double MG_W1 = 2.0 / 3.0, MG_W2 = 1.2;
 
 // static indices only (a runtime index into a by-value kernel argument goes through scratch)
 template <typename T>
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void k_mg_cnt(MLevel m, const uint8_t* __restr
 // damped-Jacobi sweep: u_out = u_in + omega D^-1 (f - A u_in); returns f*u_out
 template <typename T>
 __device__ __forceinline__ double d_smooth(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f,
-                                           const T* __restrict__ u_in, T* __restrict__ u_out, const T* dg, const T* iv, T off, long t)
+                                           const T* __restrict__ u_in, T* __restrict__ u_out, const T* dg, const T* iv, T off, T omega, long t)
 {
     int i, j, k;
     if (!mg_cell(m, t, i, j, k)) return 0;
@@ -105,7 +108,7 @@ __device__ __forceinline__ double d_smooth(const MLevel& m, const uint8_t* __res
     if (n) {
         const T fv = f[c], uc = u_in[c];
         const T nb = u_in[c - m.sx] + u_in[c + m.sx] + u_in[c - m.sy] + u_in[c + m.sy] + u_in[c - 1] + u_in[c + 1];
-        out = uc + (T)MG_OMEGA * iv[n] * (fv - (dg[n] * uc + off * nb));
+        out = uc + omega * iv[n] * (fv - (dg[n] * uc + off * nb));
         acc = (double)fv * (double)out;
     }
     u_out[c] = out;
@@ -123,11 +126,11 @@ __device__ __forceinline__ void d_smooth0(const MLevel& m, const uint8_t* __rest
     const int n = cnt[c];
     T out = 0;
     if (n) {
-        const T w = (T)MG_OMEGA;
-        auto u1 = [&](size_t q) { return w * iv[cnt[q]] * f[q]; };  // iv[0] = 0: non-unknowns give 0
-        const T fv = f[c], uc = w * iv[n] * fv;
+        const T w1 = (T)MG_W1, w2 = (T)MG_W2;
+        auto u1 = [&](size_t q) { return w1 * iv[cnt[q]] * f[q]; };  // iv[0] = 0: non-unknowns give 0
+        const T fv = f[c], uc = w1 * iv[n] * fv;
         const T nb = u1(c - m.sx) + u1(c + m.sx) + u1(c - m.sy) + u1(c + m.sy) + u1(c - 1) + u1(c + 1);
-        out = uc + w * iv[n] * (fv - (dg[n] * uc + off * nb));
+        out = uc + w2 * iv[n] * (fv - (dg[n] * uc + off * nb));
     }
     u_out[c] = out;
 }
@@ -215,7 +218,7 @@ __device__ __forceinline__ void d_prolong(const MLevel& mf, const uint8_t* __res
 // ---- per-level kernels (levels too large for one block) ---------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_mg_smooth(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u_in,
-                                                   T* __restrict__ u_out, MgCoef<T> cf, double* __restrict__ part_dot, const PcgState* ps)
+                                                   T* __restrict__ u_out, MgCoef<T> cf, T omega, double* __restrict__ part_dot, const PcgState* ps)
 {
     __shared__ double red[4];
     __shared__ T sd[8], si[8];
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void k_mg_smooth(MLevel m, const uint8_t* __re
     mg_load_coef(sd, si, cf);
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
-    if (u_in) acc = d_smooth<T>(m, cnt, f, u_in, u_out, sd, si, cf.off, t);
+    if (u_in) acc = d_smooth<T>(m, cnt, f, u_in, u_out, sd, si, cf.off, omega, t);
     else d_smooth0<T>(m, cnt, f, u_out, sd, si, cf.off, t);
     if (part_dot) {
         acc = block_sum<double, 4>(acc, red);
@@ -345,9 +348,9 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
         if (l < a.nl - 1) {
             TAIL_FOR(l) d_prolong<T>(a.m[l], a.cnt[l], a.u[l], a.m[l + 1], a.u[l + 1], t);
             __syncthreads();
-            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], a.v[l], sd[l], si[l], a.off[l], t);
+            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], a.v[l], sd[l], si[l], a.off[l], (T)MG_W2, t);
             __syncthreads();
-            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.v[l], a.u[l], sd[l], si[l], a.off[l], t);
+            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.v[l], a.u[l], sd[l], si[l], a.off[l], (T)MG_W1, t);
             __syncthreads();
         }
     }
@@ -388,10 +391,12 @@ void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, 
     hipLaunchKernelGGL(k_mg_cnt, dim3(mg_blocks(mc)), dim3(256), 0, st, mc, (const uint8_t*)tc, cnt_c);
 }
 template <typename T>
-void launch_mg_smooth(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u_in, T* u_out, MgCoef<T> cf, double* part_dot,
-                      const PcgState* ps)
+void launch_mg_smooth(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u_in, T* u_out, MgCoef<T> cf, int sweep,
+                      double* part_dot, const PcgState* ps)
 {
-    hipLaunchKernelGGL((k_mg_smooth<T>), dim3(mg_blocks(m)), dim3(256), 0, st, m, cnt, f, u_in, u_out, cf, part_dot, ps);
+    // sweep: 0 = both pre-sweeps from u = 0 (u_in == nullptr), 1 = first post-sweep (W2), 2 = second post-sweep (W1)
+    const T omega = (T)(sweep == 1 ? MG_W2 : MG_W1);
+    hipLaunchKernelGGL((k_mg_smooth<T>), dim3(mg_blocks(m)), dim3(256), 0, st, m, cnt, f, u_in, u_out, cf, omega, part_dot, ps);
 }
 template <typename T>
 void launch_mg_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* r, MgCoef<T> cf, const PcgState* ps)
@@ -424,7 +429,7 @@ void launch_mg_tail(hipStream_t st, int nl, const MLevel* lv, uint8_t* const* cn
 }
 
 #define INSTMG(T)                                                                                                                   \
-    template void launch_mg_smooth<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, double*, const PcgState*); \
+    template void launch_mg_smooth<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, int, double*, const PcgState*); \
     template void launch_mg_resid<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, const PcgState*);        \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                  \
     template void launch_mg_prolong<T>(hipStream_t, MLevel, const uint8_t*, T*, MLevel, const T*, const PcgState*);                   \
