@@ -2,6 +2,8 @@
 """Developer sweep of the marching-stencil knobs: python tools_sweep.py [n]"""
 import os, sys, json
 import numpy as np
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 fs = entry.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
