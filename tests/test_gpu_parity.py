@@ -322,3 +322,30 @@ def test_run_sh_fluid_driver(tmp_path):
         assert f.exists() and f.stat().st_size == 4 + 4 * 32 ** 3
     rho = np.fromfile(tmp_path / "simulation" / "mygrids2.f32", dtype=np.float32, offset=4).reshape(32, 32, 32)
     assert rho.max() > 0 and rho[0].max() == 0  # density inside, nothing in the solid shell
+
+
+def test_long_run_stays_convergent(fs):
+    """300 free-running steps through the splash and the spreading phase: every solve must meet Eigen's stopping
+    rule with a bounded iteration count (thin sheets, droplets and wall contact change the multigrid hierarchy every
+    step), the state stays finite and inside the tank, and the two preconditioners keep agreeing."""
+    n, ppc = 48, 4
+    pos = fs.water_cube_drop(n, ppc, seed=3)
+    mg = fs.FluidSim(n=n)                                # multigrid (default)
+    jc = fs.FluidSim(n=n, preconditioner="jacobi")
+    mg.upload_particles(pos); jc.upload_particles(pos)
+    lo, hi = fs.grid_bounds(n)
+    worst_it, worst_rel = 0, 0.0
+    for i in range(300):
+        s = mg.step()
+        assert np.isfinite(s["dt_out"]) and 0 < s["dt_out"] <= 0.1, (i, s)
+        assert s["relres"] < 2.3e-16 and s["outer_passes"] <= 12, (i, s)
+        worst_it = max(worst_it, s["cg_iters_last"]); worst_rel = max(worst_rel, s["relres"])
+        if i < 60:
+            t = jc.step()
+            assert t["num_active"] == s["num_active"] and t["outer_passes"] == s["outer_passes"], (i, s, t)
+    p, v = mg.download_particles()
+    assert np.isfinite(p).all() and np.isfinite(v).all()
+    assert p.min() > lo + 1 and p.max() < hi - 1          # nothing tunnelled through the 2-cell solid shell
+    assert p[:, 1].mean() < pos[:, 1].mean() - 5           # the water did fall
+    print(f"300 steps: worst MG-PCG iterations {worst_it}, worst relres {worst_rel:.2e}, final dt {s['dt_out']:.4f}, numActive {s['num_active']}")
+    assert worst_it <= 80
