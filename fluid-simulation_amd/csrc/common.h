@@ -251,6 +251,12 @@ template <typename T>
 void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const uint8_t* cnt_c, T* fc, const PcgState* ps);
 template <typename T>
 void launch_mg_prolong(hipStream_t st, MLevel mf, const uint8_t* cnt_f, T* u, MLevel mc, const T* ec, const PcgState* ps);
+template <typename T>
+void launch_mg_smooth0_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MgCoef<T> cf, const PcgState* ps);
+template <typename T>
+void launch_mg_prolong_smooth(hipStream_t st, MLevel mf, const uint8_t* cnt_f, const T* f, const T* u, T* u_out, MLevel mc, const T* ec,
+                              MgCoef<T> cf, const PcgState* ps);
+constexpr long MG_FUSE_CELLS = 400000;  // levels below this are launch-bound: use the fused kernels
 constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel can hold
 constexpr long MG_TAIL_CELLS = 2048;    // a level this small (and all coarser ones) goes into the tail (one CU: 94 us at 12k cells)
 template <typename T>

@@ -268,11 +268,11 @@ def test_against_committed_golden_trace(fs):
     assert ep < TOL_F and ev < TOL_F
 
 
-def test_round_trip_properties_at_bench_size(fs):
-    """Size-independent checks at BASELINE's 128^3 size (no oracle run): particle count and ids survive the
-    sort, the unknown numbering is a permutation-free exclusive scan, the solve meets Eigen's stopping rule,
+@pytest.mark.parametrize("n", [128, 256])
+def test_round_trip_properties_at_bench_size(fs, n):
+    """Size-independent checks at BASELINE's 128^3 and 256^3 sizes (no oracle run): particle count and ids survive
+    the sort, the unknown numbering is a permutation-free exclusive scan, the solve meets Eigen's stopping rule,
     and the stencil is symmetric (s.A t == t.A s) on random vectors."""
-    n = 128
     pos = fs.water_cube_drop(n, 8, seed=0)
     sim = fs.FluidSim(n=n)
     sim.upload_particles(pos)
@@ -349,3 +349,81 @@ def test_long_run_stays_convergent(fs):
     assert p[:, 1].mean() < pos[:, 1].mean() - 5           # the water did fall
     print(f"300 steps: worst MG-PCG iterations {worst_it}, worst relres {worst_rel:.2e}, final dt {s['dt_out']:.4f}, numActive {s['num_active']}")
     assert worst_it <= 80
+
+
+def _compare_step(fs, oracle, n, pos, vel, steps=2):
+    sim = fs.FluidSim(n=n); orc = oracle.Oracle(n=n)
+    sim.upload_particles(pos, vel); orc.set_particles(pos, vel)
+    for i in range(steps):
+        sg = sim.step(); so = orc.step()
+        assert sg["num_active"] == so["num_active"], (i, sg, so)
+        assert sg["outer_passes"] == so["outer_passes"], (i, sg, so)
+        assert abs(sg["dt_out"] - so["dt_out"]) <= 1e-9 * so["dt_out"]
+    F = fs.FIELD
+    assert np.array_equal(sim.field(F.INDICES), orc.field(4))
+    assert rel_l2(sim.field(F.CONTAINER), orc.field(0)) < TOL_W
+    if len(pos):
+        p, v = sim.download_particles(); po, vo = orc.particles()
+        assert np.allclose(p, po, rtol=0, atol=1e-7) and np.allclose(v, vo, rtol=0, atol=1e-6)
+    return sim, orc
+
+
+def test_edge_no_particles(fs, oracle):
+    """Empty PointList: nothing is fluid, b = 0, the do..while ends on NaN after one pass (fluid.cc:1483-1484)."""
+    sim = fs.FluidSim(n=24)
+    sim.upload_particles(np.zeros((0, 3)))
+    s = sim.step()
+    assert s["num_active"] == 0 and s["outer_passes"] == 1 and np.isnan(s["error"]) and s["dt_out"] == 0.1
+    assert (sim.field(fs.FIELD.INDICES) == -1).all() and sim.field(fs.FIELD.CONTAINER).max() == 0
+    orc = oracle.Oracle(n=24); orc.set_particles(np.zeros((0, 3)))
+    so = orc.step()
+    assert so["num_active"] == 0 and so["outer_passes"] == 1
+
+
+def test_edge_single_particle_and_ties(fs, oracle):
+    """One particle; then particles sitting exactly on half-integer coordinates (round() half away from zero, fluid.cc:267)
+    on both sides of zero, where rint() would pick another base cell."""
+    n = 24
+    _compare_step(fs, oracle, n, np.array([[0.3, 2.2, -1.7]]), np.array([[0.5, -1.0, 0.25]]))
+    ties = np.array([[0.5, 0.5, 0.5], [-0.5, -0.5, -0.5], [1.5, -2.5, 3.5], [-3.5, 2.5, -1.5], [2.5, 2.5, 2.5], [0.0, -0.5, 0.5]])
+    sim, orc = _compare_step(fs, oracle, n, ties, np.zeros_like(ties), steps=1)
+    # the base cells really are the half-away-from-zero ones: container peaks where round() says
+    c = sim.field(fs.FIELD.CONTAINER)
+    lo, _ = fs.grid_bounds(n)
+    assert c[1 - lo, 1 - lo, 1 - lo] > 0 and c[-1 - lo, -1 - lo, -1 - lo] > 0
+
+
+def test_edge_particles_in_shell_and_off_grid(fs, oracle):
+    """Particles inside the solid shell, beyond the grid and far away contribute to nothing (fluid.cc:271-276,288) but
+    keep being advected; a fast particle aimed at the wall takes the stuck-particle branch (fluid.cc:1011-1030)."""
+    n = 24
+    lo, hi = fs.grid_bounds(n)
+    base = fs.water_cube_drop(n, 2, seed=1)
+    extra = np.array([[hi - 0.6, 0.0, 0.0], [lo + 0.4, 1.0, 1.0], [hi + 3.0, 0.0, 0.0], [0.0, lo - 7.5, 0.0], [1e6, -1e6, 3.0],
+                      [hi - 2.6, 0.2, 0.1], [0.1, lo + 2.4, 0.3]])
+    vex = np.array([[1.0, 0, 0], [0, 0, 0], [0, 0, 0], [0, 1.0, 0], [0, 0, 0], [9.0, 0.0, 0.0], [0.0, -9.0, 0.0]])
+    pos = np.concatenate([base, extra]); vel = np.concatenate([np.zeros_like(base), vex])
+    sim, orc = _compare_step(fs, oracle, n, pos, vel, steps=3)
+    p, v = sim.download_particles(); po, vo = orc.particles()
+    k = len(base)
+    assert np.array_equal(np.isfinite(p), np.isfinite(po))
+    assert np.allclose(p[k:], po[k:], rtol=1e-12, atol=1e-9) and np.allclose(v[k:], vo[k:], rtol=1e-12, atol=1e-9)
+    assert abs(v[k + 5, 0]) < 1.0 and abs(v[k + 6, 1]) < 2.0   # wall hit: the 9 cells/s component was zeroed (e = 0), both paths agree
+
+
+def test_edge_obstacle(fs, oracle):
+    """A solid block inside W (the reference's commented 'big wall', fluid.cc:1333-1345): Neumann faces inside the domain."""
+    n = 32
+    lo, hi = fs.grid_bounds(n)
+    sim = fs.FluidSim(n=n); orc = oracle.Oracle(n=n)
+    solid = sim.field(fs.FIELD.SOLID).copy()
+    solid[4:28, 2:9, 12:15] = 1
+    sim.set_solid(solid); orc.set_solid(solid)
+    pos = fs.water_cube_drop(n, 4, seed=2); pos[:, 1] -= 4.0
+    sim.upload_particles(pos); orc.set_particles(pos)
+    for i in range(12):
+        sg = sim.step(); so = orc.step()
+        assert sg["num_active"] == so["num_active"] and sg["outer_passes"] == so["outer_passes"], (i, sg, so)
+    p, v = sim.download_particles(); po, vo = orc.particles()
+    assert rel_l2(p, po) < TOL_F and rel_l2(v, vo) < TOL_F
+    assert np.array_equal(sim.field(fs.FIELD.INDICES), orc.field(4))
