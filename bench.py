@@ -45,6 +45,14 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel, n, ppc):
+    """HBM/fabric bytes per launch measured by separate rocprofv3 --pmc passes of this workload (see the file's "method")."""
+    tj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    if n != 256 or ppc != 8 or not os.path.exists(tj):
+        return None
+    return json.load(open(tj)).get("kernels_final", {}).get(kernel, {}).get("bytes_per_launch")
+
+
 def stencil_microbench(fs, n, device):
     """Dense sweep q = A s over all n^3 cells, all-fluid interior (SURVEY.md 8d micro-benchmark)."""
     out = {}
@@ -159,7 +167,8 @@ def main():
         algo = cells * (3 * T + 1)   # read u, f, count byte; write u'
         ach = algo / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "k_mg_smooth<double> level 0 (damped-Jacobi sweep of the V-cycle preconditioner)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("k_mg_smooth<double> level 0", n, ppc), "traffic_source": "profiles/r01/pmc_traffic.json (kernels_final)",
                 "algorithmic_bytes_per_launch": algo, "bytes_per_cell": 3 * T + 1, "cells_per_launch": cells,
                 "avg_launch_us": avg_ms * 1e3, "launches": 3 * mgs["launches"], "sampled": mgs["sampled"]}
     elif sq["sampled"]:
