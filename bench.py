@@ -210,8 +210,12 @@ def main():
 
     if cpu_state is not None:
         oracle = entry.load_oracle()
-        orc = oracle.Oracle(n=n)
-        orc.set_cg_tol(a.cg_tol)
+        # The reference's CPU path = serial grid sweeps + Eigen IC-PCG (fluid.cc:1352,1473-1474).  When the build of the
+        # reference's vendored Eigen travelled with the repo (oracle/_ref), the oracle's solves go through it.
+        use_ref = oracle.ref_lib() is not None
+        orc = oracle.Oracle(n=n, use_ref_solver=use_ref)
+        if not use_ref:
+            orc.set_cg_tol(a.cg_tol)
         orc.set_particles(cpu_state[0], cpu_state[1])
         orc.dt = cpu_state[2]
         csteps, csec = 0, 0.0
@@ -220,8 +224,11 @@ def main():
             orc.step()
             csec += time.perf_counter() - c0
             csteps += 1
+        solver = ("pressure solves by the reference's own vendored Eigen 3.3.4 ConjugateGradient<IncompleteCholesky> (oracle/_ref)"
+                  if use_ref else "pressure solves by the restated Jacobi-CG (oracle/_ref not present)")
         out["cpu_baseline"] = {"value": csteps / csec, "unit": "substeps/s", "cores": 1, "kind": "port",
-                               "sample": f"{csteps} oracle step(s) of the same {n}^3 workload from the state at the start of the timed region ({csec:.1f} s)"}
+                               "sample": f"{csteps} oracle step(s) of the same {n}^3 workload from the state at the start of the timed region "
+                                         f"({csec:.1f} s); {solver}"}
         # full-size parity readout: GPU vs oracle after the same number of steps from the same state
         sim2 = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol)
         sim2.upload_particles(cpu_state[0], cpu_state[1])
