@@ -100,13 +100,22 @@ def main():
         # ONE simulation decomposed into x slabs of equal particle count, one slab per GPU (strong scaling)
         fd = fs.load_dist()
         bounds = fd.partition_by_count(n, pos0, world)
+        import torch
+        comm, err = None, ""
         try:
             comm = fd.RcclComm()          # ncclSend/Recv/AllReduce enqueued on the solver stream by the C++ host
+        except Exception as e:            # noqa: BLE001
+            err = str(e)
+        # every rank must take the same transport: agree on whether the native RCCL communicator came up everywhere
+        ok = torch.tensor([1 if comm is not None else 0], device="cuda", dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
             transport = "rccl (native, stream-ordered)"
-        except Exception as e:            # noqa: BLE001 - fall back to torch.distributed callbacks
-            import torch
+        else:
+            if comm is not None:
+                comm.close()
             comm = fd.TorchComm(mode="device", device=torch.device("cuda", local_rank))
-            transport = f"torch.distributed nccl callbacks (native RCCL init failed: {e})"
+            transport = f"torch.distributed nccl callbacks (native RCCL init failed on some rank: {err})"
         sim = fd.DistFluidSim(n, bounds, comm, device=local_rank, cg_tol=a.cg_tol)
         sim.upload_global(pos0)
 

@@ -75,6 +75,7 @@ struct fluid_sim {
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
     double *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual
+    double* mg_part = nullptr;    // per-block partials of r.z when a level-0 launch has more blocks than the PCG kernels re-sum
     size_t mg_cap[MG_MAXL] = {};
     // multi-GPU (x-slab decomposition)
     bool dist = false;
@@ -220,7 +221,7 @@ int fluid_destroy(fluid_sim_t* s)
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
-                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->Zmg, s->cntL, s->part_bb, s->part_rr,
+                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->Zmg, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
                     s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -279,6 +280,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     A(dalloc((char**)&s->R, ln * se)); A(dalloc((char**)&s->S[0], ln * se)); A(dalloc((char**)&s->S[1], ln * se));
     A(dalloc((char**)&s->Q, ln * se)); A(dalloc((char**)&s->X, ln * se)); A(dalloc(&s->cntL, ln + 64));
     A(dalloc((char**)&s->Zmg, ln * se));
+    A(dalloc(&s->mg_part, ln / 256 + 64));
     A(dalloc(&s->part_bb, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rr, (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_rz[0], (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rz[1], (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_pq, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_err, (size_t)2 * MAX_PARTIALS));
@@ -329,6 +331,7 @@ int fluid_set_solid(fluid_sim_t* s, const uint8_t* solid)
 int fluid_upload_particles(fluid_sim_t* s, int64_t n, const double* pos, const double* vel)
 {
     if (!s || n < 0 || (n > 0 && !pos)) return fail(FLUID_ERR_ARG, "bad particle arguments");
+    if (s->dist) return fail(FLUID_ERR_STATE, "decomposed run: use fluid_upload_particles_ids (global ids must be unique across ranks)");
     if (n > 0x7fffffffL) return fail(FLUID_ERR_ARG, "too many particles");
     HIPCHK(hipSetDevice(s->prm.device));
     int rc = alloc_particles(s, (long)n);
@@ -349,6 +352,7 @@ int fluid_upload_particles(fluid_sim_t* s, int64_t n, const double* pos, const d
 int fluid_download_particles(fluid_sim_t* s, double* pos, double* vel)
 {
     if (!s || !pos || !vel) return fail(FLUID_ERR_ARG, "null argument");
+    if (s->dist) return fail(FLUID_ERR_STATE, "decomposed run: use fluid_download_particles_ids");
     if (s->np == 0) return FLUID_OK;
     HIPCHK(hipSetDevice(s->prm.device));
     launch_pack_particles(s->st, s->np, s->pa.shifted(s->p_off), s->stage_pos, s->stage_vel);
@@ -644,8 +648,11 @@ static int solve_mg(fluid_sim* s)
     long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
     if (max_it < 1) max_it = 1;
     const double cells = (double)s->Rb.cells();
-    const int n_rz = mg_smooth_blocks(s->mgl[0]);
-    if (n_rz > MAX_PARTIALS) return fail(FLUID_ERR_STATE, "multigrid: partial buffer too small");
+    // r.z partials come from the last level-0 sweep, one per block: re-summing them in every block of the PCG kernels
+    // is fine up to ~2k values; beyond that (512^3) one extra 1-block launch folds them into a single value
+    const int n_rz_raw = mg_smooth_blocks(s->mgl[0]);
+    const bool fold = n_rz_raw > 2048;
+    const int n_rz = fold ? 1 : n_rz_raw;
     // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
     Z = (T*)s->Zmg;
     int rc;
@@ -658,7 +665,8 @@ static int solve_mg(fluid_sim* s)
     while (!done) {
         for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = mg_vcycle(s, R, Z, s->part_rz[cur]))) return rc;
+            if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur]))) return rc;
+            if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
             launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
                              s->part_pq, s->ps, it == 0, tol, n_rz, 1);
@@ -864,13 +872,16 @@ static int phase_flip_advect(fluid_sim* s)
 
 extern "C" {
 
-int fluid_p2g(fluid_sim_t* s) { return s ? phase_p2g(s) : fail(FLUID_ERR_ARG, "null handle"); }
-int fluid_flags_index(fluid_sim_t* s) { return s ? phase_flags(s) : fail(FLUID_ERR_ARG, "null handle"); }
-int fluid_rhs_div(fluid_sim_t* s, int which) { return s ? phase_rhs_div(s, which) : fail(FLUID_ERR_ARG, "null handle"); }
-int fluid_solve(fluid_sim_t* s) { return s ? phase_solve(s) : fail(FLUID_ERR_ARG, "null handle"); }
-int fluid_vel_update(fluid_sim_t* s) { return s ? phase_vel_update(s) : fail(FLUID_ERR_ARG, "null handle"); }
-int fluid_pressure_pass(fluid_sim_t* s, double* error) { return s ? phase_pressure_pass(s, error) : fail(FLUID_ERR_ARG, "null handle"); }
-int fluid_flip_advect(fluid_sim_t* s) { return s ? phase_flip_advect(s) : fail(FLUID_ERR_ARG, "null handle"); }
+#define PHASE_GUARD(s)                                                                                        \
+    if (!(s)) return fail(FLUID_ERR_ARG, "null handle");                                                      \
+    if ((s)->dist) return fail(FLUID_ERR_STATE, "per-phase entry points are single-GPU only; a decomposed run steps with fluid_step")
+int fluid_p2g(fluid_sim_t* s) { PHASE_GUARD(s); return phase_p2g(s); }
+int fluid_flags_index(fluid_sim_t* s) { PHASE_GUARD(s); return phase_flags(s); }
+int fluid_rhs_div(fluid_sim_t* s, int which) { PHASE_GUARD(s); return phase_rhs_div(s, which); }
+int fluid_solve(fluid_sim_t* s) { PHASE_GUARD(s); return phase_solve(s); }
+int fluid_vel_update(fluid_sim_t* s) { PHASE_GUARD(s); return phase_vel_update(s); }
+int fluid_pressure_pass(fluid_sim_t* s, double* error) { PHASE_GUARD(s); return phase_pressure_pass(s, error); }
+int fluid_flip_advect(fluid_sim_t* s) { PHASE_GUARD(s); return phase_flip_advect(s); }
 
 int fluid_get_stats(fluid_sim_t* s, fluid_step_stats_t* st)
 {
@@ -1262,7 +1273,6 @@ static int dist_solve_mg(fluid_sim* s)
     if (max_it < 1) max_it = 1;
     const size_t plane = (size_t)L.Ly * L.Lz * sizeof(T);
     const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L), n_rz = mg_smooth_blocks(s->mgl[0]);
-    if (n_rz > MAX_PARTIALS) return fail(FLUID_ERR_STATE, "multigrid: partial buffer too small");
     int rc;
     auto ring = [&](T* S) -> int {
         char* b = (char*)S;
@@ -1280,8 +1290,8 @@ static int dist_solve_mg(fluid_sim* s)
     while (!done) {
         for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = mg_vcycle(s, R, Z, s->part_rz[0]))) return rc;
-            launch_sum2(s->st, s->part_rz[0], n_rz, s->part_rz[0], 0, s->grz + cur, nullptr);
+            if ((rc = mg_vcycle(s, R, Z, s->mg_part))) return rc;
+            launch_sum2(s->st, s->mg_part, n_rz, s->mg_part, 0, s->grz + cur, nullptr);
             if ((rc = comm_allreduce(s, s->grz + cur, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
             launch_pcg_s<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], cf, s->gstage[prv], s->grz + cur, s->grz + prv, s->ps, it == 0, tol, 1);
