@@ -649,9 +649,9 @@ static int solve_mg(fluid_sim* s)
     if (max_it < 1) max_it = 1;
     const double cells = (double)s->Rb.cells();
     // r.z partials come from the last level-0 sweep, one per block: re-summing them in every block of the PCG kernels
-    // is fine up to ~2k values; beyond that (512^3) one extra 1-block launch folds them into a single value
+    // costs every block ~2 x n loads from L2: above 512 values one extra 1-block launch folds them into a single value
     const int n_rz_raw = mg_smooth_blocks(s->mgl[0]);
-    const bool fold = n_rz_raw > 2048;
+    const bool fold = n_rz_raw > 512;
     const int n_rz = fold ? 1 : n_rz_raw;
     // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
     Z = (T*)s->Zmg;
