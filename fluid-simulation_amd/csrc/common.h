@@ -172,8 +172,10 @@ constexpr uint32_t PID_DEAD = 0xFFFFFFFFu;  // multi-GPU: particle handed to a n
 
 // particles
 void launch_bin_count(hipStream_t st, Grid g, long n, Particles p, int* key, int* slot, int* cell_count, int* part, StepState* ss);
-void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot, const int* cell_start, int* order);
-void launch_bin_fix(hipStream_t st, Grid g, Box box, const int* cell_start, const uint32_t* pid, int* order);
+void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot, const int* cell_start, const uint32_t* pid, int* order,
+                         uint32_t* spid);
+void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, const int* cell_start, const int* order, const uint32_t* spid,
+                     int* order2);
 void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst);
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,

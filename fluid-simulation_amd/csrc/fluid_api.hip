@@ -55,7 +55,8 @@ struct fluid_sim {
     // particles
     long np = 0, cap = 0;
     Particles pa{}, pb{};
-    int *key = nullptr, *slot = nullptr, *order = nullptr, *cell_count = nullptr, *cell_start = nullptr;
+    int *key = nullptr, *slot = nullptr, *order = nullptr, *order2 = nullptr, *cell_count = nullptr, *cell_start = nullptr;
+    uint32_t* spid = nullptr;   // original ids in sorted-position order (per-cell rank pass)
     double *stage_pos = nullptr, *stage_vel = nullptr;
     double* pw = nullptr;  // 9 axis weights per particle, SoA with stride cap
     StepState* ss = nullptr;
@@ -166,7 +167,8 @@ static void free_particles(fluid_sim* s)
         hipFree(p->px); hipFree(p->py); hipFree(p->pz); hipFree(p->vx); hipFree(p->vy); hipFree(p->vz); hipFree(p->pid);
         *p = Particles{};
     }
-    hipFree(s->key); hipFree(s->slot); hipFree(s->order); hipFree(s->stage_pos); hipFree(s->stage_vel); hipFree(s->pw);
+    hipFree(s->key); hipFree(s->slot); hipFree(s->order); hipFree(s->order2); hipFree(s->spid); hipFree(s->stage_pos); hipFree(s->stage_vel);
+    s->order2 = nullptr; s->spid = nullptr; hipFree(s->pw);
     s->pw = nullptr;
     s->key = s->slot = s->order = nullptr;
     s->stage_pos = s->stage_vel = nullptr;
@@ -182,7 +184,7 @@ static int alloc_particles(fluid_sim* s, long n)
         HIPCHK(dalloc(&p->vx, n)); HIPCHK(dalloc(&p->vy, n)); HIPCHK(dalloc(&p->vz, n));
         HIPCHK(dalloc(&p->pid, n));
     }
-    HIPCHK(dalloc(&s->key, n)); HIPCHK(dalloc(&s->slot, n)); HIPCHK(dalloc(&s->order, n));
+    HIPCHK(dalloc(&s->key, n)); HIPCHK(dalloc(&s->slot, n)); HIPCHK(dalloc(&s->order, n)); HIPCHK(dalloc(&s->order2, n)); HIPCHK(dalloc(&s->spid, n));
     HIPCHK(dalloc(&s->stage_pos, 3 * n)); HIPCHK(dalloc(&s->stage_vel, 3 * n));
     HIPCHK(dalloc(&s->pw, 9 * n));
     HIPCHK(hipDeviceSynchronize());
@@ -445,7 +447,8 @@ static int phase_sort(fluid_sim* s)
     launch_bin_count(s->st, g, s->np, s->pa.shifted(s->p_off), s->key, s->slot, s->cell_count, s->ipart, s->ss);
     // buckets: the N^3 cells, then "off the grid", then "dead" (multi-GPU migrants)
     launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
-    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->order);
+    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->pa.shifted(s->p_off).pid, s->order, s->spid);
+    launch_bin_rank(s->st, s->np, 0, s->key, s->cell_start, s->order, s->spid, s->order2);  // every position 0..np (cells, off-grid bucket)
     HIPCHK(hipGetLastError());
     int rc = read_ss(s);
     if (rc) return rc;
@@ -456,13 +459,12 @@ static int phase_sort(fluid_sim* s)
         s->Pb = Box{h.bbox_min[0], h.bbox_min[1], h.bbox_min[2], h.bbox_max[0], h.bbox_max[1], h.bbox_max[2]};
     }
     if (!box_empty(s->Pb)) {
-        launch_bin_fix(s->st, g, s->Pb, s->cell_start, s->pa.shifted(s->p_off).pid, s->order);
         s->Rb = clip_dilate(s->Pb, 1, g.N);
         s->Sb = clip_dilate(s->Pb, 2, g.N);
     } else {
         s->Rb = s->Sb = s->Pb;
     }
-    launch_reorder(s->st, s->np, s->order, s->pa.shifted(s->p_off), s->pb);
+    launch_reorder(s->st, s->np, s->order2, s->pa.shifted(s->p_off), s->pb);
     HIPCHK(hipGetLastError());
     std::swap(s->pa, s->pb);
     s->p_off = 0;
@@ -1120,7 +1122,7 @@ static int dist_sort(fluid_sim* s)
                             n2 * sizeof(int), s->cell_count + (long)(s->xe - 1) * n2, n2 * sizeof(int),
                             s->xe < N ? s->cell_count + (long)s->xe * n2 : nullptr, n2 * sizeof(int)))) return rc;
     launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
-    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->order);
+    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->pa.shifted(s->p_off).pid, s->order, s->spid);
     HIPCHK(hipGetLastError());
     // offsets: [4] start of plane xs, [5] start of plane xs+1, [6] start of plane xe-1, [7] start of plane xe,
     //          [8] start of plane xe+1 (or of the off-grid bucket), [9] off-grid bucket, [10] dead bucket, [11] total
@@ -1155,8 +1157,7 @@ static int dist_sort(fluid_sim* s)
     if (!box_empty(s->Pb)) {
         s->Rb = clip_dilate(s->Pb, 1, N);
         s->Sb = clip_dilate(s->Pb, 2, N);
-        const Box mine = clip_x(s->Pb, s->xs, s->xe);
-        if (!box_empty(mine)) launch_bin_fix(s->st, g, mine, s->cell_start, s->pa.shifted(s->p_off).pid, s->order);
+        // id order inside the cells of my slab (positions [gl, gl+n_slab)); ghosts arrive in their owner's order
     } else {
         s->Rb = s->Sb = s->Pb;
     }
@@ -1165,7 +1166,8 @@ static int dist_sort(fluid_sim* s)
     if (gl + s->np + gr > s->cap) return fail(FLUID_ERR_STATE, "particle capacity exceeded on this rank (ghosts)");
     // order[] is indexed by DESTINATION position; only [gl, gl+n_slab) is mine (ghost gaps are filled below,
     // the off-grid and dead tails are dropped)
-    launch_reorder(s->st, n_slab, s->order + gl, s->pa.shifted(s->p_off), s->pb.shifted(gl));
+    launch_bin_rank(s->st, n_slab, gl, s->key, s->cell_start, s->order, s->spid, s->order2);
+    launch_reorder(s->st, n_slab, s->order2 + gl, s->pa.shifted(s->p_off), s->pb.shifted(gl));
     HIPCHK(hipGetLastError());
     std::swap(s->pa, s->pb);
     s->p_off = gl;
