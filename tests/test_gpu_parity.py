@@ -351,7 +351,7 @@ def test_long_run_stays_convergent(fs):
     assert worst_it <= 80
 
 
-def _compare_step(fs, oracle, n, pos, vel, steps=2):
+def _compare_step(fs, oracle, n, pos, vel, steps=2, tol_w=TOL_W):
     sim = fs.FluidSim(n=n); orc = oracle.Oracle(n=n)
     sim.upload_particles(pos, vel); orc.set_particles(pos, vel)
     for i in range(steps):
@@ -361,7 +361,7 @@ def _compare_step(fs, oracle, n, pos, vel, steps=2):
         assert abs(sg["dt_out"] - so["dt_out"]) <= 1e-9 * so["dt_out"]
     F = fs.FIELD
     assert np.array_equal(sim.field(F.INDICES), orc.field(4))
-    assert rel_l2(sim.field(F.CONTAINER), orc.field(0)) < TOL_W
+    assert rel_l2(sim.field(F.CONTAINER), orc.field(0)) < tol_w
     if len(pos):
         p, v = sim.download_particles(); po, vo = orc.particles()
         assert np.allclose(p, po, rtol=0, atol=1e-7) and np.allclose(v, vo, rtol=0, atol=1e-6)
@@ -439,7 +439,9 @@ def test_edge_clustered_particles(fs, oracle):
     vel = rng.standard_normal(pos.shape) * 0.3
     perm = rng.permutation(len(pos))
     pos, vel = pos[perm], vel[perm]
-    sim, orc = _compare_step(fs, oracle, n, pos, vel, steps=2)
+    # float32 sums of ~1500 addends per cell: order effects grow like sqrt(k) * 6e-8, so the 1e-6 bar of the 8-per-cell
+    # case becomes 1e-5 here (measured 1.1e-6)
+    sim, orc = _compare_step(fs, oracle, n, pos, vel, steps=2, tol_w=1e-5)
     # run-to-run reproducibility of the device path (atomic slot order differs, id order must not)
     sim2 = fs.FluidSim(n=n); sim2.upload_particles(pos, vel)
     for _ in range(2):
