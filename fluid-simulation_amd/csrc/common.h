@@ -221,7 +221,7 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
                    double tol, int n_rz = -1, int zmode = 0);
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
-                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1);
+                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1, int sparse = 0);
 template <typename T>
 void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
                   const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol, int zmode = 0);

@@ -70,6 +70,7 @@ struct fluid_sim {
     // multigrid preconditioner (single-GPU fp64 solve)
     static constexpr int MG_MAXL = 8;
     int mg_nl = 0, mg_tail = 0;   // levels; first level handled by the single-block tail kernel
+    long mg_last_iters = 0;       // iteration count of the previous multigrid solve (sizes the first unpolled batch)
     int mg_csweeps = 3;           // red-black sweeps (each direction) on the coarsest level (12 -> 2 changes the PCG count by 1 in 520)
     long mg_fuse_cells = MG_FUSE_CELLS;
     bool mg_fuse0 = false;
@@ -555,15 +556,15 @@ static int mg_setup(fluid_sim* s)
             s->mg_cap[l] = cap;
         }
         // the layout changes with the box: everything outside the new domain must read as zero / solid
-        // Level 0 needs none of this for u/v/r: every cell of its domain is rewritten before it is read, and
-        // unknown cells only look at neighbours inside the domain.  Coarse levels are read through their zero ring.
+        // The V-cycle kernels write unknown cells only: everything else must read as zero for the whole step.
         HIPCHK(hipMemsetAsync(s->mg_typ[l], 0, s->mgl[l].cells, s->st));
+        HIPCHK(hipMemsetAsync(s->mg_u[l], 0, s->mgl[l].cells * 8, s->st));
+        HIPCHK(hipMemsetAsync(s->mg_v[l], 0, s->mgl[l].cells * 8, s->st));
+        HIPCHK(hipMemsetAsync(s->mg_r[l], 0, s->mgl[l].cells * 8, s->st));
+        if (l == 0) HIPCHK(hipMemsetAsync(s->Zmg, 0, s->mgl[l].cells * 8, s->st));
         if (l > 0) {
             HIPCHK(hipMemsetAsync(s->mg_cnt[l], 0, s->mgl[l].cells, s->st));
-            HIPCHK(hipMemsetAsync(s->mg_u[l], 0, s->mgl[l].cells * 8, s->st));
-            HIPCHK(hipMemsetAsync(s->mg_v[l], 0, s->mgl[l].cells * 8, s->st));
             HIPCHK(hipMemsetAsync(s->mg_f[l], 0, s->mgl[l].cells * 8, s->st));
-            HIPCHK(hipMemsetAsync(s->mg_r[l], 0, s->mgl[l].cells * 8, s->st));
         }
     }
     launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
@@ -652,6 +653,7 @@ static int solve_mg(fluid_sim* s)
     const double cells = (double)s->Rb.cells();
     // r.z partials come from the last level-0 sweep, one per block: re-summing them in every block of the PCG kernels
     // costs every block ~2 x n loads from L2: above 512 values one extra 1-block launch folds them into a single value
+    const int sparse = (double)s->stats.num_active < 0.4 * (double)L.cells();
     const int n_rz_raw = mg_smooth_blocks(s->mgl[0]);
     const bool fold = n_rz_raw > 512;
     const int n_rz = fold ? 1 : n_rz_raw;
@@ -661,11 +663,14 @@ static int solve_mg(fluid_sim* s)
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
     long it = 0;
-    const int CHECK = 4;
+    // Batching of the convergence poll.  Iteration counts barely change from one solve to the next, so the first batch
+    // runs (previous count - 1) iterations without looking; after that the state is polled every 2 iterations.
+    // Kernels of a finished solve exit at their first instruction, but each still costs a launch (~2.5 us x 19 per
+    // iteration): polling every 4 one batch behind wasted ~7 iteration-sets per solve.
+    long batch = s->mg_last_iters > 5 ? s->mg_last_iters - 1 : 4;
     bool done = false;
-    int nb = 0;
     while (!done) {
-        for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
+        for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
             if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur]))) return rc;
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
@@ -674,23 +679,26 @@ static int solve_mg(fluid_sim* s)
                              s->part_pq, s->ps, it == 0, tol, n_rz, 1);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_err, s->ps, n_rz);
+            launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_err, s->ps, n_rz, sparse);
             prof_end(s, FLUID_PROF_PCG_XR, tok);
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&s->h_ps[nb & 1], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
-        HIPCHK(hipEventRecord(s->ev_poll[nb & 1], s->st));
-        if (nb >= 1) {
-            HIPCHK(hipEventSynchronize(s->ev_poll[(nb - 1) & 1]));
-            if (s->h_ps[(nb - 1) & 1].done) done = true;
+        if (it < max_it) {
+            // the break test of the last body sits at the head of the next SQ launch: a head-only launch (its s'/q are
+            // overwritten by the real launch of that iteration if the solve goes on; the counter is put back below)
+            const int cur = (int)(it & 1), prv = cur ^ 1;
+            launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1);
         }
-        if (it >= max_it) done = true;
-        ++nb;
+        HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        done = s->h_ps[0].done || it >= max_it;
+        if (!done) {
+            s->h_ps[1] = s->h_ps[0];   // pinned slot: stays valid while the copy is in flight
+            s->h_ps[1].iters -= 1;     // the head-only launch counted a body that the next real launch counts again
+            HIPCHK(hipMemcpyAsync(s->ps, &s->h_ps[1], sizeof(PcgState), hipMemcpyHostToDevice, s->st));
+        }
+        batch = 2;
     }
-    // the break test of the last body sits at the head of the NEXT SQ launch: run one more head-only check
-    launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[0], Sx[1], Q, cf, s->part_rr, s->part_rz[0], s->part_rz[1], s->part_pq, s->ps, 0, tol, n_rz, 1);
-    HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipStreamSynchronize(s->st));
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
     if (!s->h_ps->done) iters = (int)max_it;
@@ -699,6 +707,7 @@ static int solve_mg(fluid_sim* s)
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
     s->stats.cg_iters += iters;
+    s->mg_last_iters = iters;
     s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
     if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
     return FLUID_OK;

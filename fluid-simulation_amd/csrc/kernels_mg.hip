@@ -11,7 +11,8 @@
 //   * transfer: cell-centred trilinear prolongation P (weights 3/4,1/4 per axis), restriction P^T/8;
 //   * coarsest level (<= 8^3): red-black Gauss-Seidel in LDS by one block, forward then reversed.
 // Level 0 lives in the solver's box-local layout (LBox); coarser levels use the same indexing
-// scheme (MLevel).  All kernels are one thread per cell with neighbours read through L1/L2: levels
+// scheme (MLevel).  Only unknown cells are ever written (every array is zeroed once per step), so a mostly-air
+// active box costs one count byte per air cell.  All kernels are one thread per cell with neighbours read through L1/L2: levels
 // >= 1 are tiny and launch-bound; level 0 costs ~4 stencil sweeps per cycle.
 #include "common.h"
 
@@ -36,12 +37,18 @@ __device__ __forceinline__ void mg_load_coef(T* sd, T* si, const MgCoef<T>& cf)
     __syncthreads();
 }
 
+// thread index -> domain cell; 32-bit arithmetic (a level never has 2^31 cells): the 64-bit div/mod sequence was
+// the dominant cost of these kernels on large, mostly-air boxes
 __device__ __forceinline__ bool mg_cell(const MLevel& m, long t, int& i, int& j, int& k)
 {
-    if (t >= (long)m.dx * m.dy * m.dz) return false;
-    k = (int)(t % m.dz);
-    j = (int)((t / m.dz) % m.dy);
-    i = (int)(t / ((long)m.dz * m.dy));
+    const unsigned n = (unsigned)m.dx * (unsigned)m.dy * (unsigned)m.dz;
+    if (t >= (long)n) return false;
+    const unsigned u = (unsigned)t, dz = (unsigned)m.dz, dy = (unsigned)m.dy;
+    const unsigned q = u / dz;
+    k = (int)(u - q * dz);
+    const unsigned p = q / dy;
+    j = (int)(q - p * dy);
+    i = (int)p;
     return true;
 }
 
@@ -103,16 +110,12 @@ __device__ __forceinline__ double d_smooth(const MLevel& m, const uint8_t* __res
     if (!mg_cell(m, t, i, j, k)) return 0;
     const size_t c = m.at(i, j, k);
     const int n = cnt[c];
-    T out = 0;
-    double acc = 0;
-    if (n) {
-        const T fv = f[c], uc = u_in[c];
-        const T nb = u_in[c - m.sx] + u_in[c + m.sx] + u_in[c - m.sy] + u_in[c + m.sy] + u_in[c - 1] + u_in[c + 1];
-        out = uc + omega * iv[n] * (fv - (dg[n] * uc + off * nb));
-        acc = (double)fv * (double)out;
-    }
+    if (!n) return 0;  // not an unknown: its entries stay 0 (arrays are zeroed once per step), no 8-byte store per air cell
+    const T fv = f[c], uc = u_in[c];
+    const T nb = u_in[c - m.sx] + u_in[c + m.sx] + u_in[c - m.sy] + u_in[c + m.sy] + u_in[c - 1] + u_in[c + 1];
+    const T out = uc + omega * iv[n] * (fv - (dg[n] * uc + off * nb));
     u_out[c] = out;
-    return acc;
+    return (double)fv * (double)out;
 }
 
 // two sweeps starting from u = 0 in one pass: u1 = omega D^-1 f is formed on the fly at the 7 points
@@ -124,15 +127,12 @@ __device__ __forceinline__ void d_smooth0(const MLevel& m, const uint8_t* __rest
     if (!mg_cell(m, t, i, j, k)) return;
     const size_t c = m.at(i, j, k);
     const int n = cnt[c];
-    T out = 0;
-    if (n) {
-        const T w1 = (T)MG_W1, w2 = (T)MG_W2;
-        auto u1 = [&](size_t q) { return w1 * iv[cnt[q]] * f[q]; };  // iv[0] = 0: non-unknowns give 0
-        const T fv = f[c], uc = w1 * iv[n] * fv;
-        const T nb = u1(c - m.sx) + u1(c + m.sx) + u1(c - m.sy) + u1(c + m.sy) + u1(c - 1) + u1(c + 1);
-        out = uc + w2 * iv[n] * (fv - (dg[n] * uc + off * nb));
-    }
-    u_out[c] = out;
+    if (!n) return;
+    const T w1 = (T)MG_W1, w2 = (T)MG_W2;
+    auto u1 = [&](size_t q) { return w1 * iv[cnt[q]] * f[q]; };  // iv[0] = 0: non-unknowns give 0
+    const T fv = f[c], uc = w1 * iv[n] * fv;
+    const T nb = u1(c - m.sx) + u1(c + m.sx) + u1(c - m.sy) + u1(c + m.sy) + u1(c - 1) + u1(c + 1);
+    u_out[c] = uc + w2 * iv[n] * (fv - (dg[n] * uc + off * nb));
 }
 
 template <typename T>
@@ -143,12 +143,9 @@ __device__ __forceinline__ void d_resid(const MLevel& m, const uint8_t* __restri
     if (!mg_cell(m, t, i, j, k)) return;
     const size_t c = m.at(i, j, k);
     const int n = cnt[c];
-    T out = 0;
-    if (n) {
-        const T nb = u[c - m.sx] + u[c + m.sx] + u[c - m.sy] + u[c + m.sy] + u[c - 1] + u[c + 1];
-        out = f[c] - (dg[n] * u[c] + off * nb);
-    }
-    r[c] = out;
+    if (!n) return;
+    const T nb = u[c - m.sx] + u[c + m.sx] + u[c - m.sy] + u[c + m.sy] + u[c - 1] + u[c + 1];
+    r[c] = f[c] - (dg[n] * u[c] + off * nb);
 }
 
 // f_c = (1/8) P^T r_f : a coarse cell gathers its 4x4x4 fine neighbourhood, weights (1/4,3/4,3/4,1/4) per axis
@@ -160,7 +157,8 @@ __device__ __forceinline__ void d_restrict(const MLevel& mf, const T* __restrict
     if (!mg_cell(mc, t, I, J, K)) return;
     const size_t C = mc.at(I, J, K);
     T out = 0;
-    if (cnt_c[C]) {
+    if (!cnt_c[C]) return;
+    {
         auto w = [](int a) { return (a == 0 || a == 3) ? (T)0.25 : (T)0.75; };  // no private array: no scratch
         const int i0 = 2 * I - 1, j0 = 2 * J - 1, k0 = 2 * K - 1;
         T acc = 0;
@@ -239,7 +237,8 @@ __device__ __forceinline__ void d_smooth0_resid(const MLevel& m, const uint8_t* 
     const size_t c = m.at(i, j, k);
     const int n = cnt[c];
     T uo = 0, ro = 0;
-    if (n) {
+    if (!n) return;
+    {
         uo = d_u2_at<T>(m, cnt, f, dg, iv, off, c);
         const T nb = d_u2_at<T>(m, cnt, f, dg, iv, off, c - m.sx) + d_u2_at<T>(m, cnt, f, dg, iv, off, c + m.sx) +
                      d_u2_at<T>(m, cnt, f, dg, iv, off, c - m.sy) + d_u2_at<T>(m, cnt, f, dg, iv, off, c + m.sy) +
@@ -274,7 +273,8 @@ __device__ __forceinline__ void d_prolong_smooth(const MLevel& mf, const uint8_t
     const size_t c = mf.at(i, j, k);
     const int n = cnt_f[c];
     T out = 0;
-    if (n) {
+    if (!n) return;
+    {
         const T vc = d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j, k);
         const T nb = d_upe_at<T>(mf, cnt_f, u, mc, ec, i - 1, j, k) + d_upe_at<T>(mf, cnt_f, u, mc, ec, i + 1, j, k) +
                      d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j - 1, k) + d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j + 1, k) +

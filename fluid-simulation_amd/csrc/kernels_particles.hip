@@ -171,6 +171,7 @@ constexpr int P2G_CH = 320;  // particles staged per chunk: 12 arrays x 8 B x 32
 constexpr int P2G_SEG = P2G_CH / 8 + 1;
 __device__ __forceinline__ int p2g_slot(int k) { return (k & 7) * P2G_SEG + (k >> 3); }
 constexpr int P2G_LDS = 8 * P2G_SEG;
+constexpr int P2G_HEAVY = 48;  // a longer per-lane window is swept by the whole wave
 
 // the 9 axis weights of every (sorted) particle: w[a*3+d][j] = spline(pos_a - (base_a - 1 + d))
 __global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __restrict__ w, long stride)
@@ -236,14 +237,19 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
                     sv[0][k] = p.vx[j]; sv[1][k] = p.vy[j]; sv[2][k] = p.vz[j];
                 }
                 __syncthreads();
-                if (mine) {
+                // Every lane of the wave sits on the same (x,y) column, so the x/y weight tables are wave-uniform.  A lane
+                // whose window is long (settled water piles up to ~10^4 particles into one cell) would serialise the
+                // whole wave: such windows are swept by all 64 lanes together and wave-reduced (fixed order).
 #pragma unroll
-                    for (int seg = 0; seg < 3; ++seg) {
-                        const int a = seg == 0 ? cs0 : (seg == 1 ? cs1 : cs2), b = seg == 0 ? cs1 : (seg == 1 ? cs2 : cs3);
-                        const int dzi = iz - (wz0 + seg) + 1;  // 2,1,0 away from the grid edge
-                        if (dzi < 0 || dzi > 2) continue;
-                        const double* swz = sw[6 + dzi];
-                        const int lo = a > cb ? a : cb, hi = b < ce ? b : ce;
+                for (int seg = 0; seg < 3; ++seg) {
+                    const int a = seg == 0 ? cs0 : (seg == 1 ? cs1 : cs2), b = seg == 0 ? cs1 : (seg == 1 ? cs2 : cs3);
+                    const int dzi = iz - (wz0 + seg) + 1;  // 2,1,0 away from the grid edge
+                    const bool use = mine && dzi >= 0 && dzi <= 2;
+                    int lo = a > cb ? a : cb, hi = b < ce ? b : ce;
+                    if (!use || hi < lo) hi = lo;
+                    const bool heavy = hi - lo > P2G_HEAVY;
+                    if (!heavy) {
+                        const double* swz = sw[6 + (dzi < 0 ? 0 : (dzi > 2 ? 2 : dzi))];
                         for (int j = lo; j < hi; ++j) {
                             const int k = p2g_slot(j - cb);
                             const double cw = swx[k] * swy[k] * swz[k];
@@ -251,6 +257,30 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
                             su = su + cw * sv[0][k];
                             sv_ = sv_ + cw * sv[1][k];
                             sw_ = sw_ + cw * sv[2][k];
+                        }
+                    }
+                    unsigned long long hm = __ballot(heavy);
+                    while (hm) {
+                        const int L = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        const int lo_L = __shfl(lo, L, 64), hi_L = __shfl(hi, L, 64), dz_L = __shfl(dzi, L, 64);
+                        const double* swz = sw[6 + dz_L];
+                        double aw = 0, pu = 0, pv = 0, pq = 0;
+                        for (int j = lo_L + lane; j < hi_L; j += 64) {
+                            const int k = p2g_slot(j - cb);
+                            const double cw = swx[k] * swy[k] * swz[k];
+                            aw += cw;
+                            pu += cw * sv[0][k];
+                            pv += cw * sv[1][k];
+                            pq += cw * sv[2][k];
+                        }
+                        aw = wave_sum(aw); pu = wave_sum(pu); pv = wave_sum(pv); pq = wave_sum(pq);
+                        aw = __shfl(aw, 0, 64); pu = __shfl(pu, 0, 64); pv = __shfl(pv, 0, 64); pq = __shfl(pq, 0, 64);
+                        if (lane == L) {
+                            wf = (float)((double)wf + aw);
+                            su = su + pu;
+                            sv_ = sv_ + pv;
+                            sw_ = sw_ + pq;
                         }
                     }
                 }

@@ -357,8 +357,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r,
                                                   const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rz_cur, int n_xr, const double* __restrict__ part_pq,
-                                                  int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps)
+                                                  int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps,
+                                                  int sparse)
 {
+    // sparse (box mostly air): the four vector loads of a pair are issued only if it holds an unknown — one dependent
+    // load more on the critical path, a fraction of the traffic; dense boxes keep the unconditional loads
     __shared__ double red[16];
     __shared__ int s_done;
     __shared__ T sdiag[8], sinv[8];
@@ -383,8 +386,12 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long e = base + u * 256;
-            if (e < e1) { cv[u] = c2[e]; xv[u] = x2[e]; rv[u] = r2[e]; sv[u] = s2[e]; qv[u] = q2[e]; }
-            else cv[u] = 0;
+            if (e < e1) {
+                cv[u] = c2[e];
+                if (!sparse || cv[u]) { xv[u] = x2[e]; rv[u] = r2[e]; sv[u] = s2[e]; qv[u] = q2[e]; }
+            } else {
+                cv[u] = 0;
+            }
         }
     };
     issue(i);
@@ -480,7 +487,7 @@ void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, con
                      const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps)
 {
     hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, g_rz_cur, 1,
-                       g_pq, 1, part_rr, part_rz_next, ps);
+                       g_pq, 1, part_rr, part_rz_next, ps, 0);
 }
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b)
 {
@@ -488,10 +495,10 @@ void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int n
 }
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
-                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz)
+                   const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz, int sparse)
 {
     hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
-                       n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps);
+                       n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, sparse);
 }
 template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure)
@@ -736,7 +743,7 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_pcg_sq<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
                                    const double*, double*, PcgState*, int, double, int, int);                                          \
     template void launch_pcg_xr<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, const double*, \
-                                   double*, double*, PcgState*, int);                                                                  \
+                                   double*, double*, PcgState*, int, int);                                                                \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);                                \
