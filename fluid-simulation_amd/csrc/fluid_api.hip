@@ -1296,10 +1296,11 @@ static int dist_solve_mg(fluid_sim* s)
     launch_sum2(s->st, s->part_bb, nxr, s->part_rz[0], nxr, s->gstage[1], s->gstage[1] + 1);
     if ((rc = comm_allreduce(s, s->gstage[1], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
     long it = 0;
-    const int CHECK = 8;
+    // first batch = the previous solve's count (identical on every rank), then poll every 2 iterations
+    long batch = s->mg_last_iters > 5 ? s->mg_last_iters : 8;
     bool done = false;
     while (!done) {
-        for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
+        for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
             if ((rc = mg_vcycle(s, R, Z, s->mg_part))) return rc;
             launch_sum2(s->st, s->mg_part, n_rz, s->mg_part, 0, s->grz + cur, nullptr);
@@ -1323,6 +1324,7 @@ static int dist_solve_mg(fluid_sim* s)
         HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
         HIPCHK(hipStreamSynchronize(s->st));
         done = s->h_ps->done || it >= max_it;
+        batch = 2;
     }
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
@@ -1332,6 +1334,7 @@ static int dist_solve_mg(fluid_sim* s)
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
     s->stats.cg_iters += iters;
+    s->mg_last_iters = iters;
     s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
     if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
     return FLUID_OK;
