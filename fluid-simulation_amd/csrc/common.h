@@ -205,6 +205,8 @@ void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const d
                        const double* ub, const double* vb, const double* wb, double* dcx, double* dcy, double* dcz);
 void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, const float* b2, double* part, StepState* ss);
 void launch_zero_step_state(hipStream_t st, StepState* ss, int N);
+struct ZeroList { float* f4[4]; double* f8[7]; };
+void launch_zero_fields(hipStream_t st, const ZeroList& z, size_t off, size_t cnt);
 
 // pcg (kernels_pcg.hip); T = double or float
 LBox make_lbox(const Box& b);
@@ -260,9 +262,17 @@ void launch_mg_prolong_smooth(hipStream_t st, MLevel mf, const uint8_t* cnt_f, c
                               MgCoef<T> cf, const PcgState* ps);
 constexpr long MG_FUSE_CELLS = 400000;  // levels below this are launch-bound: use the fused kernels
 constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel can hold
-constexpr long MG_TAIL_CELLS = 2048;    // a level this small (and all coarser ones) goes into the tail (one CU: 94 us at 12k cells)
+constexpr size_t MG_TAIL_LDS = 144 * 1024;  // dynamic LDS the tail kernel may use (160 KB per CU on gfx950): levels whose u, v, f + counts fit go into the tail
+size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem);
+int mg_up_blocks(const MLevel& m);
 template <typename T>
-void launch_mg_tail(hipStream_t st, int nl, const MLevel* lv, uint8_t* const* cnt, T* const* u, T* const* v, T* const* f, T* const* r,
-                    const T* off, int sweeps, const PcgState* ps);
+void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
+                    const PcgState* ps);
+template <typename T>
+void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* out, MLevel mc, const T* ec, MgCoef<T> cf,
+                  double* part_dot, const PcgState* ps);
+template <typename T>
+void launch_mg_tail(hipStream_t st, int nl, const MLevel& fine, const T* rfine, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off,
+                    int sweeps, const PcgState* ps);
 
 }  // namespace fl

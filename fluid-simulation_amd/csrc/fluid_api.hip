@@ -73,12 +73,14 @@ struct fluid_sim {
     long mg_last_iters = 0;       // iteration count of the previous multigrid solve (sizes the first unpolled batch)
     int mg_csweeps = 3;           // red-black sweeps (each direction) on the coarsest level (12 -> 2 changes the PCG count by 1 in 520)
     long mg_fuse_cells = MG_FUSE_CELLS;
+    bool mg_legacy = false;        // FLUID_MG_LEGACY=1: thread-per-cell V-cycle kernels (A/B against the LDS-tiled legs)
     bool mg_fuse0 = false;
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
     double *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual
     double* mg_part = nullptr;    // per-block partials of r.z when a level-0 launch has more blocks than the PCG kernels re-sum
-    size_t mg_cap[MG_MAXL] = {};
+    char* mg_slab = nullptr;      // one allocation behind every mg_* array and Zmg (re-carved each step)
+    size_t mg_slab_cap = 0;
     // multi-GPU (x-slab decomposition)
     bool dist = false;
     fluid_comm_t comm{};
@@ -224,14 +226,10 @@ int fluid_destroy(fluid_sim_t* s)
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
-                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->S[1], s->Q, s->X, s->Zmg, s->mg_part, s->cntL, s->part_bb, s->part_rr,
+                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
                     s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
-    for (int l = 0; l < fluid_sim::MG_MAXL; ++l) {
-        void* q[] = {s->mg_typ[l], s->mg_cnt[l], s->mg_u[l], s->mg_v[l], s->mg_f[l], s->mg_r[l]};
-        for (void* p : q) if (p) hipFree(p);
-    }
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
     if (s->h_ss) hipHostFree(s->h_ss);
@@ -260,6 +258,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     s->ncell = (size_t)p->n * p->n * p->n;
     s->dt = p->max_dt;
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments)
+    if (const char* e = getenv("FLUID_MG_LEGACY")) s->mg_legacy = atoi(e) != 0;
     if (const char* e = getenv("FLUID_MG_FUSE0")) { s->mg_fuse0 = atoi(e) != 0; if (s->mg_fuse0) s->mg_fuse_cells = 1L << 40; }
     s->xs = 0;
     s->xe = p->n;
@@ -280,9 +279,9 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     const size_t se = solver_elem(s);
     s->lmax = lbox_max_cells(p->n);  // >= n: the arrays double as N^3 scratch for fluid_stencil_apply
     const size_t ln = s->lmax;
-    A(dalloc((char**)&s->R, ln * se)); A(dalloc((char**)&s->S[0], ln * se)); A(dalloc((char**)&s->S[1], ln * se));
+    A(dalloc((char**)&s->R, ln * se)); A(dalloc((char**)&s->S[0], 2 * ln * se + 256));  // both search vectors: one slab, one memset per step
+    s->S[1] = (char*)s->S[0] + ln * se;
     A(dalloc((char**)&s->Q, ln * se)); A(dalloc((char**)&s->X, ln * se)); A(dalloc(&s->cntL, ln + 64));
-    A(dalloc((char**)&s->Zmg, ln * se));
     A(dalloc(&s->mg_part, ln / 256 + 64));
     A(dalloc(&s->part_bb, (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rr, (size_t)MAX_PARTIALS));
     A(dalloc(&s->part_rz[0], (size_t)MAX_PARTIALS)); A(dalloc(&s->part_rz[1], (size_t)MAX_PARTIALS));
@@ -429,10 +428,9 @@ static int clear_dirty(fluid_sim* s)
     if (s->dirty_x1 < s->dirty_x0) return FLUID_OK;
     const size_t N2 = (size_t)s->g.N * s->g.N;
     const size_t off = (size_t)s->dirty_x0 * N2, cnt = (size_t)(s->dirty_x1 - s->dirty_x0 + 1) * N2;
-    float* f4[] = {s->container, s->rhs, s->diver, s->diver2};
-    double* f8[] = {s->u, s->v, s->w, s->ub, s->vb, s->wb, s->pressure};
-    for (float* p : f4) HIPCHK(hipMemsetAsync(p + off, 0, cnt * sizeof(float), s->st));
-    for (double* p : f8) HIPCHK(hipMemsetAsync(p + off, 0, cnt * sizeof(double), s->st));
+    const ZeroList z = {{s->container, s->rhs, s->diver, s->diver2}, {s->u, s->v, s->w, s->ub, s->vb, s->wb, s->pressure}};
+    launch_zero_fields(s->st, z, off, cnt);
+    HIPCHK(hipGetLastError());
     s->dirty_x0 = 0;
     s->dirty_x1 = -1;
     return FLUID_OK;
@@ -520,6 +518,14 @@ static Coef<T> make_coef(const fluid_sim* s)
     return c;
 }
 
+// Both search vectors of this step, zeroed by one fill (padding and non-unknowns must read 0).
+static hipError_t zero_search(fluid_sim* s, size_t lb)
+{
+    const size_t step = (lb + 255) / 256 * 256;
+    s->S[1] = (char*)s->S[0] + step;
+    return hipMemsetAsync(s->S[0], 0, step + lb, s->st);
+}
+
 // ---- multigrid-preconditioned CG (single GPU, fp64) ----------------------------------------------
 // (multi-GPU: the same V-cycle applied per slab, neighbour-slab unknowns treated as p = 0: block preconditioner, no halo traffic)
 static bool use_mg(const fluid_sim* s) { return s->prm.reserved == 0 && s->prm.precision == FLUID_PRECISION_FP64; }
@@ -529,44 +535,46 @@ static int mg_setup(fluid_sim* s)
 {
     s->mgl[0] = mg_level0(s->L);
     int nl = 1;
-    while (nl < fluid_sim::MG_MAXL && (s->mgl[nl - 1].dx > 8 || s->mgl[nl - 1].dy > 8 || s->mgl[nl - 1].dz > 8)) {
+    while (nl < fluid_sim::MG_MAXL && (nl < 2 || s->mgl[nl - 1].dx > 8 || s->mgl[nl - 1].dy > 8 || s->mgl[nl - 1].dz > 8)) {
         s->mgl[nl] = mg_coarser(s->mgl[nl - 1]);
         ++nl;
     }
     if (s->mgl[nl - 1].dx > 8 || s->mgl[nl - 1].dy > 8 || s->mgl[nl - 1].dz > 8) return fail(FLUID_ERR_STATE, "multigrid: too many levels");
     s->mg_nl = nl;
     // levels small enough for one block (and everything coarser) run inside the tail kernel; level 0 never does
+    // (the tail holds its levels in LDS: as many of the coarsest levels as fit)
     int tail = nl - 1;
-    while (tail > 1 && (long)s->mgl[tail - 1].dx * s->mgl[tail - 1].dy * s->mgl[tail - 1].dz <= MG_TAIL_CELLS) --tail;
-    if (nl - tail > MG_TAIL_MAX) tail = nl - MG_TAIL_MAX;
-    if (tail < 1) tail = 1;
+    while (tail > 1 && nl - (tail - 1) <= MG_TAIL_MAX && mg_tail_lds_bytes(nl - (tail - 1), s->mgl + tail - 1, sizeof(double)) <= MG_TAIL_LDS) --tail;
+    if (mg_tail_lds_bytes(nl - tail, s->mgl + tail, sizeof(double)) > MG_TAIL_LDS) return fail(FLUID_ERR_STATE, "multigrid: coarsest level does not fit in LDS");
     s->mg_tail = tail;
+    // One slab for every per-step multigrid array (types, counts, u, v, f, r of each level and z of level 0), zeroed
+    // by ONE fill: the layout changes with the box, everything outside the new domain must read as zero / solid, and
+    // the V-cycle kernels write unknown cells only.  (30 separate fills cost ~5 us each.)
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t o = total; total += (bytes + 255) / 256 * 256; return o; };
+    size_t o_typ[fluid_sim::MG_MAXL], o_cnt[fluid_sim::MG_MAXL], o_u[fluid_sim::MG_MAXL], o_v[fluid_sim::MG_MAXL], o_f[fluid_sim::MG_MAXL],
+        o_r[fluid_sim::MG_MAXL];
     for (int l = 0; l < nl; ++l) {
-        const size_t need = s->mgl[l].cells + 64;
-        if (need > s->mg_cap[l]) {
-            void** arrs[] = {(void**)&s->mg_typ[l], (void**)&s->mg_cnt[l], (void**)&s->mg_u[l], (void**)&s->mg_v[l], (void**)&s->mg_f[l], (void**)&s->mg_r[l]};
-            for (void** p : arrs) { if (*p) hipFree(*p); *p = nullptr; }
-            const size_t cap = need + need / 4;
-            HIPCHK(hipMalloc((void**)&s->mg_typ[l], cap));
-            if (l > 0) HIPCHK(hipMalloc((void**)&s->mg_cnt[l], cap));
-            HIPCHK(hipMalloc((void**)&s->mg_u[l], cap * 8));
-            HIPCHK(hipMalloc((void**)&s->mg_v[l], cap * 8));
-            if (l > 0) HIPCHK(hipMalloc((void**)&s->mg_f[l], cap * 8));
-            HIPCHK(hipMalloc((void**)&s->mg_r[l], cap * 8));
-            s->mg_cap[l] = cap;
-        }
-        // the layout changes with the box: everything outside the new domain must read as zero / solid
-        // The V-cycle kernels write unknown cells only: everything else must read as zero for the whole step.
-        HIPCHK(hipMemsetAsync(s->mg_typ[l], 0, s->mgl[l].cells, s->st));
-        HIPCHK(hipMemsetAsync(s->mg_u[l], 0, s->mgl[l].cells * 8, s->st));
-        HIPCHK(hipMemsetAsync(s->mg_v[l], 0, s->mgl[l].cells * 8, s->st));
-        HIPCHK(hipMemsetAsync(s->mg_r[l], 0, s->mgl[l].cells * 8, s->st));
-        if (l == 0) HIPCHK(hipMemsetAsync(s->Zmg, 0, s->mgl[l].cells * 8, s->st));
-        if (l > 0) {
-            HIPCHK(hipMemsetAsync(s->mg_cnt[l], 0, s->mgl[l].cells, s->st));
-            HIPCHK(hipMemsetAsync(s->mg_f[l], 0, s->mgl[l].cells * 8, s->st));
-        }
+        const size_t c = s->mgl[l].cells + 64;
+        o_typ[l] = take(c); o_cnt[l] = take(c);
+        o_u[l] = take(c * 8); o_v[l] = take(c * 8); o_f[l] = take(c * 8); o_r[l] = take(c * 8);
     }
+    const size_t o_z = take((s->mgl[0].cells + 64) * 8);
+    if (total > s->mg_slab_cap) {
+        if (s->mg_slab) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->mg_slab); s->mg_slab = nullptr; }
+        const size_t cap = total + total / 4;
+        HIPCHK(hipMalloc((void**)&s->mg_slab, cap));
+        s->mg_slab_cap = cap;
+    }
+    for (int l = 0; l < nl; ++l) {
+        s->mg_typ[l] = (uint8_t*)(s->mg_slab + o_typ[l]);
+        s->mg_cnt[l] = l ? (uint8_t*)(s->mg_slab + o_cnt[l]) : nullptr;
+        s->mg_u[l] = (double*)(s->mg_slab + o_u[l]); s->mg_v[l] = (double*)(s->mg_slab + o_v[l]);
+        s->mg_f[l] = l ? (double*)(s->mg_slab + o_f[l]) : nullptr;
+        s->mg_r[l] = (double*)(s->mg_slab + o_r[l]);
+    }
+    s->Zmg = s->mg_slab + o_z;
+    HIPCHK(hipMemsetAsync(s->mg_slab, 0, total, s->st));
     launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
     for (int l = 1; l < nl; ++l) launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
     HIPCHK(hipGetLastError());
@@ -590,7 +598,46 @@ static MgCoef<double> mg_coef(const fluid_sim* s, int level)
 }
 
 // z = M^-1 r: V(2,2) cycle.  Level-0 rhs = `rhs0`; result in `z0`; part_rz gets the partials of rhs0.z0.
+static int mg_vcycle_legacy(fluid_sim* s, const double* rhs0, double* z0, double* part_rz);
+static int mg_rz_blocks(const fluid_sim* s) { return s->mg_legacy ? mg_smooth_blocks(s->mgl[0]) : mg_up_blocks(s->mgl[0]); }
+
+// One launch per leg and level (LDS-tiled kernels): down = both pre-sweeps + residual (+ the restriction for the
+// levels in the middle), tail, up = prolongation + both post-sweeps.
 static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+{
+    if (s->mg_legacy) return mg_vcycle_legacy(s, rhs0, z0, part_rz);
+    const int nl = s->mg_nl, tail = s->mg_tail;
+    const PcgState* ps = s->ps;
+    for (int l = 0; l < tail; ++l) {
+        const MLevel& m = s->mgl[l];
+        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
+        const double* f = l == 0 ? rhs0 : s->mg_f[l];
+        const bool last = l + 1 == tail;  // the tail restricts this level's residual itself
+        const bool fold = !last && l > 0; // restriction inside the down kernel (halo 3): not at level 0, where 5x halo reads cost more than a launch
+        launch_mg_down<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], s->mgl[l + 1], fold ? s->mg_cnt[l + 1] : nullptr,
+                               fold ? s->mg_f[l + 1] : nullptr, mg_coef(s, l), ps);
+        if (!last && !fold) launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
+    }
+    {
+        double off[fluid_sim::MG_MAXL];
+        for (int l = tail; l < nl; ++l) off[l] = mg_coef(s, l).off;
+        launch_mg_tail<double>(s->st, nl - tail, s->mgl[tail - 1], s->mg_r[tail - 1], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail,
+                               s->mg_csweeps, ps);
+    }
+    for (int l = tail - 1; l >= 0; --l) {
+        const MLevel& m = s->mgl[l];
+        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
+        const double* f = l == 0 ? rhs0 : s->mg_f[l];
+        const double* ec = l + 1 == tail ? s->mg_u[l + 1] : s->mg_v[l + 1];  // out != u: neighbouring tiles still read u
+        const int tok = l == 0 ? prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells()) : -1;
+        launch_mg_up<double>(s->st, m, cnt, f, s->mg_u[l], l == 0 ? z0 : s->mg_v[l], s->mgl[l + 1], ec, mg_coef(s, l), l == 0 ? part_rz : nullptr, ps);
+        if (l == 0) prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
+    }
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+
+static int mg_vcycle_legacy(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
     const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
@@ -606,13 +653,14 @@ static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_
             launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_u[l], cf, 0, nullptr, ps);   // two sweeps from u = 0
             launch_mg_resid<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], cf, ps);
         }
-        launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
+        if (l + 1 < tail) launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
     }
     {
+        // the tail restricts the residual of level tail-1 itself and leaves its correction in mg_u[tail]
         double off[fluid_sim::MG_MAXL];
         for (int l = tail; l < nl; ++l) off[l] = mg_coef(s, l).off;
-        launch_mg_tail<double>(s->st, nl - tail, s->mgl + tail, s->mg_cnt + tail, s->mg_u + tail, s->mg_v + tail, s->mg_f + tail, s->mg_r + tail,
-                               off + tail, s->mg_csweeps, ps);
+        launch_mg_tail<double>(s->st, nl - tail, s->mgl[tail - 1], s->mg_r[tail - 1], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail,
+                               s->mg_csweeps, ps);
     }
     for (int l = tail - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];
@@ -654,8 +702,8 @@ static int solve_mg(fluid_sim* s)
     // r.z partials come from the last level-0 sweep, one per block: re-summing them in every block of the PCG kernels
     // costs every block ~2 x n loads from L2: above 512 values one extra 1-block launch folds them into a single value
     const int sparse = (double)s->stats.num_active < 0.4 * (double)L.cells();
-    const int n_rz_raw = mg_smooth_blocks(s->mgl[0]);
-    const bool fold = n_rz_raw > 512;
+    const int n_rz_raw = mg_rz_blocks(s);
+    const bool fold = n_rz_raw > 1024;
     const int n_rz = fold ? 1 : n_rz_raw;
     // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
     Z = (T*)s->Zmg;
@@ -727,8 +775,7 @@ static int phase_flags(fluid_sim* s)
         s->L = make_lbox(s->Rb);
         launch_cnt_local(s->st, s->g, s->L, s->flags, s->cntL);
         const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
-        HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
-        HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
+        HIPCHK(zero_search(s, lb));
         HIPCHK(hipGetLastError());
         if (use_mg(s)) {
             int rc2 = mg_setup(s);
@@ -1283,7 +1330,7 @@ static int dist_solve_mg(fluid_sim* s)
     long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
     if (max_it < 1) max_it = 1;
     const size_t plane = (size_t)L.Ly * L.Lz * sizeof(T);
-    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L), n_rz = mg_smooth_blocks(s->mgl[0]);
+    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L), n_rz = mg_rz_blocks(s);
     int rc;
     auto ring = [&](T* S) -> int {
         char* b = (char*)S;
@@ -1400,8 +1447,7 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
         s->L = make_lbox(s->Rr);
         launch_cnt_local(s->st, g, s->L, s->flags, s->cntL);
         const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
-        HIPCHK(hipMemsetAsync(s->S[0], 0, lb, s->st));
-        HIPCHK(hipMemsetAsync(s->S[1], 0, lb, s->st));
+        HIPCHK(zero_search(s, lb));
         HIPCHK(hipGetLastError());
         if (use_mg(s) && (rc = mg_setup(s))) return rc;
     }

@@ -304,6 +304,294 @@ __global__ __launch_bounds__(256) void k_mg_prolong_smooth(MLevel mf, const uint
     d_prolong_smooth<T>(mf, cnt_f, f, u, u_out, mc, ec, sd, si, cf.off, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
+// ---- LDS-tiled legs of the V-cycle -----------------------------------------------------------------------
+// The solve is launch-bound (a level-0 sweep over ~700k cells is ~9 us, ~3 of them launch latency, and a level needs
+// 5-6 of them per cycle), so each leg of a level is ONE kernel: a block owns a TX x TY x TZ tile, stages the tile plus
+// a halo in LDS and recomputes the halo's share of the earlier sweeps itself instead of waiting for a grid-wide sync.
+//   down: u1 = W1 D^-1 f (tile + halo H), u2 = second pre-sweep (halo H-1), r = f - A u2 (halo H-2); with RESTRICT
+//         (H = 3) the tile's 2x2x2-coarsened cells gather their 4x4x4 residuals straight from LDS, else (H = 2) r goes
+//         to HBM for the restriction kernel / the tail;
+//   up:   v0 = u + P e (tile + halo 2, the coarse correction staged in LDS first), two post-sweeps, z = result, plus
+//         the block's partial of f.z (level 0: the r.z of PCG).
+// Index arithmetic is per-tile with compile-time region sizes (no 64-bit div/mod: the thread-per-cell kernels spent
+// a third of their VALU time there); neighbour sums keep the order of d_smooth / d_resid.
+template <int RY, int RZ>
+__device__ __forceinline__ void region_cell(int t, int& x, int& y, int& z)
+{
+    x = t / (RY * RZ);
+    const int r = t - x * (RY * RZ);
+    y = r / RZ;
+    z = r - y * RZ;
+}
+__device__ __forceinline__ bool in_level(const MLevel& m, int i, int j, int k)
+{
+    return (unsigned)i < (unsigned)m.dx && (unsigned)j < (unsigned)m.dy && (unsigned)k < (unsigned)m.dz;
+}
+
+// Thread mapping: a thread owns one (y,z) COLUMN of a region and walks along x, so the div/mod that finds the column
+// runs once per stage, addresses advance by one multiply-add, the x-neighbours of the sweeps slide through registers
+// (5 LDS reads per point instead of 7) and the in-plane part of the trilinear interpolation is shared by the fine
+// planes above one coarse plane.  (A first version that spread region points over threads by a linear index was
+// VALU-bound on exactly that index arithmetic: 26 us for the level-0 up leg.)  All global loads of a block are issued
+// up front into registers from clamped (always readable) addresses, so the in-level tests never delay a load.
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+template <typename T, int TX, int TY, int TZ, bool RESTRICT>
+__global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u,
+                                                 T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
+                                                 MgCoef<T> cf, const PcgState* ps)
+{
+    constexpr int H = RESTRICT ? 3 : 2;
+    constexpr int AX = TX + 2 * H, AY = TY + 2 * H, AZ = TZ + 2 * H;  // u1 and the count bytes
+    constexpr int BX = AX - 2, BY = AY - 2, BZ = AZ - 2;              // u2
+    constexpr int CX = BX - 2, CY = BY - 2, CZ = BZ - 2;              // r (the tile itself unless RESTRICT)
+    constexpr int NHC = 256 / (CY * CZ), XC = (CX + NHC - 1) / NHC;   // the r columns are few: NHC threads share one, XC planes each
+    static_assert(AY * AZ <= 256 && NHC >= 1 && TX % 2 == 0 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
+    __shared__ T sA[AX * AY * AZ];
+    __shared__ T sB[BX * BY * BZ];
+    __shared__ T sR[RESTRICT ? CX * CY * CZ : 1];
+    __shared__ uint8_t sC[AX * AY * AZ];
+    __shared__ T sd[8], si[8];
+    if (ps && ps->done) return;
+    const int col = threadIdx.x;
+    const int i0 = blockIdx.z * TX, j0 = blockIdx.y * TY, k0 = blockIdx.x * TZ;
+    const T w1 = (T)MG_W1, w2 = (T)MG_W2, off = cf.off;
+    const long sx = m.sx;
+    // ---- every global load of the block ----
+    const int ya = col / AZ, za = col - ya * AZ;
+    const bool actA = col < AY * AZ;
+    const bool okA = actA && (unsigned)(j0 - H + ya) < (unsigned)m.dy && (unsigned)(k0 - H + za) < (unsigned)m.dz;
+    const size_t qa = m.at(0, clampi(j0 - H + ya, m.dy - 1), clampi(k0 - H + za, m.dz - 1));
+    int ca[AX];
+    T fa[AX];
+#pragma unroll
+    for (int x = 0; x < AX; ++x) {
+        const int i = i0 - H + x;
+        const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
+        const int c = cnt[q];
+        fa[x] = f[q];
+        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
+    }
+    const int yb = col / BZ, zb = col - yb * BZ;
+    const bool actB = col < BY * BZ;
+    const size_t qb = m.at(0, clampi(j0 - H + 1 + yb, m.dy - 1), clampi(k0 - H + 1 + zb, m.dz - 1));
+    T fb[BX];
+#pragma unroll
+    for (int x = 0; x < BX; ++x) fb[x] = f[qb + (size_t)((long)clampi(i0 - H + 1 + x, m.dx - 1) * sx)];
+    const int hc = col / (CY * CZ), cc = col - hc * (CY * CZ);
+    const int yc = cc / CZ, zc = cc - yc * CZ;
+    const bool actC = hc < NHC;
+    const int xc0 = hc * XC;
+    const size_t qc = m.at(0, clampi(j0 - H + 2 + yc, m.dy - 1), clampi(k0 - H + 2 + zc, m.dz - 1));
+    T fr[XC];
+#pragma unroll
+    for (int x = 0; x < XC; ++x) fr[x] = f[qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx)];
+    mg_load_coef(sd, si, cf);
+    // ---- u1 = W1 D^-1 f on region A ----
+    if (actA) {
+#pragma unroll
+        for (int x = 0; x < AX; ++x) {
+            sC[x * AY * AZ + col] = (uint8_t)ca[x];
+            sA[x * AY * AZ + col] = w1 * si[ca[x]] * fa[x];  // si[0] = 0
+        }
+    }
+    __syncthreads();
+    // ---- u2 on region B (branch-free: a non-unknown has n = 0, si[0] = sd[0] = 0 and u1 = 0, so 0 falls out) ----
+    if (actB) {
+        const int a0 = (yb + 1) * AZ + zb + 1;
+        T cm = sA[a0], c0 = sA[a0 + AY * AZ];
+        const bool in_yz = (unsigned)(yb - (H - 1)) < (unsigned)TY && (unsigned)(zb - (H - 1)) < (unsigned)TZ;
+#pragma unroll
+        for (int x = 0; x < BX; ++x) {
+            const int a = a0 + (x + 1) * AY * AZ;
+            const T cp = sA[a + AY * AZ];
+            const int n = sC[a];
+            const T nb = cm + cp + sA[a - AZ] + sA[a + AZ] + sA[a - 1] + sA[a + 1];
+            const T v = c0 + w2 * si[n] * (fb[x] - (sd[n] * c0 + off * nb));
+            sB[(x * BY + yb) * BZ + zb] = v;
+            if (n && in_yz && x >= H - 1 && x < H - 1 + TX) u[qb + (size_t)((long)(i0 - H + 1 + x) * sx)] = v;  // n != 0: in the level, no clamp
+            cm = c0;
+            c0 = cp;
+        }
+    }
+    __syncthreads();
+    // ---- r = f - A u2 on region C ----
+    if (actC) {
+        const int b0 = ((xc0 + 1) * BY + yc + 1) * BZ + zc + 1;
+        T cm = sB[b0 - BY * BZ], c0 = sB[b0];
+#pragma unroll
+        for (int x = 0; x < XC; ++x) {
+            if (xc0 + x < CX) {
+                const int b = b0 + x * BY * BZ;
+                const T cp = sB[b + BY * BZ];
+                const int n = sC[((xc0 + x + 2) * AY + yc + 2) * AZ + zc + 2];
+                const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
+                const T v = n ? fr[x] - (sd[n] * c0 + off * nb) : (T)0;
+                if (RESTRICT) sR[((xc0 + x) * CY + yc) * CZ + zc] = v;
+                else if (n) r[qc + (size_t)((long)(i0 + xc0 + x) * sx)] = v;
+                cm = c0;
+                c0 = cp;
+            }
+        }
+    }
+    if (RESTRICT) {
+        __syncthreads();
+        constexpr int QX = TX / 2, QY = TY / 2, QZ = TZ / 2;
+        for (int t = threadIdx.x; t < QX * QY * QZ; t += 256) {
+            int X, Y, Z;
+            region_cell<QY, QZ>(t, X, Y, Z);
+            const int I = i0 / 2 + X, J = j0 / 2 + Y, K = k0 / 2 + Z;
+            if (!in_level(mc, I, J, K)) continue;
+            const size_t C = mc.at(I, J, K);
+            if (!cnt_c[C]) continue;
+            auto w = [](int a) { return (a == 0 || a == 3) ? (T)0.25 : (T)0.75; };
+            const T* p = sR + ((2 * X) * CY + 2 * Y) * CZ + 2 * Z;  // region C starts one fine cell before the tile
+            T acc = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const T* q = p + (a * CY + b) * CZ;
+                    acc += w(a) * w(b) * ((T)0.25 * (q[0] + q[3]) + (T)0.75 * (q[1] + q[2]));
+                }
+            }
+            fc[C] = acc * (T)0.125;
+        }
+    }
+}
+
+template <typename T, int TX, int TY, int TZ>
+__global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u,
+                                               T* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
+                                               double* __restrict__ part_dot, const PcgState* ps)
+{
+    constexpr int AX = TX + 4, AY = TY + 4, AZ = TZ + 4;              // v0 = u + P e and the count bytes
+    constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2;              // v1
+    constexpr int EX = TX / 2 + 4, EY = TY / 2 + 4, EZ = TZ / 2 + 4;  // coarse correction under the v0 region
+    constexpr int NE = (EX * EY * EZ + 255) / 256;
+    constexpr int NHT = 256 / (TY * TZ), XT = TX / NHT;               // NHT threads share a tile column, XT planes each
+    static_assert(AY * AZ <= 256 && 256 % (TY * TZ) == 0 && TX % NHT == 0 && TX % 2 == 0 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
+    __shared__ T sA[AX * AY * AZ];
+    __shared__ T sB[BX * BY * BZ];
+    __shared__ T sE[EX * EY * EZ];
+    __shared__ uint8_t sC[AX * AY * AZ];
+    __shared__ T sd[8], si[8];
+    __shared__ double red[4];
+    if (ps && ps->done) return;
+    const int col = threadIdx.x;
+    const int i0 = blockIdx.z * TX, j0 = blockIdx.y * TY, k0 = blockIdx.x * TZ;
+    const int I0 = i0 / 2 - 2, J0 = j0 / 2 - 2, K0 = k0 / 2 - 2;
+    const T off = cf.off;
+    const long sx = m.sx;
+    // ---- every global load of the block ----
+    T ee[NE];
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+        int x, y, z;
+        region_cell<EY, EZ>(threadIdx.x + 256 * it, x, y, z);
+        const int I = I0 + x, J = J0 + y, K = K0 + z;
+        // the coarse arrays carry a ring of zeros (indices -1 and d*), nothing beyond it
+        const bool ok = I >= -1 && I <= mc.dx && J >= -1 && J <= mc.dy && K >= -1 && K <= mc.dz;
+        const T v = ec[mc.at(min(max(I, -1), mc.dx), min(max(J, -1), mc.dy), min(max(K, -1), mc.dz))];
+        ee[it] = ok ? v : (T)0;
+    }
+    const int ya = col / AZ, za = col - ya * AZ;
+    const bool actA = col < AY * AZ;
+    const bool okA = actA && (unsigned)(j0 - 2 + ya) < (unsigned)m.dy && (unsigned)(k0 - 2 + za) < (unsigned)m.dz;
+    const size_t qa = m.at(0, clampi(j0 - 2 + ya, m.dy - 1), clampi(k0 - 2 + za, m.dz - 1));
+    int ca[AX];
+    T ua[AX];
+#pragma unroll
+    for (int x = 0; x < AX; ++x) {
+        const int i = i0 - 2 + x;
+        const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
+        const int c = cnt[q];
+        ua[x] = u[q];
+        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
+    }
+    const int yb = col / BZ, zb = col - yb * BZ;
+    const bool actB = col < BY * BZ;
+    const size_t qb = m.at(0, clampi(j0 - 1 + yb, m.dy - 1), clampi(k0 - 1 + zb, m.dz - 1));
+    T fb[BX];
+#pragma unroll
+    for (int x = 0; x < BX; ++x) fb[x] = f[qb + (size_t)((long)clampi(i0 - 1 + x, m.dx - 1) * sx)];
+    const int ht = col / (TY * TZ), ct = col - ht * (TY * TZ);
+    const int yt = ct / TZ, zt = ct - yt * TZ;
+    const int xt0 = ht * XT;
+    const size_t qt = m.at(0, clampi(j0 + yt, m.dy - 1), clampi(k0 + zt, m.dz - 1));
+    T ft[XT];
+#pragma unroll
+    for (int x = 0; x < XT; ++x) ft[x] = f[qt + (size_t)((long)clampi(i0 + xt0 + x, m.dx - 1) * sx)];
+    mg_load_coef(sd, si, cf);
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+        const int t = threadIdx.x + 256 * it;
+        if (t < EX * EY * EZ) sE[t] = ee[it];
+    }
+    __syncthreads();
+    // ---- v0 = u + P e on region A: bilinear in (y,z) once per coarse plane, then linear in x (region A starts at
+    //      the even cell i0 - 2 and sE two coarse cells before i0 / 2: fine plane x sits over coarse plane (x>>1)+1) ----
+    if (actA) {
+        const int eb = ((ya >> 1) + 1) * EZ + (za >> 1) + 1;
+        const int sy = (ya & 1) ? EZ : -EZ, sz = (za & 1) ? 1 : -1;
+        const T a = (T)0.75, b = (T)0.25;
+        T pl[EX];
+#pragma unroll
+        for (int I = 0; I < EX; ++I) {
+            const T* p = sE + I * EY * EZ + eb;
+            pl[I] = a * a * p[0] + a * b * (p[sy] + p[sz]) + b * b * p[sy + sz];
+        }
+#pragma unroll
+        for (int x = 0; x < AX; ++x) {
+            const int I = (x >> 1) + 1, In = (x & 1) ? I + 1 : I - 1;
+            const T pe = a * pl[I] + b * pl[In];
+            sC[x * AY * AZ + col] = (uint8_t)ca[x];
+            sA[x * AY * AZ + col] = ca[x] ? ua[x] + pe : (T)0;
+        }
+    }
+    __syncthreads();
+    // ---- first post-sweep on region B (branch-free: n = 0 has v0 = 0 and si[0] = 0) ----
+    if (actB) {
+        const int a0 = (yb + 1) * AZ + zb + 1;
+        T cm = sA[a0], c0 = sA[a0 + AY * AZ];
+#pragma unroll
+        for (int x = 0; x < BX; ++x) {
+            const int a = a0 + (x + 1) * AY * AZ;
+            const T cp = sA[a + AY * AZ];
+            const int n = sC[a];
+            const T nb = cm + cp + sA[a - AZ] + sA[a + AZ] + sA[a - 1] + sA[a + 1];
+            sB[(x * BY + yb) * BZ + zb] = c0 + (T)MG_W2 * si[n] * (fb[x] - (sd[n] * c0 + off * nb));
+            cm = c0;
+            c0 = cp;
+        }
+    }
+    __syncthreads();
+    // ---- second post-sweep on the tile, result + partial of f.out ----
+    double acc = 0;
+    {
+        const int b0 = ((xt0 + 1) * BY + yt + 1) * BZ + zt + 1;
+        T cm = sB[b0 - BY * BZ], c0 = sB[b0];
+#pragma unroll
+        for (int x = 0; x < XT; ++x) {
+            const int b = b0 + x * BY * BZ;
+            const T cp = sB[b + BY * BZ];
+            const int n = sC[((xt0 + x + 2) * AY + yt + 2) * AZ + zt + 2];
+            const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
+            const T o = c0 + (T)MG_W1 * si[n] * (ft[x] - (sd[n] * c0 + off * nb));
+            if (n) {
+                out[qt + (size_t)((long)(i0 + xt0 + x) * sx)] = o;  // n != 0: in the level, no clamp
+                acc += (double)ft[x] * (double)o;
+            }
+            cm = c0;
+            c0 = cp;
+        }
+    }
+    if (part_dot) {
+        acc = block_sum<double, 4>(acc, red);
+        if (threadIdx.x == 0) part_dot[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = acc;
+    }
+}
+
 // ---- per-level kernels (levels too large for one block) ---------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_mg_smooth(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u_in,
@@ -349,30 +637,36 @@ __global__ __launch_bounds__(256) void k_mg_prolong(MLevel mf, const uint8_t* __
     d_prolong<T>(mf, cnt_f, u, mc, ec, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
-// ---- tail: the whole sub-V-cycle of the small levels in ONE block ---------------------------------------
-// Levels of <= ~16k cells are pure launch latency as separate kernels (7 launches x ~3 us each).  One
-// block of 1024 threads walks down and up through them with __syncthreads() between the stages; the
-// coarsest level (<= 8^3) is solved by symmetric red-black Gauss-Seidel in LDS.
+// ---- tail: the whole sub-V-cycle of the small levels in ONE block, entirely in LDS ------------------------
+// Levels of a few thousand cells are pure latency as separate kernels (7 launches x ~3 us each), and even inside one
+// block every stage costs a global-memory round trip (~2 us) if the arrays live in HBM.  Here one block of 1024
+// threads restricts the residual of the level above into LDS, walks down and up through the tail levels with
+// __syncthreads() between the stages — u, v(=r), f and the count bytes of every tail level stay in LDS (compact
+// layout, ring of zeros) — and writes only the correction of its first level back.  The coarsest level (<= 8^3) is
+// solved by symmetric red-black Gauss-Seidel, forward then reversed.
 template <typename T>
 struct MgTail {
-    int nl;                 // levels in the tail; the last is the coarsest
-    MLevel m[MG_TAIL_MAX];
+    int nl;                          // levels in the tail; the last is the coarsest
+    MLevel mfine;                    // the level above the tail and its residual (restricted here)
+    const T* rfine;
+    MLevel mg[MG_TAIL_MAX];          // global layouts: counts in, u[0] out
     const uint8_t* cnt[MG_TAIL_MAX];
-    T* u[MG_TAIL_MAX];
-    T* v[MG_TAIL_MAX];
-    T* f[MG_TAIL_MAX];      // f[0] is the rhs handed down by the caller
-    T* r[MG_TAIL_MAX];
-    T off[MG_TAIL_MAX];     // off-diagonal of each level; diag = -off * n
+    T* u0;
+    MLevel ml[MG_TAIL_MAX];          // LDS layouts
+    int o_u[MG_TAIL_MAX], o_v[MG_TAIL_MAX], o_f[MG_TAIL_MAX], o_c[MG_TAIL_MAX];  // LDS byte offsets
+    int lds_bytes;
+    T off[MG_TAIL_MAX];              // off-diagonal of each level; diag = -off * n
     int sweeps;
 };
 
 template <typename T>
 __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* ps)
 {
+    extern __shared__ double tail_lds[];
     __shared__ T sd[MG_TAIL_MAX][8], si[MG_TAIL_MAX][8];
-    __shared__ T su[10 * 10 * 10];
     if (ps && ps->done) return;
     const int tid = threadIdx.x;
+    char* base = (char*)tail_lds;
     if (tid < a.nl * 8) {
         const int l = tid >> 3, n = tid & 7;
         T off = a.off[0];
@@ -382,68 +676,92 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
         sd[l][n] = d;
         si[l][n] = n ? (T)1 / d : (T)0;
     }
+    for (int q = tid; q < a.lds_bytes / 8; q += 1024) tail_lds[q] = 0;  // rings and non-unknowns read 0 / "not an unknown"
     __syncthreads();
-#define TAIL_FOR(lv) for (long t = tid; t < (long)a.m[lv].dx * a.m[lv].dy * a.m[lv].dz; t += 1024)
+#define TAIL_FOR(lv) for (long t = tid; t < (long)a.ml[lv].dx * a.ml[lv].dy * a.ml[lv].dz; t += 1024)
+#define TU(lv) ((T*)(base + a.o_u[lv]))
+#define TV(lv) ((T*)(base + a.o_v[lv]))
+#define TF(lv) ((T*)(base + a.o_f[lv]))
+#define TC(lv) ((uint8_t*)(base + a.o_c[lv]))
+#pragma unroll
+    for (int l = 0; l < MG_TAIL_MAX; ++l) {
+        if (l < a.nl) {
+            TAIL_FOR(l) {
+                int i, j, k;
+                mg_cell(a.ml[l], t, i, j, k);
+                TC(l)[a.ml[l].at(i, j, k)] = a.cnt[l][a.mg[l].at(i, j, k)];
+            }
+        }
+    }
+    __syncthreads();
+    TAIL_FOR(0) d_restrict<T>(a.mfine, a.rfine, a.ml[0], TC(0), TF(0), t);
+    __syncthreads();
 #pragma unroll
     for (int l = 0; l < MG_TAIL_MAX - 1; ++l) {
         if (l < a.nl - 1) {
-            TAIL_FOR(l) d_smooth0<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], sd[l], si[l], a.off[l], t);
+            TAIL_FOR(l) d_smooth0<T>(a.ml[l], TC(l), TF(l), TU(l), sd[l], si[l], a.off[l], t);
             __syncthreads();
-            TAIL_FOR(l) d_resid<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], a.r[l], sd[l], a.off[l], t);
+            TAIL_FOR(l) d_resid<T>(a.ml[l], TC(l), TF(l), TU(l), TV(l), sd[l], a.off[l], t);
             __syncthreads();
-            TAIL_FOR(l + 1) d_restrict<T>(a.m[l], a.r[l], a.m[l + 1], a.cnt[l + 1], a.f[l + 1], t);
+            TAIL_FOR(l + 1) d_restrict<T>(a.ml[l], TV(l), a.ml[l + 1], TC(l + 1), TF(l + 1), t);
             __syncthreads();
         }
     }
-    // coarsest: red-black Gauss-Seidel in LDS, forward sweeps then reversed (symmetric)
+    // coarsest: red-black Gauss-Seidel in place (u starts at 0), forward sweeps then reversed (symmetric)
 #pragma unroll
     for (int lc = 0; lc < MG_TAIL_MAX; ++lc) {
         if (lc == a.nl - 1) {
-            const MLevel& m = a.m[lc];
-            for (int q = tid; q < 1000; q += 1024) su[q] = 0;
+            const MLevel& m = a.ml[lc];
+            T* su = TU(lc);
             int i = 0, j = 0, k = 0;
             const bool ok = mg_cell(m, tid, i, j, k);
-            size_t c = 0;
-            int n = 0, lidx = 0;
+            int n = 0, c = 0;
             T fv = 0, inv = 0;
             bool isred = false;
             if (ok) {
-                c = m.at(i, j, k);
-                n = a.cnt[lc][c];
-                fv = a.f[lc][c];
+                c = (int)m.at(i, j, k);
+                n = TC(lc)[c];
+                fv = TF(lc)[c];
                 inv = si[lc][n];
-                lidx = ((i + 1) * 10 + (j + 1)) * 10 + (k + 1);
                 isred = ((i + j + k) & 1) == 0;
             }
-            __syncthreads();
+            const int sx = (int)m.sx, sy = (int)m.sy;
             for (int s = 0; s < 2 * a.sweeps; ++s) {
                 const bool fwd = s < a.sweeps;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const bool col = fwd ? (h == 0) : (h == 1);
                     if (ok && n && isred == col) {
-                        const T nb = su[lidx - 100] + su[lidx + 100] + su[lidx - 10] + su[lidx + 10] + su[lidx - 1] + su[lidx + 1];
-                        su[lidx] = (fv - a.off[lc] * nb) * inv;
+                        const T nb = su[c - sx] + su[c + sx] + su[c - sy] + su[c + sy] + su[c - 1] + su[c + 1];
+                        su[c] = (fv - a.off[lc] * nb) * inv;
                     }
                     __syncthreads();
                 }
             }
-            if (ok) a.u[lc][c] = n ? su[lidx] : (T)0;
-            __syncthreads();
         }
     }
 #pragma unroll
     for (int l = MG_TAIL_MAX - 2; l >= 0; --l) {
         if (l < a.nl - 1) {
-            TAIL_FOR(l) d_prolong<T>(a.m[l], a.cnt[l], a.u[l], a.m[l + 1], a.u[l + 1], t);
+            TAIL_FOR(l) d_prolong<T>(a.ml[l], TC(l), TU(l), a.ml[l + 1], TU(l + 1), t);
             __syncthreads();
-            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.u[l], a.v[l], sd[l], si[l], a.off[l], (T)MG_W2, t);
+            TAIL_FOR(l) d_smooth<T>(a.ml[l], TC(l), TF(l), TU(l), TV(l), sd[l], si[l], a.off[l], (T)MG_W2, t);
             __syncthreads();
-            TAIL_FOR(l) d_smooth<T>(a.m[l], a.cnt[l], a.f[l], a.v[l], a.u[l], sd[l], si[l], a.off[l], (T)MG_W1, t);
+            TAIL_FOR(l) d_smooth<T>(a.ml[l], TC(l), TF(l), TV(l), TU(l), sd[l], si[l], a.off[l], (T)MG_W1, t);
             __syncthreads();
         }
     }
+    TAIL_FOR(0) {
+        int i, j, k;
+        mg_cell(a.ml[0], t, i, j, k);
+        const size_t c = a.ml[0].at(i, j, k);
+        if (TC(0)[c]) a.u0[a.mg[0].at(i, j, k)] = TU(0)[c];
+    }
 #undef TAIL_FOR
+#undef TU
+#undef TV
+#undef TF
+#undef TC
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -513,22 +831,92 @@ void launch_mg_prolong_smooth(hipStream_t st, MLevel mf, const uint8_t* cnt_f, c
 {
     hipLaunchKernelGGL((k_mg_prolong_smooth<T>), dim3(mg_blocks(mf)), dim3(256), 0, st, mf, cnt_f, f, u, u_out, mc, ec, cf, ps);
 }
-// levels[0..nl) of the tail; f[0] = rhs of the first tail level; result in u[0]
+// tile shapes of the LDS-tiled legs
+constexpr int MG_TX = 8, MG_TY = 8, MG_TZ = 16;   // down (no restriction) and up
+constexpr int MG_RX = 8, MG_RY = 8, MG_RZ = 8;    // down with the restriction folded in (halo 3)
+static inline dim3 mg_tiles(const MLevel& m, int tx, int ty, int tz)
+{
+    return dim3((unsigned)((m.dz + tz - 1) / tz), (unsigned)((m.dy + ty - 1) / ty), (unsigned)((m.dx + tx - 1) / tx));
+}
+int mg_up_blocks(const MLevel& m)
+{
+    const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
+    return (int)(g.x * g.y * g.z);
+}
+// both pre-sweeps + residual; with a coarse level (fc != nullptr) the restricted residual goes straight to fc and r is not written
 template <typename T>
-void launch_mg_tail(hipStream_t st, int nl, const MLevel* lv, uint8_t* const* cnt, T* const* u, T* const* v, T* const* f, T* const* r,
-                    const T* off, int sweeps, const PcgState* ps)
+void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
+                    const PcgState* ps)
+{
+    if (fc)
+        hipLaunchKernelGGL((k_mg_down<T, MG_RX, MG_RY, MG_RZ, true>), mg_tiles(m, MG_RX, MG_RY, MG_RZ), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc,
+                           cf, ps);
+    else
+        hipLaunchKernelGGL((k_mg_down<T, MG_TX, MG_TY, MG_TZ, false>), mg_tiles(m, MG_TX, MG_TY, MG_TZ), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c,
+                           fc, cf, ps);
+}
+// prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
+template <typename T>
+void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* out, MLevel mc, const T* ec, MgCoef<T> cf,
+                  double* part_dot, const PcgState* ps)
+{
+    hipLaunchKernelGGL((k_mg_up<T, MG_TX, MG_TY, MG_TZ>), mg_tiles(m, MG_TX, MG_TY, MG_TZ), dim3(256), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot,
+                       ps);
+}
+
+// LDS footprint of a tail that starts at lv[0] (compact arrays with a ring of 1: u, v, f as T and one count byte)
+static MLevel tail_lds_level(const MLevel& g)
+{
+    MLevel m;
+    m.dx = g.dx; m.dy = g.dy; m.dz = g.dz;
+    m.sy = g.dz + 2; m.sx = (long)(g.dy + 2) * (g.dz + 2);
+    m.ox = m.oy = m.oz = 1;
+    m.cells = (size_t)(g.dx + 2) * m.sx;
+    return m;
+}
+size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem)
+{
+    size_t total = 0;
+    for (int l = 0; l < nl; ++l) {
+        const size_t c = tail_lds_level(lv[l]).cells;
+        total += 3 * ((c * elem + 15) / 16 * 16) + (c + 15) / 16 * 16;
+    }
+    return total;
+}
+// levels[0..nl) of the tail, `fine` = the level above with its residual rfine; result (the correction of lv[0]) in u0
+template <typename T>
+void launch_mg_tail(hipStream_t st, int nl, const MLevel& fine, const T* rfine, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off,
+                    int sweeps, const PcgState* ps)
 {
     MgTail<T> a;
     a.nl = nl;
+    a.mfine = fine; a.rfine = rfine; a.u0 = u0;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) / 16 * 16; return (int)at; };
     for (int l = 0; l < MG_TAIL_MAX; ++l) {
         const int q = l < nl ? l : nl - 1;
-        a.m[l] = lv[q]; a.cnt[l] = cnt[q]; a.u[l] = u[q]; a.v[l] = v[q]; a.f[l] = f[q]; a.r[l] = r[q]; a.off[l] = off[q];
+        a.mg[l] = lv[q]; a.cnt[l] = cnt[q]; a.off[l] = off[q];
+        a.ml[l] = tail_lds_level(lv[q]);
+        if (l < nl) {
+            const size_t c = a.ml[l].cells;
+            a.o_u[l] = take(c * sizeof(T)); a.o_v[l] = take(c * sizeof(T)); a.o_f[l] = take(c * sizeof(T)); a.o_c[l] = take(c);
+        } else {
+            a.o_u[l] = a.o_u[q]; a.o_v[l] = a.o_v[q]; a.o_f[l] = a.o_f[q]; a.o_c[l] = a.o_c[q];
+        }
     }
+    a.lds_bytes = (int)o;
     a.sweeps = sweeps;
-    hipLaunchKernelGGL((k_mg_tail<T>), dim3(1), dim3(1024), 0, st, a, ps);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_mg_tail<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_TAIL_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_mg_tail<T>), dim3(1), dim3(1024), o, st, a, ps);
 }
 
 #define INSTMG(T)                                                                                                                   \
+    template void launch_mg_down<T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*); \
+    template void launch_mg_up<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*, const PcgState*); \
     template void launch_mg_smooth<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, int, double*, const PcgState*); \
     template void launch_mg_resid<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, const PcgState*);        \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                  \
@@ -536,8 +924,7 @@ void launch_mg_tail(hipStream_t st, int nl, const MLevel* lv, uint8_t* const* cn
     template void launch_mg_smooth0_resid<T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MgCoef<T>, const PcgState*);          \
     template void launch_mg_prolong_smooth<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>,  \
                                               const PcgState*);                                                                       \
-    template void launch_mg_tail<T>(hipStream_t, int, const MLevel*, uint8_t* const*, T* const*, T* const*, T* const*, T* const*, const T*, int, \
-                                    const PcgState*);
+    template void launch_mg_tail<T>(hipStream_t, int, const MLevel&, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*);
 INSTMG(double)
 
 }  // namespace fl
