@@ -157,6 +157,23 @@ __device__ __forceinline__ double block_sum_array(const double* __restrict__ a, 
     return sm[NW];
 }
 
+// Sum three partial arrays in one pass; results broadcast to all threads.  sm: 12 doubles.
+__device__ __forceinline__ void block_sum3(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
+                                           const double* __restrict__ c, int nc, double* sm, double& ra, double& rb, double& rc)
+{
+    double va = 0, vb = 0, vc = 0;
+    for (int i = threadIdx.x; i < na; i += 256) va += a[i];
+    for (int i = threadIdx.x; i < nb; i += 256) vb += b[i];
+    for (int i = threadIdx.x; i < nc; i += 256) vc += c[i];
+    va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[w] = va; sm[4 + w] = vb; sm[8 + w] = vc; }
+    __syncthreads();
+    ra = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    rb = ((sm[4] + sm[5]) + sm[6]) + sm[7];
+    rc = ((sm[8] + sm[9]) + sm[10]) + sm[11];
+}
+
 // ---- launchers (defined in kernels_*.hip) --------------------------------------------------
 struct Particles {
     double *px, *py, *pz, *vx, *vy, *vz;
@@ -220,7 +237,7 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol, int n_rz = -1, int zmode = 0);
+                   double tol, int n_rz = -1, int zmode = 0, int n_prev = -1);
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1, int sparse = 0);
@@ -272,7 +289,6 @@ template <typename T>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* out, MLevel mc, const T* ec, MgCoef<T> cf,
                   double* part_dot, const PcgState* ps);
 template <typename T>
-void launch_mg_tail(hipStream_t st, int nl, const MLevel& fine, const T* rfine, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off,
-                    int sweeps, const PcgState* ps);
+void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps);
 
 }  // namespace fl

@@ -544,8 +544,12 @@ static int mg_setup(fluid_sim* s)
     // levels small enough for one block (and everything coarser) run inside the tail kernel; level 0 never does
     // (the tail holds its levels in LDS: as many of the coarsest levels as fit)
     int tail = nl - 1;
-    while (tail > 1 && nl - (tail - 1) <= MG_TAIL_MAX && mg_tail_lds_bytes(nl - (tail - 1), s->mgl + tail - 1, sizeof(double)) <= MG_TAIL_LDS) --tail;
-    if (mg_tail_lds_bytes(nl - tail, s->mgl + tail, sizeof(double)) > MG_TAIL_LDS) return fail(FLUID_ERR_STATE, "multigrid: coarsest level does not fit in LDS");
+    auto fits = [&](int t) {
+        const size_t b = nl - t <= MG_TAIL_MAX ? mg_tail_lds_bytes(nl - t, s->mgl + t, sizeof(double)) : 0;
+        return b > 0 && b <= MG_TAIL_LDS;
+    };
+    while (tail > 1 && fits(tail - 1)) --tail;
+    if (!fits(tail)) return fail(FLUID_ERR_STATE, "multigrid: coarsest level does not fit the tail kernel");
     s->mg_tail = tail;
     // One slab for every per-step multigrid array (types, counts, u, v, f, r of each level and z of level 0), zeroed
     // by ONE fill: the layout changes with the box, everything outside the new domain must read as zero / solid, and
@@ -612,17 +616,15 @@ static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_
         const MLevel& m = s->mgl[l];
         const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
         const double* f = l == 0 ? rhs0 : s->mg_f[l];
-        const bool last = l + 1 == tail;  // the tail restricts this level's residual itself
-        const bool fold = !last && l > 0; // restriction inside the down kernel (halo 3): not at level 0, where 5x halo reads cost more than a launch
+        const bool fold = l > 0;  // restriction inside the down kernel (halo 3): not at level 0, where 5x halo reads cost more than a launch
         launch_mg_down<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], s->mgl[l + 1], fold ? s->mg_cnt[l + 1] : nullptr,
                                fold ? s->mg_f[l + 1] : nullptr, mg_coef(s, l), ps);
-        if (!last && !fold) launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
+        if (!fold) launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
     }
     {
         double off[fluid_sim::MG_MAXL];
         for (int l = tail; l < nl; ++l) off[l] = mg_coef(s, l).off;
-        launch_mg_tail<double>(s->st, nl - tail, s->mgl[tail - 1], s->mg_r[tail - 1], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail,
-                               s->mg_csweeps, ps);
+        launch_mg_tail<double>(s->st, nl - tail, s->mg_f[tail], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail, s->mg_csweeps, ps);
     }
     for (int l = tail - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];
@@ -653,14 +655,13 @@ static int mg_vcycle_legacy(fluid_sim* s, const double* rhs0, double* z0, double
             launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_u[l], cf, 0, nullptr, ps);   // two sweeps from u = 0
             launch_mg_resid<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], cf, ps);
         }
-        if (l + 1 < tail) launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
+        launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
     }
     {
         // the tail restricts the residual of level tail-1 itself and leaves its correction in mg_u[tail]
         double off[fluid_sim::MG_MAXL];
         for (int l = tail; l < nl; ++l) off[l] = mg_coef(s, l).off;
-        launch_mg_tail<double>(s->st, nl - tail, s->mgl[tail - 1], s->mg_r[tail - 1], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail,
-                               s->mg_csweeps, ps);
+        launch_mg_tail<double>(s->st, nl - tail, s->mg_f[tail], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail, s->mg_csweeps, ps);
     }
     for (int l = tail - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];

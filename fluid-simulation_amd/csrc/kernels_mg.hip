@@ -638,26 +638,56 @@ __global__ __launch_bounds__(256) void k_mg_prolong(MLevel mf, const uint8_t* __
 }
 
 // ---- tail: the whole sub-V-cycle of the small levels in ONE block, entirely in LDS ------------------------
-// Levels of a few thousand cells are pure latency as separate kernels (7 launches x ~3 us each), and even inside one
-// block every stage costs a global-memory round trip (~2 us) if the arrays live in HBM.  Here one block of 1024
-// threads restricts the residual of the level above into LDS, walks down and up through the tail levels with
+// Levels of a few thousand cells are pure latency as separate kernels.  One block of 1024 threads loads the rhs of the
+// first tail level (restricted by the down kernel of the level above), walks down and up through the tail levels with
 // __syncthreads() between the stages — u, v(=r), f and the count bytes of every tail level stay in LDS (compact
 // layout, ring of zeros) — and writes only the correction of its first level back.  The coarsest level (<= 8^3) is
 // solved by symmetric red-black Gauss-Seidel, forward then reversed.
+// One CU runs all of it, so the kernel is bound by its instruction count: every thread works out its cells ONCE (the
+// first tail level has up to MG_TAIL_Q0 cells per thread, the others one: LDS index, count, parity, the coarse cell
+// under it, the fine block above it) and the ~20 stages are then a handful of LDS reads and flops each; the stage
+// bodies are branch-free (a non-unknown has n = 0, si[0] = sd[0] = 0 and holds 0 everywhere).
+constexpr int MG_TAIL_Q0 = 4;
 template <typename T>
 struct MgTail {
     int nl;                          // levels in the tail; the last is the coarsest
-    MLevel mfine;                    // the level above the tail and its residual (restricted here)
-    const T* rfine;
-    MLevel mg[MG_TAIL_MAX];          // global layouts: counts in, u[0] out
+    MLevel mg[MG_TAIL_MAX];          // global layouts: counts in, f0 in, u0 out
     const uint8_t* cnt[MG_TAIL_MAX];
+    const T* f0;
     T* u0;
-    MLevel ml[MG_TAIL_MAX];          // LDS layouts
+    MLevel ml[MG_TAIL_MAX];          // LDS layouts (ring: one cell below, two above)
     int o_u[MG_TAIL_MAX], o_v[MG_TAIL_MAX], o_f[MG_TAIL_MAX], o_c[MG_TAIL_MAX];  // LDS byte offsets
     int lds_bytes;
     T off[MG_TAIL_MAX];              // off-diagonal of each level; diag = -off * n
     int sweeps;
 };
+
+// what a thread knows about one of its cells
+struct TailCell {
+    int c;      // LDS index in its level (-1: no cell)
+    int n;      // count byte
+    int up;     // LDS index (coarser level) of the coarse cell under it
+    int down;   // LDS index (finer level) of the corner (2I-1, 2J-1, 2K-1) of its 4x4x4 restriction block
+    int bits;   // bit 0-2: i,j,k odd; bit 3: red
+};
+__device__ __forceinline__ TailCell tail_cell(const MLevel& m, bool has_coarser, const MLevel& coarser, bool has_finer, const MLevel& finer, int t)
+{
+    TailCell d;
+    d.c = -1; d.n = 0; d.up = 0; d.down = 0; d.bits = 0;
+    int i, j, k;
+    if (mg_cell(m, t, i, j, k)) {
+        d.c = (int)m.at(i, j, k);
+        d.bits = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2) | ((((i + j + k) & 1) == 0) << 3);
+        if (has_coarser) d.up = (int)coarser.at(i >> 1, j >> 1, k >> 1);
+        if (has_finer) d.down = (int)finer.at(2 * i - 1, 2 * j - 1, 2 * k - 1);
+    }
+    return d;
+}
+template <typename T>
+__device__ __forceinline__ T tail_nb(const T* p, int c, int sx, int sy)
+{
+    return p[c - sx] + p[c + sx] + p[c - sy] + p[c + sy] + p[c - 1] + p[c + 1];
+}
 
 template <typename T>
 __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* ps)
@@ -667,6 +697,40 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
     if (ps && ps->done) return;
     const int tid = threadIdx.x;
     char* base = (char*)tail_lds;
+#define TU(lv) ((T*)(base + a.o_u[lv]))
+#define TV(lv) ((T*)(base + a.o_v[lv]))
+#define TF(lv) ((T*)(base + a.o_f[lv]))
+#define TC(lv) ((uint8_t*)(base + a.o_c[lv]))
+    // ---- cells of this thread, counts and the rhs of the first level (all global loads up front) ----
+    TailCell z[MG_TAIL_Q0];   // first tail level
+    T zf[MG_TAIL_Q0];
+    int zg[MG_TAIL_Q0];
+#pragma unroll
+    for (int q = 0; q < MG_TAIL_Q0; ++q) {
+        z[q] = tail_cell(a.ml[0], a.nl > 1, a.ml[1], false, a.ml[0], tid + 1024 * q);
+        zg[q] = 0;
+        zf[q] = 0;
+        if (z[q].c >= 0) {
+            int i, j, k;
+            mg_cell(a.mg[0], tid + 1024 * q, i, j, k);
+            zg[q] = (int)a.mg[0].at(i, j, k);
+            z[q].n = a.cnt[0][zg[q]];
+            zf[q] = a.f0[zg[q]];
+        }
+    }
+    TailCell w[MG_TAIL_MAX];  // deeper levels: one cell per thread (w[0] unused)
+#pragma unroll
+    for (int l = 1; l < MG_TAIL_MAX; ++l) {
+        w[l].c = -1; w[l].n = 0; w[l].up = 0; w[l].down = 0; w[l].bits = 0;
+        if (l < a.nl) {
+            w[l] = tail_cell(a.ml[l], l + 1 < a.nl, a.ml[l + 1 < MG_TAIL_MAX ? l + 1 : l], true, a.ml[l - 1], tid);
+            if (w[l].c >= 0) {
+                int i, j, k;
+                mg_cell(a.mg[l], tid, i, j, k);
+                w[l].n = a.cnt[l][a.mg[l].at(i, j, k)];
+            }
+        }
+    }
     if (tid < a.nl * 8) {
         const int l = tid >> 3, n = tid & 7;
         T off = a.off[0];
@@ -678,86 +742,113 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
     }
     for (int q = tid; q < a.lds_bytes / 8; q += 1024) tail_lds[q] = 0;  // rings and non-unknowns read 0 / "not an unknown"
     __syncthreads();
-#define TAIL_FOR(lv) for (long t = tid; t < (long)a.ml[lv].dx * a.ml[lv].dy * a.ml[lv].dz; t += 1024)
-#define TU(lv) ((T*)(base + a.o_u[lv]))
-#define TV(lv) ((T*)(base + a.o_v[lv]))
-#define TF(lv) ((T*)(base + a.o_f[lv]))
-#define TC(lv) ((uint8_t*)(base + a.o_c[lv]))
 #pragma unroll
-    for (int l = 0; l < MG_TAIL_MAX; ++l) {
-        if (l < a.nl) {
-            TAIL_FOR(l) {
-                int i, j, k;
-                mg_cell(a.ml[l], t, i, j, k);
-                TC(l)[a.ml[l].at(i, j, k)] = a.cnt[l][a.mg[l].at(i, j, k)];
-            }
+    for (int q = 0; q < MG_TAIL_Q0; ++q) {
+        if (z[q].c >= 0) {
+            TC(0)[z[q].c] = (uint8_t)z[q].n;
+            TF(0)[z[q].c] = z[q].n ? zf[q] : (T)0;
         }
     }
+#pragma unroll
+    for (int l = 1; l < MG_TAIL_MAX; ++l)
+        if (l < a.nl && w[l].c >= 0) TC(l)[w[l].c] = (uint8_t)w[l].n;
     __syncthreads();
-    TAIL_FOR(0) d_restrict<T>(a.mfine, a.rfine, a.ml[0], TC(0), TF(0), t);
-    __syncthreads();
+    const T w1 = (T)MG_W1, w2 = (T)MG_W2;
+    // OWN(l, body): run body(cell) for each cell this thread owns at level l
+#define OWN(lv, ...)                                                                   \
+    do {                                                                               \
+        if ((lv) == 0) {                                                               \
+            _Pragma("unroll") for (int q_ = 0; q_ < MG_TAIL_Q0; ++q_) {                \
+                const TailCell& cell = z[q_];                                          \
+                if (cell.c >= 0) { __VA_ARGS__ }                                       \
+            }                                                                          \
+        } else {                                                                       \
+            const TailCell& cell = w[(lv) ? (lv) : 1];                                 \
+            if (cell.c >= 0) { __VA_ARGS__ }                                           \
+        }                                                                              \
+    } while (0)
+    // ---- down: two pre-sweeps, residual, restriction ----
 #pragma unroll
     for (int l = 0; l < MG_TAIL_MAX - 1; ++l) {
         if (l < a.nl - 1) {
-            TAIL_FOR(l) d_smooth0<T>(a.ml[l], TC(l), TF(l), TU(l), sd[l], si[l], a.off[l], t);
+            const int sx = (int)a.ml[l].sx, sy = (int)a.ml[l].sy;
+            T *U = TU(l), *V = TV(l), *F = TF(l);
+            const T off = a.off[l];
+            OWN(l, V[cell.c] = w1 * si[l][cell.n] * F[cell.c];);
             __syncthreads();
-            TAIL_FOR(l) d_resid<T>(a.ml[l], TC(l), TF(l), TU(l), TV(l), sd[l], a.off[l], t);
+            OWN(l, const T v = V[cell.c]; U[cell.c] = v + w2 * si[l][cell.n] * (F[cell.c] - (sd[l][cell.n] * v + off * tail_nb(V, cell.c, sx, sy))););
             __syncthreads();
-            TAIL_FOR(l + 1) d_restrict<T>(a.ml[l], TV(l), a.ml[l + 1], TC(l + 1), TF(l + 1), t);
+            OWN(l, V[cell.c] = cell.n ? F[cell.c] - (sd[l][cell.n] * U[cell.c] + off * tail_nb(U, cell.c, sx, sy)) : (T)0;);
+            __syncthreads();
+            {
+                const TailCell& cc = w[l + 1];  // f_c = (1/8) P^T r: 4x4x4 gather, weights (1/4,3/4,3/4,1/4) per axis
+                if (cc.c >= 0 && cc.n) {
+                    auto wt = [](int q) { return (q == 0 || q == 3) ? (T)0.25 : (T)0.75; };
+                    const T* p = V + cc.down;
+                    T acc = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) {
+                            const T* q = p + x * sx + y * sy;
+                            acc += wt(x) * wt(y) * ((T)0.25 * (q[0] + q[3]) + (T)0.75 * (q[1] + q[2]));
+                        }
+                    }
+                    TF(l + 1)[cc.c] = acc * (T)0.125;
+                }
+            }
             __syncthreads();
         }
     }
-    // coarsest: red-black Gauss-Seidel in place (u starts at 0), forward sweeps then reversed (symmetric)
+    // ---- coarsest: red-black Gauss-Seidel in place (u starts at 0), forward sweeps then reversed (symmetric) ----
 #pragma unroll
     for (int lc = 0; lc < MG_TAIL_MAX; ++lc) {
         if (lc == a.nl - 1) {
-            const MLevel& m = a.ml[lc];
+            const TailCell& cell = lc == 0 ? z[0] : w[lc ? lc : 1];  // <= 8^3 cells: one per thread
             T* su = TU(lc);
-            int i = 0, j = 0, k = 0;
-            const bool ok = mg_cell(m, tid, i, j, k);
-            int n = 0, c = 0;
-            T fv = 0, inv = 0;
-            bool isred = false;
-            if (ok) {
-                c = (int)m.at(i, j, k);
-                n = TC(lc)[c];
-                fv = TF(lc)[c];
-                inv = si[lc][n];
-                isred = ((i + j + k) & 1) == 0;
-            }
-            const int sx = (int)m.sx, sy = (int)m.sy;
+            const int sx = (int)a.ml[lc].sx, sy = (int)a.ml[lc].sy;
+            const bool mine = cell.c >= 0 && cell.n;
+            const bool isred = (cell.bits & 8) != 0;
+            const T fv = mine ? TF(lc)[cell.c] : (T)0, inv = si[lc][cell.n], off = a.off[lc];
             for (int s = 0; s < 2 * a.sweeps; ++s) {
                 const bool fwd = s < a.sweeps;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const bool col = fwd ? (h == 0) : (h == 1);
-                    if (ok && n && isred == col) {
-                        const T nb = su[c - sx] + su[c + sx] + su[c - sy] + su[c + sy] + su[c - 1] + su[c + 1];
-                        su[c] = (fv - a.off[lc] * nb) * inv;
-                    }
+                    if (mine && isred == col) su[cell.c] = (fv - off * tail_nb(su, cell.c, sx, sy)) * inv;
                     __syncthreads();
                 }
             }
         }
     }
+    // ---- up: prolongation, two post-sweeps ----
 #pragma unroll
     for (int l = MG_TAIL_MAX - 2; l >= 0; --l) {
         if (l < a.nl - 1) {
-            TAIL_FOR(l) d_prolong<T>(a.ml[l], TC(l), TU(l), a.ml[l + 1], TU(l + 1), t);
+            const int sx = (int)a.ml[l].sx, sy = (int)a.ml[l].sy;
+            const int cx = (int)a.ml[l + 1].sx, cy = (int)a.ml[l + 1].sy;
+            T *U = TU(l), *V = TV(l), *F = TF(l);
+            const T* E = TU(l + 1);
+            const T off = a.off[l];
+            OWN(l, {
+                const int ex = (cell.bits & 1) ? cx : -cx, ey = (cell.bits & 2) ? cy : -cy, ez = (cell.bits & 4) ? 1 : -1;
+                const T* e = E + cell.up;
+                const T p = (T)0.75, m = (T)0.25;
+                const T pe = p * p * p * e[0] + p * p * m * (e[ex] + e[ey] + e[ez]) + p * m * m * (e[ex + ey] + e[ex + ez] + e[ey + ez]) +
+                             m * m * m * e[ex + ey + ez];
+                if (cell.n) U[cell.c] += pe;
+            });
             __syncthreads();
-            TAIL_FOR(l) d_smooth<T>(a.ml[l], TC(l), TF(l), TU(l), TV(l), sd[l], si[l], a.off[l], (T)MG_W2, t);
+            OWN(l, const T v = U[cell.c]; V[cell.c] = v + w2 * si[l][cell.n] * (F[cell.c] - (sd[l][cell.n] * v + off * tail_nb(U, cell.c, sx, sy))););
             __syncthreads();
-            TAIL_FOR(l) d_smooth<T>(a.ml[l], TC(l), TF(l), TV(l), TU(l), sd[l], si[l], a.off[l], (T)MG_W1, t);
+            OWN(l, const T v = V[cell.c]; U[cell.c] = v + w1 * si[l][cell.n] * (F[cell.c] - (sd[l][cell.n] * v + off * tail_nb(V, cell.c, sx, sy))););
             __syncthreads();
         }
     }
-    TAIL_FOR(0) {
-        int i, j, k;
-        mg_cell(a.ml[0], t, i, j, k);
-        const size_t c = a.ml[0].at(i, j, k);
-        if (TC(0)[c]) a.u0[a.mg[0].at(i, j, k)] = TU(0)[c];
-    }
-#undef TAIL_FOR
+#pragma unroll
+    for (int q = 0; q < MG_TAIL_Q0; ++q)
+        if (z[q].c >= 0 && z[q].n) a.u0[zg[q]] = TU(0)[z[q].c];
+#undef OWN
 #undef TU
 #undef TV
 #undef TF
@@ -864,33 +955,36 @@ void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, cons
                        ps);
 }
 
-// LDS footprint of a tail that starts at lv[0] (compact arrays with a ring of 1: u, v, f as T and one count byte)
+// LDS footprint of a tail that starts at lv[0] (compact arrays, ring of one cell below and two above — the 4x4x4
+// restriction block of the last coarse cell of an odd-sized level reaches index d+1: u, v, f as T and one count byte)
 static MLevel tail_lds_level(const MLevel& g)
 {
     MLevel m;
     m.dx = g.dx; m.dy = g.dy; m.dz = g.dz;
-    m.sy = g.dz + 2; m.sx = (long)(g.dy + 2) * (g.dz + 2);
+    m.sy = g.dz + 3; m.sx = (long)(g.dy + 3) * (g.dz + 3);
     m.ox = m.oy = m.oz = 1;
-    m.cells = (size_t)(g.dx + 2) * m.sx;
+    m.cells = (size_t)(g.dx + 3) * m.sx;
     return m;
 }
+// 0 if the levels cannot run in the tail kernel (too many cells per thread / level), else the LDS bytes they need
 size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem)
 {
     size_t total = 0;
     for (int l = 0; l < nl; ++l) {
+        const long cells = (long)lv[l].dx * lv[l].dy * lv[l].dz;
+        if (cells > (l == 0 ? 1024L * MG_TAIL_Q0 : 1024L)) return 0;
         const size_t c = tail_lds_level(lv[l]).cells;
         total += 3 * ((c * elem + 15) / 16 * 16) + (c + 15) / 16 * 16;
     }
     return total;
 }
-// levels[0..nl) of the tail, `fine` = the level above with its residual rfine; result (the correction of lv[0]) in u0
+// levels[0..nl) of the tail, f0 = rhs of lv[0] (global layout); result (the correction of lv[0]) in u0
 template <typename T>
-void launch_mg_tail(hipStream_t st, int nl, const MLevel& fine, const T* rfine, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off,
-                    int sweeps, const PcgState* ps)
+void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps)
 {
     MgTail<T> a;
     a.nl = nl;
-    a.mfine = fine; a.rfine = rfine; a.u0 = u0;
+    a.f0 = f0; a.u0 = u0;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) / 16 * 16; return (int)at; };
     for (int l = 0; l < MG_TAIL_MAX; ++l) {
@@ -924,7 +1018,7 @@ void launch_mg_tail(hipStream_t st, int nl, const MLevel& fine, const T* rfine, 
     template void launch_mg_smooth0_resid<T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MgCoef<T>, const PcgState*);          \
     template void launch_mg_prolong_smooth<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>,  \
                                               const PcgState*);                                                                       \
-    template void launch_mg_tail<T>(hipStream_t, int, const MLevel&, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*);
+    template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*);
 INSTMG(double)
 
 }  // namespace fl

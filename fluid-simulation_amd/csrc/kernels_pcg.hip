@@ -102,23 +102,6 @@ __global__ __launch_bounds__(256) void k_cnt_local(Grid g, LBox L, const uint8_t
     cnt[t] = c;
 }
 
-// Sum three partial arrays in one pass; results broadcast to all threads.  sm: 12 doubles.
-__device__ __forceinline__ void block_sum3(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
-                                           const double* __restrict__ c, int nc, double* sm, double& ra, double& rb, double& rc)
-{
-    double va = 0, vb = 0, vc = 0;
-    for (int i = threadIdx.x; i < na; i += 256) va += a[i];
-    for (int i = threadIdx.x; i < nb; i += 256) vb += b[i];
-    for (int i = threadIdx.x; i < nc; i += 256) vc += c[i];
-    va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sm[w] = va; sm[4 + w] = vb; sm[8 + w] = vc; }
-    __syncthreads();
-    ra = ((sm[0] + sm[1]) + sm[2]) + sm[3];
-    rb = ((sm[4] + sm[5]) + sm[6]) + sm[7];
-    rc = ((sm[8] + sm[9]) + sm[10]) + sm[11];
-}
-
 // x = 0, r = b (ConjugateGradient.h:41), partial |b|^2 and r.(invdiag r) (:62-65)
 template <typename T>
 __global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const float* __restrict__ b,
@@ -462,9 +445,9 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol, int n_rz, int zmode)
+                   double tol, int n_rz, int zmode, int n_prev)
 {
-    const int nx = pcg_xr_blocks(L);
+    const int nx = n_prev > 0 ? n_prev : pcg_xr_blocks(L);  // partials behind part_rr: the XR launch's, unless the caller says otherwise
     hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
                        part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode);
 }
@@ -741,7 +724,7 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_pcg_init<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, T*, T*, Coef<T>, double*, double*,          \
                                      PcgState*);                                                                                       \
     template void launch_pcg_sq<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
-                                   const double*, double*, PcgState*, int, double, int, int);                                          \
+                                   const double*, double*, PcgState*, int, double, int, int, int);                                     \
     template void launch_pcg_xr<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, const double*, \
                                    double*, double*, PcgState*, int, int);                                                                \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
