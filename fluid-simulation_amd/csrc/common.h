@@ -237,7 +237,7 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol, int n_rz = -1, int zmode = 0, int n_prev = -1);
+                   double tol, int n_rz = -1, int zmode = 0, int sparse = 0);
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1, int sparse = 0);

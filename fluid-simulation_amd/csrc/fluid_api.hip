@@ -725,7 +725,7 @@ static int solve_mg(fluid_sim* s)
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
             launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
-                             s->part_pq, s->ps, it == 0, tol, n_rz, 1);
+                             s->part_pq, s->ps, it == 0, tol, n_rz, 1, sparse);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
             launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_err, s->ps, n_rz, sparse);
@@ -1341,8 +1341,8 @@ static int dist_solve_mg(fluid_sim* s)
     const double cells = (double)s->Rr.cells();
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
-    launch_sum2(s->st, s->part_bb, nxr, s->part_rz[0], nxr, s->gstage[1], s->gstage[1] + 1);
-    if ((rc = comm_allreduce(s, s->gstage[1], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+    // Two all-reduces per iteration: {|r|^2 of the previous body (|b|^2 before the first), r.z of this one} as one pair
+    // after the V-cycle, and s.q after the stencil.  gstage[cur] = that pair.
     long it = 0;
     // first batch = the previous solve's count (identical on every rank), then poll every 2 iterations
     long batch = s->mg_last_iters > 5 ? s->mg_last_iters : 8;
@@ -1351,20 +1351,18 @@ static int dist_solve_mg(fluid_sim* s)
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
             if ((rc = mg_vcycle(s, R, Z, s->mg_part))) return rc;
-            launch_sum2(s->st, s->mg_part, n_rz, s->mg_part, 0, s->grz + cur, nullptr);
-            if ((rc = comm_allreduce(s, s->grz + cur, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            launch_sum2(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->mg_part, n_rz, s->gstage[cur], s->gstage[cur] + 1);
+            if ((rc = comm_allreduce(s, s->gstage[cur], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-            launch_pcg_s<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], cf, s->gstage[prv], s->grz + cur, s->grz + prv, s->ps, it == 0, tol, 1);
+            launch_pcg_s<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], cf, s->gstage[cur], s->gstage[cur] + 1, s->gstage[prv] + 1, s->ps, it == 0, tol, 1);
             if ((rc = ring(Sx[cur]))) return rc;
             launch_pcg_q<T>(s->st, L, cnt, Sx[cur], Q, cf, s->part_pq, s->ps);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             launch_sum2(s->st, s->part_pq, nsq, s->part_pq, 0, s->gpq, nullptr);
             if ((rc = comm_allreduce(s, s->gpq, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            launch_pcg_xr_g<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->grz + cur, s->gpq, s->part_rr, s->part_err, s->ps);
+            launch_pcg_xr_g<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->gstage[cur] + 1, s->gpq, s->part_rr, s->part_err, s->ps);
             prof_end(s, FLUID_PROF_PCG_XR, tok);
-            launch_sum2(s->st, s->part_rr, nxr, s->part_rr, 0, s->gstage[cur], nullptr);
-            if ((rc = comm_allreduce(s, s->gstage[cur], 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
         }
         HIPCHK(hipGetLastError());
         // convergence of the last body of a batch is seen by the first S launch of the next batch (after one spare V-cycle)

@@ -313,6 +313,9 @@ __global__ __launch_bounds__(256) void k_mg_prolong_smooth(MLevel mf, const uint
 //         to HBM for the restriction kernel / the tail;
 //   up:   v0 = u + P e (tile + halo 2, the coarse correction staged in LDS first), two post-sweeps, z = result, plus
 //         the block's partial of f.z (level 0: the r.z of PCG).
+// (Skipping tiles without an unknown in mostly-air boxes was tried twice — a block-wide test of the count bytes, and
+// per-tile flags built once per step — and lost both times: in the splash 35-65 % of the tiles hold a droplet, and
+// the extra dependent load in front of every block cost more than the empty tiles saved.)
 // Index arithmetic is per-tile with compile-time region sizes (no 64-bit div/mod: the thread-per-cell kernels spent
 // a third of their VALU time there); neighbour sums keep the order of d_smooth / d_resid.
 template <int RY, int RZ>
@@ -367,11 +370,11 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
 #pragma unroll
     for (int x = 0; x < AX; ++x) {
         const int i = i0 - H + x;
-        const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
-        const int c = cnt[q];
-        fa[x] = f[q];
+        const int c = cnt[qa + (size_t)((long)clampi(i, m.dx - 1) * sx)];
         ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
+#pragma unroll
+    for (int x = 0; x < AX; ++x) fa[x] = f[qa + (size_t)((long)clampi(i0 - H + x, m.dx - 1) * sx)];
     const int yb = col / BZ, zb = col - yb * BZ;
     const bool actB = col < BY * BZ;
     const size_t qb = m.at(0, clampi(j0 - H + 1 + yb, m.dy - 1), clampi(k0 - H + 1 + zb, m.dz - 1));
@@ -484,6 +487,17 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     const T off = cf.off;
     const long sx = m.sx;
     // ---- every global load of the block ----
+    const int ya = col / AZ, za = col - ya * AZ;
+    const bool actA = col < AY * AZ;
+    const bool okA = actA && (unsigned)(j0 - 2 + ya) < (unsigned)m.dy && (unsigned)(k0 - 2 + za) < (unsigned)m.dz;
+    const size_t qa = m.at(0, clampi(j0 - 2 + ya, m.dy - 1), clampi(k0 - 2 + za, m.dz - 1));
+    int ca[AX];
+#pragma unroll
+    for (int x = 0; x < AX; ++x) {
+        const int i = i0 - 2 + x;
+        const int c = cnt[qa + (size_t)((long)clampi(i, m.dx - 1) * sx)];
+        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
+    }
     T ee[NE];
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
@@ -495,20 +509,9 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
         const T v = ec[mc.at(min(max(I, -1), mc.dx), min(max(J, -1), mc.dy), min(max(K, -1), mc.dz))];
         ee[it] = ok ? v : (T)0;
     }
-    const int ya = col / AZ, za = col - ya * AZ;
-    const bool actA = col < AY * AZ;
-    const bool okA = actA && (unsigned)(j0 - 2 + ya) < (unsigned)m.dy && (unsigned)(k0 - 2 + za) < (unsigned)m.dz;
-    const size_t qa = m.at(0, clampi(j0 - 2 + ya, m.dy - 1), clampi(k0 - 2 + za, m.dz - 1));
-    int ca[AX];
     T ua[AX];
 #pragma unroll
-    for (int x = 0; x < AX; ++x) {
-        const int i = i0 - 2 + x;
-        const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
-        const int c = cnt[q];
-        ua[x] = u[q];
-        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
-    }
+    for (int x = 0; x < AX; ++x) ua[x] = u[qa + (size_t)((long)clampi(i0 - 2 + x, m.dx - 1) * sx)];
     const int yb = col / BZ, zb = col - yb * BZ;
     const bool actB = col < BY * BZ;
     const size_t qb = m.at(0, clampi(j0 - 1 + yb, m.dy - 1), clampi(k0 - 1 + zb, m.dz - 1));

@@ -27,7 +27,24 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
         const bool dead = p.pid[i] == PID_DEAD;  // migrated to a neighbour rank: last bucket, dropped after the sort
         if (dead) { k = (int)ncell + 1; in = false; }
         key[i] = k;
-        slot[i] = atomicAdd(&cell_count[k], 1);
+        // Particles are still in last step's cell order, so neighbouring lanes mostly share a key: one returning
+        // atomic per RUN of equal keys in the wave (its leader adds the run length, the others take base + offset)
+        // instead of one per particle.  Any slot order inside a cell will do: k_bin_rank re-ranks a cell by id.
+        {
+            const int lane = threadIdx.x & 63;
+            const int kp = __shfl_up(k, 1, 64);
+            const bool head = lane == 0 || kp != k;
+            const unsigned long long hm = __ballot(head);  // lanes past n are not here: their bits are 0
+            const unsigned long long below = hm & ((2ull << lane) - 1ull);          // heads at or below me
+            const int start = 63 - __clzll((long long)below);
+            const unsigned long long above = (lane == 63) ? 0ull : (hm >> (lane + 1)) << (lane + 1);
+            const unsigned long long act = __ballot(true);
+            const int stop = above ? __ffsll((long long)above) - 1 : 64 - __clzll((long long)act) + 0;  // first head after me, or one past the last active lane
+            int base = 0;
+            if (head) base = atomicAdd(&cell_count[k], stop - start);
+            base = __shfl(base, start, 64);
+            slot[i] = base + (lane - start);
+        }
         if (in) {
             mn[0] = bx < mn[0] ? bx : mn[0]; mx[0] = bx > mx[0] ? bx : mx[0];
             mn[1] = by < mn[1] ? by : mn[1]; mx[1] = by > mx[1] ? by : mx[1];
@@ -158,13 +175,18 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
 // evaluating spline at (pos - cell)) replace 81 evaluations; the product keeps the reference's association
 // (sx*sy)*sz.
 //
-// Work decomposition: one block = 2 x 2 cell columns (x,y) x 64 cells in z; wave = one column,
+// Work decomposition: one block = P2G_T x P2G_T cell columns (x,y) x 64 cells in z; wave = one column,
 // lane = z.  The particles of a grid row (fixed x,y; z-1..z+64) are CONTIGUOUS in the sorted
-// arrays, so the block stages each of the 4 x 4 neighbouring rows into LDS with coalesced loads
+// arrays, so the block stages each of the (T+2) x (T+2) neighbouring rows into LDS with coalesced loads
 // (weights + velocities) and every lane then walks its own 3-cell window inside LDS.  (A lane-per-cell
 // loop straight from global memory makes each wave load touch ~32 cache lines and thrashes the 32 KB L1:
 // 7.4 ms at 256^3.)  Rows are visited in ascending (x,y) and particles in ascending sorted order: the sum
 // order per cell is fixed.
+// A row is staged by every tile whose window holds it: (T+2)^2 / T^2 times — 4x for T = 2 (2.2 GB of L2/HBM reads
+// per launch at 256^3).  T = 4 would read 2.25x but measured 1.8x SLOWER (1.29 ms against 0.67 ms): 16 waves per
+// block wait at the chunk barriers while at most 9 of them consume the staged row.
+constexpr int P2G_T = 2;
+constexpr int P2G_THREADS = P2G_T * P2G_T * 64;
 constexpr int P2G_CH = 320;  // particles staged per chunk: 12 arrays x 8 B x 320 = 30 KB of LDS
 // LDS slot of staged particle k: lane z reads particle a_z + t with a_z growing by ~8 (particles per cell) from
 // lane to lane; splitting by k mod 8 keeps neighbouring lanes on neighbouring slots.
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __
     }
 }
 
-__global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
+__global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
                                              const int* __restrict__ cell_start, const uint8_t* __restrict__ flags,
                                              float* __restrict__ container, double* __restrict__ u, double* __restrict__ v,
                                              double* __restrict__ w, double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
@@ -196,11 +218,11 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
     __shared__ double sv[3][P2G_LDS];   // vx, vy, vz
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int N = g.N;
-    const int ntz = (box.nz() + 63) / 64, nty = (box.ny() + 1) / 2;
+    const int ntz = (box.nz() + 63) / 64, nty = (box.ny() + P2G_T - 1) / P2G_T;
     const int tile = blockIdx.x;
     const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
-    const int tx0 = box.x0 + tx * 2, ty0 = box.y0 + ty * 2, tz0 = box.z0 + tz * 64;
-    const int ix = tx0 + (wv >> 1), iy = ty0 + (wv & 1), iz = tz0 + lane;
+    const int tx0 = box.x0 + tx * P2G_T, ty0 = box.y0 + ty * P2G_T, tz0 = box.z0 + tz * 64;
+    const int ix = tx0 + wv / P2G_T, iy = ty0 + wv % P2G_T, iz = tz0 + lane;
     const bool valid = ix <= box.x1 && iy <= box.y1 && iz <= box.z1;
     const size_t c = valid ? g.idx(ix, iy, iz) : 0;
     const bool live = valid && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
@@ -208,9 +230,9 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
     const int wz0 = iz > 0 ? iz - 1 : 0, wz1 = iz < N - 1 ? iz + 1 : N - 1;
     float wf = 0.0f;
     double su = 0, sv_ = 0, sw_ = 0;
-    for (int rx = tx0 - 1; rx <= tx0 + 2; ++rx) {
+    for (int rx = tx0 - 1; rx <= tx0 + P2G_T; ++rx) {
         if (rx < 0 || rx >= N) continue;
-        for (int ry = ty0 - 1; ry <= ty0 + 2; ++ry) {
+        for (int ry = ty0 - 1; ry <= ty0 + P2G_T; ++ry) {
             if (ry < 0 || ry >= N) continue;
             const int jb = cell_start[g.idx(rx, ry, zlo)];
             const int je = cell_start[g.idx(rx, ry, zhi) + 1];
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(256) void k_p2g(Grid g, Box box, Particles p, const
             for (int cb = jb; cb < je; cb += P2G_CH) {
                 const int ce = cb + P2G_CH < je ? cb + P2G_CH : je;
                 __syncthreads();  // the previous chunk has been consumed
-                for (int j = cb + tid; j < ce; j += 256) {
+                for (int j = cb + tid; j < ce; j += P2G_THREADS) {
                     const int k = p2g_slot(j - cb);
 #pragma unroll
                     for (int q = 0; q < 9; ++q) sw[q][k] = pw[q * wstride + j];
@@ -521,8 +543,8 @@ void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                 float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
 {
-    const unsigned nt = (unsigned)(((box.nx() + 1) / 2) * ((box.ny() + 1) / 2) * ((box.nz() + 63) / 64));
-    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(256), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb);
+    const unsigned nt = (unsigned)(((box.nx() + P2G_T - 1) / P2G_T) * ((box.ny() + P2G_T - 1) / P2G_T) * ((box.nz() + 63) / 64));
+    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb);
 }
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss)
 {

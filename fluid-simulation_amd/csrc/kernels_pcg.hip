@@ -177,8 +177,10 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
                                                   const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
                                                   const double* __restrict__ part_rz_old, double* __restrict__ part_pq, int n_prev,
-                                                  PcgState* ps, int first, double tol, int n_rz, int zmode)
+                                                  PcgState* ps, int first, double tol, int n_rz, int zmode, int sparse)
 {
+    // sparse (mostly-air box): a tile's count bytes are loaded and tested first and a tile without an unknown is
+    // skipped (its s', q stay 0 / unread) — no prefetch of the next tile then; dense boxes keep the pipelined loads
     // zmode: `r` is already z = M^-1 r (multigrid preconditioner); otherwise z = invdiag r is formed here
     __shared__ T sT[TX * PY * PZ];
     __shared__ double red[16];
@@ -199,28 +201,32 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     uint8_t fc[TX + 2], fy = 0, fz = 0;
     T rv[TX + 2], sv[TX + 2], ry = 0, sy = 0, rz = 0, sz = 0;
     long c0 = 0;
-    auto issue = [&](int tl) {
+    auto issue = [&](int tl, bool counts, bool values) {
         const int tz = tl % ntz, ty = (tl / ntz) % nty, tx = tl / (ntz * nty);
         const int i0 = 1 + tx * TX, j0 = 1 + ty * TY, k0 = LBOX_K0 + tz * TZ;
         c0 = ((long)(i0 - 1) * L.Ly + (j0 + ly)) * L.Lz + k0 + kz;
 #pragma unroll
         for (int m = 0; m < TX + 2; ++m) {
-            fc[m] = cnt[c0 + m * sx];
-            rv[m] = FUSED ? r[c0 + m * sx] : (T)0;
-            sv[m] = (FUSED && first) ? (T)0 : s_in[c0 + m * sx];
+            if (counts) fc[m] = cnt[c0 + m * sx];
+            if (values) {
+                rv[m] = FUSED ? r[c0 + m * sx] : (T)0;
+                sv[m] = (FUSED && first) ? (T)0 : s_in[c0 + m * sx];
+            }
         }
         {   // y halo: one cell per thread
             const int pl = tid >> 6, side = (tid >> 5) & 1;
             const long cy = ((long)(i0 + pl) * L.Ly + (side ? j0 + TY : j0 - 1)) * L.Lz + k0 + kz;
-            fy = cnt[cy]; ry = FUSED ? r[cy] : (T)0; sy = (FUSED && first) ? (T)0 : s_in[cy];
+            if (counts) fy = cnt[cy];
+            if (values) { ry = FUSED ? r[cy] : (T)0; sy = (FUSED && first) ? (T)0 : s_in[cy]; }
         }
         if (tid < 64) {  // z halo: 64 cells
             const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
             const long cz = ((long)(i0 + lx) * L.Ly + (j0 + l2)) * L.Lz + (side ? k0 + TZ : k0 - 1);
-            fz = cnt[cz]; rz = FUSED ? r[cz] : (T)0; sz = (FUSED && first) ? (T)0 : s_in[cz];
+            if (counts) fz = cnt[cz];
+            if (values) { rz = FUSED ? r[cz] : (T)0; sz = (FUSED && first) ? (T)0 : s_in[cz]; }
         }
     };
-    if (tile < ntiles) issue(tile);
+    if (!sparse && tile < ntiles) issue(tile, true, true);
 
     // ---- scalars ------------------------------------------------------------------------------
     T beta = 0;
@@ -232,6 +238,17 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
 
     double acc = 0;
     while (tile < ntiles) {
+        if (sparse) {
+            issue(tile, true, false);
+            int any = 0;
+#pragma unroll
+            for (int m = 1; m <= TX; ++m) any |= fc[m];
+            if (!__syncthreads_or(any)) {  // (also the barrier that frees the LDS tile of the previous round)
+                tile += gridDim.x;
+                continue;
+            }
+            issue(tile, false, true);
+        }
         // ---- combine -> LDS ---------------------------------------------------------------------
         T val[TX + 2];
 #pragma unroll
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
         }
         const int next = tile + gridDim.x;
         __syncthreads();  // LDS free for the next tile
-        if (next < ntiles) issue(next);  // next tile's loads fly while this tile finishes
+        if (!sparse && next < ntiles) issue(next, true, true);  // next tile's loads fly while this tile finishes
 #pragma unroll
         for (int lx = 0; lx < TX; ++lx) {
             const long c = cc + (lx + 1) * sx;
@@ -445,11 +462,11 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol, int n_rz, int zmode, int n_prev)
+                   double tol, int n_rz, int zmode, int sparse)
 {
-    const int nx = n_prev > 0 ? n_prev : pcg_xr_blocks(L);  // partials behind part_rr: the XR launch's, unless the caller says otherwise
+    const int nx = pcg_xr_blocks(L);
     hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
-                       part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode);
+                       part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode, sparse);
 }
 // multi-GPU pieces: n_* = 1 means "already all-reduced scalar"
 template <typename T>
@@ -463,7 +480,7 @@ template <typename T>
 void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps)
 {
     hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, (const T*)nullptr, s, (T*)nullptr, q, cf,
-                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0, 0, 0);
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0, 0, 0, 0);
 }
 template <typename T>
 void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
