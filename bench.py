@@ -168,18 +168,23 @@ def main():
     srt = sim.profile_read(fs.PROF.SORT)
     mgs = sim.profile_read(fs.PROF.MG_SMOOTH0) if transport is None else {"sampled": 0, "launches": 0}
     roof = None
-    # dominant solver kernel of the timed region: with the multigrid preconditioner the level-0 smoother
-    # (3 launches per V-cycle) outweighs the CG's own SQ kernel (1 per iteration)
-    if mgs["sampled"] and 3 * mgs["launches"] * (mgs["total_ms"] / mgs["sampled"]) > sq["launches"] * (sq["total_ms"] / max(sq["sampled"], 1)):
+    # dominant solver kernel of the timed region: with the multigrid preconditioner the level-0 up leg of the V-cycle
+    # (prolongation + both post-sweeps + r.z partials, one launch per PCG iteration) outweighs the CG's own SQ kernel
+    if mgs["sampled"] and mgs["launches"] * (mgs["total_ms"] / mgs["sampled"]) > sq["launches"] * (sq["total_ms"] / max(sq["sampled"], 1)):
         avg_ms = mgs["total_ms"] / mgs["sampled"]
         cells = mgs["cells"] / mgs["sampled"]
-        algo = cells * (3 * T + 1)   # read u, f, count byte; write u'
+        bpc = 3 * T + 2              # read u, f, count byte, 1/8 coarse value; write z
+        algo = cells * bpc
         ach = algo / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_mg_smooth<double> level 0 (damped-Jacobi sweep of the V-cycle preconditioner)",
+        kname = "k_mg_up<double, 8, 8, 16>"
+        roof = {"bound": "hbm", "kernel": kname + " at level 0 (V-cycle up leg: prolongation + two damped-Jacobi sweeps + r.z partials)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_mg_smooth<double> level 0", n, ppc), "traffic_source": "profiles/r01/pmc_traffic.json (kernels_final)",
-                "algorithmic_bytes_per_launch": algo, "bytes_per_cell": 3 * T + 1, "cells_per_launch": cells,
-                "avg_launch_us": avg_ms * 1e3, "launches": 3 * mgs["launches"], "sampled": mgs["sampled"]}
+                "traffic": pmc_traffic(kname + " (largest level)", n, ppc), "traffic_source": "profiles/r01/pmc_traffic.json (kernels_final)",
+                "algorithmic_bytes_per_launch": algo, "bytes_per_cell": bpc, "cells_per_launch": cells,
+                "avg_launch_us": avg_ms * 1e3, "launches": mgs["launches"], "sampled": mgs["sampled"],
+                "note": "the level-0 working set of this scene (~0.7 M cells, 18 MB) lives in L2/Infinity Cache and the kernel is "
+                        "VALU/LDS-bound, so the HBM fraction is low by construction; the dense 256^3 stencil sweep (stencil_microbench) "
+                        "is the bandwidth-bound kernel of this path"}
     elif sq["sampled"]:
         avg_ms = sq["total_ms"] / sq["sampled"]
         cells = sq["cells"] / sq["sampled"]
@@ -210,7 +215,7 @@ def main():
         "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),
                        "cg_iters_total": sum(s["cg_iters"] for s in stats), "relres_last": stats[-1]["relres"],
                        "box_last": [stats[-1]["box_lo"], stats[-1]["box_hi"]]},
-        "kernel_ms": {"mg_smooth0_avg": per(mgs) if mgs.get("sampled") else None, "pcg_sq_avg": per(sq), "pcg_xr_avg": per(xr), "solve_avg": per(solve), "p2g_avg": per(p2g),
+        "kernel_ms": {"mg_up0_avg": per(mgs) if mgs.get("sampled") else None, "pcg_sq_avg": per(sq), "pcg_xr_avg": per(xr), "solve_avg": per(solve), "p2g_avg": per(p2g),
                       "g2p_avg": per(g2p), "sort_avg": per(srt)},
     }
 

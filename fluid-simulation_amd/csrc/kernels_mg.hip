@@ -370,11 +370,11 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
 #pragma unroll
     for (int x = 0; x < AX; ++x) {
         const int i = i0 - H + x;
-        const int c = cnt[qa + (size_t)((long)clampi(i, m.dx - 1) * sx)];
+        const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
+        const int c = cnt[q];
+        fa[x] = f[q];  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
         ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
-#pragma unroll
-    for (int x = 0; x < AX; ++x) fa[x] = f[qa + (size_t)((long)clampi(i0 - H + x, m.dx - 1) * sx)];
     const int yb = col / BZ, zb = col - yb * BZ;
     const bool actB = col < BY * BZ;
     const size_t qb = m.at(0, clampi(j0 - H + 1 + yb, m.dy - 1), clampi(k0 - H + 1 + zb, m.dz - 1));
@@ -487,17 +487,6 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     const T off = cf.off;
     const long sx = m.sx;
     // ---- every global load of the block ----
-    const int ya = col / AZ, za = col - ya * AZ;
-    const bool actA = col < AY * AZ;
-    const bool okA = actA && (unsigned)(j0 - 2 + ya) < (unsigned)m.dy && (unsigned)(k0 - 2 + za) < (unsigned)m.dz;
-    const size_t qa = m.at(0, clampi(j0 - 2 + ya, m.dy - 1), clampi(k0 - 2 + za, m.dz - 1));
-    int ca[AX];
-#pragma unroll
-    for (int x = 0; x < AX; ++x) {
-        const int i = i0 - 2 + x;
-        const int c = cnt[qa + (size_t)((long)clampi(i, m.dx - 1) * sx)];
-        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
-    }
     T ee[NE];
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
@@ -509,9 +498,20 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
         const T v = ec[mc.at(min(max(I, -1), mc.dx), min(max(J, -1), mc.dy), min(max(K, -1), mc.dz))];
         ee[it] = ok ? v : (T)0;
     }
+    const int ya = col / AZ, za = col - ya * AZ;
+    const bool actA = col < AY * AZ;
+    const bool okA = actA && (unsigned)(j0 - 2 + ya) < (unsigned)m.dy && (unsigned)(k0 - 2 + za) < (unsigned)m.dz;
+    const size_t qa = m.at(0, clampi(j0 - 2 + ya, m.dy - 1), clampi(k0 - 2 + za, m.dz - 1));
+    int ca[AX];
     T ua[AX];
 #pragma unroll
-    for (int x = 0; x < AX; ++x) ua[x] = u[qa + (size_t)((long)clampi(i0 - 2 + x, m.dx - 1) * sx)];
+    for (int x = 0; x < AX; ++x) {
+        const int i = i0 - 2 + x;
+        const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
+        const int c = cnt[q];
+        ua[x] = u[q];
+        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
+    }
     const int yb = col / BZ, zb = col - yb * BZ;
     const bool actB = col < BY * BZ;
     const size_t qb = m.at(0, clampi(j0 - 1 + yb, m.dy - 1), clampi(k0 - 1 + zb, m.dz - 1));

@@ -4,8 +4,8 @@
 usage: tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv>
 Prints a JSON object {kernel: {fetch_bytes, write_bytes, bytes_per_launch, launches}}.
 Counters are in KB; FETCH_SIZE is doubled (gfx950 correction, see profiles/r01/pmc_traffic.json
-"method").  Level-0 multigrid kernels are told from the coarser levels by their grid size (the
-largest grid a kernel name is launched with).
+"method").  Multigrid kernels run on several levels under one name: only the launches with the largest
+grid are kept ("(largest level)": level 0 for k_mg_up / k_mg_down<..., false>, level 1 for k_mg_down<..., true>).
 """
 import csv, json, sys, collections
 
@@ -18,7 +18,7 @@ def load(path, counter):
     return rows
 
 def short(name):
-    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("fl::", "")
     return name.split("(")[0]
 
 def fold(rows, scale):
@@ -28,7 +28,7 @@ def fold(rows, scale):
         top = max(g for g, _ in v)
         if "k_mg_" in s and "tail" not in s:
             v = [x for x in v if x[0] == top]
-            s += " level 0"
+            s += " (largest level)"
         out[s] = (scale * 1024.0 * sum(c for _, c in v) / len(v), len(v))
     return out
 
