@@ -157,6 +157,14 @@ __device__ __forceinline__ double block_sum_array(const double* __restrict__ a, 
     return sm[NW];
 }
 
+// Blocks are dealt round-robin over the 8 XCDs; give each XCD (b % 8) a contiguous range of
+// virtual block ids so that neighbouring tiles share one L2 (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 // Sum three partial arrays in one pass; results broadcast to all threads.  sm: 12 doubles.
 __device__ __forceinline__ void block_sum3(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
                                            const double* __restrict__ c, int nc, double* sm, double& ra, double& rb, double& rc)

@@ -342,7 +342,7 @@ __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi)
 template <typename T, int TX, int TY, int TZ, bool RESTRICT>
 __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u,
                                                  T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
-                                                 MgCoef<T> cf, const PcgState* ps)
+                                                 MgCoef<T> cf, const PcgState* ps, int gx, int gy)
 {
     constexpr int H = RESTRICT ? 3 : 2;
     constexpr int AX = TX + 2 * H, AY = TY + 2 * H, AZ = TZ + 2 * H;  // u1 and the count bytes
@@ -357,7 +357,10 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     __shared__ T sd[8], si[8];
     if (ps && ps->done) return;
     const int col = threadIdx.x;
-    const int i0 = blockIdx.z * TX, j0 = blockIdx.y * TY, k0 = blockIdx.x * TZ;
+    // 1-D launch: virtual tile ids are dealt so that each XCD (own L2) gets a contiguous run of tiles, z fastest
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
+    const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
     const T w1 = (T)MG_W1, w2 = (T)MG_W2, off = cf.off;
     const long sx = m.sx;
     // ---- every global load of the block ----
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
 template <typename T, int TX, int TY, int TZ>
 __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u,
                                                T* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
-                                               double* __restrict__ part_dot, const PcgState* ps)
+                                               double* __restrict__ part_dot, const PcgState* ps, int gx, int gy)
 {
     constexpr int AX = TX + 4, AY = TY + 4, AZ = TZ + 4;              // v0 = u + P e and the count bytes
     constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2;              // v1
@@ -482,7 +485,9 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     __shared__ double red[4];
     if (ps && ps->done) return;
     const int col = threadIdx.x;
-    const int i0 = blockIdx.z * TX, j0 = blockIdx.y * TY, k0 = blockIdx.x * TZ;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);  // see k_mg_down
+    const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
+    const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
     const int I0 = i0 / 2 - 2, J0 = j0 / 2 - 2, K0 = k0 / 2 - 2;
     const T off = cf.off;
     const long sx = m.sx;
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     }
     if (part_dot) {
         acc = block_sum<double, 4>(acc, red);
-        if (threadIdx.x == 0) part_dot[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = acc;
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = acc;
     }
 }
 
@@ -942,20 +947,24 @@ template <typename T>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
                     const PcgState* ps)
 {
-    if (fc)
-        hipLaunchKernelGGL((k_mg_down<T, MG_RX, MG_RY, MG_RZ, true>), mg_tiles(m, MG_RX, MG_RY, MG_RZ), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc,
-                           cf, ps);
-    else
-        hipLaunchKernelGGL((k_mg_down<T, MG_TX, MG_TY, MG_TZ, false>), mg_tiles(m, MG_TX, MG_TY, MG_TZ), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c,
-                           fc, cf, ps);
+    if (fc) {
+        const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
+        hipLaunchKernelGGL((k_mg_down<T, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf, ps,
+                           (int)g.x, (int)g.y);
+    } else {
+        const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
+        hipLaunchKernelGGL((k_mg_down<T, MG_TX, MG_TY, MG_TZ, false>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf, ps,
+                           (int)g.x, (int)g.y);
+    }
 }
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
 template <typename T>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* out, MLevel mc, const T* ec, MgCoef<T> cf,
                   double* part_dot, const PcgState* ps)
 {
-    hipLaunchKernelGGL((k_mg_up<T, MG_TX, MG_TY, MG_TZ>), mg_tiles(m, MG_TX, MG_TY, MG_TZ), dim3(256), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot,
-                       ps);
+    const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
+    hipLaunchKernelGGL((k_mg_up<T, MG_TX, MG_TY, MG_TZ>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot, ps,
+                       (int)g.x, (int)g.y);
 }
 
 // LDS footprint of a tail that starts at lv[0] (compact arrays, ring of one cell below and two above — the 4x4x4

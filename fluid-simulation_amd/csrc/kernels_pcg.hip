@@ -38,14 +38,6 @@ __device__ __forceinline__ void load_coef(T* sdiag, T* sinv, const Coef<T>& cf)
     }
 }
 
-// Blocks are dealt round-robin over the 8 XCDs; give each XCD (b % 8) a contiguous range of
-// virtual block ids so that neighbouring tiles share one L2 (speed only, never correctness).
-__device__ __forceinline__ int xcd_remap(int b, int nb)
-{
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
 // ================================================================================================
 // Box-local PCG
 // ================================================================================================
