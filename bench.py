@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--ppc", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cg-tol", type=float, default=2.220446049250313e-16, help="PCG relative tolerance (reference: Eigen epsilon)")
+    ap.add_argument("--flip-blend", type=float, default=1.0, help="1 = the reference's pure FLIP; BASELINE config 1 names 0.95 (PIC/FLIP blend, build extension)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-micro", action="store_true", help="skip the dense stencil micro-benchmark")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="keep timing oracle steps until this much CPU time is spent")
@@ -94,7 +95,7 @@ def main():
     pos0 = fs.water_cube_drop(n, ppc, seed=a.seed)
     transport = None
     if world == 1 and not a.force_dist:
-        sim = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol)
+        sim = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
         sim.upload_particles(pos0)
     else:
         # ONE simulation decomposed into x slabs of equal particle count, one slab per GPU (strong scaling)
@@ -116,7 +117,7 @@ def main():
                 comm.close()
             comm = fd.TorchComm(mode="device", device=torch.device("cuda", local_rank))
             transport = f"torch.distributed nccl callbacks (native RCCL init failed on some rank: {err})"
-        sim = fd.DistFluidSim(n, bounds, comm, device=local_rank, cg_tol=a.cg_tol)
+        sim = fd.DistFluidSim(n, bounds, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
         sim.upload_global(pos0)
 
     def barrier():
@@ -208,7 +209,7 @@ def main():
         "metric": "simulated substeps/sec", "value": value, "unit": "substeps/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"water_cube_drop {n}^3 grid, {ppc} particles/cell, {len(pos0)} particles, pure FLIP",
+        "config": {"workload": f"water_cube_drop {n}^3 grid, {ppc} particles/cell, {len(pos0)} particles, " + ("pure FLIP" if a.flip_blend >= 1 else f"PIC/FLIP blend {a.flip_blend}"),
                    "grid": n, "ppc": ppc, "particles": int(len(pos0)), "cg_tol": a.cg_tol,
                    "parallelism": "single GPU" if transport is None else f"x-slab domain decomposition over {world} GPUs, transport {transport}"},
         "roofline": roof,
@@ -218,6 +219,23 @@ def main():
         "kernel_ms": {"mg_up0_avg": per(mgs) if mgs.get("sampled") else None, "pcg_sq_avg": per(sq), "pcg_xr_avg": per(xr), "solve_avg": per(solve), "p2g_avg": per(p2g),
                       "g2p_avg": per(g2p), "sort_avg": per(srt)},
     }
+
+    if not a.no_micro and world == 1 and n == 256 and ppc == 8 and a.flip_blend >= 1:
+        # BASELINE.json configs[1] taken literally (128^3, 8 particles/cell, FLIP blend 0.95), same metric, for reference
+        # beside the 256^3 line above (the metric names both sizes; `value` is the larger one)
+        sim1 = fs.FluidSim(n=128, device=local_rank, cg_tol=a.cg_tol, flip_blend=0.95)
+        sim1.upload_particles(fs.water_cube_drop(128, 8, seed=a.seed))
+        for _ in range(a.warmup):
+            sim1.step()
+        c0 = time.perf_counter()
+        it1 = 0
+        for _ in range(a.steps):
+            it1 += sim1.step()["cg_iters"]
+        c1 = time.perf_counter()
+        out["other_configs"] = {"128^3, 8 particles/cell, PIC/FLIP blend 0.95 (BASELINE configs[1])":
+                                {"value": a.steps / (c1 - c0), "unit": "substeps/s", "ms_per_step": (c1 - c0) / a.steps * 1e3,
+                                 "steps": a.steps, "cg_iters_total": it1}}
+        sim1.close()
 
     if not a.no_micro and world == 1:
         out["stencil_microbench"] = {"workload": f"dense {n}^3 all-fluid interior, q=A s", **stencil_microbench(fs, n, local_rank)}
@@ -230,6 +248,8 @@ def main():
         orc = oracle.Oracle(n=n, use_ref_solver=use_ref)
         if not use_ref:
             orc.set_cg_tol(a.cg_tol)
+        if a.flip_blend < 1:
+            orc.set_flip_blend(a.flip_blend)
         orc.set_particles(cpu_state[0], cpu_state[1])
         orc.dt = cpu_state[2]
         csteps, csec = 0, 0.0
@@ -244,7 +264,7 @@ def main():
                                "sample": f"{csteps} oracle step(s) of the same {n}^3 workload from the state at the start of the timed region "
                                          f"({csec:.1f} s); {solver}"}
         # full-size parity readout: GPU vs oracle after the same number of steps from the same state
-        sim2 = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol)
+        sim2 = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
         sim2.upload_particles(cpu_state[0], cpu_state[1])
         sim2.dt = cpu_state[2]
         for _ in range(csteps):

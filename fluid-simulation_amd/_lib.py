@@ -22,7 +22,8 @@ class Params(C.Structure):
     _fields_ = [("n", C.c_int32), ("device", C.c_int32), ("dx", C.c_double), ("rho", C.c_double),
                 ("gravity", C.c_double * 3), ("max_dt", C.c_double), ("outer_tol", C.c_double),
                 ("update_frac", C.c_double), ("cg_tol", C.c_double), ("cg_max_iters", C.c_int32),
-                ("max_outer_passes", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32)]
+                ("max_outer_passes", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32),
+                ("flip_blend", C.c_double)]
 
 
 class StepStats(C.Structure):

@@ -205,7 +205,8 @@ void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Par
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                 float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
-void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss);
+void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,
+                const double* pcy, const double* pcz, double blend, StepState* ss);
 void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss);
 void launch_pack_particles(hipStream_t st, long n, Particles p, double* pos_aos, double* vel_aos);
 void launch_classify_migrate(hipStream_t st, Grid g, long n, Particles p, int xs, int xe, int has_lo, int has_hi, double* send_lo,
@@ -227,7 +228,7 @@ void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const
 void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w,
                        double k, double g0, double g1, double g2);
 void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w,
-                       const double* ub, const double* vb, const double* wb, double* dcx, double* dcy, double* dcz);
+                       const double* ub, const double* vb, const double* wb, double* dcx, double* dcy, double* dcz, double* pcx, double* pcy, double* pcz);
 void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, const float* b2, double* part, StepState* ss);
 void launch_zero_step_state(hipStream_t st, StepState* ss, int N);
 struct ZeroList { float* f4[4]; double* f8[7]; };

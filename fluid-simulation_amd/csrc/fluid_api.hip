@@ -44,7 +44,8 @@ struct fluid_sim {
     double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
     int *indices = nullptr, *scan_sums = nullptr, *ipart = nullptr;
     // pcg
-    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr, *Zmg = nullptr;  // box-local layout (LBox)
+    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr, *Zmg = nullptr;
+    double *pcx = nullptr, *pcy = nullptr, *pcz = nullptr;  // getVelocity(c, vels) per cell: allocated on first use, PIC blend only  // box-local layout (LBox)
     uint8_t* cntL = nullptr;
     LBox L{};
     size_t lmax = 0;
@@ -216,6 +217,7 @@ int fluid_default_params(fluid_params_t* p)
     p->cg_max_iters = 0;
     p->max_outer_passes = 0;
     p->precision = FLUID_PRECISION_FP64;
+    p->flip_blend = 1.0;
     return FLUID_OK;
 }
 
@@ -228,7 +230,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
+                    s->pcx, s->pcy, s->pcz, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -245,6 +247,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     if (p->n < 8 || p->n > 1024) return fail(FLUID_ERR_ARG, "n must be in [8,1024]");
     if (!(p->dx > 0) || !(p->rho > 0) || !(p->max_dt > 0)) return fail(FLUID_ERR_ARG, "dx, rho, max_dt must be > 0");
     if (p->precision != FLUID_PRECISION_FP64 && p->precision != FLUID_PRECISION_FP32) return fail(FLUID_ERR_ARG, "bad precision");
+    if (!(p->flip_blend >= 0.0 && p->flip_blend <= 1.0)) return fail(FLUID_ERR_ARG, "flip_blend must be in [0,1] (1 = the reference's pure FLIP)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(FLUID_ERR_HIP, "no HIP device visible: libfluid_hip has no CPU path");
@@ -907,13 +910,27 @@ static int phase_pressure_pass(fluid_sim* s, double* error)
     return FLUID_OK;
 }
 
+// PIC blend (flip_blend < 1): three more cell fields, allocated when first needed
+static int pic_fields(fluid_sim* s)
+{
+    if (s->prm.flip_blend >= 1.0 || s->pcx) return FLUID_OK;
+    double** f[3] = {&s->pcx, &s->pcy, &s->pcz};
+    for (double** q : f) {
+        HIPCHK(hipMalloc((void**)q, s->ncell * sizeof(double)));
+        HIPCHK(hipMemsetAsync(*q, 0, s->ncell * sizeof(double), s->st));
+    }
+    return FLUID_OK;
+}
+
 static int phase_flip_advect(fluid_sim* s)
 {
     if (!s->have_p2g) return fail(FLUID_ERR_STATE, "flip_advect before p2g");
     HIPCHK(hipSetDevice(s->prm.device));
-    if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz);
+    int rcp = pic_fields(s);
+    if (rcp) return rcp;
+    if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    launch_g2p(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->ss);
+    launch_g2p(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
     prof_end(s, FLUID_PROF_G2P, tok);
     launch_advect(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->flags, s->prm.max_dt, s->prm.dx, s->ss);
     HIPCHK(hipGetLastError());
@@ -1486,13 +1503,14 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
         if (s->prm.max_outer_passes > 0 && s->stats.outer_passes >= s->prm.max_outer_passes) break;
     } while (error > s->prm.outer_tol);
     // ---- FLIP gather + advect (:1490) ---------------------------------------------------------------------
+    if ((rc = pic_fields(s))) return rc;
     if (!box_empty(s->Rb) && !box_empty(s->Rr))
-        launch_flip_delta(s->st, g, s->Rr, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz);
-    double* dcf[3] = {s->dcx, s->dcy, s->dcz};
-    for (int a = 0; a < 3; ++a)
+        launch_flip_delta(s->st, g, s->Rr, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
+    double* dcf[6] = {s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz};
+    for (int a = 0; a < (s->pcx ? 6 : 3); ++a)
         if ((rc = exchange_planes(s, dcf[a], 8))) return rc;
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->ss);
+    launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
     prof_end(s, FLUID_PROF_G2P, tok);
     HIPCHK(hipGetLastError());
     // non-negative doubles order like their bit patterns: MAX over int64

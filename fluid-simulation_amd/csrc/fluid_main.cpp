@@ -34,6 +34,7 @@ int main(int, char**)
     const int ppc = (int)env_long("FLUID_PPC", 10);          // 10 points per voxel, fluid.cc:1349
     const int steps = (int)env_long("FLUID_STEPS", 500);     // fluid.cc:1368
     const uint64_t seed = (uint64_t)env_long("FLUID_SEED", 0);  // mt19937(0), fluid.cc:1348
+    if (const char* b = getenv("FLUID_FLIP_BLEND")) prm.flip_blend = atof(b);  // default 1 = the reference's pure FLIP
     const char* outenv = getenv("FLUID_OUT");
     const std::string outdir = outenv ? outenv : "simulation";
 

@@ -278,7 +278,8 @@ void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, co
 __global__ __launch_bounds__(256) void k_flip_delta(Grid g, Box box, const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ w, const double* __restrict__ ub,
                                                     const double* __restrict__ vb, const double* __restrict__ wb,
-                                                    double* __restrict__ dcx, double* __restrict__ dcy, double* __restrict__ dcz)
+                                                    double* __restrict__ dcx, double* __restrict__ dcy, double* __restrict__ dcz,
+                                                    double* __restrict__ pcx, double* __restrict__ pcy, double* __restrict__ pcz)
 {
     CellIt it = box_cell(g, box);
     if (!it.ok) return;
@@ -292,13 +293,18 @@ __global__ __launch_bounds__(256) void k_flip_delta(Grid g, Box box, const doubl
     dcx[c] = cu - pu;
     dcy[c] = cv - pv;
     dcz[c] = cw - pw;
+    if (pcx) {  // PIC blend only: getVelocity(c, vels) itself (clampedCatmullRom, fluid.cc:163)
+        pcx[c] = cu;
+        pcy[c] = cv;
+        pcz[c] = cw;
+    }
 }
 
 void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w, const double* ub,
-                       const double* vb, const double* wb, double* dcx, double* dcy, double* dcz)
+                       const double* vb, const double* wb, double* dcx, double* dcy, double* dcz, double* pcx, double* pcy, double* pcz)
 {
     hipLaunchKernelGGL(k_flip_delta, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, u, v, w, ub, vb, wb, dcx, dcy,
-                       dcz);
+                       dcz, pcx, pcy, pcz);
 }
 
 // ---- error = |b-b2| / |b| --------------------------------------------------------------------

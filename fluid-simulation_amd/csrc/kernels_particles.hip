@@ -322,8 +322,11 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles 
 // ---- grid -> particle, FLIP -----------------------------------------------------------------
 // fluid.cc:978-991 + CatmullRomFLIP 210-263.  dc* holds getVelocity(new) - getVelocity(old)
 // per cell (k_flip_delta), i.e. the (velc - velp) term of :252.
+// blend < 1 (build extension): v' = blend (v + delta) + (1 - blend) v_pic with v_pic the same weighted gather of
+// getVelocity(c, vels) (pc*), i.e. the reference's unused clampedCatmullRom (fluid.cc:125-207) without its clamp.
 __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const double* __restrict__ dcx, const double* __restrict__ dcy,
-                                             const double* __restrict__ dcz, StepState* ss)
+                                             const double* __restrict__ dcz, const double* __restrict__ pcx, const double* __restrict__ pcy,
+                                             const double* __restrict__ pcz, double blend, StepState* ss)
 {
     __shared__ double sm[4];
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
             wy[d] = spline(cy - (double)(fcy - 1 + d));
             wz[d] = spline(cz - (double)(fcz - 1 + d));
         }
-        double weight = 0, d0 = 0, d1 = 0, d2 = 0;
+        double weight = 0, d0 = 0, d1 = 0, d2 = 0, q0 = 0, q1 = 0, q2 = 0;
 #pragma unroll
         for (int xi = 0; xi < 3; ++xi)
 #pragma unroll
@@ -359,6 +362,11 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
                         d0 += dcx[c] * cw;
                         d1 += dcy[c] * cw;
                         d2 += dcz[c] * cw;
+                        if (pcx) {  // block-uniform
+                            q0 += pcx[c] * cw;
+                            q1 += pcy[c] * cw;
+                            q2 += pcz[c] * cw;
+                        }
                     }
                 }
         double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
@@ -366,6 +374,11 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
             vx += d0 / weight;
             vy += d1 / weight;
             vz += d2 / weight;
+            if (pcx) {
+                vx = blend * vx + (1.0 - blend) * (q0 / weight);
+                vy = blend * vy + (1.0 - blend) * (q1 / weight);
+                vz = blend * vz + (1.0 - blend) * (q2 / weight);
+            }
             p.vx[i] = vx; p.vy[i] = vy; p.vz[i] = vz;
         }
         len = sqrt(vx * vx + vy * vy + vz * vz);  // Vec3::length, math/Vec3.h:224-230
@@ -546,9 +559,10 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, 
     const unsigned nt = (unsigned)(((box.nx() + P2G_T - 1) / P2G_T) * ((box.ny() + P2G_T - 1) / P2G_T) * ((box.nz() + 63) / 64));
     hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb);
 }
-void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, StepState* ss)
+void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,
+                const double* pcy, const double* pcz, double blend, StepState* ss)
 {
-    if (n > 0) hipLaunchKernelGGL(k_g2p, dim3(nblk(n)), dim3(256), 0, st, g, n, p, dcx, dcy, dcz, ss);
+    if (n > 0) hipLaunchKernelGGL(k_g2p, dim3(nblk(n)), dim3(256), 0, st, g, n, p, dcx, dcy, dcz, pcx, pcy, pcz, blend, ss);
 }
 void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss)
 {

@@ -74,6 +74,9 @@ typedef struct fluid_params {
     int32_t max_outer_passes; /* 0 = unlimited (reference)                                       */
     int32_t precision;        /* FLUID_PRECISION_*                                               */
     int32_t reserved;         /* preconditioner: 0 = multigrid V-cycle (fp64, one GPU), 1 = Jacobi           */
+    double flip_blend;        /* 1 = pure FLIP (the reference, fluid.cc:981); b < 1 blends in the PIC gather of
+                                 the reference's unused clampedCatmullRom (fluid.cc:125-207):
+                                 v' = b (v + delta) + (1-b) v_pic.  Build extension.      */
 } fluid_params_t;
 
 typedef struct fluid_step_stats {

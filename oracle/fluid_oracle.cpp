@@ -57,6 +57,7 @@ struct Oracle {
     double dx, rho, g[3], max_dt, outer_tol, update_frac;
     double dt;              // fluid.cc:1367 — carried from step to step
     double cg_tol;          // Eigen default: NumTraits<double>::epsilon() (IterativeSolverBase.h:283)
+    double flip_blend = 1.0;  // 1 = pure FLIP (fluid.cc:981); < 1 blends in the PIC gather of the unused clampedCatmullRom (:125-207)
     int nthreads;           // 1 = serial (deterministic order, like a serial tbb::parallel_for)
     ref_solver_fn ref_solver;
 
@@ -488,7 +489,7 @@ void flip_advect(Oracle& o)
         support(o, cx, minx, maxx);
         support(o, cy, miny, maxy);
         support(o, cz, minz, maxz);
-        double weight = 0, delta[3] = {0, 0, 0};
+        double weight = 0, delta[3] = {0, 0, 0}, pic[3] = {0, 0, 0};
         for (int x = minx; x <= maxx; ++x)
             for (int y = miny; y <= maxy; ++y)
                 for (int z = minz; z <= maxz; ++z)
@@ -501,11 +502,18 @@ void flip_advect(Oracle& o)
                         delta[0] += (velc[0] - velp[0]) * cw;  // :252
                         delta[1] += (velc[1] - velp[1]) * cw;
                         delta[2] += (velc[2] - velp[2]) * cw;
+                        pic[0] += velc[0] * cw;  // clampedCatmullRom :172-174 (same cells, same weights; its clamp is commented out)
+                        pic[1] += velc[1] * cw;
+                        pic[2] += velc[2] * cw;
                     }
         if (weight != 0) {  // :258-262
             o.pvel[3 * i + 0] += delta[0] / weight;
             o.pvel[3 * i + 1] += delta[1] / weight;
             o.pvel[3 * i + 2] += delta[2] / weight;
+            if (o.flip_blend < 1.0) {  // build extension: v' = b (v + delta) + (1 - b) v_pic
+                for (int a = 0; a < 3; ++a)
+                    o.pvel[3 * i + a] = o.flip_blend * o.pvel[3 * i + a] + (1.0 - o.flip_blend) * (pic[a] / weight);
+            }
         }
         double len = sqrt(o.pvel[3 * i] * o.pvel[3 * i] + o.pvel[3 * i + 1] * o.pvel[3 * i + 1] + o.pvel[3 * i + 2] * o.pvel[3 * i + 2]);
         if (maxSpeed < len) maxSpeed = len;
@@ -591,6 +599,7 @@ void* oracle_create(int N, double dx, double rho, const double* g, double max_dt
 void oracle_destroy(void* h) { delete (Oracle*)h; }
 void oracle_set_ref_solver(void* h, void* fn) { ((Oracle*)h)->ref_solver = (ref_solver_fn)fn; }
 void oracle_set_cg_tol(void* h, double tol) { ((Oracle*)h)->cg_tol = tol; }
+void oracle_set_flip_blend(void* h, double b) { ((Oracle*)h)->flip_blend = b; }
 void oracle_set_dt(void* h, double dt) { ((Oracle*)h)->dt = dt; }
 double oracle_get_dt(void* h) { return ((Oracle*)h)->dt; }
 // Every cell outside [wlo,whi]^3 must stay solid: the reference indexes pressure(-1) for a

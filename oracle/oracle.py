@@ -32,6 +32,7 @@ _lib.oracle_create.argtypes = [C.c_int, C.c_double, C.c_double, _P, C.c_double, 
 _lib.oracle_destroy.argtypes = [_P]
 _lib.oracle_set_ref_solver.argtypes = [_P, _P]
 _lib.oracle_set_cg_tol.argtypes = [_P, C.c_double]
+_lib.oracle_set_flip_blend.argtypes = [_P, C.c_double]
 _lib.oracle_set_dt.argtypes = [_P, C.c_double]
 _lib.oracle_get_dt.restype = C.c_double
 _lib.oracle_get_dt.argtypes = [_P]
@@ -171,6 +172,10 @@ class Oracle:
 
     def set_cg_tol(self, tol):
         _lib.oracle_set_cg_tol(self._h, tol)
+
+    def set_flip_blend(self, b):
+        """1 = the reference's pure FLIP; < 1 = PIC/FLIP blend (build extension, BASELINE config 1)."""
+        _lib.oracle_set_flip_blend(self._h, float(b))
 
     def p2g(self): _lib.oracle_p2g(self._h)
     def flags_index(self): _lib.oracle_flags_index(self._h)

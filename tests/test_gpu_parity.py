@@ -168,6 +168,25 @@ def test_free_running(fs, oracle, n, ppc, steps):
     assert np.array_equal(sim.field(fs.FIELD.INDICES), orc.field(4))
 
 
+@pytest.mark.parametrize("blend", [0.95, 0.0])
+def test_pic_flip_blend(fs, oracle, blend):
+    """flip_blend < 1 (BASELINE config 1 asks for 0.95): the PIC term is the reference's unused clampedCatmullRom
+    gather (fluid.cc:125-207); GPU and oracle must agree like the pure-FLIP path, and the blend must change the result."""
+    n, ppc, steps = 24, 4, 8
+    sim, orc, pos = make_pair(fs, oracle, n, ppc, vel_scale=0.3, flip_blend=blend)
+    orc.set_flip_blend(blend)
+    ref, _, _ = make_pair(fs, oracle, n, ppc, vel_scale=0.3)   # pure FLIP
+    for i in range(steps):
+        sg = sim.step(); so = orc.step(); ref.step()
+        assert sg["num_active"] == so["num_active"] and sg["outer_passes"] == so["outer_passes"], (i, sg, so)
+        p, v = sim.download_particles(); po, vo = orc.particles()
+        assert rel_l2(p, po) < TOL_F and rel_l2(v, vo) < TOL_F, (i, rel_l2(p, po), rel_l2(v, vo))
+    pr, vr = ref.download_particles()
+    assert rel_l2(v, vr) > 1e-3   # the blend is not a no-op
+    with pytest.raises(fs.FluidError):
+        fs.FluidSim(n=16, flip_blend=1.5)
+
+
 def test_particles_roundtrip_order(fs):
     """download_particles returns the ORIGINAL order although the device sorts by cell."""
     n = 24
