@@ -37,6 +37,7 @@ int main(int, char**)
     if (const char* b = getenv("FLUID_FLIP_BLEND")) prm.flip_blend = atof(b);  // default 1 = the reference's pure FLIP
     const char* outenv = getenv("FLUID_OUT");
     const std::string outdir = outenv ? outenv : "simulation";
+    const bool raw_f32 = env_long("FLUID_RAW", 0) != 0;
 
     fluid_sim_t* sim = nullptr;
     if (fluid_create(&prm, &sim) != FLUID_OK) {
@@ -78,14 +79,27 @@ int main(int, char**)
                 std::cerr << "fluid_download_field: " << fluid_last_error() << std::endl;
                 return 1;
             }
-            const std::string fn = outdir + "/mygrids" + std::to_string(i) + ".f32";
-            FILE* f = fopen(fn.c_str(), "wb");
-            if (!f) { std::cerr << "cannot write " << fn << std::endl; return 1; }
-            int32_t n32 = prm.n;
-            fwrite(&n32, sizeof(n32), 1, f);
-            fwrite(out.data(), sizeof(float), ncell, f);
-            fclose(f);
+            // file2.write(grids2) of fluid.cc:1503-1504: simulation/mygrids<i>.vdb.  (The reference's grids2 vector is
+            // never cleared, so its file i also repeats the grids of steps 0..i-1; this driver writes step i only.)
+            const std::string fn = outdir + "/mygrids" + std::to_string(i) + ".vdb";
+            const float* gp[1] = {out.data()};
+            if (fluid_write_vdb(fn.c_str(), prm.n, 1, gp) != FLUID_OK) { std::cerr << "cannot write " << fn << std::endl; return 1; }
+            if (raw_f32) {  // FLUID_RAW=1: also the bare float32 dump (int32 n, then n^3 floats, z fastest)
+                const std::string fr = outdir + "/mygrids" + std::to_string(i) + ".f32";
+                FILE* f = fopen(fr.c_str(), "wb");
+                if (!f) { std::cerr << "cannot write " << fr << std::endl; return 1; }
+                int32_t n32 = prm.n;
+                fwrite(&n32, sizeof(n32), 1, f);
+                fwrite(out.data(), sizeof(float), ncell, f);
+                fclose(f);
+            }
         }
+    }
+    if (!outdir.empty() && steps > 0) {  // file.write(grids) of fluid.cc:1508 (there: every step's grid; here the last)
+        const float* gp[1] = {out.data()};
+        const size_t slash = outdir.find_last_of('/');   // beside the output directory: ./mygrids.vdb for the default "simulation"
+        const std::string fin = (slash == std::string::npos ? std::string() : outdir.substr(0, slash + 1)) + "mygrids.vdb";
+        if (fluid_write_vdb(fin.c_str(), prm.n, 1, gp) != FLUID_OK) { std::cerr << "cannot write " << fin << std::endl; return 1; }
     }
     fluid_destroy(sim);
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -1,0 +1,215 @@
+// .vdb writer for the step's output FloatGrid — host only, no GPU, no OpenVDB.
+//
+// Writes what `openvdb::io::File(name).write(grids)` of the reference's OpenVDB 4.0.2 writes for grids created as in
+// fluid.cc:1161-1164 (FloatGrid::create(0), linear transform of voxel size 1, fill([lo,hi]^3, 0, active) +
+// voxelizeActiveTiles, unnamed) — restated from the library's serialisation code, file format version 224:
+//   header            io/Archive.cc:939-971   magic (int64), file version 224, library 4.0, has-offsets flag, 36-char uuid
+//   file metadata     MetaMap.cc:117-136      (empty map: count 0)
+//   grid count        io/Archive.cc:1167-1173
+//   per grid          io/Archive.cc:1243-1328 descriptor (unique name, "Tree_float_5_4_3", instance parent; three stream
+//                                             offsets, io/GridDescriptor.cc:53-73), compression flags (:704-723), metadata
+//                                             with the file_* statistics (Grid.cc:446-457), transform (math/Transform.cc:
+//                                             178-186, math/Maps.h ScaleMap::write), topology, buffers
+//   tree              tree/Tree.h:1297-1301,1439-1443  buffer count 1, then the root
+//   RootNode          tree/RootNode.h:2257-2288,2407-2412  background, #tiles, #children, children by ascending origin
+//   InternalNode      tree/InternalNode.h:2175-2195,3032-3037  child mask, value mask, compressed tile values, children
+//   LeafNode          tree/LeafNode.h:1321-1324,1444-1453  value mask (topology); value mask again + compressed values
+//   node values       io/Compression.h:462-639  one metadata byte per node; with COMPRESS_ACTIVE_MASK and every inactive
+//                                              value equal to the background only the active values follow
+//   masks             util/NodeMasks.h:565-568  raw 64-bit words, bit n of word n>>6
+//   offsets           tree/LeafNode.h:1049-1055, tree/InternalNode.h:3098-3103  x-major, z fastest
+// Compression: COMPRESS_ACTIVE_MASK only (the library's default adds ZIP or Blosc; the flags are stored per grid and any
+// combination is valid for a reader).  The reference accumulates every earlier step's grid into each file
+// (`grids2.push_back`, fluid.cc:1451,1503) — n_grids > 1 reproduces that, names get the "\x1e<k>" suffixes of
+// io/Archive.cc:1196-1206.
+// Parity status: UNPINNED against the real library (no OpenVDB here to read the files back, no sample .vdb in the
+// reference tree); tests/test_vdb.py re-reads the files with an independent restatement of the READ side.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "fluid_hip.h"
+
+namespace {
+
+struct Out {
+    std::vector<char> b;
+    void raw(const void* p, size_t n) { const char* c = (const char*)p; b.insert(b.end(), c, c + n); }
+    template <typename T> void put(T v) { raw(&v, sizeof(T)); }
+    void str(const std::string& s) { put<uint32_t>((uint32_t)s.size()); raw(s.data(), s.size()); }   // util/Name.h:57-63
+    size_t pos() const { return b.size(); }
+    void patch64(size_t at, int64_t v) { memcpy(&b[at], &v, 8); }
+};
+
+inline int floor_to(int v, int m) { return v & ~(m - 1); }  // origin of the node of size m (power of two) that holds v
+
+constexpr int LEAF = 8, INT1 = 128, INT2 = 4096;             // Tree_float_5_4_3: 8^3 leaves, 16^3 of them, 32^3 of those
+constexpr uint32_t COMPRESS_ACTIVE_MASK = 0x2;               // io/Compression.h:80
+constexpr int8_t NO_MASK_OR_INACTIVE_VALS = 0;               // io/Compression.h:94
+
+struct Dense {
+    int n, lo, hi;
+    const float* v;
+    bool inside(int x, int y, int z) const { return x >= lo && x <= hi && y >= lo && y <= hi && z >= lo && z <= hi; }
+    float at(int x, int y, int z) const { return v[((size_t)(x - lo) * n + (y - lo)) * n + (z - lo)]; }
+    bool overlaps(int ox, int oy, int oz, int dim) const
+    {
+        return ox + dim - 1 >= lo && ox <= hi && oy + dim - 1 >= lo && oy <= hi && oz + dim - 1 >= lo && oz <= hi;
+    }
+};
+
+// value mask of the leaf at (ox,oy,oz): voxels inside the box are active (fill(..., active=true), fluid.cc:1163)
+void leaf_mask(const Dense& g, int ox, int oy, int oz, uint64_t m[8])
+{
+    for (int w = 0; w < 8; ++w) m[w] = 0;
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y)
+            for (int z = 0; z < 8; ++z)
+                if (g.inside(ox + x, oy + y, oz + z)) {
+                    const int n = (x << 6) + (y << 3) + z;
+                    m[n >> 6] |= 1ull << (n & 63);
+                }
+}
+
+// an internal node with no active tiles and background tile values: all-off value mask, metadata byte 0, no values
+void internal_values(Out& o, size_t mask_bytes)
+{
+    std::vector<char> zero(mask_bytes, 0);
+    o.raw(zero.data(), mask_bytes);          // mValueMask
+    o.put<int8_t>(NO_MASK_OR_INACTIVE_VALS);   // writeCompressedValues: every inactive value == background, 0 active values
+}
+
+void write_tree(Out& o, const Dense& g, bool buffers)
+{
+    // root children in ascending (x,y,z) origin order (std::map<Coord>, math/Coord.h:180-185)
+    for (int rx = floor_to(g.lo, INT2); rx <= g.hi; rx += INT2)
+        for (int ry = floor_to(g.lo, INT2); ry <= g.hi; ry += INT2)
+            for (int rz = floor_to(g.lo, INT2); rz <= g.hi; rz += INT2) {
+                if (!buffers) {
+                    const int32_t org[3] = {rx, ry, rz};
+                    o.raw(org, sizeof(org));
+                    std::vector<uint64_t> cm(32 * 32 * 32 / 64, 0);  // child mask of the 4096^3 node: 32^3 slots of 128^3
+                    for (int a = 0; a < 32; ++a)
+                        for (int b = 0; b < 32; ++b)
+                            for (int c = 0; c < 32; ++c)
+                                if (g.overlaps(rx + a * INT1, ry + b * INT1, rz + c * INT1, INT1)) {
+                                    const int n = (a << 10) + (b << 5) + c;
+                                    cm[n >> 6] |= 1ull << (n & 63);
+                                }
+                    o.raw(cm.data(), cm.size() * 8);
+                    internal_values(o, cm.size() * 8);
+                }
+                for (int a = 0; a < 32; ++a)
+                    for (int b = 0; b < 32; ++b)
+                        for (int c = 0; c < 32; ++c) {
+                            const int ix = rx + a * INT1, iy = ry + b * INT1, iz = rz + c * INT1;
+                            if (!g.overlaps(ix, iy, iz, INT1)) continue;
+                            if (!buffers) {
+                                uint64_t cm[64] = {};  // 16^3 slots of 8^3
+                                for (int p = 0; p < 16; ++p)
+                                    for (int q = 0; q < 16; ++q)
+                                        for (int r = 0; r < 16; ++r)
+                                            if (g.overlaps(ix + p * LEAF, iy + q * LEAF, iz + r * LEAF, LEAF)) {
+                                                const int n = (p << 8) + (q << 4) + r;
+                                                cm[n >> 6] |= 1ull << (n & 63);
+                                            }
+                                o.raw(cm, sizeof(cm));
+                                internal_values(o, sizeof(cm));
+                            }
+                            for (int p = 0; p < 16; ++p)
+                                for (int q = 0; q < 16; ++q)
+                                    for (int r = 0; r < 16; ++r) {
+                                        const int lx = ix + p * LEAF, ly = iy + q * LEAF, lz = iz + r * LEAF;
+                                        if (!g.overlaps(lx, ly, lz, LEAF)) continue;
+                                        uint64_t vm[8];
+                                        leaf_mask(g, lx, ly, lz, vm);
+                                        o.raw(vm, sizeof(vm));
+                                        if (!buffers) continue;
+                                        o.put<int8_t>(NO_MASK_OR_INACTIVE_VALS);  // inactive voxels hold the background
+                                        for (int x = 0; x < 8; ++x)
+                                            for (int y = 0; y < 8; ++y)
+                                                for (int z = 0; z < 8; ++z)
+                                                    if (g.inside(lx + x, ly + y, lz + z)) o.put<float>(g.at(lx + x, ly + y, lz + z));
+                                    }
+                        }
+            }
+}
+
+template <typename T> void meta(Out& o, const char* name, const char* type, const T* v, uint32_t bytes)
+{
+    o.str(name); o.str(type); o.put<uint32_t>(bytes); o.raw(v, bytes);   // MetaMap.cc:126-135, Metadata.h:189-218
+}
+
+}  // namespace
+
+extern "C" int fluid_write_vdb(const char* path, int32_t n, int32_t n_grids, const float* const* grids)
+{
+    if (!path || n < 1 || n > 4096 || n_grids < 1 || !grids) return FLUID_ERR_ARG;
+    for (int k = 0; k < n_grids; ++k)
+        if (!grids[k]) return FLUID_ERR_ARG;
+    Out o;
+    // ---- header (io/Archive.cc:939-971) ----
+    o.put<int64_t>(0x56444220);            // OPENVDB_MAGIC, version.h:83
+    o.put<uint32_t>(224);                  // OPENVDB_FILE_VERSION, version.h:96
+    o.put<uint32_t>(4); o.put<uint32_t>(0);  // library 4.0
+    o.put<char>(1);                        // seekable: grid offsets follow each descriptor (io::File)
+    {
+        std::mt19937 ran((unsigned)(std::random_device()() + (unsigned)std::time(nullptr)));
+        char u[37];
+        const uint32_t a = ran(), b = ran(), c = ran(), d = ran();
+        // random (version 4) uuid, textual form of boost::uuids::operator<<
+        snprintf(u, sizeof(u), "%08x-%04x-4%03x-%04x-%04x%08x", a, b >> 16, b & 0xfff, 0x8000 | (c >> 18), c & 0xffff, d);
+        o.raw(u, 36);
+    }
+    o.put<uint32_t>(0);                    // file-level metadata: empty map
+    o.put<int32_t>(n_grids);
+    const int lo = -(n / 2), hi = lo + n - 1;
+    for (int k = 0; k < n_grids; ++k) {
+        const Dense g{n, lo, hi, grids[k]};
+        // ---- descriptor (io/GridDescriptor.cc:53-73); unnamed grids become "\x1e<k>" (io/Archive.cc:1196-1206) ----
+        o.str(std::string("\x1e") + std::to_string(k));
+        o.str("Tree_float_5_4_3");
+        o.str("");                         // not an instance
+        const size_t off = o.pos();
+        o.put<int64_t>(0); o.put<int64_t>(0); o.put<int64_t>(0);
+        o.patch64(off, (int64_t)o.pos());  // grid position
+        o.put<uint32_t>(COMPRESS_ACTIVE_MASK);
+        // ---- grid metadata: the statistics Archive::writeGrid adds (std::map order = by name) ----
+        long leaves = 0;
+        for (int x = floor_to(lo, LEAF); x <= hi; x += LEAF) ++leaves;
+        leaves = leaves * leaves * leaves;
+        const int32_t bmin[3] = {lo, lo, lo}, bmax[3] = {hi, hi, hi};
+        const int64_t voxels = (int64_t)n * n * n, mem = leaves * (int64_t)(512 * 4 + 64 + 32);
+        const std::string comp = "active values";  // io/Compression.cc:49-58
+        o.put<uint32_t>(5);
+        meta(o, "file_bbox_max", "vec3i", bmax, 12);
+        meta(o, "file_bbox_min", "vec3i", bmin, 12);
+        meta(o, "file_compression", "string", comp.data(), (uint32_t)comp.size());
+        meta(o, "file_mem_bytes", "int64", &mem, 8);
+        meta(o, "file_voxel_count", "int64", &voxels, 8);
+        // ---- transform: UniformScaleMap(1.0) = scale, voxel size, 1/scale, 1/scale^2, 1/(2 scale) ----
+        o.str("UniformScaleMap");
+        const double one[3] = {1, 1, 1}, half[3] = {0.5, 0.5, 0.5};
+        o.raw(one, 24); o.raw(one, 24); o.raw(one, 24); o.raw(one, 24); o.raw(half, 24);
+        // ---- topology ----
+        o.put<int32_t>(1);                 // buffer count
+        o.put<float>(0.0f);                // background
+        o.put<uint32_t>(0);                // root tiles
+        uint32_t nroot = 0;
+        for (int x = floor_to(lo, INT2); x <= hi; x += INT2) ++nroot;
+        o.put<uint32_t>(nroot * nroot * nroot);
+        write_tree(o, g, false);
+        o.patch64(off + 8, (int64_t)o.pos());   // block position
+        write_tree(o, g, true);
+        o.patch64(off + 16, (int64_t)o.pos());  // end position
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return FLUID_ERR_ARG;
+    const size_t w = fwrite(o.b.data(), 1, o.b.size(), f);
+    const int rc = fclose(f);
+    return (w == o.b.size() && rc == 0) ? FLUID_OK : FLUID_ERR_ARG;
+}

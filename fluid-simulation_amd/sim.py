@@ -18,6 +18,18 @@ def grid_bounds(n):
     return lo, lo + n - 1
 
 
+def write_vdb(path, grids):
+    """Write dense float32 (n,n,n) arrays as the unnamed FloatGrids of fluid.cc:1161-1164,1503 (OpenVDB file format 224)."""
+    import ctypes as C
+    if isinstance(grids, np.ndarray) and grids.ndim == 3:
+        grids = [grids]
+    arrs = [np.ascontiguousarray(g, dtype=np.float32) for g in grids]
+    n = arrs[0].shape[0]
+    assert all(a.shape == (n, n, n) for a in arrs)
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    check(lib.fluid_write_vdb(str(path).encode(), n, len(arrs), ptrs))
+
+
 def water_cube_drop(n, ppc, seed=0):
     """Synthetic input of SURVEY.md 8(d) (generalises fluid.cc:1176,1349): (npart,3) float64 positions."""
     cnt = lib.fluid_scene_water_cube_drop(n, ppc, seed, None)

@@ -219,6 +219,12 @@ int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, u
 /* Equal-count split of the x planes for `size` ranks from a host particle set (host-only). */
 int fluid_partition_by_count(int32_t n, int64_t np, const double* pos, int32_t size, int32_t* bounds);
 
+/* ---- OpenVDB file output (replaces file2.write(grids2), fluid.cc:1503-1504,1508) ----------
+ * Writes n_grids dense float32 N^3 arrays (z fastest, cell (0,0,0) = index coordinate (lo,lo,lo), lo = -(N/2)) as
+ * unnamed FloatGrids (Tree_float_5_4_3, background 0, voxel size 1, every cell of [lo,hi]^3 active) in OpenVDB's
+ * file format 224 — the grids fluid.cc:1161-1164,1434-1451 builds.  Host only: no GPU, no OpenVDB library. */
+int fluid_write_vdb(const char* path, int32_t n, int32_t n_grids, const float* const* grids);
+
 #ifdef __cplusplus
 }
 #endif

@@ -383,7 +383,7 @@ def test_run_sh_fluid_driver(tmp_path):
     (fluid.cc:1383-1386,1456,1486,1491,1499-1502) and one density grid per step."""
     import os, subprocess
     from conftest import ROOT
-    env = dict(os.environ, FLUID_N="32", FLUID_PPC="4", FLUID_STEPS="3", FLUID_OUT=str(tmp_path / "simulation"))
+    env = dict(os.environ, FLUID_N="32", FLUID_PPC="4", FLUID_STEPS="3", FLUID_OUT=str(tmp_path / "simulation"), FLUID_RAW="1")
     r = subprocess.run([os.path.join(ROOT, "run.sh"), "fluid"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
@@ -399,6 +399,15 @@ def test_run_sh_fluid_driver(tmp_path):
         assert f.exists() and f.stat().st_size == 4 + 4 * 32 ** 3
     rho = np.fromfile(tmp_path / "simulation" / "mygrids2.f32", dtype=np.float32, offset=4).reshape(32, 32, 32)
     assert rho.max() > 0 and rho[0].max() == 0  # density inside, nothing in the solid shell
+    # the reference's file surface: simulation/mygrids<i>.vdb per step and mygrids.vdb at the end (fluid.cc:1503,1508)
+    import vdb_reader
+    for name in [f"simulation/mygrids{i}.vdb" for i in range(3)] + ["mygrids.vdb"]:
+        assert (tmp_path / name).exists(), name
+    info, grids = vdb_reader.read(tmp_path / "simulation" / "mygrids2.vdb")
+    assert len(grids) == 1 and grids[0].type == "Tree_float_5_4_3"
+    vals, act = grids[0].dense(-16, 15)
+    assert np.array_equal(vals, rho) and act.all()
+    assert np.array_equal(vdb_reader.read(tmp_path / "mygrids.vdb")[1][0].dense(-16, 15)[0], rho)
 
 
 def test_long_run_stays_convergent(fs):
