@@ -19,9 +19,11 @@
 namespace fl {
 
 // Damped-Jacobi weights of the two sweeps on each side of the coarse correction: (W1, W2) before, (W2, W1) after
-// (reversed, so M stays symmetric).  (2/3, 1.2) instead of (2/3, 2/3) takes ~15 % fewer PCG iterations in the
-// prototype; |(1 - W1 x)(1 - W2 x)| < 1 on the spectrum (0,2) of D^-1 A, so the smoother still converges.
-constexpr double MG_W1 = 2.0 / 3.0, MG_W2 = 1.2;
+// (reversed, so M stays symmetric).  The two sweeps apply the polynomial (1 - W1 x)(1 - W2 x) of x = D^-1 A to the
+// error; 1/W1, 1/W2 are the roots of the degree-2 Chebyshev polynomial of the interval [0.5, 2] (the upper three
+// quarters of the spectrum (0,2)): |p| <= 0.22 there, < 1 on all of (0,2).  25 PCG iterations per solve at 256^3
+// against 26 for (2/3, 1.2) and 30 for plain (2/3, 2/3).
+constexpr double MG_W1 = 0.5617, MG_W2 = 1.3895;
 
 // static indices only (a runtime index into a by-value kernel argument goes through scratch)
 template <typename T>
