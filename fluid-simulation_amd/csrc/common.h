@@ -269,24 +269,10 @@ void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, c
 // multigrid preconditioner (kernels_mg.hip)
 MLevel mg_level0(const LBox& L);
 MLevel mg_coarser(const MLevel& f);
-int mg_smooth_blocks(const MLevel& m);
 void launch_mg_type0(hipStream_t st, Grid g, LBox L, MLevel m, const uint8_t* flags, const uint8_t* cnt, uint8_t* typ);
 void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, uint8_t* tc, uint8_t* cnt_c);
 template <typename T>
-void launch_mg_smooth(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u_in, T* u_out, MgCoef<T> cf, int sweep,
-                      double* part_dot, const PcgState* ps);
-template <typename T>
-void launch_mg_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* r, MgCoef<T> cf, const PcgState* ps);
-template <typename T>
 void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const uint8_t* cnt_c, T* fc, const PcgState* ps);
-template <typename T>
-void launch_mg_prolong(hipStream_t st, MLevel mf, const uint8_t* cnt_f, T* u, MLevel mc, const T* ec, const PcgState* ps);
-template <typename T>
-void launch_mg_smooth0_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MgCoef<T> cf, const PcgState* ps);
-template <typename T>
-void launch_mg_prolong_smooth(hipStream_t st, MLevel mf, const uint8_t* cnt_f, const T* f, const T* u, T* u_out, MLevel mc, const T* ec,
-                              MgCoef<T> cf, const PcgState* ps);
-constexpr long MG_FUSE_CELLS = 400000;  // levels below this are launch-bound: use the fused kernels
 constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel can hold
 constexpr size_t MG_TAIL_LDS = 144 * 1024;  // dynamic LDS the tail kernel may use (160 KB per CU on gfx950): levels whose u, v, f + counts fit go into the tail
 size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem);

@@ -73,9 +73,6 @@ struct fluid_sim {
     int mg_nl = 0, mg_tail = 0;   // levels; first level handled by the single-block tail kernel
     long mg_last_iters = 0;       // iteration count of the previous multigrid solve (sizes the first unpolled batch)
     int mg_csweeps = 3;           // red-black sweeps (each direction) on the coarsest level (12 -> 2 changes the PCG count by 1 in 520)
-    long mg_fuse_cells = MG_FUSE_CELLS;
-    bool mg_legacy = false;        // FLUID_MG_LEGACY=1: thread-per-cell V-cycle kernels (A/B against the LDS-tiled legs)
-    bool mg_fuse0 = false;
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
     double *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual
@@ -261,8 +258,6 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     s->ncell = (size_t)p->n * p->n * p->n;
     s->dt = p->max_dt;
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments)
-    if (const char* e = getenv("FLUID_MG_LEGACY")) s->mg_legacy = atoi(e) != 0;
-    if (const char* e = getenv("FLUID_MG_FUSE0")) { s->mg_fuse0 = atoi(e) != 0; if (s->mg_fuse0) s->mg_fuse_cells = 1L << 40; }
     s->xs = 0;
     s->xe = p->n;
     *out = nullptr;
@@ -605,14 +600,12 @@ static MgCoef<double> mg_coef(const fluid_sim* s, int level)
 }
 
 // z = M^-1 r: V(2,2) cycle.  Level-0 rhs = `rhs0`; result in `z0`; part_rz gets the partials of rhs0.z0.
-static int mg_vcycle_legacy(fluid_sim* s, const double* rhs0, double* z0, double* part_rz);
-static int mg_rz_blocks(const fluid_sim* s) { return s->mg_legacy ? mg_smooth_blocks(s->mgl[0]) : mg_up_blocks(s->mgl[0]); }
+static int mg_rz_blocks(const fluid_sim* s) { return mg_up_blocks(s->mgl[0]); }
 
 // One launch per leg and level (LDS-tiled kernels): down = both pre-sweeps + residual (+ the restriction for the
 // levels in the middle), tail, up = prolongation + both post-sweeps.
 static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
-    if (s->mg_legacy) return mg_vcycle_legacy(s, rhs0, z0, part_rz);
     const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
     for (int l = 0; l < tail; ++l) {
@@ -637,50 +630,6 @@ static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_
         const int tok = l == 0 ? prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells()) : -1;
         launch_mg_up<double>(s->st, m, cnt, f, s->mg_u[l], l == 0 ? z0 : s->mg_v[l], s->mgl[l + 1], ec, mg_coef(s, l), l == 0 ? part_rz : nullptr, ps);
         if (l == 0) prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
-    }
-    HIPCHK(hipGetLastError());
-    return FLUID_OK;
-}
-
-static int mg_vcycle_legacy(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
-{
-    const int nl = s->mg_nl, tail = s->mg_tail;
-    const PcgState* ps = s->ps;
-    for (int l = 0; l < tail; ++l) {
-        const MLevel& m = s->mgl[l];
-        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
-        const double* f = l == 0 ? rhs0 : s->mg_f[l];
-        const MgCoef<double> cf = mg_coef(s, l);
-        const bool fuse = (l > 0 || s->mg_fuse0) && (long)m.dx * m.dy * m.dz <= s->mg_fuse_cells;
-        if (fuse) {
-            launch_mg_smooth0_resid<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], cf, ps);
-        } else {
-            launch_mg_smooth<double>(s->st, m, cnt, f, (const double*)nullptr, s->mg_u[l], cf, 0, nullptr, ps);   // two sweeps from u = 0
-            launch_mg_resid<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], cf, ps);
-        }
-        launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
-    }
-    {
-        // the tail restricts the residual of level tail-1 itself and leaves its correction in mg_u[tail]
-        double off[fluid_sim::MG_MAXL];
-        for (int l = tail; l < nl; ++l) off[l] = mg_coef(s, l).off;
-        launch_mg_tail<double>(s->st, nl - tail, s->mg_f[tail], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail, s->mg_csweeps, ps);
-    }
-    for (int l = tail - 1; l >= 0; --l) {
-        const MLevel& m = s->mgl[l];
-        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
-        const double* f = l == 0 ? rhs0 : s->mg_f[l];
-        const MgCoef<double> cf = mg_coef(s, l);
-        const bool fuse = (l > 0 || s->mg_fuse0) && (long)m.dx * m.dy * m.dz <= s->mg_fuse_cells;
-        if (fuse) {
-            launch_mg_prolong_smooth<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_v[l], s->mgl[l + 1], s->mg_u[l + 1], cf, ps);
-        } else {
-            launch_mg_prolong<double>(s->st, m, cnt, s->mg_u[l], s->mgl[l + 1], s->mg_u[l + 1], ps);
-            const int tok = l == 0 ? prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells()) : -1;
-            launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_v[l], cf, 1, nullptr, ps);
-            if (l == 0) prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
-        }
-        launch_mg_smooth<double>(s->st, m, cnt, f, s->mg_v[l], l == 0 ? z0 : s->mg_u[l], cf, 2, l == 0 ? part_rz : nullptr, ps);
     }
     HIPCHK(hipGetLastError());
     return FLUID_OK;

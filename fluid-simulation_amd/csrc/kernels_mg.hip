@@ -100,55 +100,7 @@ __global__ __launch_bounds__(256) void k_mg_cnt(MLevel m, const uint8_t* __restr
     cnt[c] = n;
 }
 
-// ---- per-cell bodies (shared by the per-level kernels and the single-block tail kernel) ---------
 // Coefficients by neighbour count n: diag = dg[n], 1/diag = iv[n] (tables in LDS), off-diagonal = off.
-
-// damped-Jacobi sweep: u_out = u_in + omega D^-1 (f - A u_in); returns f*u_out
-template <typename T>
-__device__ __forceinline__ double d_smooth(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f,
-                                           const T* __restrict__ u_in, T* __restrict__ u_out, const T* dg, const T* iv, T off, T omega, long t)
-{
-    int i, j, k;
-    if (!mg_cell(m, t, i, j, k)) return 0;
-    const size_t c = m.at(i, j, k);
-    const int n = cnt[c];
-    if (!n) return 0;  // not an unknown: its entries stay 0 (arrays are zeroed once per step), no 8-byte store per air cell
-    const T fv = f[c], uc = u_in[c];
-    const T nb = u_in[c - m.sx] + u_in[c + m.sx] + u_in[c - m.sy] + u_in[c + m.sy] + u_in[c - 1] + u_in[c + 1];
-    const T out = uc + omega * iv[n] * (fv - (dg[n] * uc + off * nb));
-    u_out[c] = out;
-    return (double)fv * (double)out;
-}
-
-// two sweeps starting from u = 0 in one pass: u1 = omega D^-1 f is formed on the fly at the 7 points
-template <typename T>
-__device__ __forceinline__ void d_smooth0(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u_out,
-                                          const T* dg, const T* iv, T off, long t)
-{
-    int i, j, k;
-    if (!mg_cell(m, t, i, j, k)) return;
-    const size_t c = m.at(i, j, k);
-    const int n = cnt[c];
-    if (!n) return;
-    const T w1 = (T)MG_W1, w2 = (T)MG_W2;
-    auto u1 = [&](size_t q) { return w1 * iv[cnt[q]] * f[q]; };  // iv[0] = 0: non-unknowns give 0
-    const T fv = f[c], uc = w1 * iv[n] * fv;
-    const T nb = u1(c - m.sx) + u1(c + m.sx) + u1(c - m.sy) + u1(c + m.sy) + u1(c - 1) + u1(c + 1);
-    u_out[c] = uc + w2 * iv[n] * (fv - (dg[n] * uc + off * nb));
-}
-
-template <typename T>
-__device__ __forceinline__ void d_resid(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u,
-                                        T* __restrict__ r, const T* dg, T off, long t)
-{
-    int i, j, k;
-    if (!mg_cell(m, t, i, j, k)) return;
-    const size_t c = m.at(i, j, k);
-    const int n = cnt[c];
-    if (!n) return;
-    const T nb = u[c - m.sx] + u[c + m.sx] + u[c - m.sy] + u[c + m.sy] + u[c - 1] + u[c + 1];
-    r[c] = f[c] - (dg[n] * u[c] + off * nb);
-}
 
 // f_c = (1/8) P^T r_f : a coarse cell gathers its 4x4x4 fine neighbourhood, weights (1/4,3/4,3/4,1/4) per axis
 template <typename T>
@@ -194,116 +146,6 @@ __device__ __forceinline__ void d_restrict(const MLevel& mf, const T* __restrict
         out = acc * (T)0.125;
     }
     fc[C] = out;
-}
-
-// u += P e : a fine cell interpolates from its 8 nearest coarse cells (non-unknown coarse cells hold 0)
-template <typename T>
-__device__ __forceinline__ void d_prolong(const MLevel& mf, const uint8_t* __restrict__ cnt_f, T* __restrict__ u, const MLevel& mc,
-                                          const T* __restrict__ ec, long t)
-{
-    int i, j, k;
-    if (!mg_cell(mf, t, i, j, k)) return;
-    const size_t c = mf.at(i, j, k);
-    if (!cnt_f[c]) return;
-    const int I = i >> 1, J = j >> 1, K = k >> 1;
-    const int di = (i & 1) ? 1 : -1, dj = (j & 1) ? 1 : -1, dk = (k & 1) ? 1 : -1;
-    const size_t C = mc.at(I, J, K);  // the coarse arrays carry a ring of zeros: I+di etc. are always addressable
-    const long sx = (long)di * mc.sx, sy = (long)dj * mc.sy, sz = dk;
-    const T a = (T)0.75, b = (T)0.25;
-    const T v = a * a * a * ec[C] + a * a * b * (ec[C + sx] + ec[C + sy] + ec[C + sz]) +
-                a * b * b * (ec[C + sx + sy] + ec[C + sx + sz] + ec[C + sy + sz]) + b * b * b * ec[C + sx + sy + sz];
-    u[c] += v;
-}
-
-// Fused forms for the launch-bound intermediate levels (a 100k-cell level costs ~4.5 us per launch whatever it does):
-// (a) both pre-sweeps AND the residual in one pass: r = f - A u2 needs u2 at the 7 points, each of which needs
-//     u1 = W1 D^-1 f at its own 7 points (footprint radius 2 on f); (b) prolongation folded into the first post-sweep.
-template <typename T>
-__device__ __forceinline__ T d_u2_at(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* dg, const T* iv,
-                                     T off, size_t q)
-{
-    const int n = cnt[q];
-    if (!n) return (T)0;  // not an unknown (possibly a ring cell): its neighbours are never touched
-    const T w1 = (T)MG_W1, w2 = (T)MG_W2;
-    auto u1 = [&](size_t p) { return w1 * iv[cnt[p]] * f[p]; };
-    const T fv = f[q], uc = w1 * iv[n] * fv;
-    const T nb = u1(q - m.sx) + u1(q + m.sx) + u1(q - m.sy) + u1(q + m.sy) + u1(q - 1) + u1(q + 1);
-    return uc + w2 * iv[n] * (fv - (dg[n] * uc + off * nb));
-}
-template <typename T>
-__device__ __forceinline__ void d_smooth0_resid(const MLevel& m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u,
-                                                T* __restrict__ r, const T* dg, const T* iv, T off, long t)
-{
-    int i, j, k;
-    if (!mg_cell(m, t, i, j, k)) return;
-    const size_t c = m.at(i, j, k);
-    const int n = cnt[c];
-    T uo = 0, ro = 0;
-    if (!n) return;
-    {
-        uo = d_u2_at<T>(m, cnt, f, dg, iv, off, c);
-        const T nb = d_u2_at<T>(m, cnt, f, dg, iv, off, c - m.sx) + d_u2_at<T>(m, cnt, f, dg, iv, off, c + m.sx) +
-                     d_u2_at<T>(m, cnt, f, dg, iv, off, c - m.sy) + d_u2_at<T>(m, cnt, f, dg, iv, off, c + m.sy) +
-                     d_u2_at<T>(m, cnt, f, dg, iv, off, c - 1) + d_u2_at<T>(m, cnt, f, dg, iv, off, c + 1);
-        ro = f[c] - (dg[n] * uo + off * nb);
-    }
-    u[c] = uo;
-    r[c] = ro;
-}
-// value of (u + P e) at fine array index q = at(i,j,k) (0 for a non-unknown)
-template <typename T>
-__device__ __forceinline__ T d_upe_at(const MLevel& mf, const uint8_t* __restrict__ cnt_f, const T* __restrict__ u, const MLevel& mc,
-                                      const T* __restrict__ ec, int i, int j, int k)
-{
-    const size_t q = mf.at(i, j, k);
-    if (!cnt_f[q]) return (T)0;
-    const int I = i >> 1, J = j >> 1, K = k >> 1;
-    const int di = (i & 1) ? 1 : -1, dj = (j & 1) ? 1 : -1, dk = (k & 1) ? 1 : -1;
-    const size_t C = mc.at(I, J, K);
-    const long sx = (long)di * mc.sx, sy = (long)dj * mc.sy, sz = dk;
-    const T a = (T)0.75, b = (T)0.25;
-    return u[q] + a * a * a * ec[C] + a * a * b * (ec[C + sx] + ec[C + sy] + ec[C + sz]) +
-           a * b * b * (ec[C + sx + sy] + ec[C + sx + sz] + ec[C + sy + sz]) + b * b * b * ec[C + sx + sy + sz];
-}
-template <typename T>
-__device__ __forceinline__ void d_prolong_smooth(const MLevel& mf, const uint8_t* __restrict__ cnt_f, const T* __restrict__ f,
-                                                 const T* __restrict__ u, T* __restrict__ u_out, const MLevel& mc, const T* __restrict__ ec,
-                                                 const T* dg, const T* iv, T off, long t)
-{
-    int i, j, k;
-    if (!mg_cell(mf, t, i, j, k)) return;
-    const size_t c = mf.at(i, j, k);
-    const int n = cnt_f[c];
-    T out = 0;
-    if (!n) return;
-    {
-        const T vc = d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j, k);
-        const T nb = d_upe_at<T>(mf, cnt_f, u, mc, ec, i - 1, j, k) + d_upe_at<T>(mf, cnt_f, u, mc, ec, i + 1, j, k) +
-                     d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j - 1, k) + d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j + 1, k) +
-                     d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j, k - 1) + d_upe_at<T>(mf, cnt_f, u, mc, ec, i, j, k + 1);
-        out = vc + (T)MG_W2 * iv[n] * (f[c] - (dg[n] * vc + off * nb));
-    }
-    u_out[c] = out;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_mg_smooth0_resid(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u,
-                                                          T* __restrict__ r, MgCoef<T> cf, const PcgState* ps)
-{
-    __shared__ T sd[8], si[8];
-    if (ps && ps->done) return;
-    mg_load_coef(sd, si, cf);
-    d_smooth0_resid<T>(m, cnt, f, u, r, sd, si, cf.off, (long)blockIdx.x * 256 + threadIdx.x);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void k_mg_prolong_smooth(MLevel mf, const uint8_t* __restrict__ cnt_f, const T* __restrict__ f,
-                                                           const T* __restrict__ u, T* __restrict__ u_out, MLevel mc,
-                                                           const T* __restrict__ ec, MgCoef<T> cf, const PcgState* ps)
-{
-    __shared__ T sd[8], si[8];
-    if (ps && ps->done) return;
-    mg_load_coef(sd, si, cf);
-    d_prolong_smooth<T>(mf, cnt_f, f, u, u_out, mc, ec, sd, si, cf.off, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- LDS-tiled legs of the V-cycle -----------------------------------------------------------------------
@@ -602,49 +444,13 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     }
 }
 
-// ---- per-level kernels (levels too large for one block) ---------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_mg_smooth(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u_in,
-                                                   T* __restrict__ u_out, MgCoef<T> cf, T omega, double* __restrict__ part_dot, const PcgState* ps)
-{
-    __shared__ double red[4];
-    __shared__ T sd[8], si[8];
-    if (ps && ps->done) return;  // uniform: written by an earlier launch
-    mg_load_coef(sd, si, cf);
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    double acc = 0;
-    if (u_in) acc = d_smooth<T>(m, cnt, f, u_in, u_out, sd, si, cf.off, omega, t);
-    else d_smooth0<T>(m, cnt, f, u_out, sd, si, cf.off, t);
-    if (part_dot) {
-        acc = block_sum<double, 4>(acc, red);
-        if (threadIdx.x == 0) part_dot[blockIdx.x] = acc;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_mg_resid(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u,
-                                                  T* __restrict__ r, MgCoef<T> cf, const PcgState* ps)
-{
-    __shared__ T sd[8], si[8];
-    if (ps && ps->done) return;
-    mg_load_coef(sd, si, cf);
-    d_resid<T>(m, cnt, f, u, r, sd, cf.off, (long)blockIdx.x * 256 + threadIdx.x);
-}
-
+// ---- restriction of the level-0 residual (its down kernel has no room for a halo of 3) -----------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_mg_restrict(MLevel mf, const T* __restrict__ rf, MLevel mc, const uint8_t* __restrict__ cnt_c,
                                                      T* __restrict__ fc, const PcgState* ps)
 {
     if (ps && ps->done) return;
     d_restrict<T>(mf, rf, mc, cnt_c, fc, (long)blockIdx.x * 256 + threadIdx.x);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_mg_prolong(MLevel mf, const uint8_t* __restrict__ cnt_f, T* __restrict__ u, MLevel mc,
-                                                    const T* __restrict__ ec, const PcgState* ps)
-{
-    if (ps && ps->done) return;
-    d_prolong<T>(mf, cnt_f, u, mc, ec, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- tail: the whole sub-V-cycle of the small levels in ONE block, entirely in LDS ------------------------
@@ -867,7 +673,6 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
 
 // ---- launchers ----------------------------------------------------------------------------------
 static inline unsigned mg_blocks(const MLevel& m) { return (unsigned)(((long)m.dx * m.dy * m.dz + 255) / 256); }
-int mg_smooth_blocks(const MLevel& m) { return (int)mg_blocks(m); }
 
 MLevel mg_level0(const LBox& L)
 {
@@ -899,38 +704,9 @@ void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, 
     hipLaunchKernelGGL(k_mg_cnt, dim3(mg_blocks(mc)), dim3(256), 0, st, mc, (const uint8_t*)tc, cnt_c);
 }
 template <typename T>
-void launch_mg_smooth(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u_in, T* u_out, MgCoef<T> cf, int sweep,
-                      double* part_dot, const PcgState* ps)
-{
-    // sweep: 0 = both pre-sweeps from u = 0 (u_in == nullptr), 1 = first post-sweep (W2), 2 = second post-sweep (W1)
-    const T omega = (T)(sweep == 1 ? MG_W2 : MG_W1);
-    hipLaunchKernelGGL((k_mg_smooth<T>), dim3(mg_blocks(m)), dim3(256), 0, st, m, cnt, f, u_in, u_out, cf, omega, part_dot, ps);
-}
-template <typename T>
-void launch_mg_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* r, MgCoef<T> cf, const PcgState* ps)
-{
-    hipLaunchKernelGGL((k_mg_resid<T>), dim3(mg_blocks(m)), dim3(256), 0, st, m, cnt, f, u, r, cf, ps);
-}
-template <typename T>
 void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const uint8_t* cnt_c, T* fc, const PcgState* ps)
 {
     hipLaunchKernelGGL((k_mg_restrict<T>), dim3(mg_blocks(mc)), dim3(256), 0, st, mf, rf, mc, cnt_c, fc, ps);
-}
-template <typename T>
-void launch_mg_prolong(hipStream_t st, MLevel mf, const uint8_t* cnt_f, T* u, MLevel mc, const T* ec, const PcgState* ps)
-{
-    hipLaunchKernelGGL((k_mg_prolong<T>), dim3(mg_blocks(mf)), dim3(256), 0, st, mf, cnt_f, u, mc, ec, ps);
-}
-template <typename T>
-void launch_mg_smooth0_resid(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MgCoef<T> cf, const PcgState* ps)
-{
-    hipLaunchKernelGGL((k_mg_smooth0_resid<T>), dim3(mg_blocks(m)), dim3(256), 0, st, m, cnt, f, u, r, cf, ps);
-}
-template <typename T>
-void launch_mg_prolong_smooth(hipStream_t st, MLevel mf, const uint8_t* cnt_f, const T* f, const T* u, T* u_out, MLevel mc, const T* ec,
-                              MgCoef<T> cf, const PcgState* ps)
-{
-    hipLaunchKernelGGL((k_mg_prolong_smooth<T>), dim3(mg_blocks(mf)), dim3(256), 0, st, mf, cnt_f, f, u, u_out, mc, ec, cf, ps);
 }
 // tile shapes of the LDS-tiled legs
 constexpr int MG_TX = 8, MG_TY = 8, MG_TZ = 16;   // down (no restriction) and up
@@ -1025,13 +801,7 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
 #define INSTMG(T)                                                                                                                   \
     template void launch_mg_down<T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*); \
     template void launch_mg_up<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*, const PcgState*); \
-    template void launch_mg_smooth<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, int, double*, const PcgState*); \
-    template void launch_mg_resid<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MgCoef<T>, const PcgState*);        \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                  \
-    template void launch_mg_prolong<T>(hipStream_t, MLevel, const uint8_t*, T*, MLevel, const T*, const PcgState*);                   \
-    template void launch_mg_smooth0_resid<T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MgCoef<T>, const PcgState*);          \
-    template void launch_mg_prolong_smooth<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>,  \
-                                              const PcgState*);                                                                       \
     template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*);
 INSTMG(double)
 
