@@ -277,11 +277,12 @@ constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel c
 constexpr size_t MG_TAIL_LDS = 144 * 1024;  // dynamic LDS the tail kernel may use (160 KB per CU on gfx950): levels whose u, v, f + counts fit go into the tail
 size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem);
 int mg_up_blocks(const MLevel& m);
-template <typename T>
-void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
+// T = the V-cycle's arithmetic/storage type, F / O = element types of a level's rhs / result (double at level 0)
+template <typename T, typename F>
+void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
                     const PcgState* ps);
-template <typename T>
-void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* out, MLevel mc, const T* ec, MgCoef<T> cf,
+template <typename T, typename F, typename O>
+void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
                   double* part_dot, const PcgState* ps);
 template <typename T>
 void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps);

@@ -75,7 +75,8 @@ struct fluid_sim {
     int mg_csweeps = 3;           // red-black sweeps (each direction) on the coarsest level (12 -> 2 changes the PCG count by 1 in 520)
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
-    double *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual
+    char *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual (float or double)
+    bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (FLUID_MG_FP64=1: double)
     double* mg_part = nullptr;    // per-block partials of r.z when a level-0 launch has more blocks than the PCG kernels re-sum
     char* mg_slab = nullptr;      // one allocation behind every mg_* array and Zmg (re-carved each step)
     size_t mg_slab_cap = 0;
@@ -258,6 +259,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     s->ncell = (size_t)p->n * p->n * p->n;
     s->dt = p->max_dt;
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments)
+    if (const char* e = getenv("FLUID_MG_FP64")) s->mg_fp32 = atoi(e) == 0;
     s->xs = 0;
     s->xe = p->n;
     *out = nullptr;
@@ -542,8 +544,9 @@ static int mg_setup(fluid_sim* s)
     // levels small enough for one block (and everything coarser) run inside the tail kernel; level 0 never does
     // (the tail holds its levels in LDS: as many of the coarsest levels as fit)
     int tail = nl - 1;
+    const size_t es = s->mg_fp32 ? sizeof(float) : sizeof(double);  // element size of the V-cycle's own arrays
     auto fits = [&](int t) {
-        const size_t b = nl - t <= MG_TAIL_MAX ? mg_tail_lds_bytes(nl - t, s->mgl + t, sizeof(double)) : 0;
+        const size_t b = nl - t <= MG_TAIL_MAX ? mg_tail_lds_bytes(nl - t, s->mgl + t, es) : 0;
         return b > 0 && b <= MG_TAIL_LDS;
     };
     while (tail > 1 && fits(tail - 1)) --tail;
@@ -559,7 +562,7 @@ static int mg_setup(fluid_sim* s)
     for (int l = 0; l < nl; ++l) {
         const size_t c = s->mgl[l].cells + 64;
         o_typ[l] = take(c); o_cnt[l] = take(c);
-        o_u[l] = take(c * 8); o_v[l] = take(c * 8); o_f[l] = take(c * 8); o_r[l] = take(c * 8);
+        o_u[l] = take(c * es); o_v[l] = take(c * es); o_f[l] = take(c * es); o_r[l] = take(c * es);
     }
     const size_t o_z = take((s->mgl[0].cells + 64) * 8);
     if (total > s->mg_slab_cap) {
@@ -571,9 +574,9 @@ static int mg_setup(fluid_sim* s)
     for (int l = 0; l < nl; ++l) {
         s->mg_typ[l] = (uint8_t*)(s->mg_slab + o_typ[l]);
         s->mg_cnt[l] = l ? (uint8_t*)(s->mg_slab + o_cnt[l]) : nullptr;
-        s->mg_u[l] = (double*)(s->mg_slab + o_u[l]); s->mg_v[l] = (double*)(s->mg_slab + o_v[l]);
-        s->mg_f[l] = l ? (double*)(s->mg_slab + o_f[l]) : nullptr;
-        s->mg_r[l] = (double*)(s->mg_slab + o_r[l]);
+        s->mg_u[l] = s->mg_slab + o_u[l]; s->mg_v[l] = s->mg_slab + o_v[l];
+        s->mg_f[l] = l ? s->mg_slab + o_f[l] : nullptr;
+        s->mg_r[l] = s->mg_slab + o_r[l];
     }
     s->Zmg = s->mg_slab + o_z;
     HIPCHK(hipMemsetAsync(s->mg_slab, 0, total, s->st));
@@ -603,36 +606,58 @@ static MgCoef<double> mg_coef(const fluid_sim* s, int level)
 static int mg_rz_blocks(const fluid_sim* s) { return mg_up_blocks(s->mgl[0]); }
 
 // One launch per leg and level (LDS-tiled kernels): down = both pre-sweeps + residual (+ the restriction for the
-// levels in the middle), tail, up = prolongation + both post-sweeps.
-static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+// levels in the middle), tail, up = prolongation + both post-sweeps.  V = the cycle's own arithmetic and storage type:
+// float by default — M^-1 only has to be a fixed SPD operator close to A^-1, the PCG vectors, dot products and the
+// residual recurrence around it stay double (same iteration counts as a double cycle, half the LDS and L2 traffic).
+template <typename V>
+static MgCoef<V> mg_coef_as(const fluid_sim* s, int level)
+{
+    const MgCoef<double> d = mg_coef(s, level);
+    MgCoef<V> c;
+    for (int k = 0; k < 7; ++k) { c.diag[k] = (V)d.diag[k]; c.inv[k] = (V)d.inv[k]; }
+    c.off = (V)d.off;
+    return c;
+}
+template <typename V>
+static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
     const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
+    auto U = [&](int l) { return (V*)s->mg_u[l]; };
+    auto W = [&](int l) { return (V*)s->mg_v[l]; };
+    auto F = [&](int l) { return (V*)s->mg_f[l]; };
+    auto R = [&](int l) { return (V*)s->mg_r[l]; };
     for (int l = 0; l < tail; ++l) {
         const MLevel& m = s->mgl[l];
-        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
-        const double* f = l == 0 ? rhs0 : s->mg_f[l];
         const bool fold = l > 0;  // restriction inside the down kernel (halo 3): not at level 0, where 5x halo reads cost more than a launch
-        launch_mg_down<double>(s->st, m, cnt, f, s->mg_u[l], s->mg_r[l], s->mgl[l + 1], fold ? s->mg_cnt[l + 1] : nullptr,
-                               fold ? s->mg_f[l + 1] : nullptr, mg_coef(s, l), ps);
-        if (!fold) launch_mg_restrict<double>(s->st, m, s->mg_r[l], s->mgl[l + 1], s->mg_cnt[l + 1], s->mg_f[l + 1], ps);
+        V* fc = fold ? F(l + 1) : nullptr;
+        const uint8_t* cc = fold ? s->mg_cnt[l + 1] : nullptr;
+        if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps);
+        else launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps);
+        if (!fold) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
     }
     {
-        double off[fluid_sim::MG_MAXL];
-        for (int l = tail; l < nl; ++l) off[l] = mg_coef(s, l).off;
-        launch_mg_tail<double>(s->st, nl - tail, s->mg_f[tail], s->mgl + tail, s->mg_cnt + tail, s->mg_u[tail], off + tail, s->mg_csweeps, ps);
+        V off[fluid_sim::MG_MAXL];
+        for (int l = tail; l < nl; ++l) off[l] = (V)mg_coef(s, l).off;
+        launch_mg_tail<V>(s->st, nl - tail, (const V*)F(tail), s->mgl + tail, s->mg_cnt + tail, U(tail), off + tail, s->mg_csweeps, ps);
     }
     for (int l = tail - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];
-        const uint8_t* cnt = l == 0 ? s->cntL : s->mg_cnt[l];
-        const double* f = l == 0 ? rhs0 : s->mg_f[l];
-        const double* ec = l + 1 == tail ? s->mg_u[l + 1] : s->mg_v[l + 1];  // out != u: neighbouring tiles still read u
-        const int tok = l == 0 ? prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells()) : -1;
-        launch_mg_up<double>(s->st, m, cnt, f, s->mg_u[l], l == 0 ? z0 : s->mg_v[l], s->mgl[l + 1], ec, mg_coef(s, l), l == 0 ? part_rz : nullptr, ps);
-        if (l == 0) prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
+        const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);  // out != u: neighbouring tiles still read u
+        if (l == 0) {
+            const int tok = prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells());
+            launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps);
+            prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
+        } else {
+            launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps);
+        }
     }
     HIPCHK(hipGetLastError());
     return FLUID_OK;
+}
+static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+{
+    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz) : mg_vcycle_t<double>(s, rhs0, z0, part_rz);
 }
 
 // PCG loop of ConjugateGradient.h:28-90 with z = V-cycle(r); same start, stopping rule and cap as solve_impl.
@@ -645,7 +670,7 @@ static int solve_mg(fluid_sim* s)
     T* R = (T*)s->R;
     T* Q = (T*)s->Q;
     T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
-    T* Z = s->mg_r[0] ? s->mg_v[0] : nullptr;  // placeholder, set below
+    T* Z = nullptr;  // set below
     const uint8_t* cnt = s->cntL;
     const Coef<T> cf = make_coef<T>(s);
     const double tol = s->prm.cg_tol;

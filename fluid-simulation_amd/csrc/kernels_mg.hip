@@ -183,8 +183,8 @@ __device__ __forceinline__ bool in_level(const MLevel& m, int i, int j, int k)
 // up front into registers from clamped (always readable) addresses, so the in-level tests never delay a load.
 __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
 
-template <typename T, int TX, int TY, int TZ, bool RESTRICT>
-__global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, T* __restrict__ u,
+template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT>
+__global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
                                                  T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
                                                  MgCoef<T> cf, const PcgState* ps, int gx, int gy)
 {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
         const int i = i0 - H + x;
         const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
         const int c = cnt[q];
-        fa[x] = f[q];  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
+        fa[x] = (T)f[q];  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
         ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
     const int yb = col / BZ, zb = col - yb * BZ;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     const size_t qb = m.at(0, clampi(j0 - H + 1 + yb, m.dy - 1), clampi(k0 - H + 1 + zb, m.dz - 1));
     T fb[BX];
 #pragma unroll
-    for (int x = 0; x < BX; ++x) fb[x] = f[qb + (size_t)((long)clampi(i0 - H + 1 + x, m.dx - 1) * sx)];
+    for (int x = 0; x < BX; ++x) fb[x] = (T)f[qb + (size_t)((long)clampi(i0 - H + 1 + x, m.dx - 1) * sx)];
     const int hc = col / (CY * CZ), cc = col - hc * (CY * CZ);
     const int yc = cc / CZ, zc = cc - yc * CZ;
     const bool actC = hc < NHC;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     const size_t qc = m.at(0, clampi(j0 - H + 2 + yc, m.dy - 1), clampi(k0 - H + 2 + zc, m.dz - 1));
     T fr[XC];
 #pragma unroll
-    for (int x = 0; x < XC; ++x) fr[x] = f[qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx)];
+    for (int x = 0; x < XC; ++x) fr[x] = (T)f[qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx)];
     mg_load_coef(sd, si, cf);
     // ---- u1 = W1 D^-1 f on region A ----
     if (actA) {
@@ -310,9 +310,9 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     }
 }
 
-template <typename T, int TX, int TY, int TZ>
-__global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const T* __restrict__ f, const T* __restrict__ u,
-                                               T* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
+template <typename T, typename F, typename O, int TX, int TY, int TZ>
+__global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
+                                               O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
                                                double* __restrict__ part_dot, const PcgState* ps, int gx, int gy)
 {
     constexpr int AX = TX + 4, AY = TY + 4, AZ = TZ + 4;              // v0 = u + P e and the count bytes
@@ -366,12 +366,12 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     const size_t qb = m.at(0, clampi(j0 - 1 + yb, m.dy - 1), clampi(k0 - 1 + zb, m.dz - 1));
     T fb[BX];
 #pragma unroll
-    for (int x = 0; x < BX; ++x) fb[x] = f[qb + (size_t)((long)clampi(i0 - 1 + x, m.dx - 1) * sx)];
+    for (int x = 0; x < BX; ++x) fb[x] = (T)f[qb + (size_t)((long)clampi(i0 - 1 + x, m.dx - 1) * sx)];
     const int ht = col / (TY * TZ), ct = col - ht * (TY * TZ);
     const int yt = ct / TZ, zt = ct - yt * TZ;
     const int xt0 = ht * XT;
     const size_t qt = m.at(0, clampi(j0 + yt, m.dy - 1), clampi(k0 + zt, m.dz - 1));
-    T ft[XT];
+    F ft[XT];  // the rhs in its own precision: level 0 dots it with the result (r.z of PCG)
 #pragma unroll
     for (int x = 0; x < XT; ++x) ft[x] = f[qt + (size_t)((long)clampi(i0 + xt0 + x, m.dx - 1) * sx)];
     mg_load_coef(sd, si, cf);
@@ -429,9 +429,9 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
             const T cp = sB[b + BY * BZ];
             const int n = sC[((xt0 + x + 2) * AY + yt + 2) * AZ + zt + 2];
             const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
-            const T o = c0 + (T)MG_W1 * si[n] * (ft[x] - (sd[n] * c0 + off * nb));
+            const T o = c0 + (T)MG_W1 * si[n] * ((T)ft[x] - (sd[n] * c0 + off * nb));
             if (n) {
-                out[qt + (size_t)((long)(i0 + xt0 + x) * sx)] = o;  // n != 0: in the level, no clamp
+                out[qt + (size_t)((long)(i0 + xt0 + x) * sx)] = (O)o;  // n != 0: in the level, no clamp
                 acc += (double)ft[x] * (double)o;
             }
             cm = c0;
@@ -720,28 +720,30 @@ int mg_up_blocks(const MLevel& m)
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
     return (int)(g.x * g.y * g.z);
 }
+// T = the V-cycle's own arithmetic and storage type (u, r, coarse rhs, LDS); F = element type of this level's rhs and
+// O of its result: at level 0 both are the PCG's double vectors whatever T is, on the other levels they are T.
 // both pre-sweeps + residual; with a coarse level (fc != nullptr) the restricted residual goes straight to fc and r is not written
-template <typename T>
-void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
+template <typename T, typename F>
+void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
                     const PcgState* ps)
 {
     if (fc) {
         const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
-        hipLaunchKernelGGL((k_mg_down<T, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf, ps,
-                           (int)g.x, (int)g.y);
+        hipLaunchKernelGGL((k_mg_down<T, F, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
+                           ps, (int)g.x, (int)g.y);
     } else {
         const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
-        hipLaunchKernelGGL((k_mg_down<T, MG_TX, MG_TY, MG_TZ, false>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf, ps,
-                           (int)g.x, (int)g.y);
+        hipLaunchKernelGGL((k_mg_down<T, F, MG_TX, MG_TY, MG_TZ, false>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
+                           ps, (int)g.x, (int)g.y);
     }
 }
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
-template <typename T>
-void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const T* f, const T* u, T* out, MLevel mc, const T* ec, MgCoef<T> cf,
+template <typename T, typename F, typename O>
+void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
                   double* part_dot, const PcgState* ps)
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
-    hipLaunchKernelGGL((k_mg_up<T, MG_TX, MG_TY, MG_TZ>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot, ps,
+    hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot, ps,
                        (int)g.x, (int)g.y);
 }
 
@@ -798,11 +800,18 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
     hipLaunchKernelGGL((k_mg_tail<T>), dim3(1), dim3(1024), o, st, a, ps);
 }
 
-#define INSTMG(T)                                                                                                                   \
-    template void launch_mg_down<T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*); \
-    template void launch_mg_up<T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*, const PcgState*); \
-    template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                  \
+#define INSTMG(T)                                                                                                                        \
+    template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*); \
+    template void launch_mg_up<T, T, T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*,  \
+                                        const PcgState*);                                                                               \
+    template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                     \
     template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*);
 INSTMG(double)
+INSTMG(float)
+// level 0 of a single-precision V-cycle inside the double-precision PCG
+template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
+                                            MgCoef<float>, const PcgState*);
+template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
+                                                  MgCoef<float>, double*, const PcgState*);
 
 }  // namespace fl
