@@ -168,39 +168,46 @@ def main():
     g2p = sim.profile_read(fs.PROF.G2P)
     srt = sim.profile_read(fs.PROF.SORT)
     mgs = sim.profile_read(fs.PROF.MG_SMOOTH0) if transport is None else {"sampled": 0, "launches": 0}
-    roof = None
-    # dominant solver kernel of the timed region: with the multigrid preconditioner the level-0 up leg of the V-cycle
-    # (prolongation + both post-sweeps + r.z partials, one launch per PCG iteration) outweighs the CG's own SQ kernel
-    if mgs["sampled"] and mgs["launches"] * (mgs["total_ms"] / mgs["sampled"]) > sq["launches"] * (sq["total_ms"] / max(sq["sampled"], 1)):
-        avg_ms = mgs["total_ms"] / mgs["sampled"]
-        cells = mgs["cells"] / mgs["sampled"]
-        bpc = 3 * T + 2              # read u, f, count byte, 1/8 coarse value; write z
-        algo = cells * bpc
+    # ---- roofline: every kernel class bracketed by hipEvents in the timed region, the one with the largest total
+    # time in `roofline`, the others in `roofline_others`.  Algorithmic bytes per launch:
+    #   k_p2g         96 B per particle staged once (9 axis weights + 3 velocity components) + 52 B per cell written
+    #   up leg, lvl 0 21.5 B/cell: read u (float), r (double), count byte, 1/8 coarse value (float); write z (double)
+    #   SQ            33 B/cell: read z, s, count byte; write s', q          XR   49 B/cell: read x, r, s, q, count; write x, r
+    np_ = float(len(pos0))
+    def roof_entry(name, prof, bytes_fn, key, note=None):
+        if not prof.get("sampled"):
+            return None
+        avg_ms = prof["total_ms"] / prof["sampled"]
+        cells = prof["cells"] / prof["sampled"]
+        algo = bytes_fn(cells)
         ach = algo / (avg_ms * 1e-3) / 1e9
-        kname = "k_mg_up<double, 8, 8, 16>"
-        roof = {"bound": "hbm", "kernel": kname + " at level 0 (V-cycle up leg: prolongation + two damped-Jacobi sweeps + r.z partials)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(kname + " (largest level)", n, ppc), "traffic_source": "profiles/r01/pmc_traffic.json (kernels_final)",
-                "algorithmic_bytes_per_launch": algo, "bytes_per_cell": bpc, "cells_per_launch": cells,
-                "avg_launch_us": avg_ms * 1e3, "launches": mgs["launches"], "sampled": mgs["sampled"],
-                "note": "the level-0 working set of this scene (~0.7 M cells, 18 MB) lives in L2/Infinity Cache and the kernel is "
-                        "VALU/LDS-bound, so the HBM fraction is low by construction; the dense 256^3 stencil sweep (stencil_microbench) "
-                        "is the bandwidth-bound kernel of this path"}
-    elif sq["sampled"]:
-        avg_ms = sq["total_ms"] / sq["sampled"]
-        cells = sq["cells"] / sq["sampled"]
-        algo = cells * (4 * T + 1)
-        ach = algo / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if transport is None and n == 256 and ppc == 8 and os.path.exists(tj):
-            # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes of this same workload (see the file's "method")
-            traffic = json.load(open(tj))["kernels"]["k_pcg_sq_l<double,true>"]["bytes_per_launch"]
-            traffic_src = "profiles/r01/pmc_traffic.json"
-        roof = {"bound": "hbm", "kernel": "k_pcg_sq_l<double,true> (PCG search update + 7-point apply + dot)" if transport is None else "k_pcg_s_l + ring exchange + k_pcg_sq_l<double,false>",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo,
-                "bytes_per_cell": 4 * T + 1, "cells_per_launch": cells, "avg_launch_us": avg_ms * 1e3,
-                "launches": sq["launches"], "sampled": sq["sampled"]}
+        e = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": pmc_traffic(key, n, ppc) if transport is None else None,
+             "traffic_source": "profiles/r01/pmc_traffic.json (kernels_final)", "algorithmic_bytes_per_launch": algo,
+             "cells_per_launch": cells, "avg_launch_us": avg_ms * 1e3, "launches": prof["launches"], "sampled": prof["sampled"],
+             "total_ms_in_timed_region": avg_ms * prof["launches"]}
+        if note:
+            e["note"] = note
+        return e
+    small = ("the level-0 working set of this scene (~0.7 M cells, 6 MB per vector) lives in L2/Infinity Cache and the launch is "
+             "latency-bound (~3 us of it is dispatch), so the HBM fraction is low by construction; the bandwidth-bound kernel of "
+             "this path is the dense 256^3 stencil sweep (stencil_microbench)")
+    cands = [
+        roof_entry("k_p2g (particle -> grid gather: particle rows staged through LDS, 2 x 2 columns x 64 z per block)", p2g,
+              lambda c: np_ * 96 + c * 52, "k_p2g",
+              "each particle row is staged by the 4 tiles whose 4 x 4 window holds it, so `traffic` is ~4x the algorithmic bytes: "
+              "bound by L2/Infinity-Cache -> LDS traffic at ~3.5 TB/s; 4 x 4-column tiles read 2.25x but ran 1.8x slower (16 waves "
+              "idle at the chunk barriers), DESIGN.md 3"),
+        roof_entry("k_mg_up<float, double, double, 8, 8, 16> (level-0 up leg of the V-cycle: prolongation + two damped-Jacobi sweeps + r.z partials)",
+              mgs, lambda c: c * 21.5, "k_mg_up<float, double, double, 8, 8, 16>", small),
+        roof_entry("k_pcg_sq_l<double, true> (PCG: s' = z + beta s, q = A s', partial s'.q)" if transport is None else
+              "k_pcg_s_l + ring exchange + k_pcg_sq_l<double,false>", sq, lambda c: c * 33.0, "k_pcg_sq_l<double, true>", small),
+        roof_entry("k_pcg_xr_l<double> (PCG: x += alpha s, r -= alpha q, partial r.r)", xr, lambda c: c * 49.0, "k_pcg_xr_l<double>", small),
+    ]
+    cands = [c for c in cands if c]
+    cands.sort(key=lambda c: -c["total_ms_in_timed_region"])
+    roof = cands[0] if cands else None
+    roof_others = cands[1:]
 
     def per(d):
         return None if not d["sampled"] else d["total_ms"] / d["sampled"]
@@ -213,6 +220,7 @@ def main():
                    "grid": n, "ppc": ppc, "particles": int(len(pos0)), "cg_tol": a.cg_tol,
                    "parallelism": "single GPU" if transport is None else f"x-slab domain decomposition over {world} GPUs, transport {transport}"},
         "roofline": roof,
+        "roofline_others": roof_others,
         "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),
                        "cg_iters_total": sum(s["cg_iters"] for s in stats), "relres_last": stats[-1]["relres"],
                        "box_last": [stats[-1]["box_lo"], stats[-1]["box_hi"]]},

@@ -487,8 +487,8 @@ static int phase_p2g(fluid_sim* s)
         s->stats.box_hi[a] = (&s->Rb.x1)[a];
     }
     if (!box_empty(s->Rb)) {
-        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rb.cells());
         launch_weights(s->st, s->np, s->pa, s->pw, s->cap);
+        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rb.cells());   // k_p2g alone (bench.py's roofline of the largest kernel)
         launch_p2g(s->st, s->g, s->Rb, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         prof_end(s, FLUID_PROF_P2G, tok);
         HIPCHK(hipGetLastError());
@@ -1397,8 +1397,8 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
     s->dirty_x0 = s->xs > 0 ? s->xs - 1 : 0;
     s->dirty_x1 = s->xe < N ? s->xe : N - 1;
     if (!box_empty(s->Rb) && !box_empty(s->Rr)) {
-        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
         launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
+        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
         launch_p2g(s->st, g, s->Rr, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         prof_end(s, FLUID_PROF_P2G, tok);
         HIPCHK(hipGetLastError());

@@ -26,7 +26,7 @@ def fold(rows, scale):
     for k, v in rows.items():
         s = short(k)
         top = max(g for g, _ in v)
-        if "k_mg_" in s and "tail" not in s:
+        if "k_mg_" in s and "tail" not in s and len({g for g, _ in v}) > 1:
             v = [x for x in v if x[0] == top]
             s += " (largest level)"
         out[s] = (scale * 1024.0 * sum(c for _, c in v) / len(v), len(v))
