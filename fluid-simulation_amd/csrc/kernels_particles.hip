@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
 // loop straight from global memory makes each wave load touch ~32 cache lines and thrashes the 32 KB L1:
 // 7.4 ms at 256^3.)  Rows are visited in ascending (x,y) and particles in ascending sorted order: the sum
 // order per cell is fixed.
+// Where the 0.65 ms at 256^3 go (measured by cutting the kernel in two): staging alone 0.34 ms, the gather loop alone
+// ~0.5 ms (6 LDS reads of 8 B per particle-cell pair, 142 M pairs, lanes of a wave walk windows of different length).
+// Tried without gain: a register-prefetch pipeline over the chunks with the window's cell starts in LDS (0.94 ms),
+// staging only the axis weights a tile can use (block-uniform conditional loads: 0.75 ms), two particles per trip,
+// XCD-contiguous tile ids.
 // A row is staged by every tile whose window holds it: (T+2)^2 / T^2 times — 4x for T = 2 (2.2 GB of L2/HBM reads
 // per launch at 256^3).  T = 4 would read 2.25x but measured 1.8x SLOWER (1.29 ms against 0.67 ms): 16 waves per
 // block wait at the chunk barriers while at most 9 of them consume the staged row.
