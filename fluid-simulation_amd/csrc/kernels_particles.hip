@@ -182,8 +182,9 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
 // loop straight from global memory makes each wave load touch ~32 cache lines and thrashes the 32 KB L1:
 // 7.4 ms at 256^3.)  Rows are visited in ascending (x,y) and particles in ascending sorted order: the sum
 // order per cell is fixed.
-// Where the 0.65 ms at 256^3 go (measured by cutting the kernel in two): staging alone 0.34 ms, the gather loop alone
-// ~0.5 ms (6 LDS reads of 8 B per particle-cell pair, 142 M pairs, lanes of a wave walk windows of different length).
+// Where the time at 256^3 goes (measured by cutting the kernel in two): staging alone 0.34 ms; the gather loop alone was
+// ~0.5 ms in the target-centric form (6 LDS reads of 8 B per particle-cell pair, 142 M pairs) and is ~0.3 ms in the
+// source-centric form below (8 reads per particle for its 3 pairs); together 0.48 ms.
 // Tried without gain: a register-prefetch pipeline over the chunks with the window's cell starts in LDS (0.94 ms),
 // staging only the axis weights a tile can use (block-uniform conditional loads: 0.75 ms), two particles per trip,
 // XCD-contiguous tile ids.
@@ -214,6 +215,14 @@ __global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __
     }
 }
 
+// Lane L of a wave stands for the z-cell zc = tz0 - 1 + L of its column twice over: as a SOURCE cell it walks its own
+// particles of the staged row once and forms, for each of the three target cells zc-1, zc, zc+1 it can reach, the
+// partial sums of w and w*v (12 accumulators; 8 LDS reads per particle for 3 particle-cell pairs); as a TARGET cell
+// (lanes 1..62) it then collects the partials of the sources zc-1, zc, zc+1 with two lane shifts per value.  (The first
+// version let every target lane walk the particles of its three source cells itself: 18 LDS reads per particle and
+// three times the trips.)  Sum order per target: rows ascending (x,y), sources ascending z, particles ascending.
+constexpr int P2G_ZT = 62;  // target cells per wave: lanes 0 and 63 are sources only
+
 __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
                                              const int* __restrict__ cell_start, const uint8_t* __restrict__ flags,
                                              float* __restrict__ container, double* __restrict__ u, double* __restrict__ v,
@@ -223,16 +232,17 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles 
     __shared__ double sv[3][P2G_LDS];   // vx, vy, vz
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int N = g.N;
-    const int ntz = (box.nz() + 63) / 64, nty = (box.ny() + P2G_T - 1) / P2G_T;
+    const int ntz = (box.nz() + P2G_ZT - 1) / P2G_ZT, nty = (box.ny() + P2G_T - 1) / P2G_T;
     const int tile = blockIdx.x;
     const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
-    const int tx0 = box.x0 + tx * P2G_T, ty0 = box.y0 + ty * P2G_T, tz0 = box.z0 + tz * 64;
-    const int ix = tx0 + wv / P2G_T, iy = ty0 + wv % P2G_T, iz = tz0 + lane;
-    const bool valid = ix <= box.x1 && iy <= box.y1 && iz <= box.z1;
-    const size_t c = valid ? g.idx(ix, iy, iz) : 0;
-    const bool live = valid && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
-    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + 64 < N - 1 ? tz0 + 64 : N - 1;
-    const int wz0 = iz > 0 ? iz - 1 : 0, wz1 = iz < N - 1 ? iz + 1 : N - 1;
+    const int tx0 = box.x0 + tx * P2G_T, ty0 = box.y0 + ty * P2G_T, tz0 = box.z0 + tz * P2G_ZT;
+    const int ix = tx0 + wv / P2G_T, iy = ty0 + wv % P2G_T, zc = tz0 - 1 + lane;
+    const bool col = ix <= box.x1 && iy <= box.y1;                 // my column is in the box
+    const bool src = col && zc >= 0 && zc < N;                     // my cell exists: it may hold particles
+    const bool tgt = col && lane >= 1 && lane <= P2G_ZT && zc <= box.z1;
+    const size_t c = tgt ? g.idx(ix, iy, zc) : 0;
+    const bool live = tgt && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
+    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + P2G_ZT < N - 1 ? tz0 + P2G_ZT : N - 1;
     float wf = 0.0f;
     double su = 0, sv_ = 0, sw_ = 0;
     for (int rx = tx0 - 1; rx <= tx0 + P2G_T; ++rx) {
@@ -243,17 +253,16 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles 
             const int je = cell_start[g.idx(rx, ry, zhi) + 1];
             if (je == jb) continue;  // block-uniform
             const int dxi = ix - rx + 1, dyi = iy - ry + 1;  // which axis weight of a particle of this row meets my column
-            const bool mine = live && dxi >= 0 && dxi <= 2 && dyi >= 0 && dyi <= 2;
-            int cs0 = 0, cs1 = 0, cs2 = 0, cs3 = 0;  // starts of the cells wz0, wz0+1, wz0+2 and the end of the window
+            const bool mine = src && dxi >= 0 && dxi <= 2 && dyi >= 0 && dyi <= 2;
+            int ca = 0, cz = 0;  // my source cell's particles in this row
             if (mine) {
-                const size_t r0 = g.idx(rx, ry, wz0);
-                cs0 = cell_start[r0];
-                cs1 = cell_start[r0 + 1];
-                cs2 = wz0 + 1 <= wz1 ? cell_start[r0 + 2] : cs1;
-                cs3 = wz0 + 2 <= wz1 ? cell_start[r0 + 3] : cs2;
+                const size_t r0 = g.idx(rx, ry, zc);
+                ca = cell_start[r0];
+                cz = cell_start[r0 + 1];
             }
             const double* swx = sw[dxi < 0 ? 0 : (dxi > 2 ? 2 : dxi)];
             const double* swy = sw[3 + (dyi < 0 ? 0 : (dyi > 2 ? 2 : dyi))];
+            double S[3] = {0, 0, 0}, U[3] = {0, 0, 0}, V[3] = {0, 0, 0}, W[3] = {0, 0, 0};  // by target: zc-1, zc, zc+1
             for (int cb = jb; cb < je; cb += P2G_CH) {
                 const int ce = cb + P2G_CH < je ? cb + P2G_CH : je;
                 __syncthreads();  // the previous chunk has been consumed
@@ -265,52 +274,66 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles 
                 }
                 __syncthreads();
                 // Every lane of the wave sits on the same (x,y) column, so the x/y weight tables are wave-uniform.  A lane
-                // whose window is long (settled water piles up to ~10^4 particles into one cell) would serialise the
-                // whole wave: such windows are swept by all 64 lanes together and wave-reduced (fixed order).
+                // whose cell is crowded (settled water piles up to ~10^4 particles into one cell) would serialise the
+                // whole wave: such cells are swept by all 64 lanes together and wave-reduced (fixed order).
+                int lo = ca > cb ? ca : cb, hi = cz < ce ? cz : ce;
+                if (hi < lo) hi = lo;
+                const bool heavy = hi - lo > P2G_HEAVY;
+                if (!heavy) {
+                    for (int j = lo; j < hi; ++j) {
+                        const int k = p2g_slot(j - cb);
+                        const double a = swx[k] * swy[k];   // (sx*sy)*sz: the reference's association (fluid.cc:291)
+                        const double vx = sv[0][k], vy = sv[1][k], vz = sv[2][k];
 #pragma unroll
-                for (int seg = 0; seg < 3; ++seg) {
-                    const int a = seg == 0 ? cs0 : (seg == 1 ? cs1 : cs2), b = seg == 0 ? cs1 : (seg == 1 ? cs2 : cs3);
-                    const int dzi = iz - (wz0 + seg) + 1;  // 2,1,0 away from the grid edge
-                    const bool use = mine && dzi >= 0 && dzi <= 2;
-                    int lo = a > cb ? a : cb, hi = b < ce ? b : ce;
-                    if (!use || hi < lo) hi = lo;
-                    const bool heavy = hi - lo > P2G_HEAVY;
-                    if (!heavy) {
-                        const double* swz = sw[6 + (dzi < 0 ? 0 : (dzi > 2 ? 2 : dzi))];
-                        for (int j = lo; j < hi; ++j) {
-                            const int k = p2g_slot(j - cb);
-                            const double cw = swx[k] * swy[k] * swz[k];
-                            wf = (float)((double)wf + cw);
-                            su = su + cw * sv[0][k];
-                            sv_ = sv_ + cw * sv[1][k];
-                            sw_ = sw_ + cw * sv[2][k];
-                        }
-                    }
-                    unsigned long long hm = __ballot(heavy);
-                    while (hm) {
-                        const int L = __ffsll((long long)hm) - 1;
-                        hm &= hm - 1;
-                        const int lo_L = __shfl(lo, L, 64), hi_L = __shfl(hi, L, 64), dz_L = __shfl(dzi, L, 64);
-                        const double* swz = sw[6 + dz_L];
-                        double aw = 0, pu = 0, pv = 0, pq = 0;
-                        for (int j = lo_L + lane; j < hi_L; j += 64) {
-                            const int k = p2g_slot(j - cb);
-                            const double cw = swx[k] * swy[k] * swz[k];
-                            aw += cw;
-                            pu += cw * sv[0][k];
-                            pv += cw * sv[1][k];
-                            pq += cw * sv[2][k];
-                        }
-                        aw = wave_sum(aw); pu = wave_sum(pu); pv = wave_sum(pv); pq = wave_sum(pq);
-                        aw = __shfl(aw, 0, 64); pu = __shfl(pu, 0, 64); pv = __shfl(pv, 0, 64); pq = __shfl(pq, 0, 64);
-                        if (lane == L) {
-                            wf = (float)((double)wf + aw);
-                            su = su + pu;
-                            sv_ = sv_ + pv;
-                            sw_ = sw_ + pq;
+                        for (int d = 0; d < 3; ++d) {
+                            const double cw = a * sw[6 + d][k];
+                            S[d] += cw;
+                            U[d] = U[d] + cw * vx;
+                            V[d] = V[d] + cw * vy;
+                            W[d] = W[d] + cw * vz;
                         }
                     }
                 }
+                unsigned long long hm = __ballot(heavy);
+                while (hm) {
+                    const int L = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1;
+                    const int lo_L = __shfl(lo, L, 64), hi_L = __shfl(hi, L, 64);
+                    double ps[3] = {0, 0, 0}, pu[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, pq[3] = {0, 0, 0};
+                    for (int j = lo_L + lane; j < hi_L; j += 64) {
+                        const int k = p2g_slot(j - cb);
+                        const double a = swx[k] * swy[k];
+                        const double vx = sv[0][k], vy = sv[1][k], vz = sv[2][k];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const double cw = a * sw[6 + d][k];
+                            ps[d] += cw;
+                            pu[d] += cw * vx;
+                            pv[d] += cw * vy;
+                            pq[d] += cw * vz;
+                        }
+                    }
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        double t0 = wave_sum(ps[d]), t1 = wave_sum(pu[d]), t2 = wave_sum(pv[d]), t3 = wave_sum(pq[d]);
+                        t0 = __shfl(t0, 0, 64); t1 = __shfl(t1, 0, 64); t2 = __shfl(t2, 0, 64); t3 = __shfl(t3, 0, 64);
+                        if (lane == L) { S[d] += t0; U[d] += t1; V[d] += t2; W[d] += t3; }
+                    }
+                }
+            }
+            // target zc collects: source zc-1 reaches it with its weight index 2, zc with 1, zc+1 with 0 (d = target - source + 1);
+            // container keeps the reference's float accumulator, one rounding per source cell instead of one per particle
+            const double s0 = __shfl_up(S[2], 1, 64), s2 = __shfl_down(S[0], 1, 64);
+            const double u0 = __shfl_up(U[2], 1, 64), u2 = __shfl_down(U[0], 1, 64);
+            const double v0 = __shfl_up(V[2], 1, 64), v2 = __shfl_down(V[0], 1, 64);
+            const double w0 = __shfl_up(W[2], 1, 64), w2 = __shfl_down(W[0], 1, 64);
+            if (live) {
+                wf = (float)((double)wf + s0);
+                wf = (float)((double)wf + S[1]);
+                wf = (float)((double)wf + s2);
+                su = ((su + u0) + U[1]) + u2;
+                sv_ = ((sv_ + v0) + V[1]) + v2;
+                sw_ = ((sw_ + w0) + W[1]) + w2;
             }
         }
     }
@@ -561,7 +584,7 @@ void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                 float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
 {
-    const unsigned nt = (unsigned)(((box.nx() + P2G_T - 1) / P2G_T) * ((box.ny() + P2G_T - 1) / P2G_T) * ((box.nz() + 63) / 64));
+    const unsigned nt = (unsigned)(((box.nx() + P2G_T - 1) / P2G_T) * ((box.ny() + P2G_T - 1) / P2G_T) * ((box.nz() + P2G_ZT - 1) / P2G_ZT));
     hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb);
 }
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,

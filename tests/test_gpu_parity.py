@@ -157,6 +157,9 @@ def test_solve_on_awkward_domains(fs, oracle, shape):
     sim.p2g(); sim.flags_index(); orc.p2g(); orc.flags_index()
     F = fs.FIELD
     assert np.array_equal(sim.field(F.INDICES), orc.field(4))
+    assert rel_l2(sim.field(F.VEL), orc.field(2)) < 1e-6   # the float32 weight accumulator is rounded per source cell here, per particle there
+    sim.upload_field(F.VEL, orc.field(2))    # re-synchronise (P2G sums differ in the last bits: another summation order)
+    sim.flags_index()
     sim.rhs_div(0); orc.rhs_div(); orc.build_matrix()
     assert np.array_equal(sim.field(F.DIVER), orc.field(6))
     sim.solve(); orc.solve()
