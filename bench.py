@@ -98,7 +98,7 @@ def main():
         sim = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
         sim.upload_particles(pos0)
     else:
-        # ONE simulation decomposed into x slabs of equal particle count, one slab per GPU (strong scaling)
+        # ONE simulation: particles in x slabs of equal count, one slab per GPU; the pressure block is replicated (strong scaling)
         fd = fs.load_dist()
         bounds = fd.partition_by_count(n, pos0, world)
         import torch
@@ -157,7 +157,7 @@ def main():
         return
 
     ms_per_step = elapsed / a.steps * 1e3
-    # N>1: the SAME global problem split over N GPUs -> strong scaling; value = steps of that one simulation per second
+    # N>1: the SAME global problem on N GPUs -> strong scaling; value = steps of that one simulation per second
     value = a.steps / elapsed
 
     T = 8
@@ -167,7 +167,7 @@ def main():
     p2g = sim.profile_read(fs.PROF.P2G)
     g2p = sim.profile_read(fs.PROF.G2P)
     srt = sim.profile_read(fs.PROF.SORT)
-    mgs = sim.profile_read(fs.PROF.MG_SMOOTH0) if transport is None else {"sampled": 0, "launches": 0}
+    mgs = sim.profile_read(fs.PROF.MG_SMOOTH0)
     # ---- roofline: every kernel class bracketed by hipEvents in the timed region, the one with the largest total
     # time in `roofline`, the others in `roofline_others`.  Algorithmic bytes per launch:
     #   k_p2g         96 B per particle staged once (9 axis weights + 3 velocity components) + 52 B per cell written
@@ -193,15 +193,14 @@ def main():
              "latency-bound (~3 us of it is dispatch), so the HBM fraction is low by construction; the bandwidth-bound kernel of "
              "this path is the dense 256^3 stencil sweep (stencil_microbench)")
     cands = [
-        roof_entry("k_p2g (particle -> grid gather: particle rows staged through LDS, 2 x 2 columns x 64 z per block)", p2g,
+        roof_entry("k_p2g (particle -> grid gather: particle rows staged through LDS, 2 x 2 columns x 62 z cells per block)", p2g,
               lambda c: np_ * 96 + c * 52, "k_p2g",
               "each particle row is staged by the 4 tiles whose 4 x 4 window holds it, so `traffic` is ~4x the algorithmic bytes: "
               "bound by L2/Infinity-Cache -> LDS traffic at ~3.5 TB/s; 4 x 4-column tiles read 2.25x but ran 1.8x slower (16 waves "
               "idle at the chunk barriers), DESIGN.md 3"),
         roof_entry("k_mg_up<float, double, double, 8, 8, 16> (level-0 up leg of the V-cycle: prolongation + two damped-Jacobi sweeps + r.z partials)",
               mgs, lambda c: c * 21.5, "k_mg_up<float, double, double, 8, 8, 16>", small),
-        roof_entry("k_pcg_sq_l<double, true> (PCG: s' = z + beta s, q = A s', partial s'.q)" if transport is None else
-              "k_pcg_s_l + ring exchange + k_pcg_sq_l<double,false>", sq, lambda c: c * 33.0, "k_pcg_sq_l<double, true>", small),
+        roof_entry("k_pcg_sq_l<double, true> (PCG: s' = z + beta s, q = A s', partial s'.q)", sq, lambda c: c * 33.0, "k_pcg_sq_l<double, true>", small),
         roof_entry("k_pcg_xr_l<double> (PCG: x += alpha s, r -= alpha q, partial r.r)", xr, lambda c: c * 49.0, "k_pcg_xr_l<double>", small),
     ]
     cands = [c for c in cands if c]
@@ -218,7 +217,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"water_cube_drop {n}^3 grid, {ppc} particles/cell, {len(pos0)} particles, " + ("pure FLIP" if a.flip_blend >= 1 else f"PIC/FLIP blend {a.flip_blend}"),
                    "grid": n, "ppc": ppc, "particles": int(len(pos0)), "cg_tol": a.cg_tol,
-                   "parallelism": "single GPU" if transport is None else f"x-slab domain decomposition over {world} GPUs, transport {transport}"},
+                   "parallelism": "single GPU" if transport is None else f"particles sharded over {world} x slabs (sort, migration, P2G, G2P, advect), P2G fields all-reduced, pressure block replicated on every GPU; transport {transport}"},
         "roofline": roof,
         "roofline_others": roof_others,
         "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),

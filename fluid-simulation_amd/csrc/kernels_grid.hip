@@ -389,4 +389,44 @@ void launch_zero_fields(hipStream_t st, const ZeroList& z, size_t off, size_t cn
     hipLaunchKernelGGL(k_zero_fields, dim3((unsigned)nb, 11), dim3(256), 0, st, z, off, cnt);
 }
 
+// ---- multi-GPU, replicated solve: the P2G result of every slab gathered onto every rank -----------------------
+// buf = 4 planes of box.cells() doubles [container | u | v | w]; a rank fills the cells of its own x planes [xs, xe) and
+// zeros elsewhere, the SUM all-reduce then assembles the whole box exactly (every cell has one owner, the rest add 0).
+__global__ __launch_bounds__(256) void k_pack_box(Grid g, Box box, int xs, int xe, const float* __restrict__ container,
+                                                  const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ w,
+                                                  double* __restrict__ buf)
+{
+    CellIt it = box_cell(g, box);
+    if (!it.ok) return;
+    const size_t n = (size_t)box.cells(), t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool own = it.ix >= xs && it.ix < xe;
+    buf[t] = own ? (double)container[it.c] : 0.0;
+    buf[n + t] = own ? u[it.c] : 0.0;
+    buf[2 * n + t] = own ? v[it.c] : 0.0;
+    buf[3 * n + t] = own ? w[it.c] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_unpack_box(Grid g, Box box, const double* __restrict__ buf, float* __restrict__ container,
+                                                    double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
+                                                    double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
+{
+    CellIt it = box_cell(g, box);
+    if (!it.ok) return;
+    const size_t n = (size_t)box.cells(), t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    container[it.c] = (float)buf[t];   // exact: a float widened, added to zeros, narrowed
+    const double a = buf[n + t], b = buf[2 * n + t], c = buf[3 * n + t];
+    u[it.c] = a; v[it.c] = b; w[it.c] = c;
+    ub[it.c] = a; vb[it.c] = b; wb[it.c] = c;   // velBeforeUpdate (fluid.cc:1455)
+}
+void launch_pack_box(hipStream_t st, Grid g, Box box, int xs, int xe, const float* container, const double* u, const double* v, const double* w,
+                     double* buf)
+{
+    if (box.cells() > 0) hipLaunchKernelGGL(k_pack_box, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, xs, xe, container, u, v, w, buf);
+}
+void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float* container, double* u, double* v, double* w, double* ub, double* vb,
+                       double* wb)
+{
+    if (box.cells() > 0)
+        hipLaunchKernelGGL(k_unpack_box, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, buf, container, u, v, w, ub, vb, wb);
+}
+
 }  // namespace fl
