@@ -76,6 +76,7 @@ struct fluid_sim {
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
     char *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual (float or double)
+    double mg_wc[4] = {1.25, 1.1, 1.0, 1.0};   // weight of the coarse correction at level 0 / level 1 / deeper kernel levels / inside the tail (FLUID_MG_WC=a,b,c,d)
     bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (FLUID_MG_FP64=1: double)
     double* mg_part = nullptr;    // per-block partials of r.z when a level-0 launch has more blocks than the PCG kernels re-sum
     char* mg_slab = nullptr;      // one allocation behind every mg_* array and Zmg (re-carved each step)
@@ -263,6 +264,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     s->dt = p->max_dt;
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments)
     if (const char* e = getenv("FLUID_MG_FP64")) s->mg_fp32 = atoi(e) == 0;
+    if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
     s->xs = 0;
     s->xe = p->n;
     *out = nullptr;
@@ -642,17 +644,17 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     {
         V off[fluid_sim::MG_MAXL];
         for (int l = tail; l < nl; ++l) off[l] = (V)mg_coef(s, l).off;
-        launch_mg_tail<V>(s->st, nl - tail, (const V*)F(tail), s->mgl + tail, s->mg_cnt + tail, U(tail), off + tail, s->mg_csweeps, ps);
+        launch_mg_tail<V>(s->st, nl - tail, (const V*)F(tail), s->mgl + tail, s->mg_cnt + tail, U(tail), off + tail, s->mg_csweeps, ps, s->mg_wc[3]);
     }
     for (int l = tail - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];
         const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);  // out != u: neighbouring tiles still read u
         if (l == 0) {
             const int tok = prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells());
-            launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps);
+            launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0]);
             prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
         } else {
-            launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps);
+            launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
         }
     }
     HIPCHK(hipGetLastError());

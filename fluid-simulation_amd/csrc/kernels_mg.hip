@@ -24,6 +24,11 @@ namespace fl {
 // quarters of the spectrum (0,2)): |p| <= 0.22 there, < 1 on all of (0,2).  25 PCG iterations per solve at 256^3
 // against 26 for (2/3, 1.2) and 30 for plain (2/3, 2/3).
 constexpr double MG_W1 = 0.5617, MG_W2 = 1.3895;
+// The coarse-grid correction of the two finest levels is over-weighted (k_mg_up's `wc`; fluid_api.hip: 1.25 into level 0,
+// 1.1 into level 1, 1 deeper and inside the tail): the coarse operators are re-discretisations (off-diagonal / 4 per level),
+// not Galerkin products P^T A P, and with cell-centred trilinear P they under-estimate the correction.  A scalar keeps M
+// symmetric.  PCG iterations per solve (tools/wc_sweep.sh): 128^3 23 -> 20, 256^3 25 -> 21, 512^3 31 -> 31 (there any
+// weight on the deeper levels costs iterations: uniform 1.15 gave 20.6 / 22.7 / 33).
 
 // static indices only (a runtime index into a by-value kernel argument goes through scratch)
 template <typename T>
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
 template <typename T, typename F, typename O, int TX, int TY, int TZ>
 __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
                                                O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
-                                               double* __restrict__ part_dot, const PcgState* ps, int gx, int gy)
+                                               double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc)
 {
     constexpr int AX = TX + 4, AY = TY + 4, AZ = TZ + 4;              // v0 = u + P e and the count bytes
     constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2;              // v1
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
             const int I = (x >> 1) + 1, In = (x & 1) ? I + 1 : I - 1;
             const T pe = a * pl[I] + b * pl[In];
             sC[x * AY * AZ + col] = (uint8_t)ca[x];
-            sA[x * AY * AZ + col] = ca[x] ? ua[x] + pe : (T)0;
+            sA[x * AY * AZ + col] = ca[x] ? ua[x] + wc * pe : (T)0;
         }
     }
     __syncthreads();
@@ -476,6 +481,7 @@ struct MgTail {
     int lds_bytes;
     T off[MG_TAIL_MAX];              // off-diagonal of each level; diag = -off * n
     int sweeps;
+    double wc;                       // weight of the coarse corrections inside the tail
 };
 
 // what a thread knows about one of its cells
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
                 const T p = (T)0.75, m = (T)0.25;
                 const T pe = p * p * p * e[0] + p * p * m * (e[ex] + e[ey] + e[ez]) + p * m * m * (e[ex + ey] + e[ex + ez] + e[ey + ez]) +
                              m * m * m * e[ex + ey + ez];
-                if (cell.n) U[cell.c] += pe;
+                if (cell.n) U[cell.c] += (T)a.wc * pe;
             });
             __syncthreads();
             OWN(l, const T v = U[cell.c]; V[cell.c] = v + w2 * si[l][cell.n] * (F[cell.c] - (sd[l][cell.n] * v + off * tail_nb(U, cell.c, sx, sy))););
@@ -740,11 +746,11 @@ void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T*
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps)
+                  double* part_dot, const PcgState* ps, double wc)
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
     hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot, ps,
-                       (int)g.x, (int)g.y);
+                       (int)g.x, (int)g.y, (T)wc);
 }
 
 // LDS footprint of a tail that starts at lv[0] (compact arrays, ring of one cell below and two above — the 4x4x4
@@ -772,9 +778,11 @@ size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem)
 }
 // levels[0..nl) of the tail, f0 = rhs of lv[0] (global layout); result (the correction of lv[0]) in u0
 template <typename T>
-void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps)
+void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps,
+                    double wc)
 {
     MgTail<T> a;
+    a.wc = wc;
     a.nl = nl;
     a.f0 = f0; a.u0 = u0;
     size_t o = 0;
@@ -803,15 +811,15 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
 #define INSTMG(T)                                                                                                                        \
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*); \
     template void launch_mg_up<T, T, T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*,  \
-                                        const PcgState*);                                                                               \
+                                        const PcgState*, double);                                                                               \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                     \
-    template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*);
+    template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*, double);
 INSTMG(double)
 INSTMG(float)
 // level 0 of a single-precision V-cycle inside the double-precision PCG
 template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
                                             MgCoef<float>, const PcgState*);
 template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
-                                                  MgCoef<float>, double*, const PcgState*);
+                                                  MgCoef<float>, double*, const PcgState*, double);
 
 }  // namespace fl
