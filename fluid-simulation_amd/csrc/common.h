@@ -232,7 +232,7 @@ void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const d
 void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, const float* b2, double* part, StepState* ss);
 void launch_zero_step_state(hipStream_t st, StepState* ss, int N);
 struct ZeroList { float* f4[4]; double* f8[7]; };
-void launch_zero_fields(hipStream_t st, const ZeroList& z, size_t off, size_t cnt);
+void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box);
 void launch_pack_box(hipStream_t st, Grid g, Box box, int xs, int xe, const float* container, const double* u, const double* v, const double* w,
                      double* buf);
 void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float* container, double* u, double* v, double* w, double* ub, double* vb,

@@ -64,7 +64,9 @@ struct fluid_sim {
     StepState* h_ss = nullptr;  // pinned
     // boxes
     Box Pb{0, 0, 0, -1, -1, -1}, Rb{0, 0, 0, -1, -1, -1}, Sb{0, 0, 0, -1, -1, -1};
-    int dirty_x0 = 0, dirty_x1 = -1;  // x-slab range holding non-zero field data
+    Box dirty{0, 0, 0, -1, -1, -1};   // box holding non-zero step-field data (zeroed before the next P2G)
+    int flag_x0 = 0, flag_x1 = -1;    // x planes whose flags / indices the last flags pass may have made non-trivial
+    bool flags_valid = false;         // flags / indices outside [flag_x0, flag_x1] are known to be "solid or empty" / -1
     bool sorted = false, have_p2g = false, have_flags = false;
     double dt = 0.1;
     fluid_step_stats_t stats{};
@@ -332,6 +334,7 @@ int fluid_set_solid(fluid_sim_t* s, const uint8_t* solid)
     HIPCHK(hipMemcpy(s->solid, sol.data(), s->ncell, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->flags, sol.data(), s->ncell, hipMemcpyHostToDevice));
     s->have_p2g = s->have_flags = false;
+    s->flags_valid = false;  // the next flags pass sweeps the whole grid
     return FLUID_OK;
 }
 
@@ -430,14 +433,11 @@ static int read_ss(fluid_sim* s)
 
 static int clear_dirty(fluid_sim* s)
 {
-    if (s->dirty_x1 < s->dirty_x0) return FLUID_OK;
-    const size_t N2 = (size_t)s->g.N * s->g.N;
-    const size_t off = (size_t)s->dirty_x0 * N2, cnt = (size_t)(s->dirty_x1 - s->dirty_x0 + 1) * N2;
+    if (box_empty(s->dirty)) return FLUID_OK;
     const ZeroList z = {{s->container, s->rhs, s->diver, s->diver2}, {s->u, s->v, s->w, s->ub, s->vb, s->wb, s->pressure}};
-    launch_zero_fields(s->st, z, off, cnt);
+    launch_zero_fields(s->st, z, s->g, s->dirty);
     HIPCHK(hipGetLastError());
-    s->dirty_x0 = 0;
-    s->dirty_x1 = -1;
+    s->dirty = Box{0, 0, 0, -1, -1, -1};
     return FLUID_OK;
 }
 
@@ -497,8 +497,7 @@ static int phase_p2g(fluid_sim* s)
         launch_p2g(s->st, s->g, s->Rb, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         prof_end(s, FLUID_PROF_P2G, tok);
         HIPCHK(hipGetLastError());
-        s->dirty_x0 = s->Sb.x0;
-        s->dirty_x1 = s->Sb.x1;
+        s->dirty = s->Sb;
     }
     s->have_p2g = true;
     s->have_flags = false;
@@ -747,8 +746,24 @@ static int solve_mg(fluid_sim* s)
 static int phase_flags(fluid_sim* s)
 {
     HIPCHK(hipSetDevice(s->prm.device));
-    launch_flags(s->st, s->g, s->solid, s->container, s->flags, 0, s->g.N - 1);
-    launch_index_scan(s->st, s->g, s->flags, s->indices, s->scan_sums, &s->ss->num_active);
+    // container > 0 only inside the active box, and outside [flag_x0, flag_x1] the flags / indices still hold what an
+    // empty cell gets: sweep the x planes of this box and of the previous pass only (the unknown numbering is a prefix
+    // count in linear order, so a contiguous plane range that holds every fluid cell numbers them like the full sweep)
+    int x0 = 0, x1 = s->g.N - 1;
+    const bool none = box_empty(s->Sb);
+    if (s->flags_valid) {
+        x0 = none ? s->flag_x0 : (s->flag_x1 < s->flag_x0 ? s->Sb.x0 : std::min(s->Sb.x0, s->flag_x0));
+        x1 = none ? s->flag_x1 : (s->flag_x1 < s->flag_x0 ? s->Sb.x1 : std::max(s->Sb.x1, s->flag_x1));
+    }
+    if (x1 >= x0) {
+        launch_flags(s->st, s->g, s->solid, s->container, s->flags, x0, x1);
+        launch_index_scan_range(s->st, s->g, s->flags, s->indices, s->scan_sums, &s->ss->num_active, x0, x1);
+    } else {
+        HIPCHK(hipMemsetAsync(&s->ss->num_active, 0, sizeof(int), s->st));
+    }
+    s->flag_x0 = none ? 0 : s->Sb.x0;
+    s->flag_x1 = none ? -1 : s->Sb.x1;
+    s->flags_valid = true;
     HIPCHK(hipGetLastError());
     int rc = read_ss(s);
     if (rc) return rc;
@@ -1021,8 +1036,7 @@ int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
     // an uploaded field may be non-zero anywhere: widen every box to the whole grid
     const int N = s->g.N;
     s->Rb = s->Sb = Box{0, 0, 0, N - 1, N - 1, N - 1};
-    s->dirty_x0 = 0;
-    s->dirty_x1 = N - 1;
+    s->dirty = s->Rb;
     if (field == FLUID_FIELD_CONTAINER) { s->have_p2g = true; s->have_flags = false; }
     return FLUID_OK;
 }
@@ -1404,8 +1418,7 @@ static int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
         s->stats.box_hi[a] = (&s->Rb.x1)[a];
     }
     if (!box_empty(s->Rb)) {
-        s->dirty_x0 = s->Sb.x0;
-        s->dirty_x1 = s->Sb.x1;
+        s->dirty = s->Sb;
         if (!box_empty(s->Rr)) {
             launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
             int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
@@ -1472,8 +1485,7 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
         s->stats.box_lo[a] = (&s->Rb.x0)[a];
         s->stats.box_hi[a] = (&s->Rb.x1)[a];
     }
-    s->dirty_x0 = s->xs > 0 ? s->xs - 1 : 0;
-    s->dirty_x1 = s->xe < N ? s->xe : N - 1;
+    s->dirty = Box{s->xs > 0 ? s->xs - 1 : 0, 0, 0, s->xe < N ? s->xe : N - 1, N - 1, N - 1};  // my slab + halo planes
     if (!box_empty(s->Rb) && !box_empty(s->Rr)) {
         launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
         int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
