@@ -219,6 +219,7 @@ void launch_unpack_particles(hipStream_t st, long n, const double* pos_aos, cons
 
 // grid
 void launch_exclusive_scan(hipStream_t st, const int* in, int* out, long n, int* block_sums, int* total);
+void launch_sort_tail(hipStream_t st, const int* cell_count, int* cell_start, long c1, long ncell);
 void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total);
 void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags, int x0, int x1);
 void launch_index_scan_range(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total, int x0, int x1);

@@ -68,6 +68,7 @@ struct fluid_sim {
     int flag_x0 = 0, flag_x1 = -1;    // x planes whose flags / indices the last flags pass may have made non-trivial
     bool flags_valid = false;         // flags / indices outside [flag_x0, flag_x1] are known to be "solid or empty" / -1
     bool sorted = false, have_p2g = false, have_flags = false;
+    bool sort_hint = false;   // Pb is the bounding box of THESE particles one step ago (false after an upload)
     double dt = 0.1;
     fluid_step_stats_t stats{};
     // multigrid preconditioner (single-GPU fp64 solve)
@@ -356,6 +357,7 @@ int fluid_upload_particles(fluid_sim_t* s, int64_t n, const double* pos, const d
         HIPCHK(hipStreamSynchronize(s->st));
     }
     s->sorted = s->have_p2g = s->have_flags = false;
+    s->sort_hint = false;
     return FLUID_OK;
 }
 
@@ -441,21 +443,44 @@ static int clear_dirty(fluid_sim* s)
     return FLUID_OK;
 }
 
-static int phase_sort(fluid_sim* s)
+// Buckets of the counting sort: the N^3 cells, then "off the grid", then "dead" (multi-GPU migrants).  Only the x planes
+// [ax0, ax1] are zeroed, counted into and scanned: a particle moves at most one cell per step (dt <= dx / maxSpeed,
+// fluid.cc:992-999), so the planes of the previous bounding box +- 3 hold every particle and every row a P2G window of
+// this step can touch.  The bounding box read back below tells whether that held; if not (first step, new particles)
+// the sort is simply repeated over the whole grid.
+static int sort_pass(fluid_sim* s, int ax0, int ax1)
 {
     const Grid g = s->g;
-    const long ncell = (long)s->ncell;
-    int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
+    const long ncell = (long)s->ncell, n2 = (long)g.N * g.N;
+    const long c0 = (long)ax0 * n2, c1 = (long)(ax1 + 1) * n2;
     launch_zero_step_state(s->st, s->ss, g.N);
-    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 4) * sizeof(int), s->st));
+    HIPCHK(hipMemsetAsync(s->cell_count + c0, 0, (c1 - c0) * sizeof(int), s->st));
+    HIPCHK(hipMemsetAsync(s->cell_count + ncell, 0, 4 * sizeof(int), s->st));
     launch_bin_count(s->st, g, s->np, s->pa.shifted(s->p_off), s->key, s->slot, s->cell_count, s->ipart, s->ss);
-    // buckets: the N^3 cells, then "off the grid", then "dead" (multi-GPU migrants)
-    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
+    launch_exclusive_scan(s->st, s->cell_count + c0, s->cell_start + c0, c1 - c0, s->scan_sums, s->cell_start + c1);
+    launch_sort_tail(s->st, s->cell_count, s->cell_start, c1, ncell);
     launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->pa.shifted(s->p_off).pid, s->order, s->spid);
     launch_bin_rank(s->st, s->np, 0, s->key, s->cell_start, s->order, s->spid, s->order2);  // every position 0..np (cells, off-grid bucket)
     HIPCHK(hipGetLastError());
-    int rc = read_ss(s);
+    return read_ss(s);
+}
+
+static int phase_sort(fluid_sim* s)
+{
+    const Grid g = s->g;
+    int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
+    int ax0 = 0, ax1 = g.N - 1;
+    const bool guess = s->sort_hint && !box_empty(s->Pb);
+    if (guess) {
+        ax0 = std::max(0, s->Pb.x0 - 3);
+        ax1 = std::min(g.N - 1, s->Pb.x1 + 3);
+    }
+    int rc = sort_pass(s, ax0, ax1);
     if (rc) return rc;
+    if (guess && s->h_ss->bbox_max[0] >= 0 && (s->h_ss->bbox_min[0] < std::min(ax0 + 2, s->Pb.x0) || s->h_ss->bbox_max[0] > std::max(ax1 - 2, s->Pb.x1))) {
+        if ((rc = sort_pass(s, 0, g.N - 1))) return rc;   // the guess did not hold
+    }
+    s->sort_hint = true;
     const StepState& h = *s->h_ss;
     if (h.bbox_max[0] < 0) {
         s->Pb = Box{0, 0, 0, -1, -1, -1};
@@ -1649,6 +1674,7 @@ int fluid_upload_particles_ids(fluid_sim_t* s, int64_t n, const double* pos, con
         HIPCHK(hipStreamSynchronize(s->st));
     }
     s->sorted = s->have_p2g = s->have_flags = false;
+    s->sort_hint = false;
     return FLUID_OK;
 }
 

@@ -364,6 +364,19 @@ void launch_zero_step_state(hipStream_t st, StepState* ss, int N)
     hipLaunchKernelGGL(k_zero_step_state, dim3(1), dim3(1), 0, st, ss, N);
 }
 
+// starts of the buckets behind the scanned cell range [.., c1): everything between c1 and the grid's end is empty
+__global__ void k_sort_tail(const int* __restrict__ cell_count, int* __restrict__ cell_start, long c1, long ncell)
+{
+    const int t = cell_start[c1];              // particles in the cells (the scan's total)
+    cell_start[ncell] = t;
+    cell_start[ncell + 1] = t + cell_count[ncell];
+    cell_start[ncell + 2] = t + cell_count[ncell] + cell_count[ncell + 1];
+}
+void launch_sort_tail(hipStream_t st, const int* cell_count, int* cell_start, long c1, long ncell)
+{
+    hipLaunchKernelGGL(k_sort_tail, dim3(1), dim3(1), 0, st, cell_count, cell_start, c1, ncell);
+}
+
 // Zero the cells of `box` in the 4 float and 7 double step fields in ONE launch (11 separate fills cost ~5 us each;
 // whole x planes instead of the box: 430 MB instead of 50 at 256^3).  Static indices into the by-value argument only.
 __global__ __launch_bounds__(256) void k_zero_fields(ZeroList z, Grid g, Box box)
