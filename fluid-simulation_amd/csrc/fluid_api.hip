@@ -1458,7 +1458,8 @@ static int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
         }
         launch_pack_box(s->st, g, s->Rb, s->xs, s->xe, s->container, s->u, s->v, s->w, s->repl_buf);
         HIPCHK(hipGetLastError());
-        if ((rc = comm_allreduce(s, s->repl_buf, (long)need, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+        for (size_t o = 0; o < need; o += (size_t)1 << 30)  // the transport counts in int32
+            if ((rc = comm_allreduce(s, s->repl_buf + o, (int)std::min(need - o, (size_t)1 << 30), FLUID_DT_F64, FLUID_OP_SUM))) return rc;
         launch_unpack_box(s->st, g, s->Rb, s->repl_buf, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         HIPCHK(hipGetLastError());
     }

@@ -362,17 +362,23 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
     if (i < n) {
         const double cx = p.px[i], cy = p.py[i], cz = p.pz[i];
         const int lo = g.lo, hi = g.hi, wlo = g.lo + 2, whi = g.hi - 2;
-        int fcx = (int)round(cx), fcy = (int)round(cy), fcz = (int)round(cz);
-        int minx = fcx - 1 > lo ? fcx - 1 : lo, maxx = fcx + 1 < hi ? fcx + 1 : hi;
-        int miny = fcy - 1 > lo ? fcy - 1 : lo, maxy = fcy + 1 < hi ? fcy + 1 : hi;
-        int minz = fcz - 1 > lo ? fcz - 1 : lo, maxz = fcz + 1 < hi ? fcz + 1 : hi;
-        // the 27 weights are products of 3 x 3 axis values (same values and association as spline()*spline()*spline())
+        const int fcx = (int)round(cx), fcy = (int)round(cy), fcz = (int)round(cz);
+        // The 27 weights are products of 3 x 3 axis values (same values and association as spline()*spline()*spline()).
+        // A cell takes part iff it is on the grid (clamp, :216-221) and within W (:237) — per axis: its coordinate lies in
+        // [wlo, whi].  An axis value that fails gets weight 0 and a clamped (readable) index, so the 27-cell loop has no
+        // branches: the skipped cells add exactly +0 to every sum.
         double wx[3], wy[3], wz[3];
+        int ox[3], oy[3], oz[3];
+        const int N = g.N;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            wx[d] = spline(cx - (double)(fcx - 1 + d));
-            wy[d] = spline(cy - (double)(fcy - 1 + d));
-            wz[d] = spline(cz - (double)(fcz - 1 + d));
+            const int ax = fcx - 1 + d, ay = fcy - 1 + d, az = fcz - 1 + d;
+            wx[d] = (ax >= wlo && ax <= whi) ? spline(cx - (double)ax) : 0.0;
+            wy[d] = (ay >= wlo && ay <= whi) ? spline(cy - (double)ay) : 0.0;
+            wz[d] = (az >= wlo && az <= whi) ? spline(cz - (double)az) : 0.0;
+            ox[d] = (min(max(ax, lo), hi) - lo) * N * N;   // N <= 1024: N^3 fits an int
+            oy[d] = (min(max(ay, lo), hi) - lo) * N;
+            oz[d] = min(max(az, lo), hi) - lo;
         }
         double weight = 0, d0 = 0, d1 = 0, d2 = 0, q0 = 0, q1 = 0, q2 = 0;
 #pragma unroll
@@ -381,20 +387,16 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
             for (int yi = 0; yi < 3; ++yi)
 #pragma unroll
                 for (int zi = 0; zi < 3; ++zi) {
-                    const int x = fcx - 1 + xi, y = fcy - 1 + yi, z = fcz - 1 + zi;
-                    if (x < minx || x > maxx || y < miny || y > maxy || z < minz || z > maxz) continue;  // clamp to the grid (:216-221)
-                    if (x >= wlo && x <= whi && y >= wlo && y <= whi && z >= wlo && z <= whi) {  // :237
-                        const size_t c = g.idx(x - lo, y - lo, z - lo);
-                        const double cw = wx[xi] * wy[yi] * wz[zi];
-                        weight += cw;
-                        d0 += dcx[c] * cw;
-                        d1 += dcy[c] * cw;
-                        d2 += dcz[c] * cw;
-                        if (pcx) {  // block-uniform
-                            q0 += pcx[c] * cw;
-                            q1 += pcy[c] * cw;
-                            q2 += pcz[c] * cw;
-                        }
+                    const int c = ox[xi] + oy[yi] + oz[zi];
+                    const double cw = wx[xi] * wy[yi] * wz[zi];
+                    weight += cw;
+                    d0 += dcx[c] * cw;
+                    d1 += dcy[c] * cw;
+                    d2 += dcz[c] * cw;
+                    if (pcx) {  // block-uniform
+                        q0 += pcx[c] * cw;
+                        q1 += pcy[c] * cw;
+                        q2 += pcz[c] * cw;
                     }
                 }
         double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
