@@ -167,7 +167,7 @@ def main():
     p2g = sim.profile_read(fs.PROF.P2G)
     g2p = sim.profile_read(fs.PROF.G2P)
     srt = sim.profile_read(fs.PROF.SORT)
-    mgs = sim.profile_read(fs.PROF.MG_SMOOTH0)
+    mgs = sim.profile_read(fs.PROF.MG_UP0)
     # ---- roofline: every kernel class bracketed by hipEvents in the timed region, the one with the largest total
     # time in `roofline`, the others in `roofline_others`.  Algorithmic bytes per launch:
     #   k_p2g         96 B per particle staged once (9 axis weights + 3 velocity components) + 52 B per cell written

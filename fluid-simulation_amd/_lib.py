@@ -46,7 +46,7 @@ class FIELD:
 
 
 class PROF:
-    PCG_SQ, PCG_XR, P2G, G2P, SORT, SOLVE, MG_SMOOTH0 = range(7)
+    PCG_SQ, PCG_XR, P2G, G2P, SORT, SOLVE, MG_UP0 = range(7)
 
 
 # every symbol include/fluid_hip.h declares: (name, restype, argtypes)

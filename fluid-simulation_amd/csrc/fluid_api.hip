@@ -674,9 +674,9 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         const MLevel& m = s->mgl[l];
         const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);  // out != u: neighbouring tiles still read u
         if (l == 0) {
-            const int tok = prof_begin(s, FLUID_PROF_MG_SMOOTH0, (double)s->Rb.cells());
+            const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)s->Rb.cells());
             launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0]);
-            prof_end(s, FLUID_PROF_MG_SMOOTH0, tok);
+            prof_end(s, FLUID_PROF_MG_UP0, tok);
         } else {
             launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
         }

@@ -161,7 +161,7 @@ int fluid_stencil_apply(fluid_sim_t* s, int reps, int box, float* avg_ms);
 #define FLUID_PROF_G2P 3
 #define FLUID_PROF_SORT 4
 #define FLUID_PROF_SOLVE 5       /* whole solve                              */
-#define FLUID_PROF_MG_SMOOTH0 6  /* level-0 damped-Jacobi sweep of the V-cycle */
+#define FLUID_PROF_MG_UP0 6  /* level-0 up leg of the V-cycle (k_mg_up)      */
 #define FLUID_PROF_COUNT 7
 /* every `sample_every`-th launch of each class is bracketed by an event pair (0 = off). */
 int fluid_profile_enable(fluid_sim_t* s, int sample_every);

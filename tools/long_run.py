@@ -21,7 +21,7 @@ sim.profile_reset(); sim.profile_enable(1)
 for i in range(20):
     s = sim.step()
 sim.profile_enable(0)
-for name in ("SORT", "P2G", "G2P", "SOLVE", "PCG_SQ", "PCG_XR", "MG_SMOOTH0"):
+for name in ("SORT", "P2G", "G2P", "SOLVE", "PCG_SQ", "PCG_XR", "MG_UP0"):
     r = sim.profile_read(getattr(fs.PROF, name))
     if r["sampled"]:
         print(f"  {name:10s} launches/step {r['launches']/20:7.1f}  avg {r['total_ms']/r['sampled']:8.3f} ms  total/step {r['total_ms']/20:8.3f} ms")
