@@ -718,11 +718,11 @@ static int solve_mg(fluid_sim* s)
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
     long it = 0;
-    // Batching of the convergence poll.  Iteration counts barely change from one solve to the next, so the first batch
-    // runs (previous count - 1) iterations without looking; after that the state is polled every 2 iterations.
-    // Kernels of a finished solve exit at their first instruction, but each still costs a launch (~2.5 us x 19 per
-    // iteration): polling every 4 one batch behind wasted ~7 iteration-sets per solve.
-    long batch = s->mg_last_iters > 5 ? s->mg_last_iters - 1 : 4;
+    // Batching of the convergence poll.  Iteration counts barely change from one solve to the next (Eigen's count i means
+    // i + 1 bodies ran), so the first batch runs exactly the bodies the previous solve needed without looking — one poll
+    // (head-only launch + 40-byte copy + stream sync, ~50 us) per solve when the count repeats; after that every body is
+    // polled.  Kernels of a finished solve exit at their first instruction, but each still costs a launch.
+    long batch = s->mg_last_iters > 5 ? s->mg_last_iters + 1 : 4;
     bool done = false;
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
@@ -752,7 +752,7 @@ static int solve_mg(fluid_sim* s)
             s->h_ps[1].iters -= 1;     // the head-only launch counted a body that the next real launch counts again
             HIPCHK(hipMemcpyAsync(s->ps, &s->h_ps[1], sizeof(PcgState), hipMemcpyHostToDevice, s->st));
         }
-        batch = 2;
+        batch = 1;
     }
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
