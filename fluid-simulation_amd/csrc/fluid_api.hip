@@ -68,6 +68,7 @@ struct fluid_sim {
     int flag_x0 = 0, flag_x1 = -1;    // x planes whose flags / indices the last flags pass may have made non-trivial
     bool flags_valid = false;         // flags / indices outside [flag_x0, flag_x1] are known to be "solid or empty" / -1
     bool sorted = false, have_p2g = false, have_flags = false;
+    long n_out = 0;           // particles whose base cell is off the grid (last bucket of the sorted array), from the last sort
     bool sort_hint = false;   // Pb is the bounding box of THESE particles one step ago (false after an upload)
     double dt = 0.1;
     fluid_step_stats_t stats{};
@@ -481,6 +482,7 @@ static int phase_sort(fluid_sim* s)
         if ((rc = sort_pass(s, 0, g.N - 1))) return rc;   // the guess did not hold
     }
     s->sort_hint = true;
+    s->n_out = s->h_ss->n_out;
     const StepState& h = *s->h_ss;
     if (h.bbox_max[0] < 0) {
         s->Pb = Box{0, 0, 0, -1, -1, -1};
@@ -949,7 +951,15 @@ static int phase_flip_advect(fluid_sim* s)
     if (rcp) return rcp;
     if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    launch_g2p(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    if (s->sorted && s->p_off == 0) {
+        // sorted by base cell and not moved since: gather through LDS tiles; the off-grid bucket (the array's tail) only has
+        // its speeds counted
+        launch_g2p_tiled(s->st, s->g, s->Pb, s->pa, s->cell_start, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+        if (s->n_out > 0)
+            launch_g2p(s->st, s->g, s->n_out, s->pa.shifted(s->np - s->n_out), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    } else {
+        launch_g2p(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    }
     prof_end(s, FLUID_PROF_G2P, tok);
     launch_advect(s->st, s->g, s->np, s->pa.shifted(s->p_off), s->flags, s->prm.max_dt, s->prm.dx, s->ss);
     HIPCHK(hipGetLastError());
