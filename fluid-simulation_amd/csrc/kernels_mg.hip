@@ -2,18 +2,22 @@
 //
 // The reference preconditions with Eigen's IncompleteCholesky (fluid.cc:1352) — serial triangular
 // solves.  Any SPD preconditioner leaves the converged solution of A p = b unchanged; this one makes
-// the iteration count independent of the grid size (27-28 at 128^3 and 256^3 against 308 / 562 for
-// Jacobi, tools/mg_prototype.py).  Structure (after McAdams, Sifakis, Teran 2010, restated):
+// the iteration count nearly independent of the grid size (20 / 21 / 31 at 128^3 / 256^3 / 512^3 against
+// 308 / 562 at the first two for Jacobi, tools/mg_prototype.py).  Structure (after McAdams, Sifakis, Teran 2010,
+// restated):
 //   * levels: cells coarsened 2x2x2; a coarse cell is AIR (Dirichlet, p=0) if any child is air,
 //     SOLID (Neumann) if all children are solid, else FLUID; operator = the same 7-point form with
 //     the off-diagonal divided by 4 per level, diagonal = (#non-solid neighbours) x |off|;
-//   * smoother: damped Jacobi (omega 2/3), 2 sweeps before and 2 after (symmetric -> M is SPD);
-//   * transfer: cell-centred trilinear prolongation P (weights 3/4,1/4 per axis), restriction P^T/8;
+//   * smoother: two damped-Jacobi sweeps before and two after the coarse correction, weights in
+//     reversed order (symmetric -> M is SPD);
+//   * transfer: cell-centred trilinear prolongation P (weights 3/4,1/4 per axis), restriction P^T/8,
+//     the correction into the two finest levels over-weighted;
 //   * coarsest level (<= 8^3): red-black Gauss-Seidel in LDS by one block, forward then reversed.
-// Level 0 lives in the solver's box-local layout (LBox); coarser levels use the same indexing
-// scheme (MLevel).  Only unknown cells are ever written (every array is zeroed once per step), so a mostly-air
-// active box costs one count byte per air cell.  All kernels are one thread per cell with neighbours read through L1/L2: levels
-// >= 1 are tiny and launch-bound; level 0 costs ~4 stencil sweeps per cycle.
+// Level 0 lives in the solver's box-local layout (LBox); coarser levels use the same indexing scheme
+// (MLevel).  Only unknown cells are ever written (every array is zeroed once per step).  The cycle is
+// latency-bound, so each level costs ONE kernel per leg (k_mg_down, k_mg_up: LDS tiles that recompute their
+// halo) and all levels of <= 4 k cells run inside one block (k_mg_tail); it computes in float inside the
+// double PCG (fluid_api.hip, mg_vcycle_t).
 #include "common.h"
 
 namespace fl {
