@@ -701,21 +701,19 @@ static int solve_mg(fluid_sim* s)
     T* R = (T*)s->R;
     T* Q = (T*)s->Q;
     T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
-    T* Z = nullptr;  // set below
+    T* Z = (T*)s->Zmg;  // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
     const uint8_t* cnt = s->cntL;
     const Coef<T> cf = make_coef<T>(s);
     const double tol = s->prm.cg_tol;
     long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
     if (max_it < 1) max_it = 1;
     const double cells = (double)s->Rb.cells();
-    // r.z partials come from the last level-0 sweep, one per block: re-summing them in every block of the PCG kernels
-    // costs every block ~2 x n loads from L2: above 512 values one extra 1-block launch folds them into a single value
-    const int sparse = (double)s->stats.num_active < 0.4 * (double)L.cells();
+    const int sparse = (double)s->stats.num_active < 0.4 * (double)L.cells();  // mostly-air box: SQ / XR test the counts before loading
+    // r.z partials come from the level-0 up leg, one per block; every block of the PCG kernels re-sums them from L2.
+    // Above 1024 values one extra 1-block launch folds them into a single value first.
     const int n_rz_raw = mg_rz_blocks(s);
     const bool fold = n_rz_raw > 1024;
     const int n_rz = fold ? 1 : n_rz_raw;
-    // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
-    Z = (T*)s->Zmg;
     int rc;
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
