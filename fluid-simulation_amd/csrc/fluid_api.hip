@@ -949,9 +949,11 @@ static int phase_flip_advect(fluid_sim* s)
     if (rcp) return rcp;
     if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    if (s->sorted && s->p_off == 0) {
-        // sorted by base cell and not moved since: gather through LDS tiles; the off-grid bucket (the array's tail) only has
-        // its speeds counted
+    if (s->sorted && s->p_off == 0 && (double)s->np >= 4.0 * (double)s->Pb.cells()) {
+        // sorted by base cell and not moved since, and the bounding box is densely filled (the falling cube: 8 per cell;
+        // the splash: 0.7 per cell with up to 10^4 in one — there one block per tile is badly balanced and the
+        // thread-per-particle kernel is 2.8x faster): gather through LDS tiles; the off-grid bucket (the array's tail)
+        // only has its speeds counted
         launch_g2p_tiled(s->st, s->g, s->Pb, s->pa, s->cell_start, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
         if (s->n_out > 0)
             launch_g2p(s->st, s->g, s->n_out, s->pa.shifted(s->np - s->n_out), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
