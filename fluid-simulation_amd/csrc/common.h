@@ -201,7 +201,7 @@ void launch_bin_scatter(hipStream_t st, long n, const int* key, const int* slot,
                          uint32_t* spid);
 void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, const int* cell_start, const int* order, const uint32_t* spid,
                      int* order2);
-void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst);
+void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst, double* w = nullptr, long wstride = 0);
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                 float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);

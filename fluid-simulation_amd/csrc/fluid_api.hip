@@ -495,7 +495,7 @@ static int phase_sort(fluid_sim* s)
     } else {
         s->Rb = s->Sb = s->Pb;
     }
-    launch_reorder(s->st, s->np, s->order2, s->pa.shifted(s->p_off), s->pb);
+    launch_reorder(s->st, s->np, s->order2, s->pa.shifted(s->p_off), s->pb, s->pw, s->cap);  // + the P2G axis weights
     HIPCHK(hipGetLastError());
     std::swap(s->pa, s->pb);
     s->p_off = 0;
@@ -519,8 +519,7 @@ static int phase_p2g(fluid_sim* s)
         s->stats.box_hi[a] = (&s->Rb.x1)[a];
     }
     if (!box_empty(s->Rb)) {
-        launch_weights(s->st, s->np, s->pa, s->pw, s->cap);
-        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rb.cells());   // k_p2g alone (bench.py's roofline of the largest kernel)
+        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rb.cells());   // k_p2g alone (the weights came with the sort's reorder pass)
         launch_p2g(s->st, s->g, s->Rb, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         prof_end(s, FLUID_PROF_P2G, tok);
         HIPCHK(hipGetLastError());

@@ -150,14 +150,31 @@ __global__ __launch_bounds__(256) void k_bin_rank(long n_pos, long pos0, const i
     order2[a + rank] = src;
 }
 
-__global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__ order, Particles s, Particles d)
+// fluid.cc:22-37 at the three cells base-1, base, base+1 of each axis (see k_p2g): w[(axis * 3 + d) * stride + j]
+__device__ __forceinline__ void axis_weights(double px, double py, double pz, double* __restrict__ w, long stride, long j)
+{
+    const double q[3] = {px, py, pz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int b = (int)round(q[a]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w[(a * 3 + d) * stride + j] = spline(q[a] - (double)(b - 1 + d));
+    }
+}
+
+// sorted order <- unsorted; w != nullptr: the 9 P2G axis weights of every particle are written on the way (the positions
+// are in registers here anyway: saves k_weights' pass over them)
+__global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__ order, Particles s, Particles d, double* __restrict__ w,
+                                                 long wstride)
 {
     long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     int i = order[j];
-    d.px[j] = s.px[i]; d.py[j] = s.py[i]; d.pz[j] = s.pz[i];
+    const double px = s.px[i], py = s.py[i], pz = s.pz[i];
+    d.px[j] = px; d.py[j] = py; d.pz[j] = pz;
     d.vx[j] = s.vx[i]; d.vy[j] = s.vy[i]; d.vz[j] = s.vz[i];
     d.pid[j] = s.pid[i];
+    if (w) axis_weights(px, py, pz, w, wstride, j);
 }
 
 // ---- particle -> grid (gather form) --------------------------------------------------------
@@ -206,13 +223,7 @@ __global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __
 {
     long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const double q[3] = {p.px[j], p.py[j], p.pz[j]};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int b = (int)round(q[a]);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) w[(a * 3 + d) * stride + j] = spline(q[a] - (double)(b - 1 + d));
-    }
+    axis_weights(p.px[j], p.py[j], p.pz[j], w, stride, j);
 }
 
 // Lane L of a wave stands for the z-cell zc = tz0 - 1 + L of its column twice over: as a SOURCE cell it walks its own
@@ -687,9 +698,9 @@ void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, cons
 {
     if (n_pos > 0) hipLaunchKernelGGL(k_bin_rank, dim3(nblk(n_pos)), dim3(256), 0, st, n_pos, pos0, key, cell_start, order, spid, order2);
 }
-void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst)
+void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst, double* w, long wstride)
 {
-    if (n > 0) hipLaunchKernelGGL(k_reorder, dim3(nblk(n)), dim3(256), 0, st, n, order, src, dst);
+    if (n > 0) hipLaunchKernelGGL(k_reorder, dim3(nblk(n)), dim3(256), 0, st, n, order, src, dst, w, wstride);
 }
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
 {
