@@ -3,7 +3,7 @@
 // The reference preconditions with Eigen's IncompleteCholesky (fluid.cc:1352) — serial triangular
 // solves.  Any SPD preconditioner leaves the converged solution of A p = b unchanged; this one makes
 // the iteration count nearly independent of the grid size (20 / 21 / 31 at 128^3 / 256^3 / 512^3 against
-// 308 / 562 at the first two for Jacobi, tools/mg_prototype.py).  Structure (after McAdams, Sifakis, Teran 2010,
+// 308 / 562 at the first two for Jacobi, tests/experiments/mg_prototype.py).  Structure (after McAdams, Sifakis, Teran 2010,
 // restated):
 //   * levels: cells coarsened 2x2x2; a coarse cell is AIR (Dirichlet, p=0) if any child is air,
 //     SOLID (Neumann) if all children are solid, else FLUID; operator = the same 7-point form with

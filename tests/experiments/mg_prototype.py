@@ -9,11 +9,11 @@ before the HIP kernels were written.  It assembles real pressure systems with th
   256^3 scene (700k unknowns): Jacobi 562 | V(2,2) Jacobi w=(2/3,2/3) 27 | w=(2/3,1.2) 22 | RBGS nu=2 19
   per-slab V-cycle (block preconditioner, multi-GPU): 83 / 118 / 133 iterations for 2 / 4 / 8 slabs
 
-Run: python tools/mg_prototype.py [n]   (n = 128 by default; 256 takes a few minutes)
+Run: python tests/experiments/mg_prototype.py [n]   (n = 128 by default; 256 takes a few minutes)
 """
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as entry
 fs = entry.load_package(); oracle = entry.load_oracle()
 
