@@ -186,11 +186,14 @@ class RcclComm:
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self.path = (path if os.path.exists(path) else "").encode()
         idbuf = (C.c_uint8 * 128)()
-        if self.rank == 0:
-            if lib.fluid_rccl_unique_id(self.path, idbuf) != 0:
-                raise RuntimeError("fluid_rccl_unique_id: " + lib.fluid_rccl_last_error().decode())
         obj = [bytes(idbuf)]
+        if self.rank == 0 and lib.fluid_rccl_unique_id(self.path, idbuf) != 0:
+            obj = [None]   # every rank must leave the broadcast below: the failure travels with it
+        elif self.rank == 0:
+            obj = [bytes(idbuf)]
         dist.broadcast_object_list(obj, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        if obj[0] is None:
+            raise RuntimeError("fluid_rccl_unique_id failed on rank 0: " + lib.fluid_rccl_last_error().decode())
         self.struct = FluidComm()
         idb = (C.c_uint8 * 128).from_buffer_copy(obj[0])
         if lib.fluid_rccl_comm_create(self.path, idb, self.rank, self.size, C.byref(self.struct)) != 0:
