@@ -36,13 +36,32 @@
 
 namespace {
 
+// buffered stream to the file (a 512^3 grid is 0.6 GB: nothing is held in memory); offsets are patched by seeking back
 struct Out {
-    std::vector<char> b;
-    void raw(const void* p, size_t n) { const char* c = (const char*)p; b.insert(b.end(), c, c + n); }
+    FILE* f = nullptr;
+    size_t at = 0;
+    bool ok = true;
+    std::vector<char> buf;
+    void flush()
+    {
+        if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) ok = false;
+        buf.clear();
+    }
+    void raw(const void* p, size_t n)
+    {
+        const char* c = (const char*)p;
+        buf.insert(buf.end(), c, c + n);
+        at += n;
+        if (buf.size() >= (size_t)8 << 20) flush();
+    }
     template <typename T> void put(T v) { raw(&v, sizeof(T)); }
     void str(const std::string& s) { put<uint32_t>((uint32_t)s.size()); raw(s.data(), s.size()); }   // util/Name.h:57-63
-    size_t pos() const { return b.size(); }
-    void patch64(size_t at, int64_t v) { memcpy(&b[at], &v, 8); }
+    size_t pos() const { return at; }
+    void patch64(size_t where, int64_t v)
+    {
+        flush();
+        if (fseek(f, (long)where, SEEK_SET) != 0 || fwrite(&v, 1, 8, f) != 8 || fseek(f, 0, SEEK_END) != 0) ok = false;
+    }
 };
 
 inline int floor_to(int v, int m) { return v & ~(m - 1); }  // origin of the node of size m (power of two) that holds v
@@ -152,6 +171,8 @@ extern "C" int fluid_write_vdb(const char* path, int32_t n, int32_t n_grids, con
     for (int k = 0; k < n_grids; ++k)
         if (!grids[k]) return FLUID_ERR_ARG;
     Out o;
+    o.f = fopen(path, "wb");
+    if (!o.f) return FLUID_ERR_ARG;
     // ---- header (io/Archive.cc:939-971) ----
     o.put<int64_t>(0x56444220);            // OPENVDB_MAGIC, version.h:83
     o.put<uint32_t>(224);                  // OPENVDB_FILE_VERSION, version.h:96
@@ -207,9 +228,7 @@ extern "C" int fluid_write_vdb(const char* path, int32_t n, int32_t n_grids, con
         write_tree(o, g, true);
         o.patch64(off + 16, (int64_t)o.pos());  // end position
     }
-    FILE* f = fopen(path, "wb");
-    if (!f) return FLUID_ERR_ARG;
-    const size_t w = fwrite(o.b.data(), 1, o.b.size(), f);
-    const int rc = fclose(f);
-    return (w == o.b.size() && rc == 0) ? FLUID_OK : FLUID_ERR_ARG;
+    o.flush();
+    const int rc = fclose(o.f);
+    return (o.ok && rc == 0) ? FLUID_OK : FLUID_ERR_ARG;
 }
