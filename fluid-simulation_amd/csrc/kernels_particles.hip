@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
 // block wait at the chunk barriers while at most 9 of them consume the staged row.
 constexpr int P2G_T = 2;
 constexpr int P2G_THREADS = P2G_T * P2G_T * 64;
-constexpr int P2G_CH = 320;  // particles staged per chunk: 12 arrays x 8 B x 320 = 30 KB of LDS
+constexpr int P2G_CH = 512;  // particles staged per chunk (two per thread): 12 arrays x 8 B x 520 = 50 KB of LDS, 3 blocks per CU.
+                             // Measured k_p2g at 256^3: 192: 0.91 ms, 256: 0.82, 320: 0.49, 384: 0.48, 448: 0.55, 512: 0.41, 576: 0.51
 // LDS slot of staged particle k: lane z reads particle a_z + t with a_z growing by ~8 (particles per cell) from
 // lane to lane; splitting by k mod 8 keeps neighbouring lanes on neighbouring slots.
 constexpr int P2G_SEG = P2G_CH / 8 + 1;
@@ -232,28 +233,29 @@ __global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __
 // (lanes 1..62) it then collects the partials of the sources zc-1, zc, zc+1 with two lane shifts per value.  (The first
 // version let every target lane walk the particles of its three source cells itself: 18 LDS reads per particle and
 // three times the trips.)  Sum order per target: rows ascending (x,y), sources ascending z, particles ascending.
-constexpr int P2G_ZT = 62;  // target cells per wave: lanes 0 and 63 are sources only
+constexpr int P2G_ZT = 62;  // most target cells a wave takes (lanes 0 and 63 are sources only); the launcher splits nz evenly
 
 __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
                                              const int* __restrict__ cell_start, const uint8_t* __restrict__ flags,
                                              float* __restrict__ container, double* __restrict__ u, double* __restrict__ v,
-                                             double* __restrict__ w, double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
+                                             double* __restrict__ w, double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb,
+                                             int zt)
 {
     __shared__ double sw[9][P2G_LDS];   // wx0..2, wy0..2, wz0..2
     __shared__ double sv[3][P2G_LDS];   // vx, vy, vz
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int N = g.N;
-    const int ntz = (box.nz() + P2G_ZT - 1) / P2G_ZT, nty = (box.ny() + P2G_T - 1) / P2G_T;
+    const int ntz = (box.nz() + zt - 1) / zt, nty = (box.ny() + P2G_T - 1) / P2G_T;  // zt <= P2G_ZT target cells per wave
     const int tile = blockIdx.x;
     const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
-    const int tx0 = box.x0 + tx * P2G_T, ty0 = box.y0 + ty * P2G_T, tz0 = box.z0 + tz * P2G_ZT;
+    const int tx0 = box.x0 + tx * P2G_T, ty0 = box.y0 + ty * P2G_T, tz0 = box.z0 + tz * zt;
     const int ix = tx0 + wv / P2G_T, iy = ty0 + wv % P2G_T, zc = tz0 - 1 + lane;
     const bool col = ix <= box.x1 && iy <= box.y1;                 // my column is in the box
     const bool src = col && zc >= 0 && zc < N;                     // my cell exists: it may hold particles
-    const bool tgt = col && lane >= 1 && lane <= P2G_ZT && zc <= box.z1;
+    const bool tgt = col && lane >= 1 && lane <= zt && zc <= box.z1;
     const size_t c = tgt ? g.idx(ix, iy, zc) : 0;
     const bool live = tgt && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
-    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + P2G_ZT < N - 1 ? tz0 + P2G_ZT : N - 1;
+    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + zt < N - 1 ? tz0 + zt : N - 1;
     float wf = 0.0f;
     double su = 0, sv_ = 0, sw_ = 0;
     for (int rx = tx0 - 1; rx <= tx0 + P2G_T; ++rx) {
@@ -709,8 +711,11 @@ void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                 float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
 {
-    const unsigned nt = (unsigned)(((box.nx() + P2G_T - 1) / P2G_T) * ((box.ny() + P2G_T - 1) / P2G_T) * ((box.nz() + P2G_ZT - 1) / P2G_ZT));
-    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb);
+    // z is cut into equal pieces of at most P2G_ZT cells (89 cells: 45 + 44, not 62 + 27): balanced tiles, and at 8 particles
+    // per cell a row segment of <= 62 cells fits one staged chunk
+    const int ntz = (box.nz() + P2G_ZT - 1) / P2G_ZT, zt = (box.nz() + ntz - 1) / ntz;
+    const unsigned nt = (unsigned)(((box.nx() + P2G_T - 1) / P2G_T) * ((box.ny() + P2G_T - 1) / P2G_T) * ntz);
+    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb, zt);
 }
 // pb = bounding box of the particles' base cells (after the sort, positions untouched since)
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,
