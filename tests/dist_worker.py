@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--vel", type=float, default=0.0)
     ap.add_argument("--uniform", action="store_true", help="uniform slabs instead of equal particle counts")
+    ap.add_argument("--blend", type=float, default=1.0, help="PIC/FLIP blend (1 = pure FLIP)")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -51,7 +52,7 @@ def main():
         comm = fd.RcclComm()
     else:
         comm = fd.TorchComm(mode=a.mode, device=torch.device("cuda", dev))
-    sim = fd.DistFluidSim(a.n, bounds, comm, device=dev)
+    sim = fd.DistFluidSim(a.n, bounds, comm, device=dev, flip_blend=a.blend)
     sim.upload_global(pos, vel)
     stats = []
     for _ in range(a.steps):

@@ -24,14 +24,16 @@ def run_dist(world, n, ppc, steps, tmp_path, extra=(), mode="staged"):
     return np.load(out)
 
 
-@pytest.mark.parametrize("world,n,ppc,steps,extra", [(2, 32, 4, 4, ()), (3, 40, 4, 3, ()), (2, 32, 4, 6, ("--uniform", "--vel", "3.0"))])
+@pytest.mark.parametrize("world,n,ppc,steps,extra", [(2, 32, 4, 4, ()), (3, 40, 4, 3, ()), (2, 32, 4, 6, ("--uniform", "--vel", "3.0")),
+                                                    (2, 32, 4, 4, ("--vel", "1.0", "--blend", "0.9"))])
 def test_dist_matches_single(fs, tmp_path, world, n, ppc, steps, extra):
     d = run_dist(world, n, ppc, steps, tmp_path, extra)
     pos = fs.water_cube_drop(n, ppc, seed=0)
     vel = None
     if "--vel" in extra:
         vel = np.random.default_rng(1).standard_normal(pos.shape) * float(extra[extra.index("--vel") + 1])
-    sim = fs.FluidSim(n=n)
+    blend = float(extra[extra.index("--blend") + 1]) if "--blend" in extra else 1.0
+    sim = fs.FluidSim(n=n, flip_blend=blend)
     sim.upload_particles(pos, vel)
     st = [sim.step() for _ in range(steps)]
     p, v = sim.download_particles()
