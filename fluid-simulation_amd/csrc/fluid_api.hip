@@ -659,7 +659,8 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     auto R = [&](int l) { return (V*)s->mg_r[l]; };
     for (int l = 0; l < tail; ++l) {
         const MLevel& m = s->mgl[l];
-        const bool fold = l > 0;  // restriction inside the down kernel (halo 3): not at level 0, where 5x halo reads cost more than a launch
+        // restriction inside the down kernel (halo 3): not at a big level 0, where 5x halo reads cost more than a launch
+        const bool fold = l > 0 || (long)m.dx * m.dy * m.dz <= 200000;
         V* fc = fold ? F(l + 1) : nullptr;
         const uint8_t* cc = fold ? s->mg_cnt[l + 1] : nullptr;
         if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps);
