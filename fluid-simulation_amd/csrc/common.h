@@ -204,7 +204,7 @@ void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, cons
 void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst, double* w = nullptr, long wstride = 0);
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
-                float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
+                double* part, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,
                       const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss);
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,

@@ -60,6 +60,8 @@ struct fluid_sim {
     uint32_t* spid = nullptr;   // original ids in sorted-position order (per-cell rank pass)
     double *stage_pos = nullptr, *stage_vel = nullptr;
     double* pw = nullptr;  // 9 axis weights per particle, SoA with stride cap
+    double* p2g_part = nullptr;  // k_p2g_rows' three x-plane partials: 12 doubles per cell of the P2G box (grown on demand)
+    size_t p2g_part_cap = 0;
     StepState* ss = nullptr;
     StepState* h_ss = nullptr;  // pinned
     // boxes
@@ -188,6 +190,7 @@ static void free_particles(fluid_sim* s)
 static int alloc_particles(fluid_sim* s, long n)
 {
     if (n <= s->cap) return FLUID_OK;
+    n = (n + 1) & ~1L;  // even: k_p2g_rows reads the particle arrays 16 B at a time
     free_particles(s);
     for (Particles* p : {&s->pa, &s->pb}) {
         HIPCHK(dalloc(&p->px, n)); HIPCHK(dalloc(&p->py, n)); HIPCHK(dalloc(&p->pz, n));
@@ -236,7 +239,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->repl_buf, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
+                    s->pcx, s->pcy, s->pcz, s->repl_buf, s->p2g_part, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -504,6 +507,19 @@ static int phase_sort(fluid_sim* s)
     return FLUID_OK;
 }
 
+// particle -> grid over box (k_p2g_rows + k_p2g_combine)
+static int run_p2g(fluid_sim* s, const Box& box)
+{
+    const size_t need = (size_t)12 * box.cells();
+    if (need > s->p2g_part_cap) {
+        if (s->p2g_part) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->p2g_part); s->p2g_part = nullptr; }
+        HIPCHK(hipMalloc((void**)&s->p2g_part, (need + need / 4) * sizeof(double)));
+        s->p2g_part_cap = need + need / 4;
+    }
+    launch_p2g(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->p2g_part, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+    return FLUID_OK;
+}
+
 static int phase_p2g(fluid_sim* s)
 {
     HIPCHK(hipSetDevice(s->prm.device));
@@ -520,8 +536,9 @@ static int phase_p2g(fluid_sim* s)
     }
     if (!box_empty(s->Rb)) {
         int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rb.cells());   // k_p2g alone (the weights came with the sort's reorder pass)
-        launch_p2g(s->st, s->g, s->Rb, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        rc = run_p2g(s, s->Rb);
         prof_end(s, FLUID_PROF_P2G, tok);
+        if (rc) return rc;
         HIPCHK(hipGetLastError());
         s->dirty = s->Sb;
     }
@@ -1457,8 +1474,9 @@ static int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
         if (!box_empty(s->Rr)) {
             launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
             int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
-            launch_p2g(s->st, g, s->Rr, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+            int rc = run_p2g(s, s->Rr);
             prof_end(s, FLUID_PROF_P2G, tok);
+            if (rc) return rc;
         }
         const size_t need = 4 * (size_t)s->Rb.cells();
         if (need > s->repl_cap) {
@@ -1525,8 +1543,9 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
     if (!box_empty(s->Rb) && !box_empty(s->Rr)) {
         launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
         int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
-        launch_p2g(s->st, g, s->Rr, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        int rc = run_p2g(s, s->Rr);
         prof_end(s, FLUID_PROF_P2G, tok);
+        if (rc) return rc;
         HIPCHK(hipGetLastError());
     }
     // halo planes of container and velocity (velBeforeUpdate = the same values)

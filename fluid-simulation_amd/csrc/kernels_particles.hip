@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_bin_rank(long n_pos, long pos0, const i
     order2[a + rank] = src;
 }
 
-// fluid.cc:22-37 at the three cells base-1, base, base+1 of each axis (see k_p2g): w[(axis * 3 + d) * stride + j]
+// fluid.cc:22-37 at the three cells base-1, base, base+1 of each axis (see k_p2g_rows): w[(axis * 3 + d) * stride + j]
 __device__ __forceinline__ void axis_weights(double px, double py, double pz, double* __restrict__ w, long stride, long j)
 {
     const double q[3] = {px, py, pz};
@@ -177,7 +177,15 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
     if (w) axis_weights(px, py, pz, w, wstride, j);
 }
 
-// ---- particle -> grid (gather form) --------------------------------------------------------
+// the 9 axis weights of every (sorted) particle (multi-GPU path: the ghost particles arrive after the sort): w[a*3+d][j] = spline(pos_a - (base_a - 1 + d))
+__global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __restrict__ w, long stride)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    axis_weights(p.px[j], p.py[j], p.pz[j], w, stride, j);
+}
+
+// ---- particle -> grid (gather form, marching over source rows) -------------------------------
 // fluid.cc:1106-1148 (P2Gtransfer) + 265-299 (p2gCatmullRom) + 843-882 (interpolate).
 // Cell c receives w*v from every particle whose base cell b satisfies |b-c|<=1 per axis
 // (support base-1..base+1 clamped to the grid, fluid.cc:271-276), unless c is solid
@@ -188,105 +196,120 @@ __global__ __launch_bounds__(256) void k_reorder(long n, const int* __restrict__
 // The post-P2G velocity is also stored as velBeforeUpdate (fluid.cc:1455).
 //
 // Separable weights: w(p,c) = sx*sy*sz with s_a = spline(pos_a - c_a) (fluid.cc:291), and a particle only ever
-// meets the cells base-1, base, base+1 per axis, so 9 spline values per particle (k_weights, bit-identical to
+// meets the cells base-1, base, base+1 per axis, so 9 spline values per particle (axis_weights, bit-identical to
 // evaluating spline at (pos - cell)) replace 81 evaluations; the product keeps the reference's association
 // (sx*sy)*sz.
 //
-// Work decomposition: one block = P2G_T x P2G_T cell columns (x,y) x 64 cells in z; wave = one column,
-// lane = z.  The particles of a grid row (fixed x,y; z-1..z+64) are CONTIGUOUS in the sorted
-// arrays, so the block stages each of the (T+2) x (T+2) neighbouring rows into LDS with coalesced loads
-// (weights + velocities) and every lane then walks its own 3-cell window inside LDS.  (A lane-per-cell
-// loop straight from global memory makes each wave load touch ~32 cache lines and thrashes the 32 KB L1:
-// 7.4 ms at 256^3.)  Rows are visited in ascending (x,y) and particles in ascending sorted order: the sum
-// order per cell is fixed.
-// Where the time at 256^3 goes (measured by cutting the kernel in two): staging alone 0.34 ms; the gather loop alone was
-// ~0.5 ms in the target-centric form (6 LDS reads of 8 B per particle-cell pair, 142 M pairs) and is ~0.3 ms in the
-// source-centric form below (8 reads per particle for its 3 pairs); together 0.48 ms.
-// Tried without gain: a register-prefetch pipeline over the chunks with the window's cell starts in LDS (0.94 ms),
-// staging only the axis weights a tile can use (block-uniform conditional loads: 0.75 ms), two particles per trip,
-// XCD-contiguous tile ids.
-// A row is staged by every tile whose window holds it: (T+2)^2 / T^2 times — 4x for T = 2 (2.2 GB of L2/HBM reads
-// per launch at 256^3).  T = 4 would read 2.25x but measured 1.8x SLOWER (1.29 ms against 0.67 ms): 16 waves per
-// block wait at the chunk barriers while at most 9 of them consume the staged row.
-constexpr int P2G_T = 2;
-constexpr int P2G_THREADS = P2G_T * P2G_T * 64;
-constexpr int P2G_CH = 512;  // particles staged per chunk (two per thread): 12 arrays x 8 B x 520 = 50 KB of LDS, 3 blocks per CU.
-                             // Measured k_p2g at 256^3: 192: 0.91 ms, 256: 0.82, 320: 0.49, 384: 0.48, 448: 0.55, 512: 0.41, 576: 0.51
+// Work decomposition.  The particles of a grid row (fixed x,y) are CONTIGUOUS in the sorted arrays.  A block owns the
+// source x-plane rx, a segment [Y0, Y1] of target columns and a z piece of <= 62 cells; it walks the source rows
+// ry = Y0-1 .. Y1+1 and stages each row's weights and velocities into LDS once with coalesced loads.  Wave e (0..2) stands for the
+// target columns X = rx - 1 + e; lane L for the z cell zc = tz0 - 1 + L twice over: as a SOURCE cell it walks its own
+// particles of the staged row once and forms all 3 (target y) x 3 (target z) products (10 LDS reads for 9
+// particle-cell pairs); as a TARGET cell (lanes 1..zt) it then collects the sums of the sources zc-1, zc, zc+1 with
+// lane shifts.  The wave keeps running sums for the target columns ry-1, ry, ry+1: after row ry the column ry-1 has met
+// its three source rows of this x-plane and its partial is written.  Each target cell so receives three partials
+// (from rx = X-1, X, X+1), added in that order by k_p2g_combine.  Sum order per target: rows ascending (x, then y),
+// sources ascending z, particles ascending (sorted order, ties by id) — a pure function of the input.  Every block
+// writes all its partials (zeros for empty rows), so nothing is cleared.
+// History (256^3 bench scene, 5.3 M particles): a lane-per-cell loop straight from global memory 7.4 ms; 2 x 2-column
+// tiles staging their 4 x 4 window of rows (every row staged by 4 tiles, 2.2 GB fetched) 0.38 ms with, per tile row,
+// at most 2.25 of 4 waves busy; 4 x 4 tiles 1.29 ms (9 of 16 waves busy); this form stages (YS+2)/YS = 1.17 x.
+// Tried without gain: computing the weights while staging (positions instead of 9 weights: +0.15 ms of fp64 work),
+// reading the next row's cell ranges a row ahead, a register-prefetch pipeline over the chunks, one 96 B record per particle
+// (array of structures: one stream per block instead of 12) for the staged data and for the partials (0.32 ms against 0.26, and
+// the reorder pass that writes them +60 us).
+#ifndef P2GR_YS
+#define P2GR_YS 12
+#endif
+#ifndef P2GR_CH
+#define P2GR_CH 384
+#endif
+constexpr int P2G_YS = P2GR_YS;   // target columns per y segment
+constexpr int P2G_THREADS = 192;
+constexpr int P2G_CH = P2GR_CH;   // particles staged per chunk: 12 x 8 B x 392 = 37.6 KB of LDS, 4 blocks per CU (158 VGPRs: 3 waves per
+                                  // SIMD).  A row piece of this scene holds ~360 particles; 256 and 320 (two chunks per row) measured 2.3 x slower
 // LDS slot of staged particle k: lane z reads particle a_z + t with a_z growing by ~8 (particles per cell) from
 // lane to lane; splitting by k mod 8 keeps neighbouring lanes on neighbouring slots.
 constexpr int P2G_SEG = P2G_CH / 8 + 1;
 __device__ __forceinline__ int p2g_slot(int k) { return (k & 7) * P2G_SEG + (k >> 3); }
 constexpr int P2G_LDS = 8 * P2G_SEG;
 constexpr int P2G_HEAVY = 48;  // a longer per-lane window is swept by the whole wave
+constexpr int P2G_ZT = 62;     // most target cells a wave takes (lanes 0 and 63 are sources only); the launcher splits nz evenly
 
-// the 9 axis weights of every (sorted) particle: w[a*3+d][j] = spline(pos_a - (base_a - 1 + d))
-__global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __restrict__ w, long stride)
+// part: [3 source x-planes][4: weight, u, v, w][cells of box].  VEC: the weight and velocity arrays are 16 B aligned with an
+// even stride (the launcher checks), so two particles are staged per lane and load
+template <bool VEC>
+__global__ __launch_bounds__(P2G_THREADS) void k_p2g_rows(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
+                                                          const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt)
 {
-    long j = (long)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    axis_weights(p.px[j], p.py[j], p.pz[j], w, stride, j);
-}
-
-// Lane L of a wave stands for the z-cell zc = tz0 - 1 + L of its column twice over: as a SOURCE cell it walks its own
-// particles of the staged row once and forms, for each of the three target cells zc-1, zc, zc+1 it can reach, the
-// partial sums of w and w*v (12 accumulators; 8 LDS reads per particle for 3 particle-cell pairs); as a TARGET cell
-// (lanes 1..62) it then collects the partials of the sources zc-1, zc, zc+1 with two lane shifts per value.  (The first
-// version let every target lane walk the particles of its three source cells itself: 18 LDS reads per particle and
-// three times the trips.)  Sum order per target: rows ascending (x,y), sources ascending z, particles ascending.
-constexpr int P2G_ZT = 62;  // most target cells a wave takes (lanes 0 and 63 are sources only); the launcher splits nz evenly
-
-__global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
-                                             const int* __restrict__ cell_start, const uint8_t* __restrict__ flags,
-                                             float* __restrict__ container, double* __restrict__ u, double* __restrict__ v,
-                                             double* __restrict__ w, double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb,
-                                             int zt)
-{
-    __shared__ double sw[9][P2G_LDS];   // wx0..2, wy0..2, wz0..2
-    __shared__ double sv[3][P2G_LDS];   // vx, vy, vz
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    __shared__ double sr[12][P2G_LDS];   // wx0..2, wy0..2, wz0..2, vx, vy, vz
+    const int tid = threadIdx.x, e = tid >> 6, lane = tid & 63;
     const int N = g.N;
-    const int ntz = (box.nz() + zt - 1) / zt, nty = (box.ny() + P2G_T - 1) / P2G_T;  // zt <= P2G_ZT target cells per wave
+    const int ntz = (box.nz() + zt - 1) / zt, nseg = (box.ny() + P2G_YS - 1) / P2G_YS;
     const int tile = blockIdx.x;
-    const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
-    const int tx0 = box.x0 + tx * P2G_T, ty0 = box.y0 + ty * P2G_T, tz0 = box.z0 + tz * zt;
-    const int ix = tx0 + wv / P2G_T, iy = ty0 + wv % P2G_T, zc = tz0 - 1 + lane;
-    const bool col = ix <= box.x1 && iy <= box.y1;                 // my column is in the box
-    const bool src = col && zc >= 0 && zc < N;                     // my cell exists: it may hold particles
-    const bool tgt = col && lane >= 1 && lane <= zt && zc <= box.z1;
-    const size_t c = tgt ? g.idx(ix, iy, zc) : 0;
-    const bool live = tgt && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
+    const int tz = tile % ntz, sy = (tile / ntz) % nseg, bx = tile / (ntz * nseg);
+    const int rx = box.x0 - 1 + bx, Y0 = box.y0 + sy * P2G_YS, tz0 = box.z0 + tz * zt;
+    const int Y1 = Y0 + P2G_YS - 1 < box.y1 ? Y0 + P2G_YS - 1 : box.y1;
+    const int X = rx - 1 + e, zc = tz0 - 1 + lane;
+    const bool colx = X >= box.x0 && X <= box.x1;                  // my target plane is in the box
+    const bool src = colx && zc >= 0 && zc < N;                    // my cell exists: it may hold particles
+    const bool tgt = colx && lane >= 1 && lane <= zt && zc <= box.z1;
+    const bool rowx = rx >= 0 && rx < N;
     const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + zt < N - 1 ? tz0 + zt : N - 1;
-    float wf = 0.0f;
-    double su = 0, sv_ = 0, sw_ = 0;
-    for (int rx = tx0 - 1; rx <= tx0 + P2G_T; ++rx) {
-        if (rx < 0 || rx >= N) continue;
-        for (int ry = ty0 - 1; ry <= ty0 + P2G_T; ++ry) {
-            if (ry < 0 || ry >= N) continue;
-            const int jb = cell_start[g.idx(rx, ry, zlo)];
-            const int je = cell_start[g.idx(rx, ry, zhi) + 1];
-            if (je == jb) continue;  // block-uniform
-            const int dxi = ix - rx + 1, dyi = iy - ry + 1;  // which axis weight of a particle of this row meets my column
-            const bool mine = src && dxi >= 0 && dxi <= 2 && dyi >= 0 && dyi <= 2;
+    const double* swx = sr[e];   // a particle of plane rx meets plane X = rx - 1 + e with its x weight e
+    // partial slot = rx - X + 1 = 2 - e
+    double* const out = part + (long)(2 - e) * 4 * cells + (long)(X - box.x0) * box.ny() * box.nz() + (zc - box.z0);
+    double C[3][4];  // running sums of the target columns ry-1, ry, ry+1: weight, u, v, w
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[a][q] = 0;
+    for (int ry = Y0 - 1; ry <= Y1 + 1; ++ry) {
+        double T[3][3][4];  // this row's sums by target y (ry-1..ry+1), target z (zc-1..zc+1), value
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) T[a][d][q] = 0;
+        int jb = 0, je = 0;
+        if (rowx && ry >= 0 && ry < N) {
+            jb = cell_start[g.idx(rx, ry, zlo)];
+            je = cell_start[g.idx(rx, ry, zhi) + 1];
+        }
+        if (je > jb) {  // block-uniform
             int ca = 0, cz = 0;  // my source cell's particles in this row
-            if (mine) {
+            if (src) {
                 const size_t r0 = g.idx(rx, ry, zc);
                 ca = cell_start[r0];
                 cz = cell_start[r0 + 1];
             }
-            const double* swx = sw[dxi < 0 ? 0 : (dxi > 2 ? 2 : dxi)];
-            const double* swy = sw[3 + (dyi < 0 ? 0 : (dyi > 2 ? 2 : dyi))];
-            double S[3] = {0, 0, 0}, U[3] = {0, 0, 0}, V[3] = {0, 0, 0}, W[3] = {0, 0, 0};  // by target: zc-1, zc, zc+1
-            for (int cb = jb; cb < je; cb += P2G_CH) {
+            for (int cb = VEC ? (jb & ~1) : jb; cb < je; cb += P2G_CH) {
                 const int ce = cb + P2G_CH < je ? cb + P2G_CH : je;
                 __syncthreads();  // the previous chunk has been consumed
-                for (int j = cb + tid; j < ce; j += P2G_THREADS) {
-                    const int k = p2g_slot(j - cb);
+                if (VEC) {
+                    // 16 B accesses from an even index; the odd particle before jb / after je - 1 is staged but never read
+                    for (int j = cb + 2 * tid; j < ce; j += 2 * P2G_THREADS) {
+                        const int k0 = p2g_slot(j - cb), k1 = p2g_slot(j + 1 - cb);
+                        double2 t[12];
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) sw[q][k] = pw[q * wstride + j];
-                    sv[0][k] = p.vx[j]; sv[1][k] = p.vy[j]; sv[2][k] = p.vz[j];
+                        for (int q = 0; q < 9; ++q) t[q] = *reinterpret_cast<const double2*>(pw + q * wstride + j);
+                        t[9] = *reinterpret_cast<const double2*>(p.vx + j);
+                        t[10] = *reinterpret_cast<const double2*>(p.vy + j);
+                        t[11] = *reinterpret_cast<const double2*>(p.vz + j);
+#pragma unroll
+                        for (int q = 0; q < 12; ++q) { sr[q][k0] = t[q].x; sr[q][k1] = t[q].y; }
+                    }
+                } else {
+                    for (int j = cb + tid; j < ce; j += P2G_THREADS) {
+                        const int k = p2g_slot(j - cb);
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) sr[q][k] = pw[q * wstride + j];
+                        sr[9][k] = p.vx[j]; sr[10][k] = p.vy[j]; sr[11][k] = p.vz[j];
+                    }
                 }
                 __syncthreads();
-                // Every lane of the wave sits on the same (x,y) column, so the x/y weight tables are wave-uniform.  A lane
+                // Every lane of the wave sits on the same target plane, so the x weight table is wave-uniform.  A lane
                 // whose cell is crowded (settled water piles up to ~10^4 particles into one cell) would serialise the
                 // whole wave: such cells are swept by all 64 lanes together and wave-reduced (fixed order).
                 int lo = ca > cb ? ca : cb, hi = cz < ce ? cz : ce;
@@ -295,15 +318,16 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles 
                 if (!heavy) {
                     for (int j = lo; j < hi; ++j) {
                         const int k = p2g_slot(j - cb);
-                        const double a = swx[k] * swy[k];   // (sx*sy)*sz: the reference's association (fluid.cc:291)
-                        const double vx = sv[0][k], vy = sv[1][k], vz = sv[2][k];
+                        const double wx = swx[k];
+                        const double vx = sr[9][k], vy = sr[10][k], vz = sr[11][k];
+                        const double z0 = sr[6][k], z1 = sr[7][k], z2 = sr[8][k];
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            const double cw = a * sw[6 + d][k];
-                            S[d] += cw;
-                            U[d] = U[d] + cw * vx;
-                            V[d] = V[d] + cw * vy;
-                            W[d] = W[d] + cw * vz;
+                        for (int a = 0; a < 3; ++a) {
+                            const double xy = wx * sr[3 + a][k];   // (sx*sy)*sz: the reference's association (fluid.cc:291)
+                            const double c0 = xy * z0, c1 = xy * z1, c2 = xy * z2;
+                            T[a][0][0] += c0; T[a][0][1] = T[a][0][1] + c0 * vx; T[a][0][2] = T[a][0][2] + c0 * vy; T[a][0][3] = T[a][0][3] + c0 * vz;
+                            T[a][1][0] += c1; T[a][1][1] = T[a][1][1] + c1 * vx; T[a][1][2] = T[a][1][2] + c1 * vy; T[a][1][3] = T[a][1][3] + c1 * vz;
+                            T[a][2][0] += c2; T[a][2][1] = T[a][2][1] + c2 * vx; T[a][2][2] = T[a][2][2] + c2 * vy; T[a][2][3] = T[a][2][3] + c2 * vz;
                         }
                     }
                 }
@@ -312,52 +336,84 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g(Grid g, Box box, Particles 
                     const int L = __ffsll((long long)hm) - 1;
                     hm &= hm - 1;
                     const int lo_L = __shfl(lo, L, 64), hi_L = __shfl(hi, L, 64);
-                    double ps[3] = {0, 0, 0}, pu[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, pq[3] = {0, 0, 0};
-                    for (int j = lo_L + lane; j < hi_L; j += 64) {
-                        const int k = p2g_slot(j - cb);
-                        const double a = swx[k] * swy[k];
-                        const double vx = sv[0][k], vy = sv[1][k], vz = sv[2][k];
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            const double cw = a * sw[6 + d][k];
-                            ps[d] += cw;
-                            pu[d] += cw * vx;
-                            pv[d] += cw * vy;
-                            pq[d] += cw * vz;
+                    for (int a = 0; a < 3; ++a) {  // one target y per sweep: 12 live sums instead of 36 (registers)
+                        double H[3][4];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) H[d][q] = 0;
+                        for (int j = lo_L + lane; j < hi_L; j += 64) {
+                            const int k = p2g_slot(j - cb);
+                            const double xy = swx[k] * sr[3 + a][k];
+                            const double vx = sr[9][k], vy = sr[10][k], vz = sr[11][k];
+                            const double zw[3] = {sr[6][k], sr[7][k], sr[8][k]};
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                const double cw = xy * zw[d];
+                                H[d][0] += cw; H[d][1] += cw * vx; H[d][2] += cw * vy; H[d][3] += cw * vz;
+                            }
                         }
-                    }
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        double t0 = wave_sum(ps[d]), t1 = wave_sum(pu[d]), t2 = wave_sum(pv[d]), t3 = wave_sum(pq[d]);
-                        t0 = __shfl(t0, 0, 64); t1 = __shfl(t1, 0, 64); t2 = __shfl(t2, 0, 64); t3 = __shfl(t3, 0, 64);
-                        if (lane == L) { S[d] += t0; U[d] += t1; V[d] += t2; W[d] += t3; }
+                        for (int d = 0; d < 3; ++d)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const double t = __shfl(wave_sum(H[d][q]), 0, 64);
+                                if (lane == L) T[a][d][q] += t;
+                            }
                     }
                 }
             }
-            // target zc collects: source zc-1 reaches it with its weight index 2, zc with 1, zc+1 with 0 (d = target - source + 1);
-            // container keeps the reference's float accumulator, one rounding per source cell instead of one per particle
-            const double s0 = __shfl_up(S[2], 1, 64), s2 = __shfl_down(S[0], 1, 64);
-            const double u0 = __shfl_up(U[2], 1, 64), u2 = __shfl_down(U[0], 1, 64);
-            const double v0 = __shfl_up(V[2], 1, 64), v2 = __shfl_down(V[0], 1, 64);
-            const double w0 = __shfl_up(W[2], 1, 64), w2 = __shfl_down(W[0], 1, 64);
-            if (live) {
-                wf = (float)((double)wf + s0);
-                wf = (float)((double)wf + S[1]);
-                wf = (float)((double)wf + s2);
-                su = ((su + u0) + U[1]) + u2;
-                sv_ = ((sv_ + v0) + V[1]) + v2;
-                sw_ = ((sw_ + w0) + W[1]) + w2;
-            }
         }
+        // target zc collects: source zc-1 reaches it with its z index 2, zc with 1, zc+1 with 0 (d = target - source + 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double below = __shfl_up(T[a][2][q], 1, 64), above = __shfl_down(T[a][0][q], 1, 64);
+                C[a][q] = ((C[a][q] + below) + T[a][1][q]) + above;
+            }
+        // column ry-1 has met rows ry-2, ry-1, ry of this x-plane
+        if (ry - 1 >= Y0 && tgt) {
+            double* o = out + (long)(ry - 1 - box.y0) * box.nz();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q * cells] = C[0][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { C[0][q] = C[1][q]; C[1][q] = C[2][q]; C[2][q] = 0; }
     }
-    if (!live) return;  // fields stay 0
+}
+
+// the three x-plane partials of a target cell, ascending source x; weights is the reference's float32 accumulator (rounded
+// once per partial here: 1e-7 from the reference's per-particle rounding, inside the reference's own TBB-order noise), the
+// velocity sums are fp64 and divided by double(weights) where weights > 0 (fluid.cc:1138-1142)
+__global__ __launch_bounds__(256) void k_p2g_combine(Grid g, Box box, const double* __restrict__ part, long cells,
+                                                     const uint8_t* __restrict__ flags, float* __restrict__ container,
+                                                     double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
+                                                     double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells) return;
+    const int nz = box.nz(), ny = box.ny();
+    const int z = (int)(i % nz), y = (int)((i / nz) % ny), x = (int)(i / ((long)nz * ny));
+    const size_t c = g.idx(box.x0 + x, box.y0 + y, box.z0 + z);
+    if (flags[c] & F_SOLID) return;  // solid cells receive nothing (:288,870): fields stay 0
+    float wf = 0.0f;
+    double s[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double* q = part + (long)k * 4 * cells + i;
+        wf = (float)((double)wf + q[0]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s[a] += q[(a + 1) * cells];
+    }
     if (wf > 0) {
         const double wd = (double)wf;
-        su /= wd; sv_ /= wd; sw_ /= wd;
+        s[0] /= wd; s[1] /= wd; s[2] /= wd;
     }
     container[c] = wf;
-    u[c] = su; v[c] = sv_; w[c] = sw_;
-    ub[c] = su; vb[c] = sv_; wb[c] = sw_;
+    u[c] = s[0]; v[c] = s[1]; w[c] = s[2];
+    ub[c] = s[0]; vb[c] = s[1]; wb[c] = s[2];
 }
 
 // ---- grid -> particle, FLIP -----------------------------------------------------------------
@@ -708,14 +764,20 @@ void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
 {
     if (n > 0) hipLaunchKernelGGL(k_weights, dim3(nblk(n)), dim3(256), 0, st, n, p, w, stride);
 }
+// pw: the particles' axis weights (launch_reorder / launch_weights); part: 12 doubles per cell of box
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
-                float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
+                double* part, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
 {
-    // z is cut into equal pieces of at most P2G_ZT cells (89 cells: 45 + 44, not 62 + 27): balanced tiles, and at 8 particles
-    // per cell a row segment of <= 62 cells fits one staged chunk
+    // z is cut into equal pieces of at most P2G_ZT cells (89 cells: 45 + 44, not 62 + 27): balanced blocks, and at 8 particles
+    // per cell a row piece of <= 46 cells fits one staged chunk
     const int ntz = (box.nz() + P2G_ZT - 1) / P2G_ZT, zt = (box.nz() + ntz - 1) / ntz;
-    const unsigned nt = (unsigned)(((box.nx() + P2G_T - 1) / P2G_T) * ((box.ny() + P2G_T - 1) / P2G_T) * ntz);
-    hipLaunchKernelGGL(k_p2g, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb, zt);
+    const int nseg = (box.ny() + P2G_YS - 1) / P2G_YS;
+    const long cells = box.cells();
+    const unsigned nt = (unsigned)((box.nx() + 2) * nseg * ntz);
+    const bool vec = ((((uintptr_t)pw | (uintptr_t)p.vx | (uintptr_t)p.vy | (uintptr_t)p.vz) & 15) == 0) && (wstride & 1) == 0;
+    if (vec) hipLaunchKernelGGL(k_p2g_rows<true>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt);
+    else hipLaunchKernelGGL(k_p2g_rows<false>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt);
+    hipLaunchKernelGGL(k_p2g_combine, dim3(nblk(cells)), dim3(256), 0, st, g, box, part, cells, flags, container, u, v, w, ub, vb, wb);
 }
 // pb = bounding box of the particles' base cells (after the sort, positions untouched since)
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,
