@@ -170,7 +170,7 @@ def main():
     mgs = sim.profile_read(fs.PROF.MG_UP0)
     # ---- roofline: every kernel class bracketed by hipEvents in the timed region, the one with the largest total
     # time in `roofline`, the others in `roofline_others`.  Algorithmic bytes per launch:
-    #   k_p2g         96 B per particle staged once (9 axis weights + 3 velocity components) + 52 B per cell written
+    #   k_p2g_rows    96 B per particle staged once (9 axis weights + 3 velocity components) + 52 B per cell written
     #   up leg, lvl 0 21.5 B/cell: read u (float), r (double), count byte, 1/8 coarse value (float); write z (double)
     #   SQ            33 B/cell: read z, s, count byte; write s', q          XR   49 B/cell: read x, r, s, q, count; write x, r
     np_ = float(len(pos0))
@@ -193,11 +193,13 @@ def main():
              "latency-bound (~3 us of it is dispatch), so the HBM fraction is low by construction; the bandwidth-bound kernel of "
              "this path is the dense 256^3 stencil sweep (stencil_microbench)")
     cands = [
-        roof_entry("k_p2g (particle -> grid gather: particle rows staged through LDS, 2 x 2 columns x 62 z cells per block)", p2g,
-              lambda c: np_ * 96 + c * 52, "k_p2g",
-              "each particle row is staged by the 4 tiles whose 4 x 4 window holds it, so `traffic` is ~4x the algorithmic bytes: "
-              "bound by L2/Infinity-Cache -> LDS traffic at ~3.5 TB/s; 4 x 4-column tiles read 2.25x but ran 1.8x slower (16 waves "
-              "idle at the chunk barriers), DESIGN.md 3"),
+        roof_entry("k_p2g_rows<true> + k_p2g_combine (particle -> grid gather: a block marches over the source rows of one x-plane, "
+                   "each row staged through LDS once; three x-plane partials per cell)", p2g,
+              lambda c: np_ * 96 + c * 52, "k_p2g_rows<true>",
+              "algorithmic bytes: 96 B per particle (9 axis weights + velocity) read once + 52 B per cell written; `traffic` (k_p2g_rows "
+              "alone) adds the two halo rows per 12-column segment (x1.17) and the 3 x 32 B per cell of partials that k_p2g_combine "
+              "reads back; the time is hipEvents around both kernels; bound by staging latency (stage -> barrier -> gather per row "
+              "with 4 blocks per CU), not by bandwidth, DESIGN.md 3"),
         roof_entry("k_mg_up<float, double, double, 8, 8, 16> (level-0 up leg of the V-cycle: prolongation + two damped-Jacobi sweeps + r.z partials)",
               mgs, lambda c: c * 21.5, "k_mg_up<float, double, double, 8, 8, 16>", small),
         roof_entry("k_pcg_sq_l<double, true> (PCG: s' = z + beta s, q = A s', partial s'.q)", sq, lambda c: c * 33.0, "k_pcg_sq_l<double, true>", small),

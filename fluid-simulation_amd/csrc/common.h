@@ -84,6 +84,8 @@ struct StepState {
     int bbox_max[3];
     int num_active;
     int n_out;                // particles whose base cell is outside the grid
+    int max_cell;             // most particles in one cell (P2G picks its kernel by it)
+    int pad_;
     unsigned long long max_speed_bits;  // max |v_p| as non-negative double bits
     double dt;                // fluid.cc:1367 / 992-999
     double err_num;           // |b-b2|^2
@@ -203,8 +205,12 @@ void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, cons
                      int* order2);
 void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst, double* w = nullptr, long wstride = 0);
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
+long p2g_max_items(Box box);
+constexpr int P2G_PILED = 256;   // a cell with more particles: the particles have piled up (walls, floor), P2G takes the tile form
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
-                double* part, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
+                double* part, int* items, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
+void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
+                      float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,
                       const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss);
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,
@@ -271,7 +277,11 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
 template <typename T>
 void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen);
 template <typename T>
-void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure);
+void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure, double* keep = nullptr,
+                           const PcgState* ps = nullptr);
+template <typename T>
+void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, T* x, T* r, Coef<T> cf,
+                           double* part_bb, double* part_rr0, PcgState* ps);
 
 // multigrid preconditioner (kernels_mg.hip)
 MLevel mg_level0(const LBox& L);

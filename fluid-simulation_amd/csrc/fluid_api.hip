@@ -42,6 +42,8 @@ struct fluid_sim {
     float *container = nullptr, *rhs = nullptr, *diver = nullptr, *diver2 = nullptr;
     double *u = nullptr, *v = nullptr, *w = nullptr, *ub = nullptr, *vb = nullptr, *wb = nullptr;
     double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
+    double* p_guess = nullptr;    // last solved pressure, never cleared: the multigrid PCG starts from it (FLUID_WARM_START=0: from 0 like the reference)
+    bool warm = true, have_guess = false;
     int *indices = nullptr, *scan_sums = nullptr, *ipart = nullptr;
     // pcg
     void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr, *Zmg = nullptr;
@@ -62,6 +64,10 @@ struct fluid_sim {
     double* pw = nullptr;  // 9 axis weights per particle, SoA with stride cap
     double* p2g_part = nullptr;  // k_p2g_rows' three x-plane partials: 12 doubles per cell of the P2G box (grown on demand)
     size_t p2g_part_cap = 0;
+    int* p2g_items = nullptr;    // k_p2g_rows' work list (count + int4 items), grown on demand; the count is 0 between launches
+    size_t p2g_items_cap = 0;
+    int max_cell = 0;            // most particles in one cell after the last sort (all ranks' cells when distributed)
+    int p2g_force = 0;           // FLUID_P2G_FORM=rows|tiles: 1 / 2, for experiments
     StepState* ss = nullptr;
     StepState* h_ss = nullptr;  // pinned
     // boxes
@@ -237,9 +243,9 @@ int fluid_destroy(fluid_sim_t* s)
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
-                    s->dcz, s->pressure, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
+                    s->dcz, s->pressure, s->p_guess, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->repl_buf, s->p2g_part, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
+                    s->pcx, s->pcy, s->pcz, s->repl_buf, s->p2g_part, s->p2g_items, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -271,6 +277,8 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     s->dt = p->max_dt;
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments)
     if (const char* e = getenv("FLUID_MG_FP64")) s->mg_fp32 = atoi(e) == 0;
+    if (const char* e = getenv("FLUID_WARM_START")) s->warm = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
     s->xs = 0;
     s->xe = p->n;
@@ -285,6 +293,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     A(dalloc(&s->ub, n)); A(dalloc(&s->vb, n)); A(dalloc(&s->wb, n));
     A(dalloc(&s->dcx, n)); A(dalloc(&s->dcy, n)); A(dalloc(&s->dcz, n));
     A(dalloc(&s->pressure, n));
+    if (s->warm) { A(dalloc(&s->p_guess, n)); if (hipMemset(s->p_guess, 0, n * sizeof(double)) != hipSuccess) return bail(FLUID_ERR_HIP); }
     A(dalloc(&s->indices, n));
     A(dalloc(&s->scan_sums, (n + 2) / 2048 + 16));
     A(dalloc(&s->ipart, (size_t)1024 * 8));
@@ -361,6 +370,7 @@ int fluid_upload_particles(fluid_sim_t* s, int64_t n, const double* pos, const d
         HIPCHK(hipStreamSynchronize(s->st));
     }
     s->sorted = s->have_p2g = s->have_flags = false;
+    s->have_guess = false;  // a new particle set: the first solve starts from 0
     s->sort_hint = false;
     return FLUID_OK;
 }
@@ -486,6 +496,7 @@ static int phase_sort(fluid_sim* s)
     }
     s->sort_hint = true;
     s->n_out = s->h_ss->n_out;
+    s->max_cell = s->h_ss->max_cell;
     const StepState& h = *s->h_ss;
     if (h.bbox_max[0] < 0) {
         s->Pb = Box{0, 0, 0, -1, -1, -1};
@@ -510,13 +521,26 @@ static int phase_sort(fluid_sim* s)
 // particle -> grid over box (k_p2g_rows + k_p2g_combine)
 static int run_p2g(fluid_sim* s, const Box& box)
 {
+    // piled particles (a pure function of the sorted particle set, the same on every rank): the tile form
+    if (s->p2g_force ? s->p2g_force == 2 : s->max_cell > P2G_PILED) {
+        launch_p2g_tiles(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        return FLUID_OK;
+    }
     const size_t need = (size_t)12 * box.cells();
     if (need > s->p2g_part_cap) {
         if (s->p2g_part) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->p2g_part); s->p2g_part = nullptr; }
         HIPCHK(hipMalloc((void**)&s->p2g_part, (need + need / 4) * sizeof(double)));
         s->p2g_part_cap = need + need / 4;
     }
-    launch_p2g(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->p2g_part, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+    const size_t ni = 4 + 4 * (size_t)p2g_max_items(box);
+    if (ni > s->p2g_items_cap) {
+        if (s->p2g_items) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->p2g_items); s->p2g_items = nullptr; }
+        HIPCHK(hipMalloc((void**)&s->p2g_items, (ni + ni / 4) * sizeof(int)));
+        HIPCHK(hipMemsetAsync(s->p2g_items, 0, 4 * sizeof(int), s->st));
+        s->p2g_items_cap = ni + ni / 4;
+    }
+    launch_p2g(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->p2g_part, s->p2g_items, s->container, s->u, s->v, s->w, s->ub,
+               s->vb, s->wb);
     return FLUID_OK;
 }
 
@@ -733,7 +757,12 @@ static int solve_mg(fluid_sim* s)
     const int n_rz = fold ? 1 : n_rz_raw;
     int rc;
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
-    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
+    // Start: x = 0 like the reference's cg.solve(b) — or, by default, the previous solve's pressure (Eigen's solveWithGuess
+    // form of the same loop: r0 = b - A x0, same threshold tol^2 |b|^2).  The converged p does not depend on the start
+    // beyond the tolerance; a settled pool needs far fewer iterations.  r0.r0 partials travel in part_rz[1] (unused by body 0).
+    const bool guess = s->warm && s->have_guess;
+    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, s->p_guess, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
+    else launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
     long it = 0;
     // Batching of the convergence poll.  Iteration counts barely change from one solve to the next (Eigen's count i means
     // i + 1 bodies ran), so the first batch runs exactly the bodies the previous solve needed without looking — one poll
@@ -748,7 +777,7 @@ static int solve_mg(fluid_sim* s)
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
             launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
-                             s->part_pq, s->ps, it == 0, tol, n_rz, 1, sparse);
+                             s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
             launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_err, s->ps, n_rz, sparse);
@@ -774,7 +803,8 @@ static int solve_mg(fluid_sim* s)
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
     if (!s->h_ps->done) iters = (int)max_it;
-    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, s->warm ? s->p_guess : nullptr, s->ps);
+    s->have_guess = s->warm;
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
@@ -1261,10 +1291,12 @@ static int dist_sort(fluid_sim* s)
             v[a] = h.bbox_max[a] < 0 ? 0x7fffffff : h.bbox_min[a];
             v[3 + a] = h.bbox_max[a] < 0 ? 0x7fffffff : -h.bbox_max[a];
         }
-        HIPCHK(hipMemcpyAsync(s->d_small + 16, v, 6 * sizeof(int), hipMemcpyHostToDevice, s->st));
-        if ((rc = comm_allreduce(s, s->d_small + 16, 6, FLUID_DT_I32, FLUID_OP_MIN))) return rc;
-        if ((rc = read_ints(s, s->d_small + 16, 6, s->h_small + 16))) return rc;
+        v[6] = -h.max_cell;  // and the fullest cell of any rank (it picks the P2G kernel: every rank must take the same)
+        HIPCHK(hipMemcpyAsync(s->d_small + 16, v, 7 * sizeof(int), hipMemcpyHostToDevice, s->st));
+        if ((rc = comm_allreduce(s, s->d_small + 16, 7, FLUID_DT_I32, FLUID_OP_MIN))) return rc;
+        if ((rc = read_ints(s, s->d_small + 16, 7, s->h_small + 16))) return rc;
         HIPCHK(hipStreamSynchronize(s->st));
+        s->max_cell = -v[6];
         if (v[0] == 0x7fffffff) s->Pb = Box{0, 0, 0, -1, -1, -1};
         else s->Pb = Box{v[0], v[1], v[2], -v[3], -v[4], -v[5]};
     }

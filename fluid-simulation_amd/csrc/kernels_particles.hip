@@ -16,9 +16,9 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
                                                    int* __restrict__ cell_count, int* __restrict__ part)
 {
     // per-block bbox partials (no same-address atomics: 80k waves hammering 6 words cost 5.6 ms)
-    __shared__ int sm[4][7];
+    __shared__ int sm[4][8];
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
-    int nout = 0;
+    int nout = 0, cmax = 0;
     const long ncell = (long)g.N * g.N * g.N;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         int bx = (int)round(p.px[i]) - g.lo, by = (int)round(p.py[i]) - g.lo, bz = (int)round(p.pz[i]) - g.lo;
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
             const unsigned long long act = __ballot(true);
             const int stop = above ? __ffsll((long long)above) - 1 : 64 - __clzll((long long)act) + 0;  // first head after me, or one past the last active lane
             int base = 0;
-            if (head) base = atomicAdd(&cell_count[k], stop - start);
+            if (head) {
+                base = atomicAdd(&cell_count[k], stop - start);
+                if (in && base + stop - start > cmax) cmax = base + stop - start;  // the last add of a cell sees its full count
+            }
             base = __shfl(base, start, 64);
             slot[i] = base + (lane - start);
         }
@@ -66,14 +69,15 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
         if (lane == 0) { sm[w][a] = lo; sm[w][3 + a] = hi; }
     }
     nout = wave_sum(nout);
-    if (lane == 0) sm[w][6] = nout;
+    cmax = wave_max(cmax);
+    if (lane == 0) { sm[w][6] = nout; sm[w][7] = cmax; }
     __syncthreads();
-    if (threadIdx.x < 7) {
+    if (threadIdx.x < 8) {
         const int a = threadIdx.x;
         int v = sm[0][a];
         for (int k = 1; k < 4; ++k) {
             int t = sm[k][a];
-            v = a < 3 ? (t < v ? t : v) : (a < 6 ? (t > v ? t : v) : v + t);
+            v = a < 3 ? (t < v ? t : v) : (a == 6 ? v + t : (t > v ? t : v));
         }
         part[blockIdx.x * 8 + a] = v;
     }
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
 
 __global__ __launch_bounds__(256) void k_bin_bbox(const int* __restrict__ part, int nb, StepState* ss)
 {
-    __shared__ int sm[4][7];
-    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1}, nout = 0;
+    __shared__ int sm[4][8];
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1}, nout = 0, cmax = 0;
     for (int b = threadIdx.x; b < nb; b += 256) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(256) void k_bin_bbox(const int* __restrict__ part, 
             mx[a] = h > mx[a] ? h : mx[a];
         }
         nout += part[b * 8 + 6];
+        cmax = part[b * 8 + 7] > cmax ? part[b * 8 + 7] : cmax;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(256) void k_bin_bbox(const int* __restrict__ part, 
         if (lane == 0) { sm[w][a] = lo; sm[w][3 + a] = hi; }
     }
     nout = wave_sum(nout);
-    if (lane == 0) sm[w][6] = nout;
+    cmax = wave_max(cmax);
+    if (lane == 0) { sm[w][6] = nout; sm[w][7] = cmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int a = 0; a < 3; ++a) {
@@ -118,6 +124,9 @@ __global__ __launch_bounds__(256) void k_bin_bbox(const int* __restrict__ part, 
             ss->bbox_max[a] = hi;
         }
         ss->n_out = sm[0][6] + sm[1][6] + sm[2][6] + sm[3][6];
+        int cm = sm[0][7];
+        for (int k = 1; k < 4; ++k) cm = sm[k][7] > cm ? sm[k][7] : cm;
+        ss->max_cell = cm;
     }
 }
 
@@ -218,13 +227,10 @@ __global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __
 // reading the next row's cell ranges a row ahead, a register-prefetch pipeline over the chunks, one 96 B record per particle
 // (array of structures: one stream per block instead of 12) for the staged data and for the partials (0.32 ms against 0.26, and
 // the reorder pass that writes them +60 us).
-#ifndef P2GR_YS
-#define P2GR_YS 12
-#endif
 #ifndef P2GR_CH
 #define P2GR_CH 384
 #endif
-constexpr int P2G_YS = P2GR_YS;   // target columns per y segment
+constexpr int P2G_SLOTS = 256 * 4;  // blocks resident at once: 256 CUs x 4 (37.6 KB of LDS, 168 VGPRs)
 constexpr int P2G_THREADS = 192;
 constexpr int P2G_CH = P2GR_CH;   // particles staged per chunk: 12 x 8 B x 392 = 37.6 KB of LDS, 4 blocks per CU (158 VGPRs: 3 waves per
                                   // SIMD).  A row piece of this scene holds ~360 particles; 256 and 320 (two chunks per row) measured 2.3 x slower
@@ -234,22 +240,21 @@ constexpr int P2G_SEG = P2G_CH / 8 + 1;
 __device__ __forceinline__ int p2g_slot(int k) { return (k & 7) * P2G_SEG + (k >> 3); }
 constexpr int P2G_LDS = 8 * P2G_SEG;
 constexpr int P2G_HEAVY = 48;  // a longer per-lane window is swept by the whole wave
+constexpr int P2G_BUDGET = 8192;  // particles per work item and z piece before a y segment is cut further (a regular 256^3 segment: ~6500)
 constexpr int P2G_ZT = 62;     // most target cells a wave takes (lanes 0 and 63 are sources only); the launcher splits nz evenly
 
 // part: [3 source x-planes][4: weight, u, v, w][cells of box].  VEC: the weight and velocity arrays are 16 B aligned with an
 // even stride (the launcher checks), so two particles are staged per lane and load
 template <bool VEC>
-__global__ __launch_bounds__(P2G_THREADS) void k_p2g_rows(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
-                                                          const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt)
+__global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
+                                                          const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt, const int* __restrict__ items, int heavy_min)
 {
     __shared__ double sr[12][P2G_LDS];   // wx0..2, wy0..2, wz0..2, vx, vy, vz
     const int tid = threadIdx.x, e = tid >> 6, lane = tid & 63;
     const int N = g.N;
-    const int ntz = (box.nz() + zt - 1) / zt, nseg = (box.ny() + P2G_YS - 1) / P2G_YS;
-    const int tile = blockIdx.x;
-    const int tz = tile % ntz, sy = (tile / ntz) % nseg, bx = tile / (ntz * nseg);
-    const int rx = box.x0 - 1 + bx, Y0 = box.y0 + sy * P2G_YS, tz0 = box.z0 + tz * zt;
-    const int Y1 = Y0 + P2G_YS - 1 < box.y1 ? Y0 + P2G_YS - 1 : box.y1;
+    for (int item = blockIdx.x; item < items[0]; item += gridDim.x) {   // items[0]: block-uniform count
+    const int4 wi = reinterpret_cast<const int4*>(items)[1 + item];      // x-plane, first and last target column, z piece
+    const int rx = box.x0 - 1 + wi.x, Y0 = wi.y, Y1 = wi.z, tz0 = box.z0 + wi.w * zt;
     const int X = rx - 1 + e, zc = tz0 - 1 + lane;
     const bool colx = X >= box.x0 && X <= box.x1;                  // my target plane is in the box
     const bool src = colx && zc >= 0 && zc < N;                    // my cell exists: it may hold particles
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_rows(Grid g, Box box, Parti
                 // whole wave: such cells are swept by all 64 lanes together and wave-reduced (fixed order).
                 int lo = ca > cb ? ca : cb, hi = cz < ce ? cz : ce;
                 if (hi < lo) hi = lo;
-                const bool heavy = hi - lo > P2G_HEAVY;
+                const bool heavy = hi - lo > heavy_min;
                 if (!heavy) {
                     for (int j = lo; j < hi; ++j) {
                         const int k = p2g_slot(j - cb);
@@ -382,6 +387,33 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_rows(Grid g, Box box, Parti
 #pragma unroll
         for (int q = 0; q < 4; ++q) { C[0][q] = C[1][q]; C[1][q] = C[2][q]; C[2][q] = 0; }
     }
+    }  // items
+}
+
+// The work list of k_p2g_rows.  A regular cut (x-plane) x (nseg equal y segments) x (z piece) would hand every row of a
+// plane where particles have piled up (against a wall, after the splash) to the same few blocks: 15 ms instead of 0.25 at
+// 256^3.  So a segment is cut further by its particle count, down to single columns: the particles of rows Y0-1..Y1+1 of a
+// plane are one contiguous range of the sorted arrays (two cell_start reads), `budget` of them per item and z piece.
+// items: [0] count (zero on entry; k_p2g_combine puts it back), then int4 (plane, Y0, Y1, z piece) from int 4 on.
+__global__ __launch_bounds__(256) void k_p2g_items(Grid g, Box box, const int* __restrict__ cell_start, int nseg, int ntz, int budget,
+                                                   int* __restrict__ items)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (box.nx() + 2) * nseg) return;
+    const int sy = t % nseg, bx = t / nseg, N = g.N;
+    const int rx = box.x0 - 1 + bx;
+    const int Y0 = box.y0 + sy * box.ny() / nseg, Y1 = box.y0 + (sy + 1) * box.ny() / nseg - 1, len = Y1 - Y0 + 1;
+    long c = 0;
+    if (rx >= 0 && rx < N) {
+        const int ya = Y0 > 0 ? Y0 - 1 : 0, yb = Y1 < N - 1 ? Y1 + 1 : N - 1;
+        c = (long)cell_start[g.idx(rx, yb, N - 1) + 1] - cell_start[g.idx(rx, ya, 0)];
+    }
+    long nsub = (c + (long)budget * ntz - 1) / ((long)budget * ntz);
+    nsub = nsub < 1 ? 1 : (nsub > len ? len : nsub);
+    const int base = atomicAdd(items, (int)nsub * ntz);  // the order of the items does not reach the sums
+    int4* o = reinterpret_cast<int4*>(items) + 1 + base;
+    for (int i = 0; i < (int)nsub; ++i)
+        for (int tz = 0; tz < ntz; ++tz) o[i * ntz + tz] = make_int4(bx, Y0 + (int)(i * len / nsub), Y0 + (int)((i + 1) * len / nsub) - 1, tz);
 }
 
 // the three x-plane partials of a target cell, ascending source x; weights is the reference's float32 accumulator (rounded
@@ -390,9 +422,11 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_rows(Grid g, Box box, Parti
 __global__ __launch_bounds__(256) void k_p2g_combine(Grid g, Box box, const double* __restrict__ part, long cells,
                                                      const uint8_t* __restrict__ flags, float* __restrict__ container,
                                                      double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
-                                                     double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
+                                                     double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb,
+                                                     int* __restrict__ items)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) items[0] = 0;  // k_p2g_rows is done with the work list: empty for the next k_p2g_items
     if (i >= cells) return;
     const int nz = box.nz(), ny = box.ny();
     const int z = (int)(i % nz), y = (int)((i / nz) % ny), x = (int)(i / ((long)nz * ny));
@@ -414,6 +448,151 @@ __global__ __launch_bounds__(256) void k_p2g_combine(Grid g, Box box, const doub
     container[c] = wf;
     u[c] = s[0]; v[c] = s[1]; w[c] = s[2];
     ub[c] = s[0]; vb[c] = s[1]; wb[c] = s[2];
+}
+
+// ---- particle -> grid, tile form (piled particles) -------------------------------------------------
+// The same sums per 2 x 2 target columns: a block stages the 4 x 4 window of source rows around its columns (every row is
+// staged by 4 tiles) and wave = column.  Slower than k_p2g_rows on evenly filled water (0.38 ms against 0.25 at 256^3) but
+// its 16 rows come from four x-planes, so particles piled against an x wall (600 k in one plane, 10^5 in one row after the
+// 256^3 splash has settled) are spread over many more blocks: 1.8 ms where the row-marching form needs 4-15 ms.  The host
+// takes this one once a cell holds more than P2G_PILED particles.
+constexpr int P2GT_T = 2;
+constexpr int P2GT_THREADS = P2GT_T * P2GT_T * 64;
+constexpr int P2GT_CH = 512;  // particles staged per chunk (two per thread): 12 arrays x 8 B x 520 = 50 KB of LDS, 3 blocks per CU.
+                              // Measured at 256^3: 192: 0.91 ms, 256: 0.82, 320: 0.49, 384: 0.48, 448: 0.55, 512: 0.41, 576: 0.51
+constexpr int P2GT_SEG = P2GT_CH / 8 + 1;
+__device__ __forceinline__ int p2gt_slot(int k) { return (k & 7) * P2GT_SEG + (k >> 3); }
+constexpr int P2GT_LDS = 8 * P2GT_SEG;
+// Lane L of a wave stands for the z-cell zc = tz0 - 1 + L of its column twice over: as a SOURCE cell it walks its own
+// particles of the staged row once and forms, for each of the three target cells zc-1, zc, zc+1 it can reach, the
+// partial sums of w and w*v (12 accumulators; 8 LDS reads per particle for 3 particle-cell pairs); as a TARGET cell
+// (lanes 1..62) it then collects the partials of the sources zc-1, zc, zc+1 with two lane shifts per value.  (The first
+// version let every target lane walk the particles of its three source cells itself: 18 LDS reads per particle and
+// three times the trips.)  Sum order per target: rows ascending (x,y), sources ascending z, particles ascending.
+
+__global__ __launch_bounds__(P2GT_THREADS) void k_p2g_tiles(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
+                                             const int* __restrict__ cell_start, const uint8_t* __restrict__ flags,
+                                             float* __restrict__ container, double* __restrict__ u, double* __restrict__ v,
+                                             double* __restrict__ w, double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb,
+                                             int zt)
+{
+    __shared__ double sw[9][P2GT_LDS];   // wx0..2, wy0..2, wz0..2
+    __shared__ double sv[3][P2GT_LDS];   // vx, vy, vz
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int N = g.N;
+    const int ntz = (box.nz() + zt - 1) / zt, nty = (box.ny() + P2GT_T - 1) / P2GT_T;  // zt <= P2G_ZT target cells per wave
+    const int tile = blockIdx.x;
+    const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
+    const int tx0 = box.x0 + tx * P2GT_T, ty0 = box.y0 + ty * P2GT_T, tz0 = box.z0 + tz * zt;
+    const int ix = tx0 + wv / P2GT_T, iy = ty0 + wv % P2GT_T, zc = tz0 - 1 + lane;
+    const bool col = ix <= box.x1 && iy <= box.y1;                 // my column is in the box
+    const bool src = col && zc >= 0 && zc < N;                     // my cell exists: it may hold particles
+    const bool tgt = col && lane >= 1 && lane <= zt && zc <= box.z1;
+    const size_t c = tgt ? g.idx(ix, iy, zc) : 0;
+    const bool live = tgt && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
+    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + zt < N - 1 ? tz0 + zt : N - 1;
+    float wf = 0.0f;
+    double su = 0, sv_ = 0, sw_ = 0;
+    for (int rx = tx0 - 1; rx <= tx0 + P2GT_T; ++rx) {
+        if (rx < 0 || rx >= N) continue;
+        for (int ry = ty0 - 1; ry <= ty0 + P2GT_T; ++ry) {
+            if (ry < 0 || ry >= N) continue;
+            const int jb = cell_start[g.idx(rx, ry, zlo)];
+            const int je = cell_start[g.idx(rx, ry, zhi) + 1];
+            if (je == jb) continue;  // block-uniform
+            const int dxi = ix - rx + 1, dyi = iy - ry + 1;  // which axis weight of a particle of this row meets my column
+            const bool mine = src && dxi >= 0 && dxi <= 2 && dyi >= 0 && dyi <= 2;
+            int ca = 0, cz = 0;  // my source cell's particles in this row
+            if (mine) {
+                const size_t r0 = g.idx(rx, ry, zc);
+                ca = cell_start[r0];
+                cz = cell_start[r0 + 1];
+            }
+            const double* swx = sw[dxi < 0 ? 0 : (dxi > 2 ? 2 : dxi)];
+            const double* swy = sw[3 + (dyi < 0 ? 0 : (dyi > 2 ? 2 : dyi))];
+            double S[3] = {0, 0, 0}, U[3] = {0, 0, 0}, V[3] = {0, 0, 0}, W[3] = {0, 0, 0};  // by target: zc-1, zc, zc+1
+            for (int cb = jb; cb < je; cb += P2GT_CH) {
+                const int ce = cb + P2GT_CH < je ? cb + P2GT_CH : je;
+                __syncthreads();  // the previous chunk has been consumed
+                for (int j = cb + tid; j < ce; j += P2GT_THREADS) {
+                    const int k = p2gt_slot(j - cb);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sw[q][k] = pw[q * wstride + j];
+                    sv[0][k] = p.vx[j]; sv[1][k] = p.vy[j]; sv[2][k] = p.vz[j];
+                }
+                __syncthreads();
+                // Every lane of the wave sits on the same (x,y) column, so the x/y weight tables are wave-uniform.  A lane
+                // whose cell is crowded (settled water piles up to ~10^4 particles into one cell) would serialise the
+                // whole wave: such cells are swept by all 64 lanes together and wave-reduced (fixed order).
+                int lo = ca > cb ? ca : cb, hi = cz < ce ? cz : ce;
+                if (hi < lo) hi = lo;
+                const bool heavy = hi - lo > P2G_HEAVY;
+                if (!heavy) {
+                    for (int j = lo; j < hi; ++j) {
+                        const int k = p2gt_slot(j - cb);
+                        const double a = swx[k] * swy[k];   // (sx*sy)*sz: the reference's association (fluid.cc:291)
+                        const double vx = sv[0][k], vy = sv[1][k], vz = sv[2][k];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const double cw = a * sw[6 + d][k];
+                            S[d] += cw;
+                            U[d] = U[d] + cw * vx;
+                            V[d] = V[d] + cw * vy;
+                            W[d] = W[d] + cw * vz;
+                        }
+                    }
+                }
+                unsigned long long hm = __ballot(heavy);
+                while (hm) {
+                    const int L = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1;
+                    const int lo_L = __shfl(lo, L, 64), hi_L = __shfl(hi, L, 64);
+                    double ps[3] = {0, 0, 0}, pu[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, pq[3] = {0, 0, 0};
+                    for (int j = lo_L + lane; j < hi_L; j += 64) {
+                        const int k = p2gt_slot(j - cb);
+                        const double a = swx[k] * swy[k];
+                        const double vx = sv[0][k], vy = sv[1][k], vz = sv[2][k];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const double cw = a * sw[6 + d][k];
+                            ps[d] += cw;
+                            pu[d] += cw * vx;
+                            pv[d] += cw * vy;
+                            pq[d] += cw * vz;
+                        }
+                    }
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        double t0 = wave_sum(ps[d]), t1 = wave_sum(pu[d]), t2 = wave_sum(pv[d]), t3 = wave_sum(pq[d]);
+                        t0 = __shfl(t0, 0, 64); t1 = __shfl(t1, 0, 64); t2 = __shfl(t2, 0, 64); t3 = __shfl(t3, 0, 64);
+                        if (lane == L) { S[d] += t0; U[d] += t1; V[d] += t2; W[d] += t3; }
+                    }
+                }
+            }
+            // target zc collects: source zc-1 reaches it with its weight index 2, zc with 1, zc+1 with 0 (d = target - source + 1);
+            // container keeps the reference's float accumulator, one rounding per source cell instead of one per particle
+            const double s0 = __shfl_up(S[2], 1, 64), s2 = __shfl_down(S[0], 1, 64);
+            const double u0 = __shfl_up(U[2], 1, 64), u2 = __shfl_down(U[0], 1, 64);
+            const double v0 = __shfl_up(V[2], 1, 64), v2 = __shfl_down(V[0], 1, 64);
+            const double w0 = __shfl_up(W[2], 1, 64), w2 = __shfl_down(W[0], 1, 64);
+            if (live) {
+                wf = (float)((double)wf + s0);
+                wf = (float)((double)wf + S[1]);
+                wf = (float)((double)wf + s2);
+                su = ((su + u0) + U[1]) + u2;
+                sv_ = ((sv_ + v0) + V[1]) + v2;
+                sw_ = ((sw_ + w0) + W[1]) + w2;
+            }
+        }
+    }
+    if (!live) return;  // fields stay 0
+    if (wf > 0) {
+        const double wd = (double)wf;
+        su /= wd; sv_ /= wd; sw_ /= wd;
+    }
+    container[c] = wf;
+    u[c] = su; v[c] = sv_; w[c] = sw_;
+    ub[c] = su; vb[c] = sv_; wb[c] = sw_;
 }
 
 // ---- grid -> particle, FLIP -----------------------------------------------------------------
@@ -764,20 +943,54 @@ void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
 {
     if (n > 0) hipLaunchKernelGGL(k_weights, dim3(nblk(n)), dim3(256), 0, st, n, p, w, stride);
 }
-// pw: the particles' axis weights (launch_reorder / launch_weights); part: 12 doubles per cell of box
-void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
-                double* part, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
+// z pieces and regular y segments of a P2G launch over box; items needed: 4 + 4 * p2g_max_items(box) ints
+static void p2g_cut(const Box& box, int& ntz, int& zt, int& nseg)
 {
     // z is cut into equal pieces of at most P2G_ZT cells (89 cells: 45 + 44, not 62 + 27): balanced blocks, and at 8 particles
     // per cell a row piece of <= 46 cells fits one staged chunk
-    const int ntz = (box.nz() + P2G_ZT - 1) / P2G_ZT, zt = (box.nz() + ntz - 1) / ntz;
-    const int nseg = (box.ny() + P2G_YS - 1) / P2G_YS;
+    ntz = (box.nz() + P2G_ZT - 1) / P2G_ZT;
+    zt = (box.nz() + ntz - 1) / ntz;
+    // y segments: a segment of ys columns costs ys + 2 staged rows, and the blocks run in rounds of P2G_SLOTS at a time;
+    // take the count with the shortest estimated makespan (256^3 bench box, 92 columns: 5 segments, 930 blocks, one round)
+    nseg = 1;
+    long best = -1;
+    const long per = (long)(box.nx() + 2) * ntz;
+    for (int k = 1; k <= box.ny(); ++k) {
+        const long ys = (box.ny() + k - 1) / k, rounds = (per * k + P2G_SLOTS - 1) / P2G_SLOTS, cost = rounds * (ys + 2);
+        if (best < 0 || cost < best) { best = cost; nseg = k; }
+    }
+    if (const char* e = getenv("FLUID_P2G_NSEG")) { const int k = atoi(e); if (k >= 1 && k <= box.ny()) nseg = k; }
+}
+long p2g_max_items(Box box)
+{
+    int ntz, zt, nseg;
+    p2g_cut(box, ntz, zt, nseg);
+    return (long)(box.nx() + 2) * box.ny() * ntz;  // every segment cut down to single columns
+}
+// pw: the particles' axis weights (launch_reorder / launch_weights); part: 12 doubles per cell of box; items: work list,
+// 4 + 4 * p2g_max_items(box) ints, items[0] == 0 on entry and on exit
+void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
+                double* part, int* items, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
+{
+    int ntz, zt, nseg;
+    p2g_cut(box, ntz, zt, nseg);
     const long cells = box.cells();
-    const unsigned nt = (unsigned)((box.nx() + 2) * nseg * ntz);
+    int hv = P2G_HEAVY, budget = P2G_BUDGET;
+    if (const char* e = getenv("FLUID_P2G_HEAVY")) hv = atoi(e);
+    if (const char* e = getenv("FLUID_P2G_BUDGET")) budget = atoi(e) > 0 ? atoi(e) : budget;
+    const unsigned nt = (unsigned)((box.nx() + 2) * nseg * ntz);  // the regular cut fills the chip; further items are taken in a grid-stride loop
+    hipLaunchKernelGGL(k_p2g_items, dim3(nblk((long)(box.nx() + 2) * nseg)), dim3(256), 0, st, g, box, cell_start, nseg, ntz, budget, items);
     const bool vec = ((((uintptr_t)pw | (uintptr_t)p.vx | (uintptr_t)p.vy | (uintptr_t)p.vz) & 15) == 0) && (wstride & 1) == 0;
-    if (vec) hipLaunchKernelGGL(k_p2g_rows<true>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt);
-    else hipLaunchKernelGGL(k_p2g_rows<false>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt);
-    hipLaunchKernelGGL(k_p2g_combine, dim3(nblk(cells)), dim3(256), 0, st, g, box, part, cells, flags, container, u, v, w, ub, vb, wb);
+    if (vec) hipLaunchKernelGGL(k_p2g_rows<true>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, hv);
+    else hipLaunchKernelGGL(k_p2g_rows<false>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, hv);
+    hipLaunchKernelGGL(k_p2g_combine, dim3(nblk(cells)), dim3(256), 0, st, g, box, part, cells, flags, container, u, v, w, ub, vb, wb, items);
+}
+void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
+                      float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
+{
+    const int ntz = (box.nz() + P2G_ZT - 1) / P2G_ZT, zt = (box.nz() + ntz - 1) / ntz;
+    const unsigned nt = (unsigned)(((box.nx() + P2GT_T - 1) / P2GT_T) * ((box.ny() + P2GT_T - 1) / P2GT_T) * ntz);
+    hipLaunchKernelGGL(k_p2g_tiles, dim3(nt), dim3(P2GT_THREADS), 0, st, g, box, p, pw, wstride, cell_start, flags, container, u, v, w, ub, vb, wb, zt);
 }
 // pb = bounding box of the particles' base cells (after the sort, positions untouched since)
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,

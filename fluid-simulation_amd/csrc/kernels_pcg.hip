@@ -125,6 +125,46 @@ __global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_
     if (threadIdx.x == 0) { part_bb[blockIdx.x] = abb; part_rz0[blockIdx.x] = arz; }
 }
 
+// Start from a guess (Eigen's solveWithGuess, ConjugateGradient.h:37-43: residual = rhs - mat * x): x0 = `guess` (a global
+// field, e.g. the previous solve's pressure) at the unknown cells, r0 = b - A x0, partials of b.b (threshold) and r0.r0.
+// A neighbour contributes only if it is an unknown NOW (its count byte), whatever the guess field holds there.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const float* __restrict__ b,
+                                                          const double* __restrict__ guess, T* __restrict__ x, T* __restrict__ r, Coef<T> cf,
+                                                          double* __restrict__ part_bb, double* __restrict__ part_rr0, PcgState* ps)
+{
+    __shared__ double red[4];
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ps->done = 0; ps->iters = 0; ps->breakdown = 0; ps->bb = 0; ps->thr = 0; ps->rr = 0; }
+    const long n = (long)L.cells();
+    const long sx = (long)L.Ly * L.Lz, sy = L.Lz;
+    double abb = 0, arr = 0;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+        const uint8_t c = cnt[t];
+        T rv = 0, xv = 0;
+        if (c) {  // unknowns are interior cells: all six neighbours exist in both layouts
+            const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
+            const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
+            const size_t gx = (size_t)g.N * g.N, gy = (size_t)g.N;
+            const T bv = (T)b[gc];
+            xv = (T)guess[gc];
+            const T nb = (cnt[t - sx] ? (T)guess[gc - gx] : (T)0) + (cnt[t + sx] ? (T)guess[gc + gx] : (T)0) +
+                         (cnt[t - sy] ? (T)guess[gc - gy] : (T)0) + (cnt[t + sy] ? (T)guess[gc + gy] : (T)0) +
+                         (cnt[t - 1] ? (T)guess[gc - 1] : (T)0) + (cnt[t + 1] ? (T)guess[gc + 1] : (T)0);
+            rv = bv - (sdiag[c] * xv + cf.off * nb);
+            abb += (double)bv * (double)bv;
+            arr += (double)rv * (double)rv;
+        }
+        x[t] = xv;
+        r[t] = rv;
+    }
+    abb = block_sum<double, 4>(abb, red);
+    arr = block_sum<double, 4>(arr, red);
+    if (threadIdx.x == 0) { part_bb[blockIdx.x] = abb; part_rr0[blockIdx.x] = arr; }
+}
+
 // Start of a CG body (ConjugateGradient.h:45-60 for the first, :75-85 for the others): sums the
 // previous launch's partials (or reads the all-reduced scalars when n_prev == 1), decides
 // convergence identically in every block, returns beta.  false = this block must exit.
@@ -136,16 +176,19 @@ __device__ __forceinline__ bool pcg_head(const double* __restrict__ part_rr, con
     const int tid = threadIdx.x;
     beta = 0;
     if (first) {
-        // b == 0 -> x = 0, done.
-        double bb, d1, d2;
-        block_sum3(part_rr, n_prev, part_rr, 0, part_rr, 0, red, bb, d1, d2);
+        // b == 0 -> x = 0, done.  first == 2 (started from a guess): part_rz_old holds the partials of r0.r0, and a guess
+        // that already meets the threshold ends the solve with 0 iterations (ConjugateGradient.h:51-56)
+        double bb, rr0, d2;
+        block_sum3(part_rr, n_prev, part_rz_old, first == 2 ? n_prev : 0, part_rr, 0, red, bb, rr0, d2);
+        if (first != 2) rr0 = bb;
+        const bool go = bb > 0 && !(rr0 < tol * tol * bb);
         if (blockIdx.x == 0 && tid == 0) {
             ps->bb = bb;
             ps->thr = tol * tol * bb;
-            ps->rr = bb;
-            if (!(bb > 0)) ps->done = 1;
+            ps->rr = rr0;
+            if (!go) ps->done = 1;
         }
-        return bb > 0;
+        return go;
     }
     double rr, rzn, rzo;
     block_sum3(part_rr, n_prev, part_rz_new, n_rz, part_rz_old, n_rz, red, rr, rzn, rzo);
@@ -432,13 +475,20 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
 // local x -> global pressure field (VectorXd p scattered back to cells, fluid.cc:637)
 template <typename T>
 __global__ __launch_bounds__(256) void k_store_pressure_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ x,
-                                                          double* __restrict__ pressure)
+                                                          double* __restrict__ pressure, double* __restrict__ keep, const PcgState* ps)
 {
+    // keep != nullptr: a second copy that no per-step clearing touches (the next solve's starting guess); the solve
+    // started from a guess, and for b == 0 the answer is x = 0 whatever the guess was (ConjugateGradient.h:45-50)
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)L.cells()) return;
     const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
-    if (i >= 1 && i <= L.nx && j >= 1 && j <= L.ny && k >= LBOX_K0 && k < LBOX_K0 + L.nz)
-        pressure[g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0)] = cnt[t] ? (double)x[t] : 0.0;
+    if (i >= 1 && i <= L.nx && j >= 1 && j <= L.ny && k >= LBOX_K0 && k < LBOX_K0 + L.nz) {
+        const bool zero = keep && !(ps->bb > 0);
+        const double pv = cnt[t] && !zero ? (double)x[t] : 0.0;
+        const size_t c = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
+        pressure[c] = pv;
+        if (keep) keep[c] = pv;
+    }
 }
 
 void launch_cnt_local(hipStream_t st, Grid g, LBox L, const uint8_t* flags, uint8_t* cnt)
@@ -450,6 +500,12 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
                      double* part_rz0, PcgState* ps)
 {
     hipLaunchKernelGGL((k_pcg_init_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, x, r, cf, part_bb, part_rz0, ps);
+}
+template <typename T>
+void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, T* x, T* r, Coef<T> cf,
+                           double* part_bb, double* part_rr0, PcgState* ps)
+{
+    hipLaunchKernelGGL((k_pcg_init_guess_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, guess, x, r, cf, part_bb, part_rr0, ps);
 }
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
@@ -493,9 +549,9 @@ void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const
                        n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, sparse);
 }
 template <typename T>
-void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure)
+void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure, double* keep, const PcgState* ps)
 {
-    hipLaunchKernelGGL((k_store_pressure_l<T>), dim3((unsigned)((L.cells() + 255) / 256)), dim3(256), 0, st, g, L, cnt, x, pressure);
+    hipLaunchKernelGGL((k_store_pressure_l<T>), dim3((unsigned)((L.cells() + 255) / 256)), dim3(256), 0, st, g, L, cnt, x, pressure, keep, ps);
 }
 
 // ================================================================================================
@@ -738,7 +794,9 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
                                    double*, double*, PcgState*, int, int);                                                                \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
-    template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*);                                \
+    template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*, double*, const PcgState*);      \
+    template void launch_pcg_init_guess<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, const double*, T*, T*, Coef<T>,      \
+                                           double*, double*, PcgState*);                                                               \
     template void launch_pcg_s<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, Coef<T>, const double*, const double*,     \
                                   const double*, PcgState*, int, double, int);                                                           \
     template void launch_pcg_q<T>(hipStream_t, LBox, const uint8_t*, const T*, T*, Coef<T>, double*, PcgState*);                        \

@@ -52,6 +52,28 @@ def test_p2g_and_flags(fs, oracle, n, ppc):
     assert np.array_equal((flags >> 2)[fluid], ad[fluid])
 
 
+@pytest.mark.parametrize("n,ppc", [(32, 8), (33, 3)])
+def test_p2g_forms_agree(fs, oracle, n, ppc, monkeypatch):
+    """The two particle -> grid kernels (row-marching for evenly filled water, 2 x 2 tiles once particles pile up; the
+    host switches by the fullest cell) form the same sums in a different association: both against the oracle, and
+    against each other."""
+    out = {}
+    for form in ("rows", "tiles"):
+        monkeypatch.setenv("FLUID_P2G_FORM", form)
+        sim, orc, pos = make_pair(fs, oracle, n, ppc, vel_scale=1.0)
+        sim.p2g(); sim.flags_index()
+        orc.p2g(); orc.flags_index()
+        F = fs.FIELD
+        out[form] = (sim.field(F.CONTAINER), sim.field(F.VEL))
+        assert rel_l2(out[form][0], orc.field(0)) < TOL_W
+        assert rel_l2(out[form][1], orc.field(2)) < 1e-6
+        sim.close()
+    assert np.array_equal(out["rows"][0] > 0, out["tiles"][0] > 0)
+    assert rel_l2(out["rows"][0], out["tiles"][0]) < TOL_W
+    # the velocity is divided by the float32 weight sum, whose rounding sequence is the form's: 6e-8, the bar of the oracle
+    assert rel_l2(out["rows"][1], out["tiles"][1]) < 1e-6
+
+
 def orc_adiag_counts(orc):
     orc.rhs_div(); orc.build_matrix()
     ad = orc.field(10)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the particle -> grid phase alone on the bench scene: python tools/p2g_time.py [n] [reps]
+"""Time the particle -> grid phase alone on the bench scene: python tools/p2g_time.py [n] [reps] [steps before]
 (two full steps first, then fluid_p2g() repeatedly on the sorted particles; hipEvent time per call)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 sim = fs.FluidSim(n=n)
 sim.upload_particles(fs.water_cube_drop(n, 8, seed=0))
-for _ in range(2):
+pre = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+for _ in range(pre):
     sim.step()
 sim.p2g()
 sim.profile_reset()
