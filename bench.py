@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-micro", action="store_true", help="skip the dense stencil micro-benchmark")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="keep timing oracle steps until this much CPU time is spent")
     ap.add_argument("--force-dist", action="store_true", help="run the decomposed code path even with one rank (overhead check)")
-    ap.add_argument("--sample-every", type=int, default=8, help="bracket every k-th PCG launch with hipEvents")
+    ap.add_argument("--sample-every", type=int, default=32, help="bracket every k-th PCG launch (and every k/8-th P2G / sort / G2P / solve) with a hipEvent pair; each record stalls the stream ~5-10 us")
     return ap.parse_args()
 
 

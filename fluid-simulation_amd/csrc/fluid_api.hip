@@ -134,7 +134,9 @@ static int prof_begin(fluid_sim* s, int k, double cells)
 {
     ProfClass& p = s->prof[k];
     p.launches++;
-    if (s->prof_every <= 0 || (p.launches - 1) % s->prof_every) return -1;
+    const bool per_iter = k == FLUID_PROF_PCG_SQ || k == FLUID_PROF_PCG_XR || k == FLUID_PROF_MG_UP0;
+    const int every = per_iter ? s->prof_every : (s->prof_every >= 8 ? s->prof_every / 8 : (s->prof_every > 0 ? 1 : 0));
+    if (every <= 0 || (p.launches - 1) % every) return -1;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
     hipEventRecord(a, s->st);

@@ -163,7 +163,9 @@ int fluid_stencil_apply(fluid_sim_t* s, int reps, int box, float* avg_ms);
 #define FLUID_PROF_SOLVE 5       /* whole solve                              */
 #define FLUID_PROF_MG_UP0 6  /* level-0 up leg of the V-cycle (k_mg_up)      */
 #define FLUID_PROF_COUNT 7
-/* every `sample_every`-th launch of each class is bracketed by an event pair (0 = off). */
+/* Every `sample_every`-th launch of the per-iteration classes (PCG_SQ, PCG_XR, MG_UP0) and every max(1, sample_every / 8)-th
+ * launch of the per-step classes (P2G, G2P, SORT, SOLVE) is bracketed by an event pair (0 = off).  An event record stalls the
+ * stream by ~5-10 us: sample sparsely inside a timed region. */
 int fluid_profile_enable(fluid_sim_t* s, int sample_every);
 /* Resolves pending events; n_launches = launches seen, n_sampled = launches timed,
  * total_ms = sum over the timed ones, cells = sum of cells swept by the timed ones. */
