@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--vel", type=float, default=0.0)
     ap.add_argument("--uniform", action="store_true", help="uniform slabs instead of equal particle counts")
     ap.add_argument("--blend", type=float, default=1.0, help="PIC/FLIP blend (1 = pure FLIP)")
+    ap.add_argument("--pile", type=int, default=0, help="extra particles packed around the first one (a cell past the P2G form switch)")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -41,6 +42,8 @@ def main():
     fs = entry.load_package()
     fd = fs.load_dist()
     pos = fs.water_cube_drop(a.n, a.ppc, seed=0)
+    if a.pile:
+        pos = np.concatenate([pos, np.round(pos[0]) + np.random.default_rng(5).uniform(-0.4, 0.4, size=(a.pile, 3))])
     vel = None
     if a.vel:
         vel = np.random.default_rng(1).standard_normal(pos.shape) * a.vel

@@ -25,10 +25,14 @@ def run_dist(world, n, ppc, steps, tmp_path, extra=(), mode="staged"):
 
 
 @pytest.mark.parametrize("world,n,ppc,steps,extra", [(2, 32, 4, 4, ()), (3, 40, 4, 3, ()), (2, 32, 4, 6, ("--uniform", "--vel", "3.0")),
-                                                    (2, 32, 4, 4, ("--vel", "1.0", "--blend", "0.9"))])
+                                                    (2, 32, 4, 4, ("--vel", "1.0", "--blend", "0.9")),
+                                                    (2, 32, 4, 3, ("--pile", "600"))])
 def test_dist_matches_single(fs, tmp_path, world, n, ppc, steps, extra):
     d = run_dist(world, n, ppc, steps, tmp_path, extra)
     pos = fs.water_cube_drop(n, ppc, seed=0)
+    if "--pile" in extra:  # one cell past the P2G form switch: every rank must take the tile form, like the single GPU does
+        k = int(extra[extra.index("--pile") + 1])
+        pos = np.concatenate([pos, np.round(pos[0]) + np.random.default_rng(5).uniform(-0.4, 0.4, size=(k, 3))])
     vel = None
     if "--vel" in extra:
         vel = np.random.default_rng(1).standard_normal(pos.shape) * float(extra[extra.index("--vel") + 1])
