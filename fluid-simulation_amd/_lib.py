@@ -64,6 +64,7 @@ SYMBOLS = [
     ("fluid_set_dt", C.c_int, [_P, C.c_double]),
     ("fluid_get_dt", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("fluid_scene_water_cube_drop", C.c_int64, [C.c_int32, C.c_int32, C.c_uint64, _P]),
+    ("fluid_scene_uniform_scatter", C.c_int64, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_float, C.c_uint32, C.c_int32, _P]),
     ("fluid_step", C.c_int, [_P, C.POINTER(StepStats)]),
     ("fluid_p2g", C.c_int, [_P]),
     ("fluid_flags_index", C.c_int, [_P]),

@@ -4,10 +4,11 @@
 // one fluid_step() call into libfluid_hip.so (hand-written HIP, gfx950).
 //
 // Like the reference it takes no arguments.  Environment overrides (all optional):
-//   FLUID_N (121)  FLUID_PPC (10)  FLUID_STEPS (500)  FLUID_SEED (0)  FLUID_DEVICE (0)
-//   FLUID_OUT (simulation)  — directory for mygrids<i>.f32; "" disables output.
-// Output: until the .vdb writer lands each step writes
-// <out>/mygrids<i>.f32 = int32 N, then N^3 float32 (z fastest) of outputGrid (fluid.cc:1444,1503).
+//   FLUID_N (121)  FLUID_PPC (10)  FLUID_STEPS (500)  FLUID_SEED (0)  FLUID_DEVICE (0)  FLUID_FLIP_BLEND (1)
+//   FLUID_OUT (simulation)  — directory for mygrids<i>.vdb (fluid.cc:1371,1503-1510); "" disables output; FLUID_RAW=1 adds .f32 dumps.
+// Initial particles: with the defaults (N = 121, 10 per voxel) exactly the reference's — fill(CoordBBox(-20, 20)) scattered by
+// UniformPointScatter with std::mt19937(FLUID_SEED) (fluid_scene_uniform_scatter: 689210 points); any other N / PPC takes the
+// scaled synthetic cube (fluid_scene_water_cube_drop).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -44,9 +45,13 @@ int main(int, char**)
         std::cerr << "fluid_create: " << fluid_last_error() << std::endl;
         return 1;
     }
-    const int64_t np = fluid_scene_water_cube_drop(prm.n, ppc, seed, nullptr);
+    const bool ref_scene = prm.n == 121 && ppc == 10;   // fluid.cc:1176,1347-1350
+    const int32_t flo[3] = {-20, -20, -20}, fhi[3] = {20, 20, 20};
+    const int64_t np = ref_scene ? fluid_scene_uniform_scatter(flo, fhi, 10.f, (uint32_t)seed, 60, nullptr)
+                                 : fluid_scene_water_cube_drop(prm.n, ppc, seed, nullptr);
     std::vector<double> pos((size_t)3 * np);
-    fluid_scene_water_cube_drop(prm.n, ppc, seed, pos.data());
+    if (ref_scene) fluid_scene_uniform_scatter(flo, fhi, 10.f, (uint32_t)seed, 60, pos.data());
+    else fluid_scene_water_cube_drop(prm.n, ppc, seed, pos.data());
     if (fluid_upload_particles(sim, np, pos.data(), nullptr) != FLUID_OK) {
         std::cerr << "fluid_upload_particles: " << fluid_last_error() << std::endl;
         return 1;

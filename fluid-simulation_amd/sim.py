@@ -41,6 +41,21 @@ def water_cube_drop(n, ppc, seed=0):
     return pos
 
 
+def reference_scatter(lo=-20, hi=20, points_per_volume=10.0, seed=0, boundary=60):
+    """The reference's own initial particles (fluid.cc:1176,1347-1350: fill(CoordBBox(lo,hi)) + UniformPointScatter with
+    std::mt19937(seed)), restated on the host (csrc/scene_scatter.cpp): (npart,3) float64 positions.  The defaults are the
+    reference's scene on its 121^3 grid: 689210 particles."""
+    l3 = (C.c_int32 * 3)(*([lo] * 3 if np.isscalar(lo) else lo))
+    h3 = (C.c_int32 * 3)(*([hi] * 3 if np.isscalar(hi) else hi))
+    cnt = lib.fluid_scene_uniform_scatter(l3, h3, points_per_volume, seed, boundary, None)
+    if cnt < 0:
+        raise ValueError("bad scene arguments")
+    pos = np.empty((cnt, 3), dtype=np.float64)
+    got = lib.fluid_scene_uniform_scatter(l3, h3, points_per_volume, seed, boundary, pos.ctypes.data_as(C.c_void_p))
+    assert got == cnt
+    return pos
+
+
 class FluidSim:
     """One simulation on one MI355X.  Mirrors what main() owns in the reference:
     grids + PointList + dt, and one ``step()`` = one iteration of fluid.cc:1378-1490."""

@@ -125,6 +125,15 @@ int fluid_get_dt(fluid_sim_t* s, double* dt);
  * voxel at c - 0.5 + U[0,1)^3 (counter-based RNG).  pos==NULL -> returns the count only.
  * Needs no GPU. */
 int64_t fluid_scene_water_cube_drop(int32_t n, int32_t ppc, uint64_t seed, double* pos);
+/* Host-only: the reference's own initial particles — what
+ *   fluidGrid->fill(CoordBBox(lo, hi), 0, true); std::mt19937 r(seed);
+ *   UniformPointScatter<PointList, std::mt19937>(pos, points_per_volume, r)(*fluidGrid);      fluid.cc:1176,1347-1350
+ * leaves in PointList::positions (openvdb/tools/PointScatter.h:143-185, tree fill + ValueOn order, libstdc++'s mt19937 /
+ * uniform_int / uniform_real, g++'s right-to-left argument evaluation), with PointList::add's |p| < boundary - 2 filter
+ * (fluid.cc:841; boundary <= 0: none).  The reference's scene: lo = -20, hi = 20, 10.f, seed 0, boundary 60 -> 689210
+ * points for a 121^3 grid.  pos == NULL -> returns the count only; < 0 on bad arguments.  Needs no GPU. */
+int64_t fluid_scene_uniform_scatter(const int32_t lo[3], const int32_t hi[3], float points_per_volume, uint32_t seed,
+                                    int32_t boundary, double* pos);
 
 /* ---- the step ------------------------------------------------------------------------- */
 /* One iteration of the loop body fluid.cc:1378-1490 (everything except the .vdb write). */

@@ -479,6 +479,16 @@ def _compare_step(fs, oracle, n, pos, vel, steps=2, tol_w=TOL_W):
     return sim, orc
 
 
+def test_reference_scene_first_steps(fs, oracle):
+    """The reference program's own start: 121^3 grid, fill(CoordBBox(-20, 20)) scattered by UniformPointScatter with
+    std::mt19937(0) (689210 particles, fluid.cc:1176,1347-1350; tests/test_scatter.py), two iterations of its loop."""
+    pos = fs.reference_scatter()
+    assert len(pos) == 689210
+    sim, orc = _compare_step(fs, oracle, 121, pos, None, steps=2)
+    F = fs.FIELD
+    assert rel_l2(sim.field(F.PRESSURE), orc.field(7)) < TOL_F
+
+
 def test_edge_no_particles(fs, oracle):
     """Empty PointList: nothing is fluid, b = 0, the do..while ends on NaN after one pass (fluid.cc:1483-1484)."""
     sim = fs.FluidSim(n=24)
