@@ -1,0 +1,52 @@
+// Host-only entry points under AddressSanitizer + UBSan (tests/test_host_sanitizers.py builds and runs this with g++;
+// GPU sanitizers are not available on the pool).  Exercises the scatter (voxels, 8^3 tiles, a 128^3 tile, the filter,
+// count-only calls, bad arguments) and the .vdb writer (one and two grids, odd size).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fluid_hip.h"
+
+static int fail(const char* what)
+{
+    std::fprintf(stderr, "FAILED: %s\n", what);
+    return 1;
+}
+
+int main(int argc, char** argv)
+{
+    const char* dir = argc > 1 ? argv[1] : ".";
+    {
+        const int32_t lo[3] = {-20, -20, -20}, hi[3] = {20, 20, 20};
+        const int64_t n = fluid_scene_uniform_scatter(lo, hi, 10.f, 0, 60, nullptr);
+        if (n != 689210) return fail("reference scene count");
+        std::vector<double> pos((size_t)3 * n);
+        if (fluid_scene_uniform_scatter(lo, hi, 10.f, 0, 60, pos.data()) != n) return fail("reference scene fill");
+    }
+    {
+        const int32_t lo[3] = {-130, -9, 3}, hi[3] = {5, 13, 3};   // mixed: a thin slab crossing the origin in x
+        const int64_t n = fluid_scene_uniform_scatter(lo, hi, 2.f, 5, 0, nullptr);
+        if (n != 2 * 136 * 23 * 1) return fail("slab count");
+        std::vector<double> pos((size_t)3 * n);
+        if (fluid_scene_uniform_scatter(lo, hi, 2.f, 5, 0, pos.data()) != n) return fail("slab fill");
+    }
+    {
+        const int32_t lo[3] = {-130, -130, -130}, hi[3] = {5, 5, 5};  // holds the whole node [-128, -1]^3
+        if (fluid_scene_uniform_scatter(lo, hi, 1.f, 3, 0, nullptr) != 136L * 136 * 136) return fail("128^3 tile count");
+        const int32_t bad[3] = {6, 6, 6};
+        if (fluid_scene_uniform_scatter(bad, hi, 1.f, 3, 0, nullptr) >= 0) return fail("lo > hi accepted");
+        if (fluid_scene_uniform_scatter(lo, hi, 0.f, 3, 0, nullptr) >= 0) return fail("density 0 accepted");
+        if (fluid_scene_uniform_scatter(nullptr, hi, 1.f, 3, 0, nullptr) >= 0) return fail("null box accepted");
+    }
+    for (int n : {8, 21}) {
+        std::vector<float> a((size_t)n * n * n), b(a.size());
+        for (size_t i = 0; i < a.size(); ++i) { a[i] = (i % 7 == 0) ? 0.f : (float)(i % 13) * 0.25f; b[i] = (float)(i % 3); }
+        const float* grids[2] = {a.data(), b.data()};
+        char path[512];
+        std::snprintf(path, sizeof path, "%s/san_%d.vdb", dir, n);
+        if (fluid_write_vdb(path, n, n == 8 ? 1 : 2, grids) != FLUID_OK) return fail("fluid_write_vdb");
+    }
+    if (fluid_write_vdb("/nonexistent-dir/x.vdb", 8, 1, nullptr) == FLUID_OK) return fail("bad path accepted");
+    std::puts("host sanitizer run: ok");
+    return 0;
+}
