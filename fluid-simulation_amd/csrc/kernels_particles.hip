@@ -222,17 +222,16 @@ __global__ __launch_bounds__(256) void k_weights(long n, Particles p, double* __
 // writes all its partials (zeros for empty rows), so nothing is cleared.
 // History (256^3 bench scene, 5.3 M particles): a lane-per-cell loop straight from global memory 7.4 ms; 2 x 2-column
 // tiles staging their 4 x 4 window of rows (every row staged by 4 tiles, 2.2 GB fetched) 0.38 ms with, per tile row,
-// at most 2.25 of 4 waves busy; 4 x 4 tiles 1.29 ms (9 of 16 waves busy); this form stages (YS+2)/YS = 1.17 x.
+// at most 2.25 of 4 waves busy; 4 x 4 tiles 1.29 ms (9 of 16 waves busy); this form stages (ys + 2) / ys x for segments of ys
+// columns (1.1-1.2 x on the bench scene): 0.21 ms + 0.02 for k_p2g_combine.
 // Tried without gain: computing the weights while staging (positions instead of 9 weights: +0.15 ms of fp64 work),
 // reading the next row's cell ranges a row ahead, a register-prefetch pipeline over the chunks, one 96 B record per particle
 // (array of structures: one stream per block instead of 12) for the staged data and for the partials (0.32 ms against 0.26, and
-// the reorder pass that writes them +60 us).
-#ifndef P2GR_CH
-#define P2GR_CH 384
-#endif
+// the reorder pass that writes them +60 us), a kernel of its own pre-reducing the cells above 256 particles (no change where
+// particles pile up: there the per-row latency of whole wall planes is the critical path, see k_p2g_tiles).
 constexpr int P2G_SLOTS = 256 * 4;  // blocks resident at once: 256 CUs x 4 (37.6 KB of LDS, 168 VGPRs)
 constexpr int P2G_THREADS = 192;
-constexpr int P2G_CH = P2GR_CH;   // particles staged per chunk: 12 x 8 B x 392 = 37.6 KB of LDS, 4 blocks per CU (158 VGPRs: 3 waves per
+constexpr int P2G_CH = 384;       // particles staged per chunk: 12 x 8 B x 392 = 37.6 KB of LDS, 4 blocks per CU (168 VGPRs: 3 waves per
                                   // SIMD).  A row piece of this scene holds ~360 particles; 256 and 320 (two chunks per row) measured 2.3 x slower
 // LDS slot of staged particle k: lane z reads particle a_z + t with a_z growing by ~8 (particles per cell) from
 // lane to lane; splitting by k mod 8 keeps neighbouring lanes on neighbouring slots.
@@ -247,7 +246,7 @@ constexpr int P2G_ZT = 62;     // most target cells a wave takes (lanes 0 and 63
 // even stride (the launcher checks), so two particles are staged per lane and load
 template <bool VEC>
 __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
-                                                          const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt, const int* __restrict__ items, int heavy_min)
+                                                          const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt, const int* __restrict__ items)
 {
     __shared__ double sr[12][P2G_LDS];   // wx0..2, wy0..2, wz0..2, vx, vy, vz
     const int tid = threadIdx.x, e = tid >> 6, lane = tid & 63;
@@ -319,7 +318,7 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
                 // whole wave: such cells are swept by all 64 lanes together and wave-reduced (fixed order).
                 int lo = ca > cb ? ca : cb, hi = cz < ce ? cz : ce;
                 if (hi < lo) hi = lo;
-                const bool heavy = hi - lo > heavy_min;
+                const bool heavy = hi - lo > P2G_HEAVY;
                 if (!heavy) {
                     for (int j = lo; j < hi; ++j) {
                         const int k = p2g_slot(j - cb);
@@ -959,7 +958,6 @@ static void p2g_cut(const Box& box, int& ntz, int& zt, int& nseg)
         const long ys = (box.ny() + k - 1) / k, rounds = (per * k + P2G_SLOTS - 1) / P2G_SLOTS, cost = rounds * (ys + 2);
         if (best < 0 || cost < best) { best = cost; nseg = k; }
     }
-    if (const char* e = getenv("FLUID_P2G_NSEG")) { const int k = atoi(e); if (k >= 1 && k <= box.ny()) nseg = k; }
 }
 long p2g_max_items(Box box)
 {
@@ -975,14 +973,12 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, 
     int ntz, zt, nseg;
     p2g_cut(box, ntz, zt, nseg);
     const long cells = box.cells();
-    int hv = P2G_HEAVY, budget = P2G_BUDGET;
-    if (const char* e = getenv("FLUID_P2G_HEAVY")) hv = atoi(e);
-    if (const char* e = getenv("FLUID_P2G_BUDGET")) budget = atoi(e) > 0 ? atoi(e) : budget;
+    const int budget = P2G_BUDGET;
     const unsigned nt = (unsigned)((box.nx() + 2) * nseg * ntz);  // the regular cut fills the chip; further items are taken in a grid-stride loop
     hipLaunchKernelGGL(k_p2g_items, dim3(nblk((long)(box.nx() + 2) * nseg)), dim3(256), 0, st, g, box, cell_start, nseg, ntz, budget, items);
     const bool vec = ((((uintptr_t)pw | (uintptr_t)p.vx | (uintptr_t)p.vy | (uintptr_t)p.vz) & 15) == 0) && (wstride & 1) == 0;
-    if (vec) hipLaunchKernelGGL(k_p2g_rows<true>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, hv);
-    else hipLaunchKernelGGL(k_p2g_rows<false>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, hv);
+    if (vec) hipLaunchKernelGGL(k_p2g_rows<true>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items);
+    else hipLaunchKernelGGL(k_p2g_rows<false>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items);
     hipLaunchKernelGGL(k_p2g_combine, dim3(nblk(cells)), dim3(256), 0, st, g, box, part, cells, flags, container, u, v, w, ub, vb, wb, items);
 }
 void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
