@@ -103,6 +103,18 @@ __device__ __forceinline__ double spline(double x)
     return 0;
 }
 
+// spline(p - c) for the cell c = round(p) - 1 + d, d = 0..2 (the only cells a particle meets per axis).  For the outer two
+// |p - c| lies in [0.5, 1.5] — round() is half away from zero, so |p - round(p)| <= 0.5, and the one subtraction p - c
+// cannot round below 0.5 — and spline()'s first branch is never taken: the same values with half the arithmetic.
+__device__ __forceinline__ double spline_at(double p, int c, int d)
+{
+    double x = p - (double)c;
+    if (d == 1) return spline(x);
+    if (x < 0) x *= -1.0;
+    if (x < 1.0) return 1.5 * ((-8.0 * (x * x * x) / 6.0) + 4.0 * x * x - 4.0 * x + 4.0 / 3.0);
+    return 0;
+}
+
 // ---- wave64 / block reductions ------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v)

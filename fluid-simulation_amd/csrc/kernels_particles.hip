@@ -167,7 +167,7 @@ __device__ __forceinline__ void axis_weights(double px, double py, double pz, do
     for (int a = 0; a < 3; ++a) {
         const int b = (int)round(q[a]);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) w[(a * 3 + d) * stride + j] = spline(q[a] - (double)(b - 1 + d));
+        for (int d = 0; d < 3; ++d) w[(a * 3 + d) * stride + j] = spline_at(q[a], b - 1 + d, d);
     }
 }
 
@@ -620,9 +620,9 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int ax = fcx - 1 + d, ay = fcy - 1 + d, az = fcz - 1 + d;
-            wx[d] = (ax >= wlo && ax <= whi) ? spline(cx - (double)ax) : 0.0;
-            wy[d] = (ay >= wlo && ay <= whi) ? spline(cy - (double)ay) : 0.0;
-            wz[d] = (az >= wlo && az <= whi) ? spline(cz - (double)az) : 0.0;
+            wx[d] = (ax >= wlo && ax <= whi) ? spline_at(cx, ax, d) : 0.0;
+            wy[d] = (ay >= wlo && ay <= whi) ? spline_at(cy, ay, d) : 0.0;
+            wz[d] = (az >= wlo && az <= whi) ? spline_at(cz, az, d) : 0.0;
             ox[d] = (min(max(ax, lo), hi) - lo) * N * N;   // N <= 1024: N^3 fits an int
             oy[d] = (min(max(ay, lo), hi) - lo) * N;
             oz[d] = min(max(az, lo), hi) - lo;
@@ -732,9 +732,9 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const int ax = fcx - 1 + d, ay = fcy - 1 + d, az = fcz - 1 + d;
-                wx[d] = (ax >= wlo && ax <= whi) ? spline(cx - (double)ax) : 0.0;
-                wy[d] = (ay >= wlo && ay <= whi) ? spline(cy - (double)ay) : 0.0;
-                wz[d] = (az >= wlo && az <= whi) ? spline(cz - (double)az) : 0.0;
+                wx[d] = (ax >= wlo && ax <= whi) ? spline_at(cx, ax, d) : 0.0;
+                wy[d] = (ay >= wlo && ay <= whi) ? spline_at(cy, ay, d) : 0.0;
+                wz[d] = (az >= wlo && az <= whi) ? spline_at(cz, az, d) : 0.0;
             }
             const int lb = ((fcx - lo - x0) * LY + (fcy - lo - y0)) * LZ + (fcz - lo - z0);  // cell (base-1) in tile coordinates
             double weight = 0, d0 = 0, d1 = 0, d2 = 0, q0 = 0, q1 = 0, q2 = 0;
