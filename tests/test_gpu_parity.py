@@ -74,6 +74,41 @@ def test_p2g_forms_agree(fs, oracle, n, ppc, monkeypatch):
     assert rel_l2(out["rows"][1], out["tiles"][1]) < 1e-6
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_p2g_forms_agree_on_piles(fs, oracle, seed, monkeypatch):
+    """Random piles of 60 .. 12000 particles per cell on a thin background, some against the walls: the wave-swept heavy
+    cells, rows longer than a staged chunk and the work list's cut of crowded planes (more than 8192 particles in a plane
+    segment) in the row-marching form, against the tile form and the oracle."""
+    n = 24
+    rng = np.random.default_rng(100 + seed)
+    lo, hi = fs.grid_bounds(n)
+    parts = [fs.water_cube_drop(n, 2, seed=seed)]
+    for k in (60, 200, 500, 2000, 12000)[: 3 + seed % 3]:
+        for _ in range(2):
+            c = rng.integers(lo + 3, hi - 2, size=3).astype(np.float64)
+            if rng.random() < 0.5:
+                c[rng.integers(0, 3)] = (lo + 3) if rng.random() < 0.5 else (hi - 3)   # first / last cell inside the walls
+            parts.append(c + rng.uniform(-0.49, 0.49, size=(k, 3)))
+    pos = np.concatenate(parts)
+    pos = pos[rng.permutation(len(pos))]
+    vel = rng.standard_normal(pos.shape)
+    orc = oracle.Oracle(n=n); orc.set_particles(pos, vel); orc.p2g(); orc.flags_index()
+    out = {}
+    for form in ("rows", "tiles"):
+        monkeypatch.setenv("FLUID_P2G_FORM", form)
+        sim = fs.FluidSim(n=n); sim.upload_particles(pos, vel)
+        sim.p2g(); sim.flags_index()
+        F = fs.FIELD
+        out[form] = (sim.field(F.CONTAINER), sim.field(F.VEL), sim.field(F.INDICES))
+        assert np.array_equal(out[form][2], orc.field(4))
+        # float32 sums of thousands of addends per cell: order effects grow like sqrt(k) * 6e-8
+        assert rel_l2(out[form][0], orc.field(0)) < 1e-5
+        assert rel_l2(out[form][1], orc.field(2)) < 1e-5
+        sim.close()
+    assert rel_l2(out["rows"][0], out["tiles"][0]) < 1e-5
+    assert rel_l2(out["rows"][1], out["tiles"][1]) < 1e-5
+
+
 def orc_adiag_counts(orc):
     orc.rhs_div(); orc.build_matrix()
     ad = orc.field(10)
