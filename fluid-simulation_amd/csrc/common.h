@@ -86,6 +86,7 @@ struct StepState {
     int n_out;                // particles whose base cell is outside the grid
     int max_cell;             // most particles in one cell (P2G picks its kernel by it)
     int pad_;
+    int n_tl_mg, n_tl_sq;     // active tiles of the level-0 V-cycle legs / of SQ and XR (mostly-air boxes)
     unsigned long long max_speed_bits;  // max |v_p| as non-negative double bits
     double dt;                // fluid.cc:1367 / 992-999
     double err_num;           // |b-b2|^2
@@ -275,6 +276,16 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1, int sparse = 0);
+// the same two over a list of active SQ tiles (mostly-air box).  n_prev = partials of the previous launch in part_rr (the init
+// kernel's pcg_xr_blocks(L) for the first body, pcg_list_blocks(nlist) afterwards); both write pcg_list_blocks(nlist) partials
+int pcg_list_blocks(int nlist);
+template <typename T>
+void launch_pcg_sq_list(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
+                        const double* part_rr, int n_prev, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps,
+                        int first, double tol, int n_rz, int zmode, const int* tlist, int nlist);
+template <typename T>
+void launch_pcg_xr_list(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
+                        int n_rz, const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* tlist, int nlist);
 template <typename T>
 void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
                   const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol, int zmode = 0);
@@ -309,10 +320,16 @@ int mg_up_blocks(const MLevel& m);
 // T = the V-cycle's arithmetic/storage type, F / O = element types of a level's rhs / result (double at level 0)
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
-                    const PcgState* ps);
+                    const PcgState* ps, const int* tlist = nullptr, int nlist = 0);
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps, double wc);
+                  double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0);
+// Active-tile lists of a mostly-air box (level 0 only): flags per tile of the V-cycle legs / of the SQ kernel, and their
+// compaction in ascending tile order (list[0..*count)); the legs, SQ and XR are then launched over the listed tiles only.
+void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags);
+void launch_sq_tile_flags(hipStream_t st, LBox L, const uint8_t* cnt, uint8_t* flags);
+int sq_tile_count(const LBox& L);
+void launch_compact_flags(hipStream_t st, const uint8_t* flags, int n, int* list, int* count);
 template <typename T>
 void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps,
                     double wc);

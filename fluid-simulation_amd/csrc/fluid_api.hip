@@ -67,6 +67,14 @@ struct fluid_sim {
     int* p2g_items = nullptr;    // k_p2g_rows' work list (count + int4 items), grown on demand; the count is 0 between launches
     size_t p2g_items_cap = 0;
     int max_cell = 0;            // most particles in one cell after the last sort (all ranks' cells when distributed)
+    // mostly-air box (splash, settled pool): level-0 legs, SQ and XR run over compacted lists of the tiles that hold an unknown
+    uint8_t* tl_flags = nullptr;  // per-tile flags (both tile shapes, one after the other)
+    int *tl_mg = nullptr, *tl_sq = nullptr;
+    size_t tl_cap = 0;
+    int n_tl_mg = 0, n_tl_sq = 0;
+    bool lists_hint = false;      // the previous step's box was mostly air: build the lists before this step's flags sync
+    bool lists_on = false;        // this step's solves use them
+    int lists_force = -1;         // FLUID_TILE_LISTS=0|1
     int p2g_force = 0;           // FLUID_P2G_FORM=rows|tiles: 1 / 2, for experiments
     StepState* ss = nullptr;
     StepState* h_ss = nullptr;  // pinned
@@ -247,7 +255,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->repl_buf, s->p2g_part, s->p2g_items, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
+                    s->pcx, s->pcy, s->pcz, s->repl_buf, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -280,6 +288,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments)
     if (const char* e = getenv("FLUID_MG_FP64")) s->mg_fp32 = atoi(e) == 0;
     if (const char* e = getenv("FLUID_WARM_START")) s->warm = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_TILE_LISTS")) s->lists_force = atoi(e) != 0;
     if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
     s->xs = 0;
@@ -676,7 +685,7 @@ static MgCoef<double> mg_coef(const fluid_sim* s, int level)
 }
 
 // z = M^-1 r: V(2,2) cycle.  Level-0 rhs = `rhs0`; result in `z0`; part_rz gets the partials of rhs0.z0.
-static int mg_rz_blocks(const fluid_sim* s) { return mg_up_blocks(s->mgl[0]); }
+static int mg_rz_blocks(const fluid_sim* s) { return s->lists_on ? s->n_tl_mg : mg_up_blocks(s->mgl[0]); }
 
 // One launch per leg and level (LDS-tiled kernels): down = both pre-sweeps + residual (+ the restriction for the
 // levels in the middle), tail, up = prolongation + both post-sweeps.  V = the cycle's own arithmetic and storage type:
@@ -706,7 +715,8 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         const bool fold = l > 0 || (long)m.dx * m.dy * m.dz <= 200000;
         V* fc = fold ? F(l + 1) : nullptr;
         const uint8_t* cc = fold ? s->mg_cnt[l + 1] : nullptr;
-        if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps);
+        const bool lst = s->lists_on && !fold;
+        if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
         else launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps);
         if (!fold) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
     }
@@ -720,7 +730,8 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);  // out != u: neighbouring tiles still read u
         if (l == 0) {
             const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)s->Rb.cells());
-            launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0]);
+            launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0],
+                                            s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg);
             prof_end(s, FLUID_PROF_MG_UP0, tok);
         } else {
             launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
@@ -752,6 +763,8 @@ static int solve_mg(fluid_sim* s)
     if (max_it < 1) max_it = 1;
     const double cells = (double)s->Rb.cells();
     const int sparse = (double)s->stats.num_active < 0.4 * (double)L.cells();  // mostly-air box: SQ / XR test the counts before loading
+    const bool lists = s->lists_on;          // ... or, with the active-tile lists of this step, sweep those tiles only
+    const int n_init = pcg_xr_blocks(L), n_list = pcg_list_blocks(s->n_tl_sq);  // partials of the init kernel / of a list-mode launch
     // r.z partials come from the level-0 up leg, one per block; every block of the PCG kernels re-sums them from L2.
     // Above 1024 values one extra 1-block launch folds them into a single value first.
     const int n_rz_raw = mg_rz_blocks(s);
@@ -778,11 +791,20 @@ static int solve_mg(fluid_sim* s)
             if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur]))) return rc;
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-            launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
-                             s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse);
+            if (lists)
+                launch_pcg_sq_list<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, it == 0 ? n_init : n_list,
+                                      s->part_rz[cur], s->part_rz[prv], s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, s->tl_sq,
+                                      s->n_tl_sq);
+            else
+                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
+                                 s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_err, s->ps, n_rz, sparse);
+            if (lists)
+                launch_pcg_xr_list<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], n_rz, s->part_pq, s->part_rr, s->part_err, s->ps,
+                                      s->tl_sq, s->n_tl_sq);
+            else
+                launch_pcg_xr<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], s->part_pq, s->part_rr, s->part_err, s->ps, n_rz, sparse);
             prof_end(s, FLUID_PROF_PCG_XR, tok);
         }
         HIPCHK(hipGetLastError());
@@ -790,7 +812,11 @@ static int solve_mg(fluid_sim* s)
             // the break test of the last body sits at the head of the next SQ launch: a head-only launch (its s'/q are
             // overwritten by the real launch of that iteration if the solve goes on; the counter is put back below)
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1);
+            if (lists)
+                launch_pcg_sq_list<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, n_list, s->part_rz[prv], s->part_rz[prv], s->part_pq,
+                                      s->ps, 0, tol, n_rz, 1, s->tl_sq, s->n_tl_sq);
+            else
+                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1);
         }
         HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
         HIPCHK(hipStreamSynchronize(s->st));
@@ -839,13 +865,45 @@ static int phase_flags(fluid_sim* s)
     s->flag_x1 = none ? -1 : s->Sb.x1;
     s->flags_valid = true;
     HIPCHK(hipGetLastError());
+    bool built = false;
+    if (!box_empty(s->Rb)) {
+        // box-local solver layout of this step: diag counts (and, in a mostly-air box, the lists of the tiles that hold an
+        // unknown: their lengths come back with num_active in the one read below)
+        s->L = make_lbox(s->Rb);
+        launch_cnt_local(s->st, s->g, s->L, s->flags, s->cntL);
+        if (use_mg(s) && (s->lists_force >= 0 ? s->lists_force == 1 : s->lists_hint)) {
+            const MLevel m0 = mg_level0(s->L);
+            const int n_mg = mg_up_blocks(m0), n_sq = sq_tile_count(s->L);
+            const size_t need = (size_t)n_mg + n_sq;
+            if (need > s->tl_cap) {
+                HIPCHK(hipStreamSynchronize(s->st));
+                hipFree(s->tl_flags); hipFree(s->tl_mg); hipFree(s->tl_sq);
+                s->tl_flags = nullptr; s->tl_mg = s->tl_sq = nullptr;
+                const size_t cap = need + need / 4;
+                HIPCHK(hipMalloc((void**)&s->tl_flags, cap));
+                HIPCHK(hipMalloc((void**)&s->tl_mg, cap * sizeof(int)));
+                HIPCHK(hipMalloc((void**)&s->tl_sq, cap * sizeof(int)));
+                s->tl_cap = cap;
+            }
+            launch_mg_tile_flags(s->st, m0, s->cntL, s->tl_flags);
+            launch_compact_flags(s->st, s->tl_flags, n_mg, s->tl_mg, &s->ss->n_tl_mg);
+            launch_sq_tile_flags(s->st, s->L, s->cntL, s->tl_flags + n_mg);
+            launch_compact_flags(s->st, s->tl_flags + n_mg, n_sq, s->tl_sq, &s->ss->n_tl_sq);
+            built = true;
+        }
+        HIPCHK(hipGetLastError());
+    }
     int rc = read_ss(s);
     if (rc) return rc;
     s->stats.num_active = s->h_ss->num_active;
+    s->lists_on = false;
+    s->lists_hint = false;
     if (!box_empty(s->Rb)) {
-        // box-local solver layout of this step: diag counts + zeroed search vectors (padding must read 0)
-        s->L = make_lbox(s->Rb);
-        launch_cnt_local(s->st, s->g, s->L, s->flags, s->cntL);
+        // mostly air and big enough for the sweep over empty tiles to matter (a dense box keeps the XCD-ordered dense launches)
+        const bool airy = (double)s->stats.num_active < 0.45 * (double)s->L.cells() && s->L.cells() > (size_t)1500000;
+        s->lists_hint = airy;
+        s->n_tl_mg = s->h_ss->n_tl_mg; s->n_tl_sq = s->h_ss->n_tl_sq;
+        s->lists_on = built && s->n_tl_mg > 0 && s->n_tl_sq > 0 && (s->lists_force == 1 || airy);
         const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
         HIPCHK(zero_search(s, lb));
         HIPCHK(hipGetLastError());

@@ -212,8 +212,10 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
                                                   const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
                                                   const double* __restrict__ part_rz_old, double* __restrict__ part_pq, int n_prev,
-                                                  PcgState* ps, int first, double tol, int n_rz, int zmode, int sparse)
+                                                  PcgState* ps, int first, double tol, int n_rz, int zmode, int sparse,
+                                                  const int* __restrict__ tlist, int nlist)
 {
+    // tlist: only the listed tiles (those holding an unknown, ascending) are swept, block b takes entries b, b + gridDim.x, ...
     // sparse (mostly-air box): a tile's count bytes are loaded and tested first and a tile without an unknown is
     // skipped (its s', q stay 0 / unread) — no prefetch of the next tile then; dense boxes keep the pipelined loads
     // zmode: `r` is already z = M^-1 r (multigrid preconditioner); otherwise z = invdiag r is formed here
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     const long sx = (long)L.Ly * L.Lz;
     const int ly = tid >> 5, kz = tid & 31;
 
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int lidx = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring list entries (tiles) on the same XCD
+    int tile = tlist ? (lidx < nlist ? tlist[lidx] : ntiles) : lidx;
     // ---- issue the first tile's loads -------------------------------------------------------
     uint8_t fc[TX + 2], fy = 0, fz = 0;
     T rv[TX + 2], sv[TX + 2], ry = 0, sy = 0, rz = 0, sz = 0;
@@ -309,7 +312,8 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
             cen[lx] = val[lx + 1];
             nbv[lx] = val[lx] + val[lx + 2] + sT[o - PZ] + sT[o + PZ] + sT[o - 1] + sT[o + 1];
         }
-        const int next = tile + gridDim.x;
+        int next = tile + gridDim.x;
+        if (tlist) { lidx += gridDim.x; next = lidx < nlist ? tlist[lidx] : ntiles; }
         __syncthreads();  // LDS free for the next tile
         if (!sparse && next < ntiles) issue(next, true, true);  // next tile's loads fly while this tile finishes
 #pragma unroll
@@ -472,6 +476,120 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
     if (threadIdx.x == 0) { part_rr[blockIdx.x] = arr; part_rz_next[blockIdx.x] = arz; }
 }
 
+
+// XR over the listed SQ tiles (mostly-air box): the same update and partials as k_pcg_xr_l, thread = one (y, z) column of the
+// tile's TX planes, block b takes list entries b, b + gridDim.x, ...
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_xr_t(LBox L, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r,
+                                                  const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
+                                                  const double* __restrict__ part_rz_cur, int n_xr, const double* __restrict__ part_pq,
+                                                  int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps,
+                                                  const int* __restrict__ tlist, int nlist)
+{
+    __shared__ double red[16];
+    __shared__ int s_done;
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    if (threadIdx.x == 0) s_done = ps->done;
+    const int nty = (L.ny + TY - 1) / TY, ntz = (L.nz + TZ - 1) / TZ;
+    const long sx = (long)L.Ly * L.Lz;
+    const int ly = threadIdx.x >> 5, kz = threadIdx.x & 31;
+    uint8_t cv[TX];
+    T xv[TX], rv[TX], sv[TX], qv[TX];
+    long c0 = 0;
+    auto issue = [&](int tl) {
+        const int tz = tl % ntz, ty = (tl / ntz) % nty, tx = tl / (ntz * nty);
+        c0 = ((long)(1 + tx * TX) * L.Ly + (1 + ty * TY + ly)) * L.Lz + LBOX_K0 + tz * TZ + kz;
+#pragma unroll
+        for (int m = 0; m < TX; ++m) {
+            const long c = c0 + m * sx;
+            cv[m] = cnt[c];
+            xv[m] = x[c]; rv[m] = r[c]; sv[m] = s[c]; qv[m] = q[c];
+        }
+    };
+    int lidx = xcd_remap(blockIdx.x, gridDim.x);
+    if (lidx < nlist) issue(tlist[lidx]);
+    __syncthreads();
+    if (s_done) return;
+    double rz, pq, d3;
+    block_sum3(part_rz_cur, n_xr, part_pq, n_sq, part_pq, 0, red, rz, pq, d3);
+    if (!(pq > 0) || !(rz == rz)) {  // not SPD / NaN: stop instead of spreading NaNs
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ps->breakdown = 1; ps->done = 1; }
+        return;
+    }
+    const T alpha = (T)(rz / pq);
+    double arr = 0, arz = 0;
+    while (lidx < nlist) {
+        const long cc = c0;
+        uint8_t cw[TX];
+        T xo[TX], ro[TX];
+#pragma unroll
+        for (int m = 0; m < TX; ++m) {
+            cw[m] = cv[m];
+            xo[m] = xv[m] + alpha * sv[m];
+            ro[m] = rv[m] - alpha * qv[m];
+        }
+        lidx += gridDim.x;
+        if (lidx < nlist) issue(tlist[lidx]);   // the next tile's loads fly while this one is written
+#pragma unroll
+        for (int m = 0; m < TX; ++m) {
+            if (cw[m]) {
+                const T z = ro[m] * sinv[cw[m]];
+                arr += (double)ro[m] * (double)ro[m];
+                arz += (double)ro[m] * (double)z;
+                x[cc + m * sx] = xo[m];
+                r[cc + m * sx] = ro[m];
+            }
+        }
+    }
+    arr = block_sum<double, 4>(arr, red);
+    arz = block_sum<double, 4>(arz, red);
+    if (threadIdx.x == 0) { part_rr[blockIdx.x] = arr; part_rz_next[blockIdx.x] = arz; }
+}
+
+// flags[t] = SQ tile t (numbered as k_pcg_sq_l decodes it) holds an unknown
+__global__ __launch_bounds__(256) void k_sq_tile_flags(LBox L, const uint8_t* __restrict__ cnt, uint8_t* __restrict__ flags)
+{
+    const int nty = (L.ny + TY - 1) / TY, ntz = (L.nz + TZ - 1) / TZ;
+    const int tl = blockIdx.x;
+    const int tz = tl % ntz, ty = (tl / ntz) % nty, tx = tl / (ntz * nty);
+    const int ly = threadIdx.x >> 5, kz = threadIdx.x & 31;
+    const long c0 = ((long)(1 + tx * TX) * L.Ly + (1 + ty * TY + ly)) * L.Lz + LBOX_K0 + tz * TZ + kz;
+    int any = 0;
+#pragma unroll
+    for (int m = 0; m < TX; ++m) any |= cnt[c0 + m * (long)L.Ly * L.Lz];
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) flags[tl] = any != 0;
+}
+
+// list[0..count) = the indices i < n with flags[i] != 0, ascending (one block: a few thousand tiles)
+__global__ __launch_bounds__(1024) void k_compact_flags(const uint8_t* __restrict__ flags, int n, int* __restrict__ list, int* __restrict__ count)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const bool f = i < n && flags[i];
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        if (f) list[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int k = 0; k < 16; ++k) t += wsum[k];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+
 // local x -> global pressure field (VectorXd p scattered back to cells, fluid.cc:637)
 template <typename T>
 __global__ __launch_bounds__(256) void k_store_pressure_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ x,
@@ -514,7 +632,7 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
 {
     const int nx = pcg_xr_blocks(L);
     hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
-                       part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode, sparse);
+                       part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode, sparse, (const int*)nullptr, 0);
 }
 // multi-GPU pieces: n_* = 1 means "already all-reduced scalar"
 template <typename T>
@@ -528,7 +646,7 @@ template <typename T>
 void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps)
 {
     hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, (const T*)nullptr, s, (T*)nullptr, q, cf,
-                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0, 0, 0, 0);
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0, 0, 0, 0, (const int*)nullptr, 0);
 }
 template <typename T>
 void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
@@ -547,6 +665,34 @@ void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const
 {
     hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
                        n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, sparse);
+}
+
+int sq_tile_count(const LBox& L) { return sq_tiles(L); }
+// (every block re-sums the previous launch's partials: 2048 blocks and more measured slower than 1024 with ~5 tiles each)
+int pcg_list_blocks(int nlist) { return nlist < 1 ? 1 : (nlist < SQ_MAX_BLOCKS ? nlist : SQ_MAX_BLOCKS); }
+void launch_sq_tile_flags(hipStream_t st, LBox L, const uint8_t* cnt, uint8_t* flags)
+{
+    hipLaunchKernelGGL(k_sq_tile_flags, dim3(sq_tiles(L)), dim3(256), 0, st, L, cnt, flags);
+}
+void launch_compact_flags(hipStream_t st, const uint8_t* flags, int n, int* list, int* count)
+{
+    hipLaunchKernelGGL(k_compact_flags, dim3(1), dim3(1024), 0, st, flags, n, list, count);
+}
+template <typename T>
+void launch_pcg_sq_list(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
+                        const double* part_rr, int n_prev, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps,
+                        int first, double tol, int n_rz, int zmode, const int* tlist, int nlist)
+{
+    hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_list_blocks(nlist)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
+                       part_rz_new, part_rz_old, part_pq, n_prev, ps, first, tol, n_rz, zmode, 0, tlist, nlist);
+}
+template <typename T>
+void launch_pcg_xr_list(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
+                        int n_rz, const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* tlist, int nlist)
+{
+    const int nb = pcg_list_blocks(nlist);
+    hipLaunchKernelGGL((k_pcg_xr_t<T>), dim3(nb), dim3(256), 0, st, L, cnt, x, r, s, q, cf, part_rz_cur, n_rz, part_pq, nb, part_rr,
+                       part_rz_next, ps, tlist, nlist);
 }
 template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure, double* keep, const PcgState* ps)
@@ -792,6 +938,10 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
                                    const double*, double*, PcgState*, int, double, int, int, int);                                     \
     template void launch_pcg_xr<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, const double*, \
                                    double*, double*, PcgState*, int, int);                                                                \
+    template void launch_pcg_sq_list<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, int,      \
+                                        const double*, const double*, double*, PcgState*, int, double, int, int, const int*, int);      \
+    template void launch_pcg_xr_list<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, int,      \
+                                        const double*, double*, double*, PcgState*, const int*, int);                                    \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*, double*, const PcgState*);      \

@@ -201,10 +201,14 @@ def _shape_particles(fs, n, shape, rng):
     raise ValueError(shape)
 
 
+@pytest.mark.parametrize("lists", [False, True])
 @pytest.mark.parametrize("shape", ["sheet", "needle", "blobs", "corner", "odd"])
-def test_solve_on_awkward_domains(fs, oracle, shape):
+def test_solve_on_awkward_domains(fs, oracle, shape, lists, monkeypatch):
     """The LDS-tiled V-cycle legs (partial tiles, levels of odd size, tail of 1-4 levels) on domains unlike the cube:
-    same system as the oracle, solved to Eigen's stopping rule, compared with the vendored Eigen IC-PCG if present."""
+    same system as the oracle, solved to Eigen's stopping rule, compared with the vendored Eigen IC-PCG if present.
+    lists: the level-0 legs, SQ and XR swept over the compacted lists of tiles that hold an unknown (what a big
+    mostly-air box switches to by itself)."""
+    monkeypatch.setenv("FLUID_TILE_LISTS", "1" if lists else "0")
     n = 48
     rng = np.random.default_rng(5)
     pos = _shape_particles(fs, n, shape, rng)
