@@ -504,7 +504,11 @@ __global__ __launch_bounds__(P2GT_THREADS) void k_p2g_tiles(Grid g, Box box, Par
     const int N = g.N;
     const int ntz = (box.nz() + zt - 1) / zt, nty = (box.ny() + P2GT_T - 1) / P2GT_T;  // zt <= P2G_ZT target cells per wave
     const int tile = blockIdx.x;
-    const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
+    // faces first: piles form against the walls, and a block that starts late with a crowded wall plane is the kernel's tail.
+    // x tiles are taken alternately from both ends (the slowest index, so the first blocks dispatched are the two x faces)
+    const int tz = tile % ntz, ty = (tile / ntz) % nty, txs = tile / (ntz * nty);
+    const int ntx = (box.nx() + P2GT_T - 1) / P2GT_T;
+    const int tx = (txs & 1) ? ntx - 1 - (txs >> 1) : (txs >> 1);
     const int tx0 = box.x0 + tx * P2GT_T, ty0 = box.y0 + ty * P2GT_T, tz0 = box.z0 + tz * zt;
     const int ix = tx0 + wv / P2GT_T, iy = ty0 + wv % P2GT_T, zc = tz0 - 1 + lane;
     const bool col = ix <= box.x1 && iy <= box.y1;                 // my column is in the box
