@@ -76,6 +76,7 @@ struct fluid_sim {
     bool lists_on = false;        // this step's solves use them
     int lists_force = -1;         // FLUID_TILE_LISTS=0|1
     int p2g_force = 0;           // FLUID_P2G_FORM=rows|tiles: 1 / 2, for experiments
+    long last_num_active = 0;    // unknowns of the previous step (the same on every rank)
     StepState* ss = nullptr;
     StepState* h_ss = nullptr;  // pinned
     // boxes
@@ -532,8 +533,10 @@ static int phase_sort(fluid_sim* s)
 // particle -> grid over box (k_p2g_rows + k_p2g_combine)
 static int run_p2g(fluid_sim* s, const Box& box)
 {
-    // piled particles (a pure function of the sorted particle set, the same on every rank): the tile form
-    if (s->p2g_force ? s->p2g_force == 2 : s->max_cell > P2G_PILED) {
+    // The tile form for piled particles and for a mostly empty box (the splash: under 30 % of the box were unknowns last step —
+    // the row form pays its per-row latency for thousands of nearly empty rows).  Both inputs are the same on every rank.
+    const bool airy = s->last_num_active > 0 && (double)s->last_num_active < 0.3 * (double)s->Rb.cells();
+    if (s->p2g_force ? s->p2g_force == 2 : (s->max_cell > P2G_PILED || airy)) {
         launch_p2g_tiles(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         return FLUID_OK;
     }
@@ -896,6 +899,7 @@ static int phase_flags(fluid_sim* s)
     int rc = read_ss(s);
     if (rc) return rc;
     s->stats.num_active = s->h_ss->num_active;
+    s->last_num_active = s->stats.num_active;
     s->lists_on = false;
     s->lists_hint = false;
     if (!box_empty(s->Rb)) {
@@ -1668,6 +1672,7 @@ static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
         }
         launch_add_offset(s->st, s->indices + (long)s->xs * n2, (long)(s->xe - s->xs) * n2, (int)off);
         s->stats.num_active = tot;
+        s->last_num_active = tot;
     }
     // local solver layout: my part of the active box in x, the GLOBAL active extent in y and z
     if (!box_empty(s->Rb)) {
