@@ -536,7 +536,8 @@ static int run_p2g(fluid_sim* s, const Box& box)
     // The tile form for piled particles and for a mostly empty box (the splash: under 30 % of the box were unknowns last step —
     // the row form pays its per-row latency for thousands of nearly empty rows).  Both inputs are the same on every rank.
     const bool airy = s->last_num_active > 0 && (double)s->last_num_active < 0.3 * (double)s->Rb.cells();
-    if (s->p2g_force ? s->p2g_force == 2 : (s->max_cell > P2G_PILED || airy)) {
+    const bool huge = (size_t)12 * sizeof(double) * (size_t)s->Rb.cells() > ((size_t)16 << 30);  // the row form's partials: 96 B per box cell
+    if (s->p2g_force ? s->p2g_force == 2 : (s->max_cell > P2G_PILED || airy || huge)) {
         launch_p2g_tiles(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         return FLUID_OK;
     }
