@@ -113,6 +113,22 @@ def test_other_seed_box_and_filter():
     assert np.abs(a).max() < 10.0
 
 
+def test_random_boxes_against_the_restatement():
+    """Seeded sweep over small boxes anywhere in the two 128^3 blocks around the origin (tiles, partial leaves, boxes that
+    straddle the origin in some axes only), densities 1-3, with and without the boundary filter."""
+    rng = np.random.default_rng(2024)
+    for _ in range(25):
+        side = int(rng.integers(1, 22))
+        lo = int(rng.integers(-100, 100 - side))
+        hi = lo + side - 1
+        ppv = float(rng.integers(1, 4))
+        seed = int(rng.integers(0, 2 ** 31))
+        boundary = int(rng.choice([0, max(abs(lo), abs(hi)) + 1, 200]))
+        a = fs.reference_scatter(lo=lo, hi=hi, points_per_volume=ppv, seed=seed, boundary=boundary)
+        b = _restated_scatter(lo, hi, ppv, seed, boundary)
+        assert a.shape == b.shape and np.array_equal(a, b), (lo, hi, ppv, seed, boundary)
+
+
 def test_box_with_a_whole_128_tile():
     """[-130, 5]^3 covers the node [-128, -1]^3 completely: one active tile of 128^3 voxels at the second tree level."""
     n = 136
