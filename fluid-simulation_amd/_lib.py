@@ -31,13 +31,13 @@ class StepStats(C.Structure):
     _fields_ = [("dt_in", C.c_double), ("dt_out", C.c_double), ("error", C.c_double), ("max_speed", C.c_double),
                 ("relres", C.c_double), ("num_active", C.c_int64), ("outer_passes", C.c_int32),
                 ("cg_iters", C.c_int32), ("cg_iters_last", C.c_int32), ("box_lo", C.c_int32 * 3),
-                ("box_hi", C.c_int32 * 3), ("reserved", C.c_int32)]
+                ("box_hi", C.c_int32 * 3), ("paths", C.c_int32)]
 
     def as_dict(self):
         return {"dt_in": self.dt_in, "dt_out": self.dt_out, "error": self.error, "max_speed": self.max_speed,
                 "relres": self.relres, "num_active": self.num_active, "outer_passes": self.outer_passes,
                 "cg_iters": self.cg_iters, "cg_iters_last": self.cg_iters_last,
-                "box_lo": list(self.box_lo), "box_hi": list(self.box_hi)}
+                "box_lo": list(self.box_lo), "box_hi": list(self.box_hi), "paths": self.paths}
 
 
 class FIELD:

@@ -538,6 +538,7 @@ static int run_p2g(fluid_sim* s, const Box& box)
     const bool airy = s->last_num_active > 0 && (double)s->last_num_active < 0.3 * (double)s->Rb.cells();
     const bool huge = (size_t)12 * sizeof(double) * (size_t)s->Rb.cells() > ((size_t)16 << 30);  // the row form's partials: 96 B per box cell
     if (s->p2g_force ? s->p2g_force == 2 : (s->max_cell > P2G_PILED || airy || huge)) {
+        s->stats.paths |= FLUID_PATH_P2G_TILES;
         launch_p2g_tiles(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         return FLUID_OK;
     }
@@ -909,6 +910,7 @@ static int phase_flags(fluid_sim* s)
         s->lists_hint = airy;
         s->n_tl_mg = s->h_ss->n_tl_mg; s->n_tl_sq = s->h_ss->n_tl_sq;
         s->lists_on = built && s->n_tl_mg > 0 && s->n_tl_sq > 0 && (s->lists_force == 1 || airy);
+        if (s->lists_on) s->stats.paths |= FLUID_PATH_TILE_LISTS;
         const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
         HIPCHK(zero_search(s, lb));
         HIPCHK(hipGetLastError());

@@ -91,8 +91,10 @@ typedef struct fluid_step_stats {
     int32_t cg_iters_last;    /* iterations of the last solve                                    */
     int32_t box_lo[3];        /* active box of this step (index space, inclusive)                */
     int32_t box_hi[3];
-    int32_t reserved;
+    int32_t paths;            /* kernel forms this step took: FLUID_PATH_* bits                  */
 } fluid_step_stats_t;
+#define FLUID_PATH_P2G_TILES 1   /* particle -> grid in its 2 x 2-column tile form (piled particles, mostly empty box) */
+#define FLUID_PATH_TILE_LISTS 2  /* level-0 solver kernels over the lists of tiles that hold an unknown (mostly-air box) */
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 /* Reference defaults (N=121, g=(0,-10,0), dx=1, rho=1, max_dt=0.1, outer_tol=0.1,

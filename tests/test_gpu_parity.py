@@ -528,6 +528,40 @@ def test_reference_scene_first_steps(fs, oracle):
     assert rel_l2(sim.field(F.PRESSURE), orc.field(7)) < TOL_F
 
 
+def test_forms_switch_by_themselves(fs, monkeypatch):
+    """A big, mostly empty box (blobs far apart on a 160^3 grid: 3 M box cells, a few per cent unknowns): from the second
+    step on the solver takes the active-tile lists and P2G its tile form without being told (stats.paths), and the run
+    agrees with one where both are pinned to the dense / row forms."""
+    n = 160
+    rng = np.random.default_rng(77)
+    lo, hi = fs.grid_bounds(n)
+    centres = [(x, y, z) for x in (lo + 12, hi - 12) for y in (lo + 12, hi - 40) for z in (lo + 12, hi - 12)]
+    pos = np.concatenate([np.array(c, dtype=np.float64) + rng.uniform(-6, 6, size=(6000, 3)) for c in centres])
+    vel = rng.standard_normal(pos.shape) * 0.5
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim = fs.FluidSim(n=n); sim.upload_particles(pos, vel)
+        st = [sim.step() for _ in range(4)]
+        p, v = sim.download_particles()
+        pr = sim.field(fs.FIELD.PRESSURE)
+        sim.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return st, p, v, pr
+
+    sa, pa, va, pra = run({})
+    sb, pb, vb, prb = run({"FLUID_TILE_LISTS": "0", "FLUID_P2G_FORM": "rows"})
+    assert sa[0]["paths"] & 2 == 0                      # no hint yet in the first step
+    assert all(s["paths"] & 2 for s in sa[1:])          # active-tile lists from then on
+    assert all(s["paths"] & 1 for s in sa[1:])          # and P2G in its tile form (mostly empty box)
+    assert all(s["paths"] == 0 for s in sb)
+    assert [s["num_active"] for s in sa] == [s["num_active"] for s in sb]
+    assert [s["outer_passes"] for s in sa] == [s["outer_passes"] for s in sb]
+    assert rel_l2(pra, prb) < 1e-6 and rel_l2(pa, pb) < 1e-9 and rel_l2(va, vb) < 1e-6
+
+
 def test_edge_no_particles(fs, oracle):
     """Empty PointList: nothing is fluid, b = 0, the do..while ends on NaN after one pass (fluid.cc:1483-1484)."""
     sim = fs.FluidSim(n=24)
