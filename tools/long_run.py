@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Step time through the whole drop -> splash -> spread sequence: python tools/long_run.py [n] [steps]"""
+"""Step time through the whole drop -> splash -> spread sequence: python tools/long_run.py [n] [steps] [particles per cell]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
@@ -7,7 +7,7 @@ fs = entry.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 sim = fs.FluidSim(n=n)
-sim.upload_particles(fs.water_cube_drop(n, 8, seed=0))
+sim.upload_particles(fs.water_cube_drop(n, int(sys.argv[3]) if len(sys.argv) > 3 else 8, seed=0))
 t0 = time.perf_counter(); it = 0; passes = 0; tsim = 0.0
 for i in range(steps):
     s = sim.step(); it += s["cg_iters"]; passes += s["outer_passes"]; tsim += s["dt_out"]
