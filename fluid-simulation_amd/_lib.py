@@ -22,8 +22,9 @@ class Params(C.Structure):
     _fields_ = [("n", C.c_int32), ("device", C.c_int32), ("dx", C.c_double), ("rho", C.c_double),
                 ("gravity", C.c_double * 3), ("max_dt", C.c_double), ("outer_tol", C.c_double),
                 ("update_frac", C.c_double), ("cg_tol", C.c_double), ("cg_max_iters", C.c_int32),
-                ("max_outer_passes", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32),
-                ("flip_blend", C.c_double)]
+                ("max_outer_passes", C.c_int32), ("precision", C.c_int32), ("preconditioner", C.c_int32),
+                ("flip_blend", C.c_double), ("solve_start", C.c_int32), ("mg_precision", C.c_int32),
+                ("dist_solve", C.c_int32), ("pad_", C.c_int32)]
 
 
 class StepStats(C.Structure):
@@ -83,9 +84,14 @@ SYMBOLS = [
     ("fluid_write_vdb", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_P)]),
     # multi-GPU (argtypes with the comm struct are completed in dist.py)
     ("fluid_create_dist", C.c_int, None),
-    ("fluid_upload_particles_ids", C.c_int, None),
-    ("fluid_download_particles_ids", C.c_int64, None),
-    ("fluid_partition_by_count", C.c_int, None),
+    ("fluid_window", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("fluid_upload_particles_ids", C.c_int, [_P, C.c_int64, _P, _P, _P]),
+    ("fluid_download_particles_ids", C.c_int64, [_P, _P, _P, _P]),
+    ("fluid_partition_blocks", C.c_int, [C.c_int32, C.c_int64, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("fluid_local_group_create", C.c_int, [C.c_int32, C.POINTER(_P)]),
+    ("fluid_local_group_destroy", C.c_int, [_P]),
+    ("fluid_local_group_abort", C.c_int, [_P]),
+    ("fluid_local_comm_create", C.c_int, None),
     ("fluid_rccl_unique_id", C.c_int, None),
     ("fluid_rccl_comm_create", C.c_int, None),
     ("fluid_rccl_comm_destroy", C.c_int, None),

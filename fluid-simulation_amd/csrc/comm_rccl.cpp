@@ -3,8 +3,9 @@
 // RCCL is reached through dlopen of the librccl.so the caller names — in bench.py the one inside
 // the running PyTorch, so the process holds exactly one RCCL — and every call is enqueued on the
 // solver's own HIP stream: no host synchronisation and no Python inside the PCG loop.
-// Message sizes here: one (Ly x Lz) plane of the search vector per neighbour and iteration
-// (256^3: ~0.1-0.5 MB), and 1-2 double all-reduces — latency-bound, not bandwidth-bound.
+// Message sizes here: block faces of a few cells' width per neighbour (256^3 in 2 x 2 x 2: 128^2 x 4 cells x 8 B =
+// 0.5 MB, edges and corners a few KB), the gathered coarse level of the V-cycle (<= 0.6 MB) and 1-2 double
+// all-reduces per PCG iteration — latency-bound, not bandwidth-bound.
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
@@ -17,7 +18,7 @@ namespace {
 typedef void* ncclComm_t;
 struct ncclUniqueId { char internal[128]; };
 typedef int ncclResult_t;
-enum { ncclUint8 = 1, ncclInt32 = 2, ncclInt64 = 4, ncclFloat64 = 8 };
+enum { ncclUint8 = 1, ncclInt32 = 2, ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8 };
 enum { ncclSum = 0, ncclMax = 2, ncclMin = 3 };
 
 struct Api {
@@ -61,26 +62,29 @@ struct Ctx {
     int rank = 0, size = 1;
 };
 
-int cb_sendrecv(void* vctx, const void* send_lo, size_t nlo_s, void* recv_lo, size_t nlo_r, const void* send_hi, size_t nhi_s, void* recv_hi,
-                size_t nhi_r, void* stream)
+// One grouped launch for all the neighbours of a halo exchange (<= 26 peers): receives posted first, then sends.
+int cb_exchange(void* vctx, int32_t n, const int32_t* peer, const void* const* sbuf, const size_t* sbytes, void* const* rbuf,
+                const size_t* rbytes, void* stream)
 {
     Ctx* c = (Ctx*)vctx;
-    if (!(nlo_s || nlo_r || nhi_s || nhi_r)) return 0;
+    bool any = false;
+    for (int i = 0; i < n; ++i) any = any || sbytes[i] || rbytes[i];
+    if (!any) return 0;
     ncclResult_t r = c->api.GroupStart();
-    if (!r && nlo_r) r = c->api.Recv(recv_lo, nlo_r, ncclUint8, c->rank - 1, c->comm, stream);
-    if (!r && nhi_r) r = c->api.Recv(recv_hi, nhi_r, ncclUint8, c->rank + 1, c->comm, stream);
-    if (!r && nlo_s) r = c->api.Send(send_lo, nlo_s, ncclUint8, c->rank - 1, c->comm, stream);
-    if (!r && nhi_s) r = c->api.Send(send_hi, nhi_s, ncclUint8, c->rank + 1, c->comm, stream);
+    for (int i = 0; i < n && !r; ++i)
+        if (rbytes[i]) r = c->api.Recv(rbuf[i], rbytes[i], ncclUint8, peer[i], c->comm, stream);
+    for (int i = 0; i < n && !r; ++i)
+        if (sbytes[i]) r = c->api.Send(sbuf[i], sbytes[i], ncclUint8, peer[i], c->comm, stream);
     ncclResult_t e = c->api.GroupEnd();
     if (!r) r = e;
-    if (r) { g_rccl_err = std::string("rccl sendrecv: ") + c->api.GetErrorString(r); fprintf(stderr, "%s\n", g_rccl_err.c_str()); }
+    if (r) { g_rccl_err = std::string("rccl exchange: ") + c->api.GetErrorString(r); fprintf(stderr, "%s\n", g_rccl_err.c_str()); }
     return r;
 }
 
-int cb_allreduce(void* vctx, void* buf, int32_t count, int32_t dtype, int32_t op, void* stream)
+int cb_allreduce(void* vctx, void* buf, int64_t count, int32_t dtype, int32_t op, void* stream)
 {
     Ctx* c = (Ctx*)vctx;
-    const int dt = dtype == FLUID_DT_F64 ? ncclFloat64 : (dtype == FLUID_DT_I32 ? ncclInt32 : ncclInt64);
+    const int dt = dtype == FLUID_DT_F64 ? ncclFloat64 : (dtype == FLUID_DT_I32 ? ncclInt32 : (dtype == FLUID_DT_F32 ? ncclFloat32 : (dtype == FLUID_DT_U8 ? ncclUint8 : ncclInt64)));
     const int ro = op == FLUID_OP_SUM ? ncclSum : (op == FLUID_OP_MAX ? ncclMax : ncclMin);
     ncclResult_t r = c->api.AllReduce(buf, buf, (size_t)count, dt, ro, c->comm, stream);
     if (r) { g_rccl_err = std::string("rccl allreduce: ") + c->api.GetErrorString(r); fprintf(stderr, "%s\n", g_rccl_err.c_str()); }
@@ -118,7 +122,7 @@ int fluid_rccl_comm_create(const char* librccl_path, const void* id128, int32_t 
     out->rank = rank;
     out->size = size;
     out->ctx = c;
-    out->sendrecv = cb_sendrecv;
+    out->exchange = cb_exchange;
     out->allreduce = cb_allreduce;
     return FLUID_OK;
 }

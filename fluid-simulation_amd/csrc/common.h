@@ -13,14 +13,30 @@ constexpr uint8_t F_SOLID = 1;
 constexpr uint8_t F_FLUID = 2;
 constexpr int F_CNT_SHIFT = 2;
 
+// The dense field arrays of a handle cover a WINDOW of the global grid: all of it on one GPU (nx = ny = nz = N, origin 0),
+// the owned block + a halo ring on a rank of a decomposed run.  Kernels index with window-local (ix, iy, iz); a window
+// edge is either an edge of the global grid (reads beyond it return the reference's background 0) or an interior cut
+// whose halo is wide enough that no compute box reaches it.
 struct Grid {
-    int N;    // cells per axis
-    int lo;   // coordinate of index 0
-    int hi;   // coordinate of index N-1
+    int N;    // GLOBAL cells per axis
+    int lo;   // global coordinate of global index 0
+    int hi;   // global coordinate of global index N-1
+    int nx, ny, nz;     // window dims = array dims
+    int ox, oy, oz;     // global index of window index 0
     __host__ __device__ inline size_t idx(int ix, int iy, int iz) const
     {
-        return ((size_t)ix * N + (size_t)iy) * N + (size_t)iz;
+        return ((size_t)ix * ny + (size_t)iy) * nz + (size_t)iz;
     }
+    __host__ __device__ inline size_t cells() const { return (size_t)nx * ny * nz; }
+    __host__ __device__ inline long sx() const { return (long)ny * nz; }   // x stride
+    // coordinate of window index 0 per axis
+    __host__ __device__ inline int cx0() const { return lo + ox; }
+    __host__ __device__ inline int cy0() const { return lo + oy; }
+    __host__ __device__ inline int cz0() const { return lo + oz; }
+    // coordinate of the last window cell per axis
+    __host__ __device__ inline int cx1() const { return lo + ox + nx - 1; }
+    __host__ __device__ inline int cy1() const { return lo + oy + ny - 1; }
+    __host__ __device__ inline int cz1() const { return lo + oz + nz - 1; }
 };
 
 // inclusive box in index space
@@ -230,8 +246,6 @@ void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, 
                 const double* pcy, const double* pcz, double blend, StepState* ss);
 void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss);
 void launch_pack_particles(hipStream_t st, long n, Particles p, double* pos_aos, double* vel_aos);
-void launch_classify_migrate(hipStream_t st, Grid g, long n, Particles p, int xs, int xe, int has_lo, int has_hi, double* send_lo,
-                             double* send_hi, int cap, int* counters);
 void launch_unpack_records(hipStream_t st, long n, const double* rec, Particles p, long off);
 void launch_pack_records(hipStream_t st, long n, Particles p, long off, double* rec);
 void launch_unpack_ids(hipStream_t st, long n, const double* pos, const double* vel, const uint32_t* ids, Particles p);
@@ -244,7 +258,6 @@ void launch_sort_tail(hipStream_t st, const int* cell_count, int* cell_start, lo
 void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total);
 void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags, int x0, int x1);
 void launch_index_scan_range(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total, int x0, int x1);
-void launch_add_offset(hipStream_t st, int* idx, long n, int off);
 void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w,
                     float* rhs, float* diver, double dx, double gdt0, double gdt1, double gdt2);
 void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w,
@@ -255,8 +268,6 @@ void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, cons
 void launch_zero_step_state(hipStream_t st, StepState* ss, int N);
 struct ZeroList { float* f4[4]; double* f8[7]; };
 void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box);
-void launch_pack_box(hipStream_t st, Grid g, Box box, int xs, int xe, const float* container, const double* u, const double* v, const double* w,
-                     double* buf);
 void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float* container, double* u, double* v, double* w, double* ub, double* vb,
                        double* wb);
 
@@ -287,13 +298,11 @@ template <typename T>
 void launch_pcg_xr_list(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                         int n_rz, const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* tlist, int nlist);
 template <typename T>
-void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
-                  const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol, int zmode = 0);
+void launch_pcg_sq_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf, const double* g_rr,
+                        const double* g_rz_new, const double* g_rz_old, double* part_pq, PcgState* ps, int first, double tol, int zmode);
 template <typename T>
-void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps);
-template <typename T>
-void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
-                     const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps);
+void launch_pcg_xr_dist(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
+                        const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps);
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b);
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf);
@@ -311,6 +320,8 @@ MLevel mg_level0(const LBox& L);
 MLevel mg_coarser(const MLevel& f);
 void launch_mg_type0(hipStream_t st, Grid g, LBox L, MLevel m, const uint8_t* flags, const uint8_t* cnt, uint8_t* typ);
 void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, uint8_t* tc, uint8_t* cnt_c);
+void launch_mg_coarsen_types(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, uint8_t* tc);   // the two halves of launch_mg_coarsen
+void launch_mg_counts(hipStream_t st, MLevel m, const uint8_t* typ, uint8_t* cnt);
 template <typename T>
 void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const uint8_t* cnt_c, T* fc, const PcgState* ps);
 constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel can hold
@@ -323,7 +334,7 @@ void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T*
                     const PcgState* ps, const int* tlist = nullptr, int nlist = 0);
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0);
+                  double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0, const uint8_t* own = nullptr);
 // Active-tile lists of a mostly-air box (level 0 only): flags per tile of the V-cycle legs / of the SQ kernel, and their
 // compaction in ascending tile order (list[0..*count)); the legs, SQ and XR are then launched over the listed tiles only.
 void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags);

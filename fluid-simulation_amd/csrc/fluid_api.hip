@@ -1,145 +1,31 @@
 // libfluid_hip.so — C ABI (include/fluid_hip.h) and host orchestration of the step
 // fluid.cc:1378-1490 on one MI355X.  One handle = one HIP stream; all fields live in HBM.
-#include "common.h"
-#include "../../include/fluid_hip.h"
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
+#include "sim.h"
 
 using namespace fl;
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg)
+int fluid_fail(int code, const std::string& msg)
 {
     g_err = msg;
     return code;
 }
-#define HIPCHK(expr)                                                                                              \
-    do {                                                                                                          \
-        hipError_t e_ = (expr);                                                                                   \
-        if (e_ != hipSuccess)                                                                                     \
-            return fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
-    } while (0)
+#define fail fluid_fail
 
-struct ProfClass {
-    long launches = 0, sampled = 0;
-    double ms = 0, cells = 0;
-    std::vector<hipEvent_t> e0, e1;
-    std::vector<double> pc;
-};
-
-struct fluid_sim {
-    fluid_params_t prm;
-    Grid g;
-    size_t ncell = 0;
-    hipStream_t st = nullptr;
-    // grid fields
-    uint8_t *solid = nullptr, *flags = nullptr;
-    float *container = nullptr, *rhs = nullptr, *diver = nullptr, *diver2 = nullptr;
-    double *u = nullptr, *v = nullptr, *w = nullptr, *ub = nullptr, *vb = nullptr, *wb = nullptr;
-    double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
-    double* p_guess = nullptr;    // last solved pressure, never cleared: the multigrid PCG starts from it (FLUID_WARM_START=0: from 0 like the reference)
-    bool warm = true, have_guess = false;
-    int *indices = nullptr, *scan_sums = nullptr, *ipart = nullptr;
-    // pcg
-    void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr, *Zmg = nullptr;
-    double *pcx = nullptr, *pcy = nullptr, *pcz = nullptr;  // getVelocity(c, vels) per cell: allocated on first use, PIC blend only  // box-local layout (LBox)
-    uint8_t* cntL = nullptr;
-    LBox L{};
-    size_t lmax = 0;
-    double *part_bb = nullptr, *part_rr = nullptr, *part_rz[2] = {nullptr, nullptr}, *part_pq = nullptr, *part_err = nullptr;
-    PcgState* ps = nullptr;
-    PcgState* h_ps = nullptr;  // pinned, 2 slots
-    hipEvent_t ev_poll[2] = {nullptr, nullptr};
-    // particles
-    long np = 0, cap = 0;
-    Particles pa{}, pb{};
-    int *key = nullptr, *slot = nullptr, *order = nullptr, *order2 = nullptr, *cell_count = nullptr, *cell_start = nullptr;
-    uint32_t* spid = nullptr;   // original ids in sorted-position order (per-cell rank pass)
-    double *stage_pos = nullptr, *stage_vel = nullptr;
-    double* pw = nullptr;  // 9 axis weights per particle, SoA with stride cap
-    double* p2g_part = nullptr;  // k_p2g_rows' three x-plane partials: 12 doubles per cell of the P2G box (grown on demand)
-    size_t p2g_part_cap = 0;
-    int* p2g_items = nullptr;    // k_p2g_rows' work list (count + int4 items), grown on demand; the count is 0 between launches
-    size_t p2g_items_cap = 0;
-    int max_cell = 0;            // most particles in one cell after the last sort (all ranks' cells when distributed)
-    // mostly-air box (splash, settled pool): level-0 legs, SQ and XR run over compacted lists of the tiles that hold an unknown
-    uint8_t* tl_flags = nullptr;  // per-tile flags (both tile shapes, one after the other)
-    int *tl_mg = nullptr, *tl_sq = nullptr;
-    size_t tl_cap = 0;
-    int n_tl_mg = 0, n_tl_sq = 0;
-    bool lists_hint = false;      // the previous step's box was mostly air: build the lists before this step's flags sync
-    bool lists_on = false;        // this step's solves use them
-    int lists_force = -1;         // FLUID_TILE_LISTS=0|1
-    int p2g_force = 0;           // FLUID_P2G_FORM=rows|tiles: 1 / 2, for experiments
-    long last_num_active = 0;    // unknowns of the previous step (the same on every rank)
-    StepState* ss = nullptr;
-    StepState* h_ss = nullptr;  // pinned
-    // boxes
-    Box Pb{0, 0, 0, -1, -1, -1}, Rb{0, 0, 0, -1, -1, -1}, Sb{0, 0, 0, -1, -1, -1};
-    Box dirty{0, 0, 0, -1, -1, -1};   // box holding non-zero step-field data (zeroed before the next P2G)
-    int flag_x0 = 0, flag_x1 = -1;    // x planes whose flags / indices the last flags pass may have made non-trivial
-    bool flags_valid = false;         // flags / indices outside [flag_x0, flag_x1] are known to be "solid or empty" / -1
-    bool sorted = false, have_p2g = false, have_flags = false;
-    long n_out = 0;           // particles whose base cell is off the grid (last bucket of the sorted array), from the last sort
-    bool sort_hint = false;   // Pb is the bounding box of THESE particles one step ago (false after an upload)
-    double dt = 0.1;
-    fluid_step_stats_t stats{};
-    // multigrid preconditioner (single-GPU fp64 solve)
-    static constexpr int MG_MAXL = 8;
-    int mg_nl = 0, mg_tail = 0;   // levels; first level handled by the single-block tail kernel
-    long mg_last_iters = 0;       // iteration count of the previous multigrid solve (sizes the first unpolled batch)
-    int mg_csweeps = 3;           // red-black sweeps (each direction) on the coarsest level (12 -> 2 changes the PCG count by 1 in 520)
-    MLevel mgl[MG_MAXL];
-    uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
-    char *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual (float or double)
-    double mg_wc[4] = {1.25, 1.1, 1.0, 1.0};   // weight of the coarse correction at level 0 / level 1 / deeper kernel levels / inside the tail (FLUID_MG_WC=a,b,c,d)
-    bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (FLUID_MG_FP64=1: double)
-    double* mg_part = nullptr;    // per-block partials of r.z when a level-0 launch has more blocks than the PCG kernels re-sum
-    char* mg_slab = nullptr;      // one allocation behind every mg_* array and Zmg (re-carved each step)
-    size_t mg_slab_cap = 0;
-    // multi-GPU (x-slab decomposition)
-    bool dist = false;
-    bool dist_repl = true;        // multi-GPU: particles sharded, pressure block replicated on every rank (FLUID_DIST_SOLVE=1: distributed PCG)
-    double* repl_buf = nullptr;   // staging of the all-reduce that assembles the P2G fields of the whole box
-    size_t repl_cap = 0;
-    fluid_comm_t comm{};
-    std::vector<int> bounds;
-    int xs = 0, xe = 0;          // owned x planes [xs, xe)
-    long p_off = 0;              // my live particles are pa[p_off .. p_off+np)
-    long p2g_total = 0;          // left ghosts + mine + right ghosts: the range P2G may read
-    long n_dropped = 0;          // particles that left the grid on this rank (inert)
-    double *mig_lo = nullptr, *mig_hi = nullptr, *mig_rlo = nullptr, *mig_rhi = nullptr;  // 7-double records
-    long mig_cap = 0;
-    int* d_small = nullptr;      // device scratch ints: [0..1] migrate counters, [2..3] received counts, [4..19] misc
-    int* h_small = nullptr;      // pinned mirror
-    double *gstage[2] = {nullptr, nullptr}, *gpq = nullptr, *grz = nullptr;  // all-reduced PCG scalars (grz: 2 slots, multigrid r.z)
-    void *zplane = nullptr, *splane = nullptr;               // zero / scratch ring planes for an empty local box
-    Box Rr{0, 0, 0, -1, -1, -1}, Sr{0, 0, 0, -1, -1, -1};    // local parts of Rb / Sb
-    // profiling
-    int prof_every = 0;
-    ProfClass prof[FLUID_PROF_COUNT];
-};
-
-static Box clip_dilate(const Box& b, int d, int N)
+Box fl::clip_dilate(const Box& b, int d, const Grid& g)
 {
     Box r;
     r.x0 = b.x0 - d < 0 ? 0 : b.x0 - d;
     r.y0 = b.y0 - d < 0 ? 0 : b.y0 - d;
     r.z0 = b.z0 - d < 0 ? 0 : b.z0 - d;
-    r.x1 = b.x1 + d > N - 1 ? N - 1 : b.x1 + d;
-    r.y1 = b.y1 + d > N - 1 ? N - 1 : b.y1 + d;
-    r.z1 = b.z1 + d > N - 1 ? N - 1 : b.z1 + d;
+    r.x1 = b.x1 + d > g.nx - 1 ? g.nx - 1 : b.x1 + d;
+    r.y1 = b.y1 + d > g.ny - 1 ? g.ny - 1 : b.y1 + d;
+    r.z1 = b.z1 + d > g.nz - 1 ? g.nz - 1 : b.z1 + d;
     return r;
 }
-static bool box_empty(const Box& b) { return b.x1 < b.x0 || b.y1 < b.y0 || b.z1 < b.z0; }
 
 // ---- profiling helpers ----------------------------------------------------------------------
-static int prof_begin(fluid_sim* s, int k, double cells)
+int fl::prof_begin(fluid_sim* s, int k, double cells)
 {
     ProfClass& p = s->prof[k];
     p.launches++;
@@ -154,7 +40,7 @@ static int prof_begin(fluid_sim* s, int k, double cells)
     p.pc.push_back(cells);
     return (int)p.e1.size() - 1;
 }
-static void prof_end(fluid_sim* s, int k, int tok)
+void fl::prof_end(fluid_sim* s, int k, int tok)
 {
     if (tok >= 0) hipEventRecord(s->prof[k].e1[tok], s->st);
 }
@@ -180,15 +66,6 @@ static void prof_resolve(fluid_sim* s)
 }
 
 // ---- memory ------------------------------------------------------------------------------------
-template <typename T>
-static hipError_t dalloc(T** p, size_t n)
-{
-    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
-    if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
-    return e;
-}
-
-static size_t solver_elem(const fluid_sim* s) { return s->prm.precision == FLUID_PRECISION_FP32 ? 4 : 8; }
 
 static void free_particles(fluid_sim* s)
 {
@@ -204,7 +81,7 @@ static void free_particles(fluid_sim* s)
     s->cap = 0;
 }
 
-static int alloc_particles(fluid_sim* s, long n)
+int fl::alloc_particles(fluid_sim* s, long n)
 {
     if (n <= s->cap) return FLUID_OK;
     n = (n + 1) & ~1L;  // even: k_p2g_rows reads the particle arrays 16 B at a time
@@ -219,6 +96,40 @@ static int alloc_particles(fluid_sim* s, long n)
     HIPCHK(dalloc(&s->pw, 9 * n));
     HIPCHK(hipDeviceSynchronize());
     s->cap = n;
+    return FLUID_OK;
+}
+
+// More room, the live particles kept (a decomposed run: a block's share grows as the fluid spreads into it).
+int fl::grow_particles(fluid_sim* s, long need)
+{
+    if (need <= s->cap) return FLUID_OK;
+    HIPCHK(hipStreamSynchronize(s->st));
+    const long keep = s->p_off + s->np;
+    Particles old = s->pa;
+    s->pa = Particles{};
+    const long ncap = ((need + need / 2) + 1) & ~1L;
+    Particles nw{};
+    HIPCHK(dalloc(&nw.px, ncap)); HIPCHK(dalloc(&nw.py, ncap)); HIPCHK(dalloc(&nw.pz, ncap));
+    HIPCHK(dalloc(&nw.vx, ncap)); HIPCHK(dalloc(&nw.vy, ncap)); HIPCHK(dalloc(&nw.vz, ncap));
+    HIPCHK(dalloc(&nw.pid, ncap));
+    if (keep > 0) {
+        HIPCHK(hipMemcpy(nw.px, old.px, keep * 8, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nw.py, old.py, keep * 8, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nw.pz, old.pz, keep * 8, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nw.vx, old.vx, keep * 8, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nw.vy, old.vy, keep * 8, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nw.vz, old.vz, keep * 8, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nw.pid, old.pid, keep * 4, hipMemcpyDeviceToDevice));
+    }
+    hipFree(old.px); hipFree(old.py); hipFree(old.pz); hipFree(old.vx); hipFree(old.vy); hipFree(old.vz); hipFree(old.pid);
+    free_particles(s);   // the second buffer and the scratch arrays hold nothing between steps
+    s->pa = nw;
+    Particles* p = &s->pb;
+    HIPCHK(dalloc(&p->px, ncap)); HIPCHK(dalloc(&p->py, ncap)); HIPCHK(dalloc(&p->pz, ncap));
+    HIPCHK(dalloc(&p->vx, ncap)); HIPCHK(dalloc(&p->vy, ncap)); HIPCHK(dalloc(&p->vz, ncap));
+    HIPCHK(dalloc(&p->pid, ncap));
+    HIPCHK(dalloc(&s->key, ncap)); HIPCHK(dalloc(&s->slot, ncap)); HIPCHK(dalloc(&s->order, ncap)); HIPCHK(dalloc(&s->order2, ncap)); HIPCHK(dalloc(&s->spid, ncap));
+    HIPCHK(dalloc(&s->stage_pos, 3 * ncap)); HIPCHK(dalloc(&s->stage_vel, 3 * ncap));
+    HIPCHK(dalloc(&s->pw, 9 * ncap));
+    HIPCHK(hipDeviceSynchronize());
+    s->cap = ncap;
     return FLUID_OK;
 }
 
@@ -243,7 +154,11 @@ int fluid_default_params(fluid_params_t* p)
     p->cg_max_iters = 0;
     p->max_outer_passes = 0;
     p->precision = FLUID_PRECISION_FP64;
+    p->preconditioner = FLUID_PRECOND_MG;
     p->flip_blend = 1.0;
+    p->solve_start = FLUID_START_WARM;
+    p->mg_precision = FLUID_MG_FP32;
+    p->dist_solve = FLUID_DIST_AUTO;
     return FLUID_OK;
 }
 
@@ -251,12 +166,13 @@ int fluid_destroy(fluid_sim_t* s)
 {
     if (!s) return FLUID_OK;
     if (s->st) hipStreamSynchronize(s->st);
+    if (s->ds) dist_destroy(s);
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->repl_buf, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->mig_lo, s->mig_hi, s->mig_rlo, s->mig_rhi, s->d_small, s->gstage[0], s->gstage[1], s->gpq, s->grz, s->zplane, s->splane};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -270,10 +186,29 @@ int fluid_destroy(fluid_sim_t* s)
 int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
 {
     if (!p || !out) return fail(FLUID_ERR_ARG, "null argument");
+    Grid g;
+    g.N = p->n;
+    g.lo = -(p->n / 2);
+    g.hi = g.lo + p->n - 1;
+    g.nx = g.ny = g.nz = p->n;
+    g.ox = g.oy = g.oz = 0;
+    return fluid_create_window(p, g, out);
+}
+
+}  // extern "C"
+
+// The handle's field arrays cover the window g (all of the grid on one GPU; block + halo on a rank of a decomposed run).
+int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t** out)
+{
+    if (!p || !out) return fail(FLUID_ERR_ARG, "null argument");
     if (p->n < 8 || p->n > 1024) return fail(FLUID_ERR_ARG, "n must be in [8,1024]");
     if (!(p->dx > 0) || !(p->rho > 0) || !(p->max_dt > 0)) return fail(FLUID_ERR_ARG, "dx, rho, max_dt must be > 0");
     if (p->precision != FLUID_PRECISION_FP64 && p->precision != FLUID_PRECISION_FP32) return fail(FLUID_ERR_ARG, "bad precision");
     if (!(p->flip_blend >= 0.0 && p->flip_blend <= 1.0)) return fail(FLUID_ERR_ARG, "flip_blend must be in [0,1] (1 = the reference's pure FLIP)");
+    if (p->preconditioner != FLUID_PRECOND_MG && p->preconditioner != FLUID_PRECOND_JACOBI) return fail(FLUID_ERR_ARG, "bad preconditioner");
+    if (p->solve_start != FLUID_START_WARM && p->solve_start != FLUID_START_ZERO) return fail(FLUID_ERR_ARG, "bad solve_start");
+    if (p->mg_precision != FLUID_MG_FP32 && p->mg_precision != FLUID_MG_FP64) return fail(FLUID_ERR_ARG, "bad mg_precision");
+    if (p->dist_solve < FLUID_DIST_AUTO || p->dist_solve > FLUID_DIST_REPLICATED || p->pad_ != 0) return fail(FLUID_ERR_ARG, "bad dist_solve / pad_");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(FLUID_ERR_HIP, "no HIP device visible: libfluid_hip has no CPU path");
@@ -281,19 +216,17 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     HIPCHK(hipSetDevice(p->device));
     fluid_sim* s = new fluid_sim();
     s->prm = *p;
-    s->g.N = p->n;
-    s->g.lo = -(p->n / 2);
-    s->g.hi = s->g.lo + p->n - 1;
-    s->ncell = (size_t)p->n * p->n * p->n;
+    s->g = g;
+    s->ncell = g.cells();
     s->dt = p->max_dt;
-    if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments)
+    s->mg_fp32 = p->mg_precision == FLUID_MG_FP32;
+    s->warm = p->solve_start == FLUID_START_WARM;
+    if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments): they override the params
     if (const char* e = getenv("FLUID_MG_FP64")) s->mg_fp32 = atoi(e) == 0;
     if (const char* e = getenv("FLUID_WARM_START")) s->warm = atoi(e) != 0;
     if (const char* e = getenv("FLUID_TILE_LISTS")) s->lists_force = atoi(e) != 0;
     if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
-    s->xs = 0;
-    s->xe = p->n;
     *out = nullptr;
     auto bail = [&](int rc) { fluid_destroy(s); return rc; };
 #define A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
@@ -310,7 +243,7 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     A(dalloc(&s->scan_sums, (n + 2) / 2048 + 16));
     A(dalloc(&s->ipart, (size_t)1024 * 8));
     const size_t se = solver_elem(s);
-    s->lmax = lbox_max_cells(p->n);  // >= n: the arrays double as N^3 scratch for fluid_stencil_apply
+    s->lmax = lbox_max_cells(std::max(g.nx, std::max(g.ny, g.nz)));  // >= n: the arrays double as N^3 scratch for fluid_stencil_apply
     const size_t ln = s->lmax;
     A(dalloc((char**)&s->R, ln * se)); A(dalloc((char**)&s->S[0], 2 * ln * se + 256));  // both search vectors: one slab, one memset per step
     s->S[1] = (char*)s->S[0] + ln * se;
@@ -331,10 +264,12 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     // default solid shell: solid outside W (fluid.cc:1256-1266)
     std::vector<uint8_t> sol(n, 0);
     const int N = p->n;
-    for (int x = 0; x < N; ++x)
-        for (int y = 0; y < N; ++y)
-            for (int z = 0; z < N; ++z)
-                if (x < 2 || x > N - 3 || y < 2 || y > N - 3 || z < 2 || z > N - 3) sol[((size_t)x * N + y) * N + z] = 1;
+    for (int x = 0; x < g.nx; ++x)
+        for (int y = 0; y < g.ny; ++y)
+            for (int z = 0; z < g.nz; ++z) {
+                const int X = x + g.ox, Y = y + g.oy, Z = z + g.oz;   // global index
+                if (X < 2 || X > N - 3 || Y < 2 || Y > N - 3 || Z < 2 || Z > N - 3) sol[g.idx(x, y, z)] = 1;
+            }
     hipError_t e = hipMemcpy(s->solid, sol.data(), n, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->flags, sol.data(), n, hipMemcpyHostToDevice);  // F_SOLID == 1
     if (e == hipSuccess) e = hipDeviceSynchronize();  // hipMemset above ran on the null stream; s->st does not wait for it
@@ -343,24 +278,32 @@ int fluid_create(const fluid_params_t* p, fluid_sim_t** out)
     return FLUID_OK;
 }
 
+extern "C" {
+
+/* solid: the GLOBAL N^3 array on every rank of a decomposed run; each keeps its window */
 int fluid_set_solid(fluid_sim_t* s, const uint8_t* solid)
 {
     if (!s || !solid) return fail(FLUID_ERR_ARG, "null argument");
     const int N = s->g.N;
-    std::vector<uint8_t> sol(s->ncell);
+    const Grid g = s->g;
     for (int x = 0; x < N; ++x)
         for (int y = 0; y < N; ++y)
             for (int z = 0; z < N; ++z) {
                 size_t c = ((size_t)x * N + y) * N + z;
                 bool outsideW = x < 2 || x > N - 3 || y < 2 || y > N - 3 || z < 2 || z > N - 3;
                 if (outsideW && !solid[c]) return fail(FLUID_ERR_ARG, "cells outside W=[lo+2,hi-2]^3 must be solid");
-                sol[c] = solid[c] ? 1 : 0;
             }
+    std::vector<uint8_t> sol(s->ncell);
+    for (int x = 0; x < g.nx; ++x)
+        for (int y = 0; y < g.ny; ++y)
+            for (int z = 0; z < g.nz; ++z)
+                sol[g.idx(x, y, z)] = solid[((size_t)(x + g.ox) * N + (y + g.oy)) * N + (z + g.oz)] ? 1 : 0;
     HIPCHK(hipStreamSynchronize(s->st));
     HIPCHK(hipMemcpy(s->solid, sol.data(), s->ncell, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->flags, sol.data(), s->ncell, hipMemcpyHostToDevice));
     s->have_p2g = s->have_flags = false;
     s->flags_valid = false;  // the next flags pass sweeps the whole grid
+    s->have_guess = false;   // a new obstacle: the next solve starts from 0
     return FLUID_OK;
 }
 
@@ -452,14 +395,14 @@ int64_t fluid_scene_water_cube_drop(int32_t n, int32_t ppc, uint64_t seed, doubl
 }  // extern "C"
 
 // ---- phases ---------------------------------------------------------------------------------------
-static int read_ss(fluid_sim* s)
+int fl::read_ss(fluid_sim* s)
 {
     HIPCHK(hipMemcpyAsync(s->h_ss, s->ss, sizeof(StepState), hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
     return FLUID_OK;
 }
 
-static int clear_dirty(fluid_sim* s)
+int fl::clear_dirty(fluid_sim* s)
 {
     if (box_empty(s->dirty)) return FLUID_OK;
     const ZeroList z = {{s->container, s->rhs, s->diver, s->diver2}, {s->u, s->v, s->w, s->ub, s->vb, s->wb, s->pressure}};
@@ -477,7 +420,7 @@ static int clear_dirty(fluid_sim* s)
 static int sort_pass(fluid_sim* s, int ax0, int ax1)
 {
     const Grid g = s->g;
-    const long ncell = (long)s->ncell, n2 = (long)g.N * g.N;
+    const long ncell = (long)s->ncell, n2 = g.sx();
     const long c0 = (long)ax0 * n2, c1 = (long)(ax1 + 1) * n2;
     launch_zero_step_state(s->st, s->ss, g.N);
     HIPCHK(hipMemsetAsync(s->cell_count + c0, 0, (c1 - c0) * sizeof(int), s->st));
@@ -495,16 +438,16 @@ static int phase_sort(fluid_sim* s)
 {
     const Grid g = s->g;
     int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
-    int ax0 = 0, ax1 = g.N - 1;
+    int ax0 = 0, ax1 = g.nx - 1;
     const bool guess = s->sort_hint && !box_empty(s->Pb);
     if (guess) {
         ax0 = std::max(0, s->Pb.x0 - 3);
-        ax1 = std::min(g.N - 1, s->Pb.x1 + 3);
+        ax1 = std::min(g.nx - 1, s->Pb.x1 + 3);
     }
     int rc = sort_pass(s, ax0, ax1);
     if (rc) return rc;
     if (guess && s->h_ss->bbox_max[0] >= 0 && (s->h_ss->bbox_min[0] < std::min(ax0 + 2, s->Pb.x0) || s->h_ss->bbox_max[0] > std::max(ax1 - 2, s->Pb.x1))) {
-        if ((rc = sort_pass(s, 0, g.N - 1))) return rc;   // the guess did not hold
+        if ((rc = sort_pass(s, 0, g.nx - 1))) return rc;   // the guess did not hold
     }
     s->sort_hint = true;
     s->n_out = s->h_ss->n_out;
@@ -516,8 +459,8 @@ static int phase_sort(fluid_sim* s)
         s->Pb = Box{h.bbox_min[0], h.bbox_min[1], h.bbox_min[2], h.bbox_max[0], h.bbox_max[1], h.bbox_max[2]};
     }
     if (!box_empty(s->Pb)) {
-        s->Rb = clip_dilate(s->Pb, 1, g.N);
-        s->Sb = clip_dilate(s->Pb, 2, g.N);
+        s->Rb = clip_dilate(s->Pb, 1, g);
+        s->Sb = clip_dilate(s->Pb, 2, g);
     } else {
         s->Rb = s->Sb = s->Pb;
     }
@@ -531,12 +474,14 @@ static int phase_sort(fluid_sim* s)
 }
 
 // particle -> grid over box (k_p2g_rows + k_p2g_combine)
-static int run_p2g(fluid_sim* s, const Box& box)
+int fl::run_p2g(fluid_sim* s, const Box& box)
 {
     // The tile form for piled particles and for a mostly empty box (the splash: under 30 % of the box were unknowns last step —
     // the row form pays its per-row latency for thousands of nearly empty rows).  Both inputs are the same on every rank.
-    const bool airy = s->last_num_active > 0 && (double)s->last_num_active < 0.3 * (double)s->Rb.cells();
-    const bool huge = (size_t)12 * sizeof(double) * (size_t)s->Rb.cells() > ((size_t)16 << 30);  // the row form's partials: 96 B per box cell
+    // (a decomposed run takes the GLOBAL active box here, so that every rank picks the form the one-GPU step would)
+    const long ref_cells = s->p2g_ref_cells > 0 ? s->p2g_ref_cells : s->Rb.cells();
+    const bool airy = s->last_num_active > 0 && (double)s->last_num_active < 0.3 * (double)ref_cells;
+    const bool huge = (size_t)12 * sizeof(double) * (size_t)box.cells() > ((size_t)16 << 30);  // the row form's partials: 96 B per box cell
     if (s->p2g_force ? s->p2g_force == 2 : (s->max_cell > P2G_PILED || airy || huge)) {
         s->stats.paths |= FLUID_PATH_P2G_TILES;
         launch_p2g_tiles(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
@@ -588,7 +533,7 @@ static int phase_p2g(fluid_sim* s)
 }
 
 template <typename T>
-static Coef<T> make_coef(const fluid_sim* s)
+Coef<T> fl::make_coef(const fluid_sim* s)
 {
     // setA, fluid.cc:306: scale = dt/(rho dx dx); Adiag accumulates float(Adiag + scale); Aplus = float(-1*scale)
     const double scale = s->dt / (s->prm.rho * s->prm.dx * s->prm.dx);
@@ -606,7 +551,7 @@ static Coef<T> make_coef(const fluid_sim* s)
 }
 
 // Both search vectors of this step, zeroed by one fill (padding and non-unknowns must read 0).
-static hipError_t zero_search(fluid_sim* s, size_t lb)
+hipError_t fl::zero_search(fluid_sim* s, size_t lb)
 {
     const size_t step = (lb + 255) / 256 * 256;
     s->S[1] = (char*)s->S[0] + step;
@@ -615,7 +560,6 @@ static hipError_t zero_search(fluid_sim* s, size_t lb)
 
 // ---- multigrid-preconditioned CG (single GPU, fp64) ----------------------------------------------
 // (multi-GPU: the same V-cycle applied per slab, neighbour-slab unknowns treated as p = 0: block preconditioner, no halo traffic)
-static bool use_mg(const fluid_sim* s) { return s->prm.reserved == 0 && s->prm.precision == FLUID_PRECISION_FP64; }
 
 // Level hierarchy of this step: level 0 = the box-local solver layout, coarsened until <= 8^3.
 static int mg_setup(fluid_sim* s)
@@ -673,7 +617,7 @@ static int mg_setup(fluid_sim* s)
     return FLUID_OK;
 }
 
-static MgCoef<double> mg_coef(const fluid_sim* s, int level)
+MgCoef<double> fl::mg_coef(const fluid_sim* s, int level)
 {
     MgCoef<double> c;
     if (level == 0) {
@@ -848,13 +792,13 @@ static int solve_mg(fluid_sim* s)
     return FLUID_OK;
 }
 
-static int phase_flags(fluid_sim* s)
+int fl::phase_flags(fluid_sim* s)
 {
     HIPCHK(hipSetDevice(s->prm.device));
     // container > 0 only inside the active box, and outside [flag_x0, flag_x1] the flags / indices still hold what an
     // empty cell gets: sweep the x planes of this box and of the previous pass only (the unknown numbering is a prefix
     // count in linear order, so a contiguous plane range that holds every fluid cell numbers them like the full sweep)
-    int x0 = 0, x1 = s->g.N - 1;
+    int x0 = 0, x1 = s->g.nx - 1;
     const bool none = box_empty(s->Sb);
     if (s->flags_valid) {
         x0 = none ? s->flag_x0 : (s->flag_x1 < s->flag_x0 ? s->Sb.x0 : std::min(s->Sb.x0, s->flag_x0));
@@ -1023,7 +967,7 @@ static int phase_vel_update(fluid_sim* s)
     return FLUID_OK;
 }
 
-static int phase_pressure_pass(fluid_sim* s, double* error)
+int fl::phase_pressure_pass(fluid_sim* s, double* error)
 {
     int rc;
     if ((rc = phase_rhs_div(s, 0))) return rc;
@@ -1044,7 +988,7 @@ static int phase_pressure_pass(fluid_sim* s, double* error)
 }
 
 // PIC blend (flip_blend < 1): three more cell fields, allocated when first needed
-static int pic_fields(fluid_sim* s)
+int fl::pic_fields(fluid_sim* s)
 {
     if (s->prm.flip_blend >= 1.0 || s->pcx) return FLUID_OK;
     double** f[3] = {&s->pcx, &s->pcy, &s->pcz};
@@ -1109,7 +1053,6 @@ int fluid_get_stats(fluid_sim_t* s, fluid_step_stats_t* st)
     return FLUID_OK;
 }
 
-static int dist_step(fluid_sim* s, fluid_step_stats_t* stats);
 
 int fluid_step(fluid_sim_t* s, fluid_step_stats_t* stats)
 {
@@ -1183,8 +1126,7 @@ int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
         HIPCHK(hipMemcpy(p, src, nb, hipMemcpyHostToDevice));
     }
     // an uploaded field may be non-zero anywhere: widen every box to the whole grid
-    const int N = s->g.N;
-    s->Rb = s->Sb = Box{0, 0, 0, N - 1, N - 1, N - 1};
+    s->Rb = s->Sb = Box{0, 0, 0, s->g.nx - 1, s->g.ny - 1, s->g.nz - 1};
     s->dirty = s->Rb;
     if (field == FLUID_FIELD_CONTAINER) { s->have_p2g = true; s->have_flags = false; }
     return FLUID_OK;
@@ -1253,601 +1195,6 @@ int fluid_profile_reset(fluid_sim_t* s)
         s->prof[k].launches = s->prof[k].sampled = 0;
         s->prof[k].ms = s->prof[k].cells = 0;
     }
-    return FLUID_OK;
-}
-
-}  // extern "C"
-
-// =====================================================================================================
-// Multi-GPU: x-slab domain decomposition.  Every rank holds full-size field arrays
-// and computes its slab [xs,xe) only; halo planes live at their global index.  All communication
-// goes through the caller's fluid_comm_t (RCCL via torch.distributed in bench.py, gloo in tests).
-// =====================================================================================================
-#define COMMCHK(expr)                                                                              \
-    do {                                                                                           \
-        if ((expr) != 0) return fail(FLUID_ERR_HIP, std::string("comm callback failed: ") + #expr); \
-    } while (0)
-
-static int comm_sendrecv(fluid_sim* s, const void* send_lo, size_t nlo_s, void* recv_lo, size_t nlo_r, const void* send_hi, size_t nhi_s,
-                         void* recv_hi, size_t nhi_r)
-{
-    const bool has_lo = s->comm.rank > 0, has_hi = s->comm.rank < s->comm.size - 1;
-    if (!has_lo) nlo_s = nlo_r = 0;
-    if (!has_hi) nhi_s = nhi_r = 0;
-    COMMCHK(s->comm.sendrecv(s->comm.ctx, send_lo, nlo_s, recv_lo, nlo_r, send_hi, nhi_s, recv_hi, nhi_r, (void*)s->st));
-    return FLUID_OK;
-}
-static int comm_allreduce(fluid_sim* s, void* buf, int count, int dtype, int op)
-{
-    COMMCHK(s->comm.allreduce(s->comm.ctx, buf, count, dtype, op, (void*)s->st));
-    return FLUID_OK;
-}
-// boundary planes of a global-layout field: my first/last owned plane -> the neighbours' halo planes
-static int exchange_planes(fluid_sim* s, void* field, size_t elem)
-{
-    const size_t n2 = (size_t)s->g.N * s->g.N, pb = n2 * elem;
-    char* f = (char*)field;
-    return comm_sendrecv(s, f + (size_t)s->xs * pb, pb, s->xs > 0 ? f + (size_t)(s->xs - 1) * pb : nullptr, pb,
-                         f + (size_t)(s->xe - 1) * pb, pb, s->xe < s->g.N ? f + (size_t)s->xe * pb : nullptr, pb);
-}
-static int read_ints(fluid_sim* s, const int* dev, int n, int* host_slot)
-{
-    HIPCHK(hipMemcpyAsync(host_slot, dev, n * sizeof(int), hipMemcpyDeviceToHost, s->st));
-    return FLUID_OK;
-}
-static Box clip_x(const Box& b, int xs, int xe)
-{
-    Box r = b;
-    if (r.x0 < xs) r.x0 = xs;
-    if (r.x1 > xe - 1) r.x1 = xe - 1;
-    if (r.x1 < r.x0) { r.x0 = xs; r.x1 = xs - 1; }  // empty in x, still a valid (y,z) extent
-    return r;
-}
-
-static int dist_sort(fluid_sim* s)
-{
-    const Grid g = s->g;
-    const int N = g.N;
-    const long ncell = (long)s->ncell, n2 = (long)N * N;
-    const bool has_lo = s->comm.rank > 0, has_hi = s->comm.rank < s->comm.size - 1;
-    int rc;
-    int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
-    // ---- A. hand particles that left the slab to the neighbours -------------------------------------
-    HIPCHK(hipMemsetAsync(s->d_small, 0, 32 * sizeof(int), s->st));
-    launch_classify_migrate(s->st, g, s->np, s->pa.shifted(s->p_off), s->xs, s->xe, has_lo, has_hi, s->mig_lo, s->mig_hi, (int)s->mig_cap,
-                            s->d_small);
-    HIPCHK(hipGetLastError());
-    if ((rc = comm_sendrecv(s, s->d_small + 0, sizeof(int), s->d_small + 2, sizeof(int), s->d_small + 1, sizeof(int), s->d_small + 3, sizeof(int)))) return rc;
-    if ((rc = read_ints(s, s->d_small, 4, s->h_small))) return rc;
-    HIPCHK(hipStreamSynchronize(s->st));
-    const long nl = s->h_small[0], nr = s->h_small[1], ml = s->h_small[2], mr = s->h_small[3];
-    if (nl > s->mig_cap || nr > s->mig_cap || ml > s->mig_cap || mr > s->mig_cap)
-        return fail(FLUID_ERR_STATE, "particle migration buffer overflow");
-    if ((rc = comm_sendrecv(s, s->mig_lo, (size_t)nl * 56, s->mig_rlo, (size_t)ml * 56, s->mig_hi, (size_t)nr * 56, s->mig_rhi, (size_t)mr * 56))) return rc;
-    if (s->p_off + s->np + ml + mr > s->cap) return fail(FLUID_ERR_STATE, "particle capacity exceeded on this rank");
-    launch_unpack_records(s->st, ml, s->mig_rlo, s->pa, s->p_off + s->np);
-    launch_unpack_records(s->st, mr, s->mig_rhi, s->pa, s->p_off + s->np + ml);
-    s->np += ml + mr;
-    // ---- B. count per cell (dead -> last bucket) ------------------------------------------------------
-    launch_zero_step_state(s->st, s->ss, N);
-    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 4) * sizeof(int), s->st));
-    launch_bin_count(s->st, g, s->np, s->pa.shifted(s->p_off), s->key, s->slot, s->cell_count, s->ipart, s->ss);
-    HIPCHK(hipGetLastError());
-    // ---- C. neighbours' boundary-plane counts become my ghost planes xs-1 and xe ------------------------
-    if ((rc = comm_sendrecv(s, s->cell_count + (long)s->xs * n2, n2 * sizeof(int), s->xs > 0 ? s->cell_count + (long)(s->xs - 1) * n2 : nullptr,
-                            n2 * sizeof(int), s->cell_count + (long)(s->xe - 1) * n2, n2 * sizeof(int),
-                            s->xe < N ? s->cell_count + (long)s->xe * n2 : nullptr, n2 * sizeof(int)))) return rc;
-    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
-    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->pa.shifted(s->p_off).pid, s->order, s->spid);
-    HIPCHK(hipGetLastError());
-    // offsets: [4] start of plane xs, [5] start of plane xs+1, [6] start of plane xe-1, [7] start of plane xe,
-    //          [8] start of plane xe+1 (or of the off-grid bucket), [9] off-grid bucket, [10] dead bucket, [11] total
-    const long o_xs = (long)s->xs * n2, o_xe = (long)s->xe * n2;
-    if ((rc = read_ints(s, s->cell_start + o_xs, 1, s->h_small + 4))) return rc;
-    if ((rc = read_ints(s, s->cell_start + o_xs + n2, 1, s->h_small + 5))) return rc;
-    if ((rc = read_ints(s, s->cell_start + o_xe - n2, 1, s->h_small + 6))) return rc;
-    if ((rc = read_ints(s, s->cell_start + o_xe, 1, s->h_small + 7))) return rc;
-    if ((rc = read_ints(s, s->cell_start + (s->xe < N ? o_xe + n2 : ncell), 1, s->h_small + 8))) return rc;
-    if ((rc = read_ints(s, s->cell_start + ncell, 3, s->h_small + 9))) return rc;
-    // global particle bounding box: MIN over [min3, -max3]
-    if ((rc = read_ss(s))) return rc;
-    {
-        const StepState& h = *s->h_ss;
-        int* v = s->h_small + 16;
-        for (int a = 0; a < 3; ++a) {
-            v[a] = h.bbox_max[a] < 0 ? 0x7fffffff : h.bbox_min[a];
-            v[3 + a] = h.bbox_max[a] < 0 ? 0x7fffffff : -h.bbox_max[a];
-        }
-        v[6] = -h.max_cell;  // and the fullest cell of any rank (it picks the P2G kernel: every rank must take the same)
-        HIPCHK(hipMemcpyAsync(s->d_small + 16, v, 7 * sizeof(int), hipMemcpyHostToDevice, s->st));
-        if ((rc = comm_allreduce(s, s->d_small + 16, 7, FLUID_DT_I32, FLUID_OP_MIN))) return rc;
-        if ((rc = read_ints(s, s->d_small + 16, 7, s->h_small + 16))) return rc;
-        HIPCHK(hipStreamSynchronize(s->st));
-        s->max_cell = -v[6];
-        if (v[0] == 0x7fffffff) s->Pb = Box{0, 0, 0, -1, -1, -1};
-        else s->Pb = Box{v[0], v[1], v[2], -v[3], -v[4], -v[5]};
-    }
-    const long gl = s->h_small[4];                         // left ghosts precede my first plane
-    const long gr = s->h_small[8] - s->h_small[7];         // right ghosts = plane xe
-    const long n_slab = s->h_small[7] - s->h_small[4];     // my particles inside the slab
-    const long n_oog = s->h_small[10] - s->h_small[9];     // off the grid on an outer rank: inert, dropped
-    s->n_dropped += n_oog;
-    if (!box_empty(s->Pb)) {
-        s->Rb = clip_dilate(s->Pb, 1, N);
-        s->Sb = clip_dilate(s->Pb, 2, N);
-        // id order inside the cells of my slab (positions [gl, gl+n_slab)); ghosts arrive in their owner's order
-    } else {
-        s->Rb = s->Sb = s->Pb;
-    }
-    s->Rr = box_empty(s->Rb) ? s->Rb : clip_x(s->Rb, s->xs, s->xe);
-    s->Sr = box_empty(s->Sb) ? s->Sb : clip_x(s->Sb, s->xs, s->xe);
-    if (gl + s->np + gr > s->cap) return fail(FLUID_ERR_STATE, "particle capacity exceeded on this rank (ghosts)");
-    // order[] is indexed by DESTINATION position; only [gl, gl+n_slab) is mine (ghost gaps are filled below,
-    // the off-grid and dead tails are dropped)
-    launch_bin_rank(s->st, n_slab, gl, s->key, s->cell_start, s->order, s->spid, s->order2);
-    launch_reorder(s->st, n_slab, s->order2 + gl, s->pa.shifted(s->p_off), s->pb.shifted(gl));
-    HIPCHK(hipGetLastError());
-    std::swap(s->pa, s->pb);
-    s->p_off = gl;
-    s->np = n_slab;
-    // ---- D. ghost particles: my first/last plane -> neighbours; theirs into the gaps the scan left ------
-    const long n_slo = s->h_small[5] - s->h_small[4], n_shi = s->h_small[7] - s->h_small[6];
-    if (n_slo > s->mig_cap || n_shi > s->mig_cap || gl > s->mig_cap || gr > s->mig_cap)
-        return fail(FLUID_ERR_STATE, "ghost particle buffer overflow");
-    launch_pack_records(s->st, n_slo, s->pa, s->h_small[4], s->mig_lo);
-    launch_pack_records(s->st, n_shi, s->pa, s->h_small[6], s->mig_hi);
-    HIPCHK(hipGetLastError());
-    if ((rc = comm_sendrecv(s, s->mig_lo, (size_t)n_slo * 56, s->mig_rlo, (size_t)gl * 56, s->mig_hi, (size_t)n_shi * 56, s->mig_rhi, (size_t)gr * 56))) return rc;
-    launch_unpack_records(s->st, gl, s->mig_rlo, s->pa, 0);
-    launch_unpack_records(s->st, gr, s->mig_rhi, s->pa, s->h_small[7]);
-    s->p2g_total = s->h_small[7] + gr;
-    HIPCHK(hipGetLastError());
-    prof_end(s, FLUID_PROF_SORT, tok);
-    s->sorted = true;
-    return FLUID_OK;
-}
-
-template <typename T>
-static int dist_solve_impl(fluid_sim* s)
-{
-    const Grid g = s->g;
-    const LBox L = s->L;
-    T* X = (T*)s->X;
-    T* R = (T*)s->R;
-    T* Q = (T*)s->Q;
-    T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
-    const uint8_t* cnt = s->cntL;
-    const Coef<T> cf = make_coef<T>(s);
-    const double tol = s->prm.cg_tol;
-    long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
-    if (max_it < 1) max_it = 1;
-    const size_t plane = (size_t)L.Ly * L.Lz * sizeof(T);
-    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L);
-    int rc;
-    auto ring = [&](T* S) -> int {
-        char* b = (char*)S;
-        if (L.nx > 0) return comm_sendrecv(s, b + plane, plane, b, plane, b + (size_t)L.nx * plane, plane, b + (size_t)(L.nx + 1) * plane, plane);
-        return comm_sendrecv(s, s->zplane, plane, s->splane, plane, s->zplane, plane, (char*)s->splane + plane, plane);
-    };
-    const double cells = (double)s->Rr.cells();
-    int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
-    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
-    launch_sum2(s->st, s->part_bb, nxr, s->part_rz[0], nxr, s->gstage[1], s->gstage[1] + 1);
-    if ((rc = comm_allreduce(s, s->gstage[1], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-    long it = 0;
-    const int CHECK = 16;
-    bool done = false;
-    while (!done) {
-        for (int k = 0; k < CHECK && it < max_it; ++k, ++it) {
-            const int cur = (int)(it & 1), prv = cur ^ 1;
-            // stage[prv] = [|r|^2, r.z] of the previous body (or of the start); stage[cur][1] = the r.z before that
-            int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-            launch_pcg_s<T>(s->st, L, cnt, R, Sx[prv], Sx[cur], cf, s->gstage[prv], s->gstage[prv] + 1, s->gstage[cur] + 1, s->ps, it == 0, tol);
-            if ((rc = ring(Sx[cur]))) return rc;
-            launch_pcg_q<T>(s->st, L, cnt, Sx[cur], Q, cf, s->part_pq, s->ps);
-            prof_end(s, FLUID_PROF_PCG_SQ, tok);
-            launch_sum2(s->st, s->part_pq, nsq, s->part_pq, 0, s->gpq, nullptr);
-            if ((rc = comm_allreduce(s, s->gpq, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-            tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            launch_pcg_xr_g<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->gstage[prv] + 1, s->gpq, s->part_rr, s->part_rz[0], s->ps);
-            prof_end(s, FLUID_PROF_PCG_XR, tok);
-            launch_sum2(s->st, s->part_rr, nxr, s->part_rz[0], nxr, s->gstage[cur], s->gstage[cur] + 1);
-            if ((rc = comm_allreduce(s, s->gstage[cur], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-        }
-        HIPCHK(hipGetLastError());
-        // every rank must leave the loop at the same iteration: agree on the flag
-        if ((rc = comm_allreduce(s, &s->ps->done, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
-        HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
-        HIPCHK(hipStreamSynchronize(s->st));
-        done = s->h_ps->done || it >= max_it;
-    }
-    int iters = s->h_ps->iters;
-    const double rr = s->h_ps->rr;
-    if (!s->h_ps->done) iters = (int)max_it;
-    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
-    HIPCHK(hipGetLastError());
-    prof_end(s, FLUID_PROF_SOLVE, tsolve);
-    s->stats.cg_iters_last = iters;
-    s->stats.cg_iters += iters;
-    s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
-    if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
-    return FLUID_OK;
-}
-
-// Distributed PCG with the per-slab V-cycle as preconditioner (block Jacobi of multigrid solves):
-// per iteration one ring exchange and three small all-reduces (r.z, s.q, |r|^2), nothing inside the V-cycle.
-static int dist_solve_mg(fluid_sim* s)
-{
-    typedef double T;
-    const Grid g = s->g;
-    const LBox L = s->L;
-    T* X = (T*)s->X;
-    T* R = (T*)s->R;
-    T* Q = (T*)s->Q;
-    T* Z = (T*)s->Zmg;
-    T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
-    const uint8_t* cnt = s->cntL;
-    const Coef<T> cf = make_coef<T>(s);
-    const double tol = s->prm.cg_tol;
-    long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
-    if (max_it < 1) max_it = 1;
-    const size_t plane = (size_t)L.Ly * L.Lz * sizeof(T);
-    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L), n_rz = mg_rz_blocks(s);
-    int rc;
-    auto ring = [&](T* S) -> int {
-        char* b = (char*)S;
-        if (L.nx > 0) return comm_sendrecv(s, b + plane, plane, b, plane, b + (size_t)L.nx * plane, plane, b + (size_t)(L.nx + 1) * plane, plane);
-        return comm_sendrecv(s, s->zplane, plane, s->splane, plane, s->zplane, plane, (char*)s->splane + plane, plane);
-    };
-    const double cells = (double)s->Rr.cells();
-    int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
-    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
-    // Two all-reduces per iteration: {|r|^2 of the previous body (|b|^2 before the first), r.z of this one} as one pair
-    // after the V-cycle, and s.q after the stencil.  gstage[cur] = that pair.
-    long it = 0;
-    // first batch = the previous solve's count (identical on every rank), then poll every 2 iterations
-    long batch = s->mg_last_iters > 5 ? s->mg_last_iters : 8;
-    bool done = false;
-    while (!done) {
-        for (long k = 0; k < batch && it < max_it; ++k, ++it) {
-            const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = mg_vcycle(s, R, Z, s->mg_part))) return rc;
-            launch_sum2(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->mg_part, n_rz, s->gstage[cur], s->gstage[cur] + 1);
-            if ((rc = comm_allreduce(s, s->gstage[cur], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-            int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-            launch_pcg_s<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], cf, s->gstage[cur], s->gstage[cur] + 1, s->gstage[prv] + 1, s->ps, it == 0, tol, 1);
-            if ((rc = ring(Sx[cur]))) return rc;
-            launch_pcg_q<T>(s->st, L, cnt, Sx[cur], Q, cf, s->part_pq, s->ps);
-            prof_end(s, FLUID_PROF_PCG_SQ, tok);
-            launch_sum2(s->st, s->part_pq, nsq, s->part_pq, 0, s->gpq, nullptr);
-            if ((rc = comm_allreduce(s, s->gpq, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-            tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            launch_pcg_xr_g<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->gstage[cur] + 1, s->gpq, s->part_rr, s->part_err, s->ps);
-            prof_end(s, FLUID_PROF_PCG_XR, tok);
-        }
-        HIPCHK(hipGetLastError());
-        // convergence of the last body of a batch is seen by the first S launch of the next batch (after one spare V-cycle)
-        if ((rc = comm_allreduce(s, &s->ps->done, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
-        HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
-        HIPCHK(hipStreamSynchronize(s->st));
-        done = s->h_ps->done || it >= max_it;
-        batch = 2;
-    }
-    int iters = s->h_ps->iters;
-    const double rr = s->h_ps->rr;
-    if (!s->h_ps->done) iters = (int)max_it;
-    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
-    HIPCHK(hipGetLastError());
-    prof_end(s, FLUID_PROF_SOLVE, tsolve);
-    s->stats.cg_iters_last = iters;
-    s->stats.cg_iters += iters;
-    s->mg_last_iters = iters;
-    s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
-    if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
-    return FLUID_OK;
-}
-
-// Multi-GPU step with the pressure block REPLICATED: particles (sort, migration, P2G, G2P, advect) are sharded by x slab
-// as in dist_step; the P2G result of the whole active box is then assembled on every rank by one SUM all-reduce of
-// [container | u | v | w] over the box (20 MB at 256^3: every cell has exactly one owner, the others add exact zeros, so the
-// fields are bit-identical to a one-GPU P2G), and flags, numbering, the pressure do..while with the single-GPU multigrid
-// PCG and the FLIP delta field run identically on every rank with no communication at all.  At 256^3 (0.7 M unknowns)
-// the distributed PCG needs 87-105 iterations of >= 3 exchanges each against 25 local ones: replicating
-// a 2.3 ms solve is several times faster than distributing it.  FLUID_DIST_SOLVE=1 selects the distributed solve.
-static int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
-{
-    const Grid g = s->g;
-    int rc;
-    HIPCHK(hipSetDevice(s->prm.device));
-    if ((rc = dist_sort(s))) return rc;             // sort + migration + ghosts: Rb / Sb are the GLOBAL boxes, Rr / Sr my parts
-    if ((rc = clear_dirty(s))) return rc;
-    memset(&s->stats, 0, sizeof(s->stats));
-    s->stats.dt_in = s->dt;
-    s->stats.dt_out = s->dt;
-    for (int a = 0; a < 3; ++a) {
-        s->stats.box_lo[a] = (&s->Rb.x0)[a];
-        s->stats.box_hi[a] = (&s->Rb.x1)[a];
-    }
-    if (!box_empty(s->Rb)) {
-        s->dirty = s->Sb;
-        if (!box_empty(s->Rr)) {
-            launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
-            int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
-            int rc = run_p2g(s, s->Rr);
-            prof_end(s, FLUID_PROF_P2G, tok);
-            if (rc) return rc;
-        }
-        const size_t need = 4 * (size_t)s->Rb.cells();
-        if (need > s->repl_cap) {
-            if (s->repl_buf) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->repl_buf); s->repl_buf = nullptr; }
-            HIPCHK(hipMalloc((void**)&s->repl_buf, (need + need / 4) * sizeof(double)));
-            s->repl_cap = need + need / 4;
-        }
-        launch_pack_box(s->st, g, s->Rb, s->xs, s->xe, s->container, s->u, s->v, s->w, s->repl_buf);
-        HIPCHK(hipGetLastError());
-        for (size_t o = 0; o < need; o += (size_t)1 << 30)  // the transport counts in int32
-            if ((rc = comm_allreduce(s, s->repl_buf + o, (int)std::min(need - o, (size_t)1 << 30), FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-        launch_unpack_box(s->st, g, s->Rb, s->repl_buf, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
-        HIPCHK(hipGetLastError());
-    }
-    s->have_p2g = true;
-    s->have_flags = false;
-    if ((rc = phase_flags(s))) return rc;           // whole grid on every rank: global numbering, no offsets
-    double error = NAN;
-    do {
-        if ((rc = phase_pressure_pass(s, &error))) return rc;
-        if (s->prm.max_outer_passes > 0 && s->stats.outer_passes >= s->prm.max_outer_passes) break;
-    } while (error > s->prm.outer_tol);
-    // ---- FLIP gather + advect of my particles (:1490) ----
-    if ((rc = pic_fields(s))) return rc;
-    if (!box_empty(s->Rb)) launch_flip_delta(s->st, g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
-    int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
-    prof_end(s, FLUID_PROF_G2P, tok);
-    HIPCHK(hipGetLastError());
-    if ((rc = comm_allreduce(s, &s->ss->max_speed_bits, 1, FLUID_DT_I64, FLUID_OP_MAX))) return rc;  // non-negative doubles order like their bits
-    launch_advect(s->st, g, s->np, s->pa.shifted(s->p_off), s->flags, s->prm.max_dt, s->prm.dx, s->ss);
-    HIPCHK(hipGetLastError());
-    if ((rc = read_ss(s))) return rc;
-    s->dt = s->h_ss->dt;
-    double ms;
-    memcpy(&ms, &s->h_ss->max_speed_bits, sizeof(double));
-    s->stats.max_speed = ms;
-    s->stats.dt_out = s->dt;
-    s->sorted = false;
-    s->have_p2g = false;
-    if (stats) *stats = s->stats;
-    return FLUID_OK;
-}
-
-static int dist_step(fluid_sim* s, fluid_step_stats_t* stats)
-{
-    if (s->dist_repl) return dist_step_replicated(s, stats);
-    const Grid g = s->g;
-    const int N = g.N;
-    const long n2 = (long)N * N;
-    int rc;
-    HIPCHK(hipSetDevice(s->prm.device));
-    // ---- sort + migration + ghosts; P2G on my slab (fluid.cc:1378-1413) ---------------------------------
-    if ((rc = dist_sort(s))) return rc;
-    if ((rc = clear_dirty(s))) return rc;
-    memset(&s->stats, 0, sizeof(s->stats));
-    s->stats.dt_in = s->dt;
-    s->stats.dt_out = s->dt;
-    for (int a = 0; a < 3; ++a) {
-        s->stats.box_lo[a] = (&s->Rb.x0)[a];
-        s->stats.box_hi[a] = (&s->Rb.x1)[a];
-    }
-    s->dirty = Box{s->xs > 0 ? s->xs - 1 : 0, 0, 0, s->xe < N ? s->xe : N - 1, N - 1, N - 1};  // my slab + halo planes
-    if (!box_empty(s->Rb) && !box_empty(s->Rr)) {
-        launch_weights(s->st, s->p2g_total, s->pa, s->pw, s->cap);  // ghosts included
-        int tok = prof_begin(s, FLUID_PROF_P2G, (double)s->Rr.cells());
-        int rc = run_p2g(s, s->Rr);
-        prof_end(s, FLUID_PROF_P2G, tok);
-        if (rc) return rc;
-        HIPCHK(hipGetLastError());
-    }
-    // halo planes of container and velocity (velBeforeUpdate = the same values)
-    if ((rc = exchange_planes(s, s->container, 4))) return rc;
-    double* vf[3] = {s->u, s->v, s->w};
-    double* vbf[3] = {s->ub, s->vb, s->wb};
-    for (int a = 0; a < 3; ++a) {
-        if ((rc = exchange_planes(s, vf[a], 8))) return rc;
-        if (s->xs > 0) HIPCHK(hipMemcpyAsync(vbf[a] + (long)(s->xs - 1) * n2, vf[a] + (long)(s->xs - 1) * n2, n2 * 8, hipMemcpyDeviceToDevice, s->st));
-        if (s->xe < N) HIPCHK(hipMemcpyAsync(vbf[a] + (long)s->xe * n2, vf[a] + (long)s->xe * n2, n2 * 8, hipMemcpyDeviceToDevice, s->st));
-    }
-    // ---- flags on my slab + halo planes; unknown numbering with the lower ranks' offset (:1416-1433) ----
-    const int fx0 = s->xs > 0 ? s->xs - 1 : 0, fx1 = s->xe < N ? s->xe : N - 1;
-    launch_flags(s->st, g, s->solid, s->container, s->flags, fx0, fx1);
-    launch_index_scan_range(s->st, g, s->flags, s->indices, s->scan_sums, &s->ss->num_active, s->xs, s->xe - 1);
-    HIPCHK(hipGetLastError());
-    {
-        // all-gather of the per-rank counts as an all-reduce of a one-hot vector
-        HIPCHK(hipMemsetAsync(s->d_small + 16, 0, 16 * sizeof(int), s->st));
-        HIPCHK(hipMemcpyAsync(s->d_small + 16 + s->comm.rank, &s->ss->num_active, sizeof(int), hipMemcpyDeviceToDevice, s->st));
-        if ((rc = comm_allreduce(s, s->d_small + 16, s->comm.size, FLUID_DT_I32, FLUID_OP_SUM))) return rc;
-        if ((rc = read_ints(s, s->d_small + 16, s->comm.size, s->h_small + 16))) return rc;
-        HIPCHK(hipStreamSynchronize(s->st));
-        long off = 0, tot = 0;
-        for (int r = 0; r < s->comm.size; ++r) {
-            if (r < s->comm.rank) off += s->h_small[16 + r];
-            tot += s->h_small[16 + r];
-        }
-        launch_add_offset(s->st, s->indices + (long)s->xs * n2, (long)(s->xe - s->xs) * n2, (int)off);
-        s->stats.num_active = tot;
-        s->last_num_active = tot;
-    }
-    // local solver layout: my part of the active box in x, the GLOBAL active extent in y and z
-    if (!box_empty(s->Rb)) {
-        s->L = make_lbox(s->Rr);
-        launch_cnt_local(s->st, g, s->L, s->flags, s->cntL);
-        const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
-        HIPCHK(zero_search(s, lb));
-        HIPCHK(hipGetLastError());
-        if (use_mg(s) && (rc = mg_setup(s))) return rc;
-    }
-    s->have_p2g = s->have_flags = true;
-    // ---- pressure do..while (:1457-1484) ------------------------------------------------------------------
-    double error = NAN;
-    do {
-        const double dt = s->dt;
-        if (!box_empty(s->Rb)) {
-            if (!box_empty(s->Rr))
-                launch_rhs_div(s->st, g, s->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver, s->prm.dx, s->prm.gravity[0] * dt,
-                               s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);
-            if (use_mg(s)) rc = dist_solve_mg(s);
-            else rc = s->prm.precision == FLUID_PRECISION_FP32 ? dist_solve_impl<float>(s) : dist_solve_impl<double>(s);
-            if (rc) return rc;
-            if ((rc = exchange_planes(s, s->pressure, 8))) return rc;
-            const double dtp = dt * s->prm.update_frac, k = dtp / (s->prm.rho * s->prm.dx);
-            if (!box_empty(s->Sr))
-                launch_vel_update(s->st, g, s->Sr, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,
-                                  s->prm.gravity[2] * dtp);
-            for (int a = 0; a < 3; ++a)
-                if ((rc = exchange_planes(s, vf[a], 8))) return rc;
-            if (!box_empty(s->Rr)) {
-                launch_rhs_div(s->st, g, s->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver2, s->prm.dx, s->prm.gravity[0] * dt,
-                               s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);
-                launch_err_norm(s->st, g, s->Rr, s->flags, s->diver, s->diver2, s->part_err, s->ss);
-            } else {
-                HIPCHK(hipMemsetAsync(&s->ss->err_num, 0, 2 * sizeof(double), s->st));
-            }
-            HIPCHK(hipGetLastError());
-            if ((rc = comm_allreduce(s, &s->ss->err_num, 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-            if ((rc = read_ss(s))) return rc;
-            error = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);
-        }
-        s->stats.error = error;
-        s->stats.outer_passes++;
-        if (s->prm.max_outer_passes > 0 && s->stats.outer_passes >= s->prm.max_outer_passes) break;
-    } while (error > s->prm.outer_tol);
-    // ---- FLIP gather + advect (:1490) ---------------------------------------------------------------------
-    if ((rc = pic_fields(s))) return rc;
-    if (!box_empty(s->Rb) && !box_empty(s->Rr))
-        launch_flip_delta(s->st, g, s->Rr, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
-    double* dcf[6] = {s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz};
-    for (int a = 0; a < (s->pcx ? 6 : 3); ++a)
-        if ((rc = exchange_planes(s, dcf[a], 8))) return rc;
-    int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
-    prof_end(s, FLUID_PROF_G2P, tok);
-    HIPCHK(hipGetLastError());
-    // non-negative doubles order like their bit patterns: MAX over int64
-    if ((rc = comm_allreduce(s, &s->ss->max_speed_bits, 1, FLUID_DT_I64, FLUID_OP_MAX))) return rc;
-    launch_advect(s->st, g, s->np, s->pa.shifted(s->p_off), s->flags, s->prm.max_dt, s->prm.dx, s->ss);
-    HIPCHK(hipGetLastError());
-    if ((rc = read_ss(s))) return rc;
-    s->dt = s->h_ss->dt;
-    double ms;
-    memcpy(&ms, &s->h_ss->max_speed_bits, sizeof(double));
-    s->stats.max_speed = ms;
-    s->stats.dt_out = s->dt;
-    s->sorted = false;
-    s->have_p2g = false;
-    if (stats) *stats = s->stats;
-    return FLUID_OK;
-}
-
-extern "C" {
-
-int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const int32_t* bounds, fluid_sim_t** out)
-{
-    if (!p || !comm || !bounds || !out) return fail(FLUID_ERR_ARG, "null argument");
-    if (comm->size < 1 || comm->size > 16 || comm->rank < 0 || comm->rank >= comm->size) return fail(FLUID_ERR_ARG, "bad rank/size (max 16 ranks)");
-    if (!comm->sendrecv || !comm->allreduce) return fail(FLUID_ERR_ARG, "comm callbacks missing");
-    if (bounds[0] != 0 || bounds[comm->size] != p->n) return fail(FLUID_ERR_ARG, "bounds must start at 0 and end at n");
-    for (int r = 0; r < comm->size; ++r)
-        if (bounds[r + 1] <= bounds[r]) return fail(FLUID_ERR_ARG, "every rank needs at least one x plane");
-    int rc = fluid_create(p, out);
-    if (rc) return rc;
-    fluid_sim* s = *out;
-    s->dist = true;
-    if (const char* e = getenv("FLUID_DIST_SOLVE")) s->dist_repl = atoi(e) == 0;
-    s->comm = *comm;
-    s->bounds.assign(bounds, bounds + comm->size + 1);
-    s->xs = bounds[comm->rank];
-    s->xe = bounds[comm->rank + 1];
-    auto bail = [&](const std::string& m) { fluid_destroy(s); *out = nullptr; return fail(FLUID_ERR_HIP, m); };
-    if (dalloc(&s->gstage[0], (size_t)2) != hipSuccess || dalloc(&s->gstage[1], (size_t)2) != hipSuccess || dalloc(&s->gpq, (size_t)1) != hipSuccess ||
-        dalloc(&s->grz, (size_t)2) != hipSuccess)
-        return bail("alloc of reduction scalars failed");
-    const LBox Lm = make_lbox(Box{0, 0, 0, p->n - 1, p->n - 1, p->n - 1});
-    const size_t plane = (size_t)Lm.Ly * Lm.Lz * 8;
-    if (dalloc((char**)&s->zplane, plane) != hipSuccess || dalloc((char**)&s->splane, 2 * plane) != hipSuccess) return bail("alloc of ring planes failed");
-    if (hipDeviceSynchronize() != hipSuccess) return bail("device sync failed");
-    return FLUID_OK;
-}
-
-int fluid_upload_particles_ids(fluid_sim_t* s, int64_t n, const double* pos, const double* vel, const uint32_t* ids)
-{
-    if (!s || n < 0 || (n > 0 && (!pos || !ids))) return fail(FLUID_ERR_ARG, "bad particle arguments");
-    HIPCHK(hipSetDevice(s->prm.device));
-    // room for ghosts and for particles that migrate in later (slabs re-balance as the fluid spreads)
-    const long cap = 4 * (long)n + (1L << 20);
-    int rc = alloc_particles(s, cap);
-    if (rc) return rc;
-    if (s->dist && !s->mig_lo) {
-        s->mig_cap = cap / 4 + (1L << 16);
-        HIPCHK(dalloc(&s->mig_lo, (size_t)s->mig_cap * 7)); HIPCHK(dalloc(&s->mig_hi, (size_t)s->mig_cap * 7));
-        HIPCHK(dalloc(&s->mig_rlo, (size_t)s->mig_cap * 7)); HIPCHK(dalloc(&s->mig_rhi, (size_t)s->mig_cap * 7));
-        HIPCHK(hipDeviceSynchronize());
-    }
-    s->np = (long)n;
-    s->p_off = 0;
-    if (n > 0) {
-        uint32_t* dids = (uint32_t*)s->order;  // staging: order[] is free between steps
-        HIPCHK(hipMemcpyAsync(s->stage_pos, pos, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
-        if (vel) HIPCHK(hipMemcpyAsync(s->stage_vel, vel, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
-        HIPCHK(hipMemcpyAsync(dids, ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
-        launch_unpack_ids(s->st, s->np, s->stage_pos, vel ? s->stage_vel : nullptr, dids, s->pa);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s->st));
-    }
-    s->sorted = s->have_p2g = s->have_flags = false;
-    s->sort_hint = false;
-    return FLUID_OK;
-}
-
-int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, uint32_t* ids)
-{
-    if (!s) return -1;
-    if (!pos || !vel || !ids) return s->np;
-    if (s->np == 0) return 0;
-    if (hipSetDevice(s->prm.device) != hipSuccess) return -1;
-    uint32_t* dids = (uint32_t*)s->order;
-    launch_pack_ids(s->st, s->np, s->pa, s->p_off, s->stage_pos, s->stage_vel, dids);
-    if (hipMemcpyAsync(pos, s->stage_pos, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
-    if (hipMemcpyAsync(vel, s->stage_vel, 3 * s->np * sizeof(double), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
-    if (hipMemcpyAsync(ids, dids, s->np * sizeof(uint32_t), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
-    if (hipStreamSynchronize(s->st) != hipSuccess) return -1;
-    return s->np;
-}
-
-int fluid_partition_by_count(int32_t n, int64_t np, const double* pos, int32_t size, int32_t* bounds)
-{
-    if (n < 8 || size < 1 || !bounds || (np > 0 && !pos)) return fail(FLUID_ERR_ARG, "bad argument");
-    if (size > n) return fail(FLUID_ERR_ARG, "more ranks than x planes");
-    const int lo = -(n / 2);
-    std::vector<int64_t> hist(n, 0);
-    for (int64_t i = 0; i < np; ++i) {
-        long bx = std::lround(pos[3 * i]) - lo;  // C round(): half away from zero, like the base cell (fluid.cc:267)
-        if (bx < 0) bx = 0;
-        if (bx > n - 1) bx = n - 1;
-        hist[bx]++;
-    }
-    bounds[0] = 0;
-    int64_t acc = 0;
-    int x = 0;
-    for (int r = 1; r < size; ++r) {
-        const int64_t target = np * r / size;
-        while (x < n && acc + hist[x] <= target) acc += hist[x++];
-        int b = x;
-        if (b <= bounds[r - 1]) b = bounds[r - 1] + 1;          // at least one plane per rank
-        if (b > n - (size - r)) b = n - (size - r);             // leave planes for the ranks above
-        while (x < b) acc += hist[x++];
-        bounds[r] = b;
-    }
-    bounds[size] = n;
     return FLUID_OK;
 }
 

@@ -1,0 +1,1077 @@
+// Multi-GPU step: 3-D block decomposition, one process (or host thread) per GPU (include/fluid_hip.h).
+//
+// The reference is single-process (fluid.cc has no communication of any kind): everything here is new design.
+//   particles   a block owns the particles whose base cell lies in it; per step they migrate to the <= 26 adjacent
+//               blocks, and the ones touching an interior face are copied to the blocks behind it as ghosts, so that
+//               every block forms the complete P2G sums of ITS cells in the one-GPU summation order (cell lists
+//               ranked by global id);
+//   fields      (decomposed solve) window arrays = block + 4 halo cells; halo exchanges of flags (4 wide), velocity,
+//               pressure and the FLIP delta (1 wide) — one grouped exchange with all neighbours each;
+//   numbering   the reference's x-major unknown numbering from all-reduced row-segment counts;
+//   solve       PCG on the owned unknowns with a GLOBALLY COUPLED V-cycle: the levels below `split` (1 or 2) live on
+//               the block + halo (the residual / coarse correction halos are exchanged, the kernels recompute inside
+//               the halo what the one-GPU cycle computes there), the levels from `split` on are gathered by one
+//               all-reduce and run redundantly on every rank.  Per cell the arithmetic is the one-GPU cycle's on the
+//               same hierarchy, so the iteration count does not depend on the number of blocks.
+//   replicated  (small boxes) full-size arrays, P2G result all-reduced, pressure block solved identically on every rank.
+#include "sim.h"
+#include "dist_kernels.h"
+
+using namespace fl;
+#define fail fluid_fail
+
+#define COMMCHK(expr)                                                                              \
+    do {                                                                                           \
+        if ((expr) != 0) return fail(FLUID_ERR_HIP, std::string("comm callback failed: ") + #expr); \
+    } while (0)
+
+namespace {
+
+constexpr int HALO_W = 4;   // window halo = halo of every locally held multigrid level (cells of that level)
+
+struct IBox {   // half-open box in some global cell index space
+    int lo[3], hi[3];
+};
+inline bool ib_empty(const IBox& b) { return b.hi[0] <= b.lo[0] || b.hi[1] <= b.lo[1] || b.hi[2] <= b.lo[2]; }
+inline IBox ib_isect(const IBox& a, const IBox& b)
+{
+    IBox r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = std::max(a.lo[k], b.lo[k]); r.hi[k] = std::min(a.hi[k], b.hi[k]); }
+    if (ib_empty(r)) for (int k = 0; k < 3; ++k) { r.lo[k] = a.lo[k]; r.hi[k] = a.lo[k]; }
+    return r;
+}
+inline IBox ib_grow(const IBox& a, int w)
+{
+    IBox r = a;
+    if (ib_empty(a)) return r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] -= w; r.hi[k] += w; }
+    return r;
+}
+inline long ib_cells(const IBox& b) { return ib_empty(b) ? 0 : (long)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); }
+// inclusive Box of b in the coordinates of an array whose cell 0 is global cell org
+inline Box to_box(const IBox& b, const int org[3])
+{
+    if (ib_empty(b)) return Box{0, 0, 0, -1, -1, -1};
+    return Box{b.lo[0] - org[0], b.lo[1] - org[1], b.lo[2] - org[2], b.hi[0] - 1 - org[0], b.hi[1] - 1 - org[1], b.hi[2] - 1 - org[2]};
+}
+
+struct HaloPlan {
+    int n = 0;
+    int peer[HALO_MAX_BOX];
+    HaloArgs snd{}, rcv{};
+    size_t scount[HALO_MAX_BOX], rcount[HALO_MAX_BOX];
+    size_t stotal = 0, rtotal = 0;
+};
+
+struct DLevel {   // a multigrid level held on block + halo
+    IBox dom{};   // cells of the level this rank holds (level-global indices); empty if the block misses the active box
+    IBox own{};
+    MLevel m{};
+    HaloPlan plan;
+    uint8_t *typ = nullptr, *cnt = nullptr;
+    char *u = nullptr, *v = nullptr, *f = nullptr, *r = nullptr;
+};
+
+}  // namespace
+
+struct DistState {
+    fluid_comm_t comm{};
+    int dims[3] = {1, 1, 1}, bc[3] = {0, 0, 0};
+    std::vector<int> cuts[3];
+    OwnBox ob{};
+    int nbr[27];
+    bool repl = false;
+    // halo staging
+    char *hs = nullptr, *hr = nullptr;
+    size_t hs_cap = 0, hr_cap = 0;
+    // particle routing
+    double *mig_s = nullptr, *mig_r = nullptr;
+    long mig_cap = 0;
+    int *d_cnt = nullptr, *h_cnt = nullptr;   // [0..27) send counts / cursors, [32..59) receive counts, [64..] misc
+    // replicated mode
+    double* repl_buf = nullptr;
+    size_t repl_cap = 0;
+    // numbering
+    int *rows = nullptr, *row_starts = nullptr;
+    size_t rows_cap = 0;
+    Box idx_box{0, 0, 0, -1, -1, -1};   // window cells whose indices may differ from -1
+    // this step's boxes, global cell indices
+    IBox Pg{}, Rg{}, Sg{};
+    Box Rr{0, 0, 0, -1, -1, -1}, Sr{0, 0, 0, -1, -1, -1};   // owned parts, window coordinates
+    // plans
+    HaloPlan plan_flags, plan_f1;
+    // solver
+    int split = 1, split_force = 0;
+    IBox dom0{};                      // global level-0 multigrid domain [A, B)
+    DLevel lv[2];
+    uint8_t* cnt_pcg = nullptr;
+    double *gstage[2] = {nullptr, nullptr}, *gpq = nullptr;
+    long n_routed = 0;                // particles sent away so far (statistics)
+};
+
+namespace {
+
+// ---- geometry --------------------------------------------------------------------------------------------------
+inline int rank_of(const DistState* d, int bx, int by, int bz) { return (bx * d->dims[1] + by) * d->dims[2] + bz; }
+IBox block_of(const DistState* d, int rank)
+{
+    const int bz = rank % d->dims[2], by = (rank / d->dims[2]) % d->dims[1], bx = rank / (d->dims[1] * d->dims[2]);
+    const int b[3] = {bx, by, bz};
+    IBox r;
+    for (int a = 0; a < 3; ++a) { r.lo[a] = d->cuts[a][b[a]]; r.hi[a] = d->cuts[a][b[a] + 1]; }
+    return r;
+}
+// block of `rank` in the cell indices of multigrid level l (interior cuts are multiples of 4; the last cut is the grid's end)
+IBox block_level(const DistState* d, int rank, int l, int N)
+{
+    IBox r = block_of(d, rank);
+    for (int a = 0; a < 3; ++a) {
+        r.lo[a] >>= l;
+        r.hi[a] = r.hi[a] == N ? ((N - 1) >> l) + 1 : r.hi[a] >> l;
+    }
+    return r;
+}
+
+// Plan of one halo exchange: rank r owns own(r) (some global index space); my array holds own(me) grown by w; layout:
+// array cell (i, j, k) = global cell org + (i, j, k), at element base + i*sx + j*sy + k.  I receive grow(own(me), w) ∩ own(nb)
+// from each adjacent block nb and send grow(own(nb), w) ∩ own(me) — the two sides compute the same boxes.
+template <typename OwnFn>
+void make_plan(const DistState* d, HaloPlan& p, OwnFn own, int w, const int org[3], long base, long sx, long sy)
+{
+    p.n = 0;
+    p.stotal = p.rtotal = 0;
+    p.snd.base = p.rcv.base = base;
+    p.snd.sx = p.rcv.sx = sx;
+    p.snd.sy = p.rcv.sy = sy;
+    const IBox mine = own(d->comm.rank);
+    for (int dd = 0; dd < 27; ++dd) {
+        if (dd == 13 || d->nbr[dd] < 0) continue;
+        const int nb = d->nbr[dd];
+        const IBox theirs = own(nb);
+        const IBox rb = ib_isect(ib_grow(mine, w), theirs), sb = ib_isect(ib_grow(theirs, w), mine);
+        const long rc = ib_cells(rb), sc = ib_cells(sb);
+        if (!rc && !sc) continue;
+        const int k = p.n++;
+        p.peer[k] = nb;
+        for (int a = 0; a < 3; ++a) {
+            p.snd.lo[k][a] = sb.lo[a] - org[a]; p.snd.n[k][a] = sc ? sb.hi[a] - sb.lo[a] : 0;
+            p.rcv.lo[k][a] = rb.lo[a] - org[a]; p.rcv.n[k][a] = rc ? rb.hi[a] - rb.lo[a] : 0;
+        }
+        p.snd.off[k] = (long)p.stotal; p.rcv.off[k] = (long)p.rtotal;
+        p.scount[k] = (size_t)sc; p.rcount[k] = (size_t)rc;
+        p.stotal += (size_t)sc; p.rtotal += (size_t)rc;
+    }
+    p.snd.nbox = p.rcv.nbox = p.n;
+}
+
+int ensure_stage(fluid_sim* s, size_t sbytes, size_t rbytes)
+{
+    DistState* d = s->ds;
+    if (sbytes > d->hs_cap) {
+        if (d->hs) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->hs); d->hs = nullptr; }
+        d->hs_cap = sbytes + sbytes / 2 + 4096;
+        HIPCHK(hipMalloc((void**)&d->hs, d->hs_cap));
+    }
+    if (rbytes > d->hr_cap) {
+        if (d->hr) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->hr); d->hr = nullptr; }
+        d->hr_cap = rbytes + rbytes / 2 + 4096;
+        HIPCHK(hipMalloc((void**)&d->hr, d->hr_cap));
+    }
+    return FLUID_OK;
+}
+
+// exchange the halos of `narr` arrays of element size `elem` that share the plan's layout
+int halo_exchange(fluid_sim* s, HaloPlan& p, int elem, int narr, void* const* arrays)
+{
+    DistState* d = s->ds;
+    if (p.n == 0) return FLUID_OK;
+    int rc = ensure_stage(s, p.stotal * narr * elem, p.rtotal * narr * elem);
+    if (rc) return rc;
+    p.snd.narr = p.rcv.narr = narr;
+    for (int a = 0; a < HALO_MAX_ARR; ++a) p.snd.arr[a] = p.rcv.arr[a] = a < narr ? arrays[a] : arrays[0];
+    launch_halo_copy(s->st, p.snd, elem, d->hs, true);
+    HIPCHK(hipGetLastError());
+    const void* sb[HALO_MAX_BOX];
+    void* rb[HALO_MAX_BOX];
+    size_t sn[HALO_MAX_BOX], rn[HALO_MAX_BOX];
+    for (int k = 0; k < p.n; ++k) {
+        sb[k] = d->hs + (size_t)p.snd.off[k] * narr * elem;
+        rb[k] = d->hr + (size_t)p.rcv.off[k] * narr * elem;
+        sn[k] = p.scount[k] * narr * elem;
+        rn[k] = p.rcount[k] * narr * elem;
+    }
+    COMMCHK(d->comm.exchange(d->comm.ctx, p.n, p.peer, sb, sn, rb, rn, (void*)s->st));
+    launch_halo_copy(s->st, p.rcv, elem, d->hr, false);
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+int halo_exchange1(fluid_sim* s, HaloPlan& p, int elem, void* a)
+{
+    void* arr[1] = {a};
+    return halo_exchange(s, p, elem, 1, arr);
+}
+
+int comm_allreduce(fluid_sim* s, void* buf, long count, int dtype, int op)
+{
+    COMMCHK(s->ds->comm.allreduce(s->ds->comm.ctx, buf, (int64_t)count, dtype, op, (void*)s->st));
+    return FLUID_OK;
+}
+
+// ---- particles: migration + ghosts + sort ----------------------------------------------------------------------------------
+// One routing round (migrants or ghosts): count per direction, exchange the counts, write and exchange the records,
+// append what arrived behind the live particles.
+int route_round(fluid_sim* s, bool ghost)
+{
+    DistState* d = s->ds;
+    const Grid g = s->g;
+    int rc;
+    HIPCHK(hipMemsetAsync(d->d_cnt, 0, 64 * sizeof(int), s->st));
+    launch_route(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off), d->d_cnt, nullptr, 0, ghost);
+    HIPCHK(hipGetLastError());
+    // counts to / from the neighbours
+    int np = 0, peer[26], dir[26];
+    const void* sb[26];
+    void* rb[26];
+    size_t sn[26], rn[26];
+    for (int dd = 0; dd < 27; ++dd) {
+        if (dd == 13 || d->nbr[dd] < 0) continue;
+        peer[np] = d->nbr[dd];
+        dir[np] = dd;
+        sb[np] = d->d_cnt + dd;            // what I send towards dd ...
+        rb[np] = d->d_cnt + 32 + dd;       // ... and what the block in direction dd sends to me
+        sn[np] = rn[np] = sizeof(int);
+        ++np;
+    }
+    if (np) COMMCHK(d->comm.exchange(d->comm.ctx, np, peer, sb, sn, rb, rn, (void*)s->st));
+    HIPCHK(hipMemcpyAsync(d->h_cnt, d->d_cnt, 64 * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    long soff[27], roff[27], stot = 0, rtot = 0;
+    for (int dd = 0; dd < 27; ++dd) {
+        soff[dd] = stot; roff[dd] = rtot;
+        if (dd == 13 || d->nbr[dd] < 0) continue;
+        stot += d->h_cnt[dd];
+        rtot += d->h_cnt[32 + dd];
+    }
+    // room for what arrives (a block's share grows as the fluid spreads into it): grown on demand, never a per-rank failure
+    // that would leave the peers waiting in the next exchange
+    if (stot > d->mig_cap || rtot > d->mig_cap) {
+        HIPCHK(hipStreamSynchronize(s->st));
+        hipFree(d->mig_s); hipFree(d->mig_r);
+        d->mig_s = d->mig_r = nullptr;
+        d->mig_cap = std::max(stot, rtot) * 3 / 2 + 4096;
+        HIPCHK(hipMalloc((void**)&d->mig_s, (size_t)d->mig_cap * 56));
+        HIPCHK(hipMalloc((void**)&d->mig_r, (size_t)d->mig_cap * 56));
+    }
+    if ((rc = grow_particles(s, s->p_off + s->np + rtot))) return rc;
+    int cur[27];
+    for (int dd = 0; dd < 27; ++dd) cur[dd] = (int)soff[dd];
+    memcpy(d->h_cnt + 64, cur, sizeof(cur));
+    HIPCHK(hipMemcpyAsync(d->d_cnt, d->h_cnt + 64, 27 * sizeof(int), hipMemcpyHostToDevice, s->st));
+    if (stot) launch_route(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off), d->d_cnt, d->mig_s, 1, ghost);
+    HIPCHK(hipGetLastError());
+    for (int k = 0; k < np; ++k) {
+        const int dd = dir[k];
+        sb[k] = d->mig_s + (size_t)soff[dd] * 7;
+        rb[k] = d->mig_r + (size_t)roff[dd] * 7;
+        sn[k] = (size_t)d->h_cnt[dd] * 56;
+        rn[k] = (size_t)d->h_cnt[32 + dd] * 56;
+    }
+    if (np) COMMCHK(d->comm.exchange(d->comm.ctx, np, peer, sb, sn, rb, rn, (void*)s->st));
+    launch_unpack_records(s->st, rtot, d->mig_r, s->pa, s->p_off + s->np);
+    HIPCHK(hipGetLastError());
+    s->np += rtot;
+    if (!ghost) d->n_routed += stot;
+    return FLUID_OK;
+}
+
+// migration, ghosts, counting sort of everything by window cell, global particle bounding box
+int dist_particles(fluid_sim* s)
+{
+    DistState* d = s->ds;
+    const Grid g = s->g;
+    const long ncell = (long)s->ncell;
+    int rc;
+    int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
+    if ((rc = route_round(s, false))) return rc;
+    if ((rc = route_round(s, true))) return rc;
+    // sort: cells of the window, then "off the window" (= off the grid: only an edge block can hold such a particle), then dead
+    launch_zero_step_state(s->st, s->ss, std::max(g.nx, std::max(g.ny, g.nz)));
+    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 4) * sizeof(int), s->st));
+    launch_bin_count(s->st, g, s->np, s->pa.shifted(s->p_off), s->key, s->slot, s->cell_count, s->ipart, s->ss);
+    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
+    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->pa.shifted(s->p_off).pid, s->order, s->spid);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d->h_cnt, s->cell_start + ncell, 3 * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    if ((rc = read_ss(s))) return rc;
+    const long live = d->h_cnt[1];   // cells + off-grid bucket; the dead (last step's ghosts, this step's migrants) are dropped
+    s->n_out = d->h_cnt[1] - d->h_cnt[0];
+    launch_bin_rank(s->st, live, 0, s->key, s->cell_start, s->order, s->spid, s->order2);
+    launch_reorder(s->st, live, s->order2, s->pa.shifted(s->p_off), s->pb, s->pw, s->cap);   // + the P2G axis weights
+    HIPCHK(hipGetLastError());
+    std::swap(s->pa, s->pb);
+    s->p_off = 0;
+    s->np = live;
+    // global bounding box of the base cells (+ the fullest cell of any rank: it picks the P2G form, which every rank
+    // must take alike): MIN over [min3, -max3, -max_cell]
+    {
+        const StepState& h = *s->h_ss;
+        int* v = d->h_cnt + 64;
+        const int o[3] = {g.ox, g.oy, g.oz};
+        for (int a = 0; a < 3; ++a) {
+            v[a] = h.bbox_max[a] < 0 ? 0x7fffffff : h.bbox_min[a] + o[a];
+            v[3 + a] = h.bbox_max[a] < 0 ? 0x7fffffff : -(h.bbox_max[a] + o[a]);
+        }
+        v[6] = -h.max_cell;
+        HIPCHK(hipMemcpyAsync(d->d_cnt + 64, v, 7 * sizeof(int), hipMemcpyHostToDevice, s->st));
+        if ((rc = comm_allreduce(s, d->d_cnt + 64, 7, FLUID_DT_I32, FLUID_OP_MIN))) return rc;
+        HIPCHK(hipMemcpyAsync(v, d->d_cnt + 64, 7 * sizeof(int), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        s->max_cell = -v[6];
+        const int N = g.N;
+        if (v[0] == 0x7fffffff) {
+            d->Pg = IBox{{0, 0, 0}, {0, 0, 0}};
+        } else {
+            for (int a = 0; a < 3; ++a) { d->Pg.lo[a] = v[a]; d->Pg.hi[a] = -v[3 + a] + 1; }
+        }
+        const IBox grid{{0, 0, 0}, {N, N, N}};
+        d->Rg = ib_isect(ib_grow(d->Pg, 1), grid);
+        d->Sg = ib_isect(ib_grow(d->Pg, 2), grid);
+    }
+    const int org[3] = {g.ox, g.oy, g.oz};
+    const IBox own{{d->ob.lo[0], d->ob.lo[1], d->ob.lo[2]}, {d->ob.hi[0], d->ob.hi[1], d->ob.hi[2]}};
+    const IBox win{{g.ox, g.oy, g.oz}, {g.ox + g.nx, g.oy + g.ny, g.oz + g.nz}};
+    d->Rr = to_box(ib_isect(d->Rg, own), org);
+    d->Sr = to_box(ib_isect(d->Sg, own), org);
+    s->Rb = to_box(ib_isect(d->Rg, win), org);   // what this rank's arrays hold of the global boxes
+    s->Sb = to_box(ib_isect(d->Sg, win), org);
+    s->Pb = to_box(ib_isect(d->Pg, win), org);
+    s->p2g_ref_cells = ib_cells(d->Rg);
+    prof_end(s, FLUID_PROF_SORT, tok);
+    s->sorted = false;   // (the single-GPU gather through LDS tiles is not used here)
+    return FLUID_OK;
+}
+
+void stats_begin(fluid_sim* s)
+{
+    DistState* d = s->ds;
+    memset(&s->stats, 0, sizeof(s->stats));
+    s->stats.dt_in = s->dt;
+    s->stats.dt_out = s->dt;
+    for (int a = 0; a < 3; ++a) {
+        s->stats.box_lo[a] = d->Rg.lo[a];
+        s->stats.box_hi[a] = d->Rg.hi[a] - 1;
+    }
+}
+
+// FLIP gather + advect of the owned particles (fluid.cc:1490); the ghosts have served and are marked dead first
+int dist_g2p_advect(fluid_sim* s, fluid_step_stats_t* stats)
+{
+    DistState* d = s->ds;
+    const Grid g = s->g;
+    int rc;
+    launch_kill_ghosts(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off));
+    int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
+    launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    prof_end(s, FLUID_PROF_G2P, tok);
+    HIPCHK(hipGetLastError());
+    // non-negative doubles order like their bit patterns: MAX over int64
+    if ((rc = comm_allreduce(s, &s->ss->max_speed_bits, 1, FLUID_DT_I64, FLUID_OP_MAX))) return rc;
+    launch_advect(s->st, g, s->np, s->pa.shifted(s->p_off), s->flags, s->prm.max_dt, s->prm.dx, s->ss);
+    HIPCHK(hipGetLastError());
+    if ((rc = read_ss(s))) return rc;
+    s->dt = s->h_ss->dt;
+    double ms;
+    memcpy(&ms, &s->h_ss->max_speed_bits, sizeof(double));
+    s->stats.max_speed = ms;
+    s->stats.dt_out = s->dt;
+    s->sorted = false;
+    s->have_p2g = false;
+    if (stats) *stats = s->stats;
+    return FLUID_OK;
+}
+
+// ---- replicated pressure block ------------------------------------------------------------------------------------
+// Particles sharded by block; the P2G result of the whole active box is assembled on every rank by one SUM all-reduce of
+// [container | u | v | w] (every cell has exactly one owner, the others add exact zeros: bit-identical to a one-GPU
+// P2G), and flags, numbering, the pressure do..while with the single-GPU multigrid PCG and the FLIP delta field run
+// identically on every rank with no communication.
+int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
+{
+    DistState* d = s->ds;
+    const Grid g = s->g;
+    int rc;
+    if ((rc = dist_particles(s))) return rc;
+    if ((rc = clear_dirty(s))) return rc;
+    stats_begin(s);
+    if (!box_empty(s->Rb)) {
+        s->dirty = s->Sb;
+        if (!box_empty(d->Rr)) {
+            int tok = prof_begin(s, FLUID_PROF_P2G, (double)d->Rr.cells());
+            rc = run_p2g(s, d->Rr);
+            prof_end(s, FLUID_PROF_P2G, tok);
+            if (rc) return rc;
+        }
+        const size_t need = 4 * (size_t)s->Rb.cells();
+        if (need > d->repl_cap) {
+            if (d->repl_buf) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->repl_buf); d->repl_buf = nullptr; }
+            HIPCHK(hipMalloc((void**)&d->repl_buf, (need + need / 4) * sizeof(double)));
+            d->repl_cap = need + need / 4;
+        }
+        launch_pack_box_own(s->st, g, s->Rb, d->Rr, s->container, s->u, s->v, s->w, d->repl_buf);
+        HIPCHK(hipGetLastError());
+        if ((rc = comm_allreduce(s, d->repl_buf, (long)need, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+        launch_unpack_box(s->st, g, s->Rb, d->repl_buf, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+        HIPCHK(hipGetLastError());
+    }
+    s->have_p2g = true;
+    s->have_flags = false;
+    if ((rc = phase_flags(s))) return rc;           // whole grid on every rank: global numbering
+    double error = NAN;
+    do {
+        if ((rc = phase_pressure_pass(s, &error))) return rc;
+        if (s->prm.max_outer_passes > 0 && s->stats.outer_passes >= s->prm.max_outer_passes) break;
+    } while (error > s->prm.outer_tol);
+    if ((rc = pic_fields(s))) return rc;
+    if (!box_empty(s->Rb)) launch_flip_delta(s->st, g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
+    return dist_g2p_advect(s, stats);
+}
+
+// ---- decomposed solve: multigrid hierarchy of the step -----------------------------------------------------------------
+MLevel level_layout(int dx, int dy, int dz)   // the layout mg_coarser gives a level of these dims
+{
+    MLevel m;
+    m.dx = dx; m.dy = dy; m.dz = dz;
+    const int Lz = (16 + std::max(dz, 0) + 1 + 15) / 16 * 16;
+    m.sy = Lz; m.sx = (long)(std::max(dy, 0) + 2) * Lz;
+    m.ox = 1; m.oy = 1; m.oz = 16;
+    m.cells = (size_t)(std::max(dx, 0) + 2) * m.sx + Lz;
+    return m;
+}
+// the coarse level as the kernels of the finer level must see it: coarse cell 0 under fine cell 0
+MLevel coarse_view(const MLevel& mc, const int off[3])
+{
+    MLevel v = mc;
+    v.ox += off[0]; v.oy += off[1]; v.oz += off[2];
+    v.dx = std::max(mc.dx - off[0], 0); v.dy = std::max(mc.dy - off[1], 0); v.dz = std::max(mc.dz - off[2], 0);
+    return v;
+}
+
+// domain of global level l: cells [lo, lo + dim) of that level's index space
+struct GDom {
+    int lo[3], dim[3];
+};
+
+int dist_mg_setup(fluid_sim* s)
+{
+    DistState* d = s->ds;
+    const Grid g = s->g;
+    const int N = g.N, me = d->comm.rank;
+    int rc;
+    // level-0 domain [A, B): the active box + 1 ring, its low corner aligned down to a multiple of 4 so that the block
+    // cuts (multiples of 4) are cell boundaries of the two coarser levels
+    GDom gd[fluid_sim::MG_MAXL];
+    for (int a = 0; a < 3; ++a) {
+        const int A = std::max(0, (d->Rg.lo[a] - 1) & ~3), B = std::min(N, d->Rg.hi[a] + 1);
+        gd[0].lo[a] = A; gd[0].dim[a] = B - A;
+        d->dom0.lo[a] = A; d->dom0.hi[a] = B;
+    }
+    int nl = 1;
+    while (nl < fluid_sim::MG_MAXL && (nl < 2 || gd[nl - 1].dim[0] > 8 || gd[nl - 1].dim[1] > 8 || gd[nl - 1].dim[2] > 8)) {
+        for (int a = 0; a < 3; ++a) { gd[nl].lo[a] = gd[nl - 1].lo[a] >> 1; gd[nl].dim[a] = (gd[nl - 1].dim[a] + 1) / 2; }
+        ++nl;
+    }
+    if (gd[nl - 1].dim[0] > 8 || gd[nl - 1].dim[1] > 8 || gd[nl - 1].dim[2] > 8) return fail(FLUID_ERR_STATE, "multigrid: too many levels");
+    // levels held on block + halo: 0 .. split-1.  Level 1 is gathered (split = 1) while it is small: one all-reduce of
+    // the level instead of two halo exchanges per iteration, at the price of every rank sweeping all of it.
+    const long l1 = (long)gd[1].dim[0] * gd[1].dim[1] * gd[1].dim[2];
+    int split = d->split_force ? d->split_force : (l1 <= 300000 ? 1 : 2);
+    if (split > nl - 1) split = nl - 1;
+    if (split < 1) split = 1;
+    d->split = split;
+    s->mg_nl = nl;
+    auto gdom_box = [&](int l) { IBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = gd[l].lo[a]; b.hi[a] = gd[l].lo[a] + gd[l].dim[a]; } return b; };
+    auto own_l = [&](int l, int rank) { return ib_isect(block_level(d, rank, l, N), gdom_box(l)); };
+    // global (replicated) levels split .. nl-1 use the handle's level arrays; the tail kernel takes what fits its LDS
+    for (int l = split; l < nl; ++l) s->mgl[l] = level_layout(gd[l].dim[0], gd[l].dim[1], gd[l].dim[2]);
+    const size_t es = s->mg_fp32 ? sizeof(float) : sizeof(double);
+    int tail = nl - 1;
+    auto fits = [&](int t) {
+        const size_t b = nl - t <= MG_TAIL_MAX ? mg_tail_lds_bytes(nl - t, s->mgl + t, es) : 0;
+        return b > 0 && b <= MG_TAIL_LDS;
+    };
+    while (tail > split && fits(tail - 1)) --tail;
+    if (!fits(tail)) return fail(FLUID_ERR_STATE, "multigrid: coarsest level does not fit the tail kernel");
+    s->mg_tail = tail;
+    // local levels
+    for (int l = 0; l < split; ++l) {
+        DLevel& L = d->lv[l];
+        L.own = own_l(l, me);
+        L.dom = ib_isect(ib_grow(L.own, HALO_W), gdom_box(l));
+        if (l == 0) {
+            const int org[3] = {g.ox, g.oy, g.oz};
+            s->L = make_lbox(to_box(L.dom, org));
+            // level-0 arrays share the PCG's box-local layout; domain cell 0 = first interior cell of the LBox
+            L.m.dx = s->L.nx; L.m.dy = s->L.ny; L.m.dz = s->L.nz;
+            L.m.sx = (long)s->L.Ly * s->L.Lz; L.m.sy = s->L.Lz;
+            L.m.ox = 1; L.m.oy = 1; L.m.oz = LBOX_K0;
+            L.m.cells = s->L.cells() + 2 * (size_t)s->L.Lz;
+        } else {
+            L.m = level_layout(std::max(L.dom.hi[0] - L.dom.lo[0], 0), std::max(L.dom.hi[1] - L.dom.lo[1], 0), std::max(L.dom.hi[2] - L.dom.lo[2], 0));
+        }
+        make_plan(d, L.plan, [&](int r) { return own_l(l, r); }, HALO_W, L.dom.lo, (long)L.m.at(0, 0, 0), L.m.sx, L.m.sy);
+    }
+    s->mgl[0] = d->lv[0].m;
+    // one slab, zeroed by one fill (mg_setup of the single-GPU path does the same)
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t o = total; total += (bytes + 255) / 256 * 256; return o; };
+    size_t o_typ[fluid_sim::MG_MAXL], o_cnt[fluid_sim::MG_MAXL], o_u[fluid_sim::MG_MAXL], o_v[fluid_sim::MG_MAXL], o_f[fluid_sim::MG_MAXL], o_r[fluid_sim::MG_MAXL];
+    for (int l = 0; l < nl; ++l) {
+        const size_t c = (l < split ? d->lv[l].m.cells : s->mgl[l].cells) + 64;
+        o_typ[l] = take(c); o_cnt[l] = take(c);
+        o_u[l] = take(c * es); o_v[l] = take(c * es); o_f[l] = take(c * es); o_r[l] = take(c * es);
+    }
+    const size_t o_z = take((d->lv[0].m.cells + 64) * 8);
+    if (total > s->mg_slab_cap) {
+        if (s->mg_slab) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->mg_slab); s->mg_slab = nullptr; }
+        const size_t cap = total + total / 4;
+        HIPCHK(hipMalloc((void**)&s->mg_slab, cap));
+        s->mg_slab_cap = cap;
+    }
+    for (int l = 0; l < nl; ++l) {
+        s->mg_typ[l] = (uint8_t*)(s->mg_slab + o_typ[l]);
+        s->mg_cnt[l] = l ? (uint8_t*)(s->mg_slab + o_cnt[l]) : nullptr;
+        s->mg_u[l] = s->mg_slab + o_u[l]; s->mg_v[l] = s->mg_slab + o_v[l];
+        s->mg_f[l] = l ? s->mg_slab + o_f[l] : nullptr;
+        s->mg_r[l] = s->mg_slab + o_r[l];
+        if (l < split) {
+            DLevel& L = d->lv[l];
+            L.typ = s->mg_typ[l]; L.cnt = l ? s->mg_cnt[l] : s->cntL;
+            L.u = s->mg_u[l]; L.v = s->mg_v[l]; L.f = s->mg_f[l]; L.r = s->mg_r[l];
+        }
+    }
+    s->Zmg = s->mg_slab + o_z;
+    HIPCHK(hipMemsetAsync(s->mg_slab, 0, total, s->st));
+    // ---- count bytes and cell types -----------------------------------------------------------------------------
+    // level 0: from the flags (valid on the whole window: their halo is HALO_W wide)
+    launch_cnt_local(s->st, g, s->L, s->flags, s->cntL);
+    {
+        const int org0[3] = {d->lv[0].dom.lo[0] - 1, d->lv[0].dom.lo[1] - 1, d->lv[0].dom.lo[2] - LBOX_K0};   // global cell of LBox index 0
+        const IBox o = d->lv[0].own;
+        Box ownL = ib_empty(o) ? Box{0, 0, 0, -1, -1, -1}
+                               : Box{o.lo[0] - org0[0], o.lo[1] - org0[1], o.lo[2] - org0[2], o.hi[0] - 1 - org0[0], o.hi[1] - 1 - org0[1], o.hi[2] - 1 - org0[2]};
+        launch_cnt_pcg(s->st, s->L, ownL, s->cntL, d->cnt_pcg);
+    }
+    if (!ib_empty(d->lv[0].dom))
+        launch_mg_type_local(s->st, g, d->lv[0].m, d->lv[0].dom.lo[0] - g.ox, d->lv[0].dom.lo[1] - g.oy, d->lv[0].dom.lo[2] - g.oz, s->flags, s->cntL,
+                             d->lv[0].typ);
+    HIPCHK(hipGetLastError());
+    for (int l = 1; l < nl; ++l) {
+        if (l < split) {
+            // held on block + halo: types of the children's cells, halos from the neighbours, then the counts
+            DLevel &F = d->lv[l - 1], &C = d->lv[l];
+            if (!ib_empty(F.dom)) {
+                const int off[3] = {(F.dom.lo[0] >> 1) - C.dom.lo[0], (F.dom.lo[1] >> 1) - C.dom.lo[1], (F.dom.lo[2] >> 1) - C.dom.lo[2]};
+                launch_mg_coarsen_types(s->st, F.m, F.typ, coarse_view(C.m, off), C.typ);
+            }
+            if ((rc = halo_exchange1(s, C.plan, 1, C.typ))) return rc;
+            launch_mg_counts(s->st, C.m, C.typ, C.cnt);
+            if ((rc = halo_exchange1(s, C.plan, 1, C.cnt))) return rc;
+        } else if (l == split) {
+            // gathered: every rank types the coarse cells under its own fine cells, one all-reduce assembles the level
+            DLevel& F = d->lv[l - 1];
+            const GDom& G = gd[l];
+            if (!ib_empty(F.dom)) {
+                const int off[3] = {(F.dom.lo[0] >> 1) - G.lo[0], (F.dom.lo[1] >> 1) - G.lo[1], (F.dom.lo[2] >> 1) - G.lo[2]};
+                launch_mg_coarsen_types(s->st, F.m, F.typ, coarse_view(s->mgl[l], off), s->mg_typ[l]);
+            }
+            launch_mask_outside<uint8_t>(s->st, s->mgl[l], to_box(own_l(l, me), G.lo), s->mg_typ[l]);
+            HIPCHK(hipGetLastError());
+            if ((rc = comm_allreduce(s, s->mg_typ[l], (long)s->mgl[l].cells, FLUID_DT_U8, FLUID_OP_SUM))) return rc;
+            launch_mg_counts(s->st, s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
+        } else {
+            launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return FLUID_OK;
+}
+
+template <typename V>
+MgCoef<V> coef_as(const fluid_sim* s, int level)
+{
+    const MgCoef<double> c = mg_coef(s, level);
+    MgCoef<V> o;
+    for (int k = 0; k < 7; ++k) { o.diag[k] = (V)c.diag[k]; o.inv[k] = (V)c.inv[k]; }
+    o.off = (V)c.off;
+    return o;
+}
+
+// z0 = M^-1 rhs0: the V(2,2) cycle of kernels_mg.hip over the decomposed hierarchy.  rhs0 (the PCG residual) must be
+// valid on the whole local level-0 domain (its halo exchanged by the caller); z0 is valid on the owned cells + 1 ring.
+template <typename V>
+int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+{
+    DistState* d = s->ds;
+    const int nl = s->mg_nl, tail = s->mg_tail, split = d->split;
+    const PcgState* ps = s->ps;
+    auto U = [&](int l) { return (V*)s->mg_u[l]; };
+    auto W = [&](int l) { return (V*)s->mg_v[l]; };
+    auto F = [&](int l) { return (V*)s->mg_f[l]; };
+    auto R = [&](int l) { return (V*)s->mg_r[l]; };
+    int rc;
+    // the level under local level l as that level's kernels see it, and the global cell of its cell 0
+    auto under = [&](int l) {
+        const DLevel& Lf = d->lv[l];
+        int off[3];
+        if (l + 1 < split) for (int a = 0; a < 3; ++a) off[a] = (Lf.dom.lo[a] >> 1) - d->lv[l + 1].dom.lo[a];
+        else for (int a = 0; a < 3; ++a) off[a] = (Lf.dom.lo[a] >> 1) - (d->dom0.lo[a] >> (l + 1));
+        return coarse_view(l + 1 < split ? d->lv[l + 1].m : s->mgl[l + 1], off);
+    };
+    // ---- down: levels on block + halo ----
+    for (int l = 0; l < split; ++l) {
+        DLevel& L = d->lv[l];
+        const MLevel mc = ib_empty(L.dom) ? s->mgl[l + 1] : under(l);
+        const uint8_t* cc = l + 1 < split ? d->lv[l + 1].cnt : s->mg_cnt[l + 1];
+        if (!ib_empty(L.dom)) {
+            if (l == 0) {
+                launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps);
+                launch_mg_restrict<V>(s->st, L.m, (const V*)R(0), mc, cc, F(1), ps);
+            } else {
+                launch_mg_down<V, V>(s->st, L.m, L.cnt, (const V*)F(l), U(l), R(l), mc, cc, F(l + 1), coef_as<V>(s, l), ps);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        if (l + 1 < split) {
+            if ((rc = halo_exchange1(s, d->lv[l + 1].plan, sizeof(V), F(l + 1)))) return rc;
+        } else {
+            // gather of the first replicated level: my coarse cells, zeros elsewhere, one SUM all-reduce
+            int lo[3];
+            for (int a = 0; a < 3; ++a) lo[a] = d->dom0.lo[a] >> (l + 1);
+            IBox gb;
+            for (int a = 0; a < 3; ++a) { gb.lo[a] = lo[a]; gb.hi[a] = lo[a] + (a == 0 ? s->mgl[l + 1].dx : (a == 1 ? s->mgl[l + 1].dy : s->mgl[l + 1].dz)); }
+            const IBox o = ib_isect(block_level(d, d->comm.rank, l + 1, s->g.N), gb);
+            launch_mask_outside<V>(s->st, s->mgl[l + 1], to_box(o, lo), F(l + 1));
+            HIPCHK(hipGetLastError());
+            if ((rc = comm_allreduce(s, F(l + 1), (long)s->mgl[l + 1].cells, sizeof(V) == 4 ? FLUID_DT_F32 : FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+        }
+    }
+    // ---- replicated levels: down, tail, up (identical on every rank) ----
+    for (int l = split; l < tail; ++l)
+        launch_mg_down<V, V>(s->st, s->mgl[l], s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), coef_as<V>(s, l), ps);
+    {
+        V off[fluid_sim::MG_MAXL];
+        for (int l = tail; l < nl; ++l) off[l] = (V)mg_coef(s, l).off;
+        launch_mg_tail<V>(s->st, nl - tail, (const V*)F(tail), s->mgl + tail, s->mg_cnt + tail, U(tail), off + tail, s->mg_csweeps, ps, s->mg_wc[3]);
+    }
+    for (int l = tail - 1; l >= split; --l) {
+        const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);
+        launch_mg_up<V, V, V>(s->st, s->mgl[l], s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, coef_as<V>(s, l), nullptr, ps,
+                              s->mg_wc[l == 1 ? 1 : 2]);
+    }
+    HIPCHK(hipGetLastError());
+    // ---- up: levels on block + halo ----
+    for (int l = split - 1; l >= 0; --l) {
+        DLevel& L = d->lv[l];
+        const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);
+        if (!ib_empty(L.dom)) {
+            const MLevel mc = under(l);
+            if (l == 0) {
+                const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)ib_cells(L.dom));
+                launch_mg_up<V, double, double>(s->st, L.m, L.cnt, rhs0, (const V*)U(0), z0, mc, ec, coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0], nullptr, 0,
+                                                d->cnt_pcg);
+                prof_end(s, FLUID_PROF_MG_UP0, tok);
+            } else {
+                launch_mg_up<V, V, V>(s->st, L.m, L.cnt, (const V*)F(l), (const V*)U(l), W(l), mc, ec, coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        if (l > 0 && (rc = halo_exchange1(s, L.plan, sizeof(V), W(l)))) return rc;   // the correction the level above interpolates from
+    }
+    return FLUID_OK;
+}
+
+// PCG of ConjugateGradient.h:28-90 on the owned unknowns; z = the decomposed V-cycle (or Eigen's diagonal preconditioner).
+// Per iteration: one halo exchange of r, the V-cycle's exchanges / gather, and two small all-reduces ({|r|^2, r.z}, s.q).
+int dist_solve(fluid_sim* s)
+{
+    typedef double T;
+    DistState* d = s->ds;
+    const Grid g = s->g;
+    const LBox L = s->L;
+    T *X = (T*)s->X, *R = (T*)s->R, *Q = (T*)s->Q, *Z = (T*)s->Zmg;
+    T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
+    const uint8_t* cnt = d->cnt_pcg;
+    const Coef<T> cf = make_coef<T>(s);
+    const double tol = s->prm.cg_tol;
+    const bool mg = use_mg(s);
+    long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
+    if (max_it < 1) max_it = 1;
+    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L);
+    const int n_rz = ib_empty(d->lv[0].dom) ? 0 : mg_up_blocks(d->lv[0].m);
+    const double cells = (double)ib_cells(d->lv[0].own);
+    int rc;
+    int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
+    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
+    long it = 0;
+    long batch = s->mg_last_iters > 5 ? s->mg_last_iters : 8;   // identical on every rank
+    bool done = false;
+    while (!done) {
+        for (long k = 0; k < batch && it < max_it; ++k, ++it) {
+            const int cur = (int)(it & 1), prv = cur ^ 1;
+            if ((rc = halo_exchange1(s, d->lv[0].plan, sizeof(T), R))) return rc;
+            // gstage[cur] = {|r|^2 of the previous body (|b|^2 before the first), r.z of this one}
+            if (mg) {
+                if (s->mg_fp32) rc = dist_vcycle_t<float>(s, R, Z, s->mg_part);
+                else rc = dist_vcycle_t<double>(s, R, Z, s->mg_part);
+                if (rc) return rc;
+                launch_sum2(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->mg_part, n_rz, d->gstage[cur], d->gstage[cur] + 1);
+            } else {
+                launch_sum2(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->part_rz[0], nxr, d->gstage[cur], d->gstage[cur] + 1);
+            }
+            if ((rc = comm_allreduce(s, d->gstage[cur], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
+            launch_pcg_sq_dist<T>(s->st, L, cnt, mg ? Z : R, Sx[prv], Sx[cur], Q, cf, d->gstage[cur], d->gstage[cur] + 1, d->gstage[prv] + 1, s->part_pq, s->ps,
+                                  it == 0, tol, mg ? 1 : 0);
+            prof_end(s, FLUID_PROF_PCG_SQ, tok);
+            launch_sum2(s->st, s->part_pq, nsq, s->part_pq, 0, d->gpq, nullptr);
+            if ((rc = comm_allreduce(s, d->gpq, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
+            launch_pcg_xr_dist<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, d->gstage[cur] + 1, d->gpq, s->part_rr, s->part_rz[0], s->ps);
+            prof_end(s, FLUID_PROF_PCG_XR, tok);
+        }
+        HIPCHK(hipGetLastError());
+        // the break test of the last body sits at the head of the next SQ launch; every rank must leave at the same iteration
+        if ((rc = comm_allreduce(s, &s->ps->done, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
+        HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        done = s->h_ps->done || it >= max_it;
+        batch = 2;
+    }
+    int iters = s->h_ps->iters;
+    const double rr = s->h_ps->rr;
+    if (!s->h_ps->done) iters = (int)max_it;
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    HIPCHK(hipGetLastError());
+    prof_end(s, FLUID_PROF_SOLVE, tsolve);
+    s->stats.cg_iters_last = iters;
+    s->stats.cg_iters += iters;
+    s->mg_last_iters = iters;
+    s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
+    if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
+    return FLUID_OK;
+}
+
+// ---- decomposed step ----------------------------------------------------------------------------------------------------
+int dist_step_decomposed(fluid_sim* s, fluid_step_stats_t* stats)
+{
+    DistState* d = s->ds;
+    const Grid g = s->g;
+    const int N = g.N, me = d->comm.rank;
+    int rc;
+    if ((rc = dist_particles(s))) return rc;           // fluid.cc:1378-1413, first half: who holds what
+    if ((rc = clear_dirty(s))) return rc;
+    stats_begin(s);
+    const int org[3] = {g.ox, g.oy, g.oz};
+    const bool any = !ib_empty(d->Rg);
+    if (any) s->dirty = s->Sb;
+    if (any && !box_empty(d->Rr)) {
+        int tok = prof_begin(s, FLUID_PROF_P2G, (double)d->Rr.cells());
+        rc = run_p2g(s, d->Rr);
+        prof_end(s, FLUID_PROF_P2G, tok);
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+    }
+    // 1-wide halos of this step's fields: owned cells of the box the fields live in
+    make_plan(d, d->plan_f1, [&](int r) { return ib_isect(block_of(d, r), d->Sg); }, 1, org, 0, g.sx(), g.nz);
+    {
+        void* a[6] = {s->u, s->v, s->w, s->ub, s->vb, s->wb};   // velBeforeUpdate = the same values (fluid.cc:1455)
+        if ((rc = halo_exchange(s, d->plan_f1, 8, 6, a))) return rc;
+    }
+    // ---- flags on the owned block, halo from the owners; the reference's unknown numbering (:1416-1433) ----
+    const Box ownW = to_box(IBox{{d->ob.lo[0], d->ob.lo[1], d->ob.lo[2]}, {d->ob.hi[0], d->ob.hi[1], d->ob.hi[2]}}, org);
+    launch_flags_box(s->st, g, ownW, s->solid, s->container, s->flags);
+    HIPCHK(hipGetLastError());
+    if ((rc = halo_exchange1(s, d->plan_flags, 1, s->flags))) return rc;
+    {
+        launch_fill_box_int(s->st, g, d->idx_box, s->indices, -1);
+        d->idx_box = d->Rr;
+        const int RX = any ? d->Rg.hi[0] - d->Rg.lo[0] : 0, RY = any ? d->Rg.hi[1] - d->Rg.lo[1] : 0, nseg = d->dims[2];
+        const size_t nrow = (size_t)RX * RY * nseg;
+        if (nrow + 4 > d->rows_cap) {
+            HIPCHK(hipStreamSynchronize(s->st));
+            hipFree(d->rows); hipFree(d->row_starts);
+            d->rows = d->row_starts = nullptr;
+            d->rows_cap = nrow + nrow / 4 + 1024;
+            HIPCHK(hipMalloc((void**)&d->rows, d->rows_cap * sizeof(int)));
+            HIPCHK(hipMalloc((void**)&d->row_starts, d->rows_cap * sizeof(int)));
+        }
+        if (nrow) {
+            HIPCHK(hipMemsetAsync(d->rows, 0, nrow * sizeof(int), s->st));
+            launch_row_counts(s->st, g, d->Rr, d->Rg.lo[0], d->Rg.lo[1], RY, nseg, d->bc[2], s->flags, d->rows);
+            HIPCHK(hipGetLastError());
+            if ((rc = comm_allreduce(s, d->rows, (long)nrow, FLUID_DT_I32, FLUID_OP_SUM))) return rc;
+            launch_exclusive_scan(s->st, d->rows, d->row_starts, (long)nrow, s->scan_sums, &s->ss->num_active);
+            launch_row_number(s->st, g, d->Rr, d->Rg.lo[0], d->Rg.lo[1], RY, nseg, d->bc[2], s->flags, d->row_starts, s->indices);
+            HIPCHK(hipGetLastError());
+        } else {
+            HIPCHK(hipMemsetAsync(&s->ss->num_active, 0, sizeof(int), s->st));
+        }
+        if ((rc = read_ss(s))) return rc;
+        s->stats.num_active = s->h_ss->num_active;
+        s->last_num_active = s->stats.num_active;
+    }
+    // ---- local solver layout, multigrid hierarchy ----
+    if (any) {
+        if ((rc = dist_mg_setup(s))) return rc;
+        const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);
+        HIPCHK(zero_search(s, lb));
+    }
+    s->have_p2g = s->have_flags = true;
+    // ---- pressure do..while (:1457-1484) ----
+    double error = NAN;
+    do {
+        const double dt = s->dt;
+        if (any) {
+            if (!box_empty(d->Rr))
+                launch_rhs_div(s->st, g, d->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver, s->prm.dx, s->prm.gravity[0] * dt, s->prm.gravity[1] * dt,
+                               s->prm.gravity[2] * dt);
+            if ((rc = dist_solve(s))) return rc;
+            if ((rc = halo_exchange1(s, d->plan_f1, 8, s->pressure))) return rc;
+            const double dtp = dt * s->prm.update_frac, k = dtp / (s->prm.rho * s->prm.dx);
+            if (!box_empty(d->Sr))
+                launch_vel_update(s->st, g, d->Sr, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,
+                                  s->prm.gravity[2] * dtp);
+            {
+                void* a[3] = {s->u, s->v, s->w};
+                if ((rc = halo_exchange(s, d->plan_f1, 8, 3, a))) return rc;
+            }
+            if (!box_empty(d->Rr)) {
+                launch_rhs_div(s->st, g, d->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver2, s->prm.dx, s->prm.gravity[0] * dt, s->prm.gravity[1] * dt,
+                               s->prm.gravity[2] * dt);
+                launch_err_norm(s->st, g, d->Rr, s->flags, s->diver, s->diver2, s->part_err, s->ss);
+            } else {
+                HIPCHK(hipMemsetAsync(&s->ss->err_num, 0, 2 * sizeof(double), s->st));
+            }
+            HIPCHK(hipGetLastError());
+            if ((rc = comm_allreduce(s, &s->ss->err_num, 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            if ((rc = read_ss(s))) return rc;
+            error = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);
+        }
+        s->stats.error = error;
+        s->stats.outer_passes++;
+        if (s->prm.max_outer_passes > 0 && s->stats.outer_passes >= s->prm.max_outer_passes) break;
+    } while (error > s->prm.outer_tol);
+    // ---- FLIP delta field on the owned cells, halo from the owners, gather + advect (:1490) ----
+    if ((rc = pic_fields(s))) return rc;
+    if (any && !box_empty(d->Rr))
+        launch_flip_delta(s->st, g, d->Rr, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
+    HIPCHK(hipGetLastError());
+    {
+        void* a[6] = {s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz};
+        if ((rc = halo_exchange(s, d->plan_f1, 8, s->pcx ? 6 : 3, a))) return rc;
+    }
+    (void)N; (void)me;
+    return dist_g2p_advect(s, stats);
+}
+
+}  // namespace
+
+int fl::dist_step(fluid_sim* s, fluid_step_stats_t* stats)
+{
+    HIPCHK(hipSetDevice(s->prm.device));
+    return s->ds->repl ? dist_step_replicated(s, stats) : dist_step_decomposed(s, stats);
+}
+
+void fl::dist_destroy(fluid_sim* s)
+{
+    DistState* d = s->ds;
+    if (!d) return;
+    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (d->h_cnt) hipHostFree(d->h_cnt);
+    delete d;
+    s->ds = nullptr;
+}
+
+extern "C" {
+
+int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const fluid_decomp_t* dc, fluid_sim_t** out)
+{
+    if (!p || !comm || !dc || !out) return fail(FLUID_ERR_ARG, "null argument");
+    if (comm->size < 1 || comm->size > FLUID_MAX_RANKS || comm->rank < 0 || comm->rank >= comm->size) return fail(FLUID_ERR_ARG, "bad rank/size");
+    if (!comm->exchange || !comm->allreduce) return fail(FLUID_ERR_ARG, "comm callbacks missing");
+    if (dc->dims[0] < 1 || dc->dims[1] < 1 || dc->dims[2] < 1 || (long)dc->dims[0] * dc->dims[1] * dc->dims[2] != comm->size)
+        return fail(FLUID_ERR_ARG, "dims[0]*dims[1]*dims[2] must equal the number of ranks");
+    for (int a = 0; a < 3; ++a) {
+        const int32_t* c = dc->cuts[a];
+        if (!c || c[0] != 0 || c[dc->dims[a]] != p->n) return fail(FLUID_ERR_ARG, "cuts must start at 0 and end at n");
+        for (int b = 0; b < dc->dims[a]; ++b) {
+            if (dc->dims[a] > 1 && c[b + 1] - c[b] < 8) return fail(FLUID_ERR_ARG, "every block must be at least 8 cells wide");
+            if (b > 0 && (c[b] & 3)) return fail(FLUID_ERR_ARG, "interior cuts must be multiples of 4");
+        }
+    }
+    DistState* d = new DistState();
+    d->comm = *comm;
+    for (int a = 0; a < 3; ++a) {
+        d->dims[a] = dc->dims[a];
+        d->cuts[a].assign(dc->cuts[a], dc->cuts[a] + dc->dims[a] + 1);
+    }
+    d->bc[2] = comm->rank % d->dims[2];
+    d->bc[1] = (comm->rank / d->dims[2]) % d->dims[1];
+    d->bc[0] = comm->rank / (d->dims[1] * d->dims[2]);
+    for (int a = 0; a < 3; ++a) {
+        d->ob.lo[a] = d->cuts[a][d->bc[a]];
+        d->ob.hi[a] = d->cuts[a][d->bc[a] + 1];
+        d->ob.has_lo[a] = d->bc[a] > 0;
+        d->ob.has_hi[a] = d->bc[a] < d->dims[a] - 1;
+    }
+    for (int dd = 0; dd < 27; ++dd) {
+        const int e[3] = {dd / 9 - 1, (dd / 3) % 3 - 1, dd % 3 - 1};
+        int b[3];
+        bool ok = dd != 13;
+        for (int a = 0; a < 3; ++a) { b[a] = d->bc[a] + e[a]; ok = ok && b[a] >= 0 && b[a] < d->dims[a]; }
+        d->nbr[dd] = ok ? rank_of(d, b[0], b[1], b[2]) : -1;
+    }
+    // AUTO: the decomposed solve pays >= 4 exchanges per PCG iteration, each a few tens of microseconds over xGMI; below
+    // ~2 M unknowns per solve a single GPU runs the whole iteration in less than that, so small grids replicate the block.
+    d->repl = p->dist_solve == FLUID_DIST_REPLICATED || (p->dist_solve == FLUID_DIST_AUTO && p->n < 384);
+    if (const char* e = getenv("FLUID_DIST_SOLVE")) d->repl = atoi(e) == 0;   // developer knob, overrides the param
+    if (const char* e = getenv("FLUID_DIST_SPLIT")) d->split_force = atoi(e);
+    if (d->split_force < 0 || d->split_force > 2) d->split_force = 0;
+    Grid g;
+    g.N = p->n;
+    g.lo = -(p->n / 2);
+    g.hi = g.lo + p->n - 1;
+    if (d->repl) {
+        g.nx = g.ny = g.nz = p->n;
+        g.ox = g.oy = g.oz = 0;
+    } else {
+        int o[3], n[3];
+        for (int a = 0; a < 3; ++a) {
+            const int lo = std::max(0, d->ob.lo[a] - HALO_W), hi = std::min(p->n, d->ob.hi[a] + HALO_W);
+            o[a] = lo; n[a] = hi - lo;
+        }
+        g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
+        g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
+    }
+    fluid_params_t q = *p;
+    if (!d->repl) q.solve_start = FLUID_START_ZERO;   // the decomposed PCG starts from x0 = 0 like the reference's cg.solve(b)
+    int rc = fluid_create_window(&q, g, out);
+    if (rc) { delete d; return rc; }
+    fluid_sim* s = *out;
+    s->dist = true;
+    s->ds = d;
+    auto bail = [&](const std::string& m) { fluid_destroy(s); *out = nullptr; return fail(FLUID_ERR_HIP, m); };
+    if (dalloc(&d->gstage[0], (size_t)2) != hipSuccess || dalloc(&d->gstage[1], (size_t)2) != hipSuccess || dalloc(&d->gpq, (size_t)1) != hipSuccess ||
+        dalloc(&d->d_cnt, (size_t)128) != hipSuccess || dalloc(&d->cnt_pcg, s->lmax + 64) != hipSuccess ||
+        hipHostMalloc((void**)&d->h_cnt, 128 * sizeof(int)) != hipSuccess)
+        return bail("alloc of the decomposition's scratch failed");
+    if (!d->repl) {
+        const int org[3] = {g.ox, g.oy, g.oz};
+        make_plan(d, d->plan_flags, [&](int r) { return block_of(d, r); }, HALO_W, org, 0, g.sx(), g.nz);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return bail("device sync failed");
+    return FLUID_OK;
+}
+
+int fluid_window(fluid_sim_t* s, int32_t origin[3], int32_t dims[3], int32_t own_lo[3], int32_t own_hi[3])
+{
+    if (!s) return fail(FLUID_ERR_ARG, "null handle");
+    const Grid g = s->g;
+    const int o[3] = {g.ox, g.oy, g.oz}, n[3] = {g.nx, g.ny, g.nz};
+    for (int a = 0; a < 3; ++a) {
+        if (origin) origin[a] = o[a];
+        if (dims) dims[a] = n[a];
+        if (own_lo) own_lo[a] = s->ds ? s->ds->ob.lo[a] : 0;
+        if (own_hi) own_hi[a] = s->ds ? s->ds->ob.hi[a] : g.N;
+    }
+    return FLUID_OK;
+}
+
+int fluid_upload_particles_ids(fluid_sim_t* s, int64_t n, const double* pos, const double* vel, const uint32_t* ids)
+{
+    if (!s || n < 0 || (n > 0 && (!pos || !ids))) return fail(FLUID_ERR_ARG, "bad particle arguments");
+    HIPCHK(hipSetDevice(s->prm.device));
+    // some room for ghosts and for particles that migrate in; both the particle arrays and the routing buffers grow on demand
+    int rc = alloc_particles(s, 2 * (long)n + (1L << 16));
+    if (rc) return rc;
+    DistState* d = s->ds;
+    if (d && !d->mig_s) {
+        d->mig_cap = (long)n / 2 + (1L << 16);
+        HIPCHK(hipMalloc((void**)&d->mig_s, (size_t)d->mig_cap * 56));
+        HIPCHK(hipMalloc((void**)&d->mig_r, (size_t)d->mig_cap * 56));
+    }
+    s->np = (long)n;
+    s->p_off = 0;
+    if (n > 0) {
+        uint32_t* dids = (uint32_t*)s->order;  // staging: order[] is free between steps
+        HIPCHK(hipMemcpyAsync(s->stage_pos, pos, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
+        if (vel) HIPCHK(hipMemcpyAsync(s->stage_vel, vel, 3 * n * sizeof(double), hipMemcpyHostToDevice, s->st));
+        HIPCHK(hipMemcpyAsync(dids, ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
+        launch_unpack_ids(s->st, s->np, s->stage_pos, vel ? s->stage_vel : nullptr, dids, s->pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->st));
+    }
+    s->sorted = s->have_p2g = s->have_flags = false;
+    s->have_guess = false;  // a new particle set: the first solve starts from 0
+    s->sort_hint = false;
+    return FLUID_OK;
+}
+
+int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, uint32_t* ids)
+{
+    if (!s) return -1;
+    if (hipSetDevice(s->prm.device) != hipSuccess) return -1;
+    // the live particles (after a step the served ghosts are still in the arrays, marked dead)
+    int* cursor = s->d_small;
+    if (hipMemsetAsync(cursor, 0, sizeof(int), s->st) != hipSuccess) return -1;
+    const bool fetch = pos && vel && ids;
+    uint32_t* dids = (uint32_t*)s->order;
+    launch_pack_live(s->st, s->np, s->pa.shifted(s->p_off), fetch ? s->stage_pos : nullptr, s->stage_vel, dids, cursor);
+    int live = 0;
+    if (hipMemcpyAsync(s->h_small, cursor, sizeof(int), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s->st) != hipSuccess) return -1;
+    live = s->h_small[0];
+    if (!fetch || live == 0) return live;
+    if (hipMemcpyAsync(pos, s->stage_pos, 3 * (size_t)live * sizeof(double), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(vel, s->stage_vel, 3 * (size_t)live * sizeof(double), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(ids, dids, (size_t)live * sizeof(uint32_t), hipMemcpyDeviceToHost, s->st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s->st) != hipSuccess) return -1;
+    return live;
+}
+
+int fluid_partition_blocks(int32_t n, int64_t np, const double* pos, const int32_t dims[3], int32_t* cuts_x, int32_t* cuts_y, int32_t* cuts_z)
+{
+    if (n < 8 || !dims || !cuts_x || !cuts_y || !cuts_z || (np > 0 && !pos)) return fail(FLUID_ERR_ARG, "bad argument");
+    int32_t* cuts[3] = {cuts_x, cuts_y, cuts_z};
+    const int lo = -(n / 2);
+    for (int a = 0; a < 3; ++a) {
+        const int P = dims[a];
+        if (P < 1 || (P > 1 && n < 8 * P + 8)) return fail(FLUID_ERR_ARG, "too many blocks along an axis (each needs >= 8 cells)");
+        std::vector<int64_t> hist(n, 0);
+        for (int64_t i = 0; i < np; ++i) {
+            long b = std::lround(pos[3 * i + a]) - lo;  // C round(): half away from zero, like the base cell (fluid.cc:267)
+            b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
+            hist[b]++;
+        }
+        cuts[a][0] = 0;
+        int64_t acc = 0;
+        int x = 0;
+        for (int r = 1; r < P; ++r) {
+            const int64_t target = np * r / P;
+            while (x < n && acc + hist[x] <= target) acc += hist[x++];
+            int b = (x + 2) & ~3;                                          // nearest multiple of 4
+            const int lo_b = cuts[a][r - 1] + 8, hi_b = ((n - 8 * (P - r)) & ~3);   // >= 8 cells for this block and for the ones above
+            if (b < lo_b) b = (lo_b + 3) & ~3;
+            if (b > hi_b) b = hi_b;
+            while (x < b) acc += hist[x++];
+            cuts[a][r] = b;
+        }
+        cuts[a][P] = n;
+        for (int r = 0; r < P; ++r)
+            if (P > 1 && cuts[a][r + 1] - cuts[a][r] < 8) return fail(FLUID_ERR_ARG, "grid too small for this many blocks");
+    }
+    return FLUID_OK;
+}
+
+}  // extern "C"

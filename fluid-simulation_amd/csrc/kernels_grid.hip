@@ -112,7 +112,7 @@ void launch_exclusive_scan(hipStream_t st, const int* in, int* out, long n, int*
 }
 void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total)
 {
-    scan_impl<1>(st, flags, indices, (long)g.N * g.N * g.N, block_sums, total);
+    scan_impl<1>(st, flags, indices, (long)g.cells(), block_sums, total);
 }
 
 // ---- flags -----------------------------------------------------------------------------------
@@ -125,18 +125,17 @@ __global__ __launch_bounds__(256) void k_flags(Grid g, const uint8_t* __restrict
 {
     long c = c_begin + (long)blockIdx.x * 256 + threadIdx.x;
     if (c >= c_end) return;
-    const int N = g.N;
-    const int iz = (int)(c % N), iy = (int)((c / N) % N), ix = (int)(c / ((long)N * N));
+    const int iz = (int)(c % g.nz), iy = (int)((c / g.nz) % g.ny), ix = (int)(c / g.sx());
     const uint8_t sol = solid[c] ? F_SOLID : 0;
     uint8_t f = sol;
     if (!sol && container[c] > 0) {
         int cnt = 0;
-        cnt += (ix > 0) ? !solid[c - (long)N * N] : 1;
-        cnt += (ix < N - 1) ? !solid[c + (long)N * N] : 1;
-        cnt += (iy > 0) ? !solid[c - N] : 1;
-        cnt += (iy < N - 1) ? !solid[c + N] : 1;
+        cnt += (ix > 0) ? !solid[c - g.sx()] : 1;
+        cnt += (ix < g.nx - 1) ? !solid[c + g.sx()] : 1;
+        cnt += (iy > 0) ? !solid[c - g.nz] : 1;
+        cnt += (iy < g.ny - 1) ? !solid[c + g.nz] : 1;
         cnt += (iz > 0) ? !solid[c - 1] : 1;
-        cnt += (iz < N - 1) ? !solid[c + 1] : 1;
+        cnt += (iz < g.nz - 1) ? !solid[c + 1] : 1;
         f = (uint8_t)(F_FLUID | (cnt << F_CNT_SHIFT));
     }
     flags[c] = f;
@@ -145,28 +144,17 @@ __global__ __launch_bounds__(256) void k_flags(Grid g, const uint8_t* __restrict
 // x planes [x0, x1] (inclusive); the whole grid for x0=0, x1=N-1
 void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags, int x0, int x1)
 {
-    const long n2 = (long)g.N * g.N, c0 = (long)x0 * n2, c1 = (long)(x1 + 1) * n2;
+    const long n2 = g.sx(), c0 = (long)x0 * n2, c1 = (long)(x1 + 1) * n2;
     if (c1 <= c0) return;
     hipLaunchKernelGGL(k_flags, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, st, g, solid, container, flags, c0, c1);
 }
 
-// multi-GPU: unknown numbering of a slab = local running count + number of unknowns on lower ranks
-__global__ __launch_bounds__(256) void k_add_offset(int* __restrict__ idx, long n, int off)
-{
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n && idx[i] >= 0) idx[i] += off;
-}
 void launch_index_scan_range(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total, int x0, int x1)
 {
-    const long n2 = (long)g.N * g.N;
+    const long n2 = g.sx();
     if (x1 < x0) return;
     scan_impl<1>(st, flags + (long)x0 * n2, indices + (long)x0 * n2, (long)(x1 - x0 + 1) * n2, block_sums, total);
 }
-void launch_add_offset(hipStream_t st, int* idx, long n, int off)
-{
-    if (n > 0 && off) hipLaunchKernelGGL(k_add_offset, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, n, off);
-}
-
 // ---- box helpers -----------------------------------------------------------------------------
 struct CellIt {
     int ix, iy, iz;
@@ -197,13 +185,12 @@ __global__ __launch_bounds__(256) void k_rhs_div(Grid g, Box box, const uint8_t*
     CellIt it = box_cell(g, box);
     if (!it.ok) return;
     const size_t c = it.c;
-    const int N = g.N;
     const uint8_t f = flags[c];
     float r = 0.0f, d = 0.0f;
     if (f & F_FLUID) {
         const double scale = 1.0 / dx;
-        const long sx = (long)N * N, sy = N;
-        const bool hxm = it.ix > 0, hxp = it.ix < N - 1, hym = it.iy > 0, hyp = it.iy < N - 1, hzm = it.iz > 0, hzp = it.iz < N - 1;
+        const long sx = g.sx(), sy = g.nz;
+        const bool hxm = it.ix > 0, hxp = it.ix < g.nx - 1, hym = it.iy > 0, hyp = it.iy < g.ny - 1, hzm = it.iz > 0, hzp = it.iz < g.nz - 1;
         const double uc = u[c], vc = v[c], wc = w[c];
         const double ui = hxp ? u[c + sx] : 0.0, vj = hyp ? v[c + sy] : 0.0, wk = hzp ? w[c + 1] : 0.0;
         const bool sxm = hxm && (flags[c - sx] & F_SOLID), sxp = hxp && (flags[c + sx] & F_SOLID);
@@ -245,8 +232,7 @@ __global__ __launch_bounds__(256) void k_vel_update(Grid g, Box box, const uint8
     CellIt it = box_cell(g, box);
     if (!it.ok) return;
     const size_t c = it.c;
-    const int N = g.N;
-    const long sx = (long)N * N, sy = N;
+    const long sx = g.sx(), sy = g.nz;
     const uint8_t f = flags[c];
     const uint8_t fxm = it.ix > 0 ? flags[c - sx] : 0, fym = it.iy > 0 ? flags[c - sy] : 0, fzm = it.iz > 0 ? flags[c - 1] : 0;
     double uc = u[c], vc = v[c], wc = w[c];
@@ -284,9 +270,8 @@ __global__ __launch_bounds__(256) void k_flip_delta(Grid g, Box box, const doubl
     CellIt it = box_cell(g, box);
     if (!it.ok) return;
     const size_t c = it.c;
-    const int N = g.N;
-    const long sx = (long)N * N, sy = N;
-    const bool hxp = it.ix < N - 1, hyp = it.iy < N - 1, hzp = it.iz < N - 1;
+    const long sx = g.sx(), sy = g.nz;
+    const bool hxp = it.ix < g.nx - 1, hyp = it.iy < g.ny - 1, hzp = it.iz < g.nz - 1;
     const double cu = (u[c] + (hxp ? u[c + sx] : 0.0)) / 2.0, pu = (ub[c] + (hxp ? ub[c + sx] : 0.0)) / 2.0;
     const double cv = (v[c] + (hyp ? v[c + sy] : 0.0)) / 2.0, pv = (vb[c] + (hyp ? vb[c + sy] : 0.0)) / 2.0;
     const double cw = (w[c] + (hzp ? w[c + 1] : 0.0)) / 2.0, pw = (wb[c] + (hzp ? wb[c + 1] : 0.0)) / 2.0;
@@ -400,21 +385,7 @@ void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box)
 }
 
 // ---- multi-GPU, replicated solve: the P2G result of every slab gathered onto every rank -----------------------
-// buf = 4 planes of box.cells() doubles [container | u | v | w]; a rank fills the cells of its own x planes [xs, xe) and
-// zeros elsewhere, the SUM all-reduce then assembles the whole box exactly (every cell has one owner, the rest add 0).
-__global__ __launch_bounds__(256) void k_pack_box(Grid g, Box box, int xs, int xe, const float* __restrict__ container,
-                                                  const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ w,
-                                                  double* __restrict__ buf)
-{
-    CellIt it = box_cell(g, box);
-    if (!it.ok) return;
-    const size_t n = (size_t)box.cells(), t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool own = it.ix >= xs && it.ix < xe;
-    buf[t] = own ? (double)container[it.c] : 0.0;
-    buf[n + t] = own ? u[it.c] : 0.0;
-    buf[2 * n + t] = own ? v[it.c] : 0.0;
-    buf[3 * n + t] = own ? w[it.c] : 0.0;
-}
+// buf = 4 planes of box.cells() doubles [container | u | v | w], packed by k_pack_box_own (kernels_dist.hip) and SUM all-reduced
 __global__ __launch_bounds__(256) void k_unpack_box(Grid g, Box box, const double* __restrict__ buf, float* __restrict__ container,
                                                     double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
                                                     double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb)
@@ -426,11 +397,6 @@ __global__ __launch_bounds__(256) void k_unpack_box(Grid g, Box box, const doubl
     const double a = buf[n + t], b = buf[2 * n + t], c = buf[3 * n + t];
     u[it.c] = a; v[it.c] = b; w[it.c] = c;
     ub[it.c] = a; vb[it.c] = b; wb[it.c] = c;   // velBeforeUpdate (fluid.cc:1455)
-}
-void launch_pack_box(hipStream_t st, Grid g, Box box, int xs, int xe, const float* container, const double* u, const double* v, const double* w,
-                     double* buf)
-{
-    if (box.cells() > 0) hipLaunchKernelGGL(k_pack_box, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, xs, xe, container, u, v, w, buf);
 }
 void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float* container, double* u, double* v, double* w, double* ub, double* vb,
                        double* wb)

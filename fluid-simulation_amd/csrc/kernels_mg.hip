@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_mg_type0(Grid g, LBox L, MLevel m, cons
     const int gx = L.x0 + i - 1, gy = L.y0 + j - 1, gz = L.z0 + k - 1;
     uint8_t t = 0;
     const size_t c = m.at(i, j, k);
-    if (gx >= 0 && gx < g.N && gy >= 0 && gy < g.N && gz >= 0 && gz < g.N) {
+    if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) {
         const uint8_t f = flags[g.idx(gx, gy, gz)];
         t = (f & F_SOLID) ? 0 : (cnt[c] ? 2 : 1);
     }
@@ -324,8 +324,10 @@ template <typename T, typename F, typename O, int TX, int TY, int TZ>
 __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
                                                O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
                                                double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
-                                               const int* __restrict__ tlist)
+                                               const int* __restrict__ tlist, const uint8_t* __restrict__ own)
 {
+    // own (decomposed run, level 0): the PCG's count bytes — the partial f.out counts the rank's owned unknowns only
+    // (non-zero byte without bit 7); the result itself is written on every unknown of the local box
     constexpr int AX = TX + 4, AY = TY + 4, AZ = TZ + 4;              // v0 = u + P e and the count bytes
     constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2;              // v1
     constexpr int EX = TX / 2 + 4, EY = TY / 2 + 4, EZ = TZ / 2 + 4;  // coarse correction under the v0 region
@@ -442,8 +444,9 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
             const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
             const T o = c0 + (T)MG_W1 * si[n] * ((T)ft[x] - (sd[n] * c0 + off * nb));
             if (n) {
-                out[qt + (size_t)((long)(i0 + xt0 + x) * sx)] = (O)o;  // n != 0: in the level, no clamp
-                acc += (double)ft[x] * (double)o;
+                const size_t qo = qt + (size_t)((long)(i0 + xt0 + x) * sx);
+                out[qo] = (O)o;  // n != 0: in the level, no clamp
+                if (!own || (own[qo] && !(own[qo] & 0x80))) acc += (double)ft[x] * (double)o;
             }
             cm = c0;
             c0 = cp;
@@ -710,6 +713,14 @@ void launch_mg_type0(hipStream_t st, Grid g, LBox L, MLevel m, const uint8_t* fl
 {
     hipLaunchKernelGGL(k_mg_type0, dim3(mg_blocks(m)), dim3(256), 0, st, g, L, m, flags, cnt, typ);
 }
+void launch_mg_coarsen_types(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, uint8_t* tc)
+{
+    if (mg_blocks(mc)) hipLaunchKernelGGL(k_mg_coarsen, dim3(mg_blocks(mc)), dim3(256), 0, st, mf, tf, mc, tc);
+}
+void launch_mg_counts(hipStream_t st, MLevel m, const uint8_t* typ, uint8_t* cnt)
+{
+    if (mg_blocks(m)) hipLaunchKernelGGL(k_mg_cnt, dim3(mg_blocks(m)), dim3(256), 0, st, m, typ, cnt);
+}
 void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, uint8_t* tc, uint8_t* cnt_c)
 {
     hipLaunchKernelGGL(k_mg_coarsen, dim3(mg_blocks(mc)), dim3(256), 0, st, mf, tf, mc, tc);
@@ -718,7 +729,7 @@ void launch_mg_coarsen(hipStream_t st, MLevel mf, const uint8_t* tf, MLevel mc, 
 template <typename T>
 void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const uint8_t* cnt_c, T* fc, const PcgState* ps)
 {
-    hipLaunchKernelGGL((k_mg_restrict<T>), dim3(mg_blocks(mc)), dim3(256), 0, st, mf, rf, mc, cnt_c, fc, ps);
+    if (mg_blocks(mc)) hipLaunchKernelGGL((k_mg_restrict<T>), dim3(mg_blocks(mc)), dim3(256), 0, st, mf, rf, mc, cnt_c, fc, ps);
 }
 // tile shapes of the LDS-tiled legs
 constexpr int MG_TX = 8, MG_TY = 8, MG_TZ = 16;   // down (no restriction) and up
@@ -756,6 +767,7 @@ template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
                     const PcgState* ps, const int* tlist, int nlist)
 {
+    if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return;   // an empty local level (decomposed run)
     if (fc) {
         const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
         hipLaunchKernelGGL((k_mg_down<T, F, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
@@ -769,11 +781,12 @@ void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T*
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps, double wc, const int* tlist, int nlist)
+                  double* part_dot, const PcgState* ps, double wc, const int* tlist, int nlist, const uint8_t* own)
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
+    if (!tlist && g.x * g.y * g.z == 0) return;   // an empty local level (decomposed run: a block outside the active box)
     hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc,
-                       ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist);
+                       ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist, own);
 }
 // flags of the level-0 leg tiles (mg_up_blocks(m) of them), see k_mg_tile_flags
 void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags)
@@ -841,7 +854,7 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*, \
                                        const int*, int); \
     template void launch_mg_up<T, T, T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*,  \
-                                        const PcgState*, double, const int*, int);                                                                               \
+                                        const PcgState*, double, const int*, int, const uint8_t*);                                                                               \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                     \
     template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*, double);
 INSTMG(double)
@@ -850,6 +863,6 @@ INSTMG(float)
 template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
                                             MgCoef<float>, const PcgState*, const int*, int);
 template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
-                                                  MgCoef<float>, double*, const PcgState*, double, const int*, int);
+                                                  MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*);
 
 }  // namespace fl

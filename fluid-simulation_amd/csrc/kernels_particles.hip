@@ -19,10 +19,10 @@ __global__ __launch_bounds__(256) void k_bin_count(Grid g, long n, Particles p, 
     __shared__ int sm[4][8];
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
     int nout = 0, cmax = 0;
-    const long ncell = (long)g.N * g.N * g.N;
+    const long ncell = (long)g.cells();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        int bx = (int)round(p.px[i]) - g.lo, by = (int)round(p.py[i]) - g.lo, bz = (int)round(p.pz[i]) - g.lo;
-        bool in = bx >= 0 && bx < g.N && by >= 0 && by < g.N && bz >= 0 && bz < g.N;
+        int bx = (int)round(p.px[i]) - g.cx0(), by = (int)round(p.py[i]) - g.cy0(), bz = (int)round(p.pz[i]) - g.cz0();
+        bool in = bx >= 0 && bx < g.nx && by >= 0 && by < g.ny && bz >= 0 && bz < g.nz;
         int k = in ? (int)g.idx(bx, by, bz) : (int)ncell;
         const bool dead = p.pid[i] == PID_DEAD;  // migrated to a neighbour rank: last bucket, dropped after the sort
         if (dead) { k = (int)ncell + 1; in = false; }
@@ -273,16 +273,15 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
 {
     __shared__ double sr[12][P2G_LDS];   // wx0..2, wy0..2, wz0..2, vx, vy, vz
     const int tid = threadIdx.x, e = tid >> 6, lane = tid & 63;
-    const int N = g.N;
     for (int item = blockIdx.x; item < items[0]; item += gridDim.x) {   // items[0]: block-uniform count
     const int4 wi = reinterpret_cast<const int4*>(items)[1 + item];      // x-plane, first and last target column, z piece
     const int rx = box.x0 - 1 + wi.x, Y0 = wi.y, Y1 = wi.z, tz0 = box.z0 + wi.w * zt;
     const int X = rx - 1 + e, zc = tz0 - 1 + lane;
     const bool colx = X >= box.x0 && X <= box.x1;                  // my target plane is in the box
-    const bool src = colx && zc >= 0 && zc < N;                    // my cell exists: it may hold particles
+    const bool src = colx && zc >= 0 && zc < g.nz;                 // my cell exists: it may hold particles
     const bool tgt = colx && lane >= 1 && lane <= zt && zc <= box.z1;
-    const bool rowx = rx >= 0 && rx < N;
-    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + zt < N - 1 ? tz0 + zt : N - 1;
+    const bool rowx = rx >= 0 && rx < g.nx;
+    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + zt < g.nz - 1 ? tz0 + zt : g.nz - 1;
     const double* swx = sr[e];   // a particle of plane rx meets plane X = rx - 1 + e with its x weight e
     // partial slot = rx - X + 1 = 2 - e
     double* const out = part + (long)(2 - e) * 4 * cells + (long)(X - box.x0) * box.ny() * box.nz() + (zc - box.z0);
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
 #pragma unroll
                 for (int q = 0; q < 4; ++q) T[a][d][q] = 0;
         int jb = 0, je = 0;
-        if (rowx && ry >= 0 && ry < N) {
+        if (rowx && ry >= 0 && ry < g.ny) {
             jb = cell_start[g.idx(rx, ry, zlo)];
             je = cell_start[g.idx(rx, ry, zhi) + 1];
         }
@@ -422,13 +421,13 @@ __global__ __launch_bounds__(256) void k_p2g_items(Grid g, Box box, const int* _
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= (box.nx() + 2) * nseg) return;
-    const int sy = t % nseg, bx = t / nseg, N = g.N;
+    const int sy = t % nseg, bx = t / nseg;
     const int rx = box.x0 - 1 + bx;
     const int Y0 = box.y0 + sy * box.ny() / nseg, Y1 = box.y0 + (sy + 1) * box.ny() / nseg - 1, len = Y1 - Y0 + 1;
     long c = 0;
-    if (rx >= 0 && rx < N) {
-        const int ya = Y0 > 0 ? Y0 - 1 : 0, yb = Y1 < N - 1 ? Y1 + 1 : N - 1;
-        c = (long)cell_start[g.idx(rx, yb, N - 1) + 1] - cell_start[g.idx(rx, ya, 0)];
+    if (rx >= 0 && rx < g.nx) {
+        const int ya = Y0 > 0 ? Y0 - 1 : 0, yb = Y1 < g.ny - 1 ? Y1 + 1 : g.ny - 1;
+        c = (long)cell_start[g.idx(rx, yb, g.nz - 1) + 1] - cell_start[g.idx(rx, ya, 0)];
     }
     long nsub = (c + (long)budget * ntz - 1) / ((long)budget * ntz);
     nsub = nsub < 1 ? 1 : (nsub > len ? len : nsub);
@@ -501,7 +500,6 @@ __global__ __launch_bounds__(P2GT_THREADS) void k_p2g_tiles(Grid g, Box box, Par
     __shared__ double sw[9][P2GT_LDS];   // wx0..2, wy0..2, wz0..2
     __shared__ double sv[3][P2GT_LDS];   // vx, vy, vz
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int N = g.N;
     const int ntz = (box.nz() + zt - 1) / zt, nty = (box.ny() + P2GT_T - 1) / P2GT_T;  // zt <= P2G_ZT target cells per wave
     const int tile = blockIdx.x;
     // faces first: piles form against the walls, and a block that starts late with a crowded wall plane is the kernel's tail.
@@ -512,17 +510,17 @@ __global__ __launch_bounds__(P2GT_THREADS) void k_p2g_tiles(Grid g, Box box, Par
     const int tx0 = box.x0 + tx * P2GT_T, ty0 = box.y0 + ty * P2GT_T, tz0 = box.z0 + tz * zt;
     const int ix = tx0 + wv / P2GT_T, iy = ty0 + wv % P2GT_T, zc = tz0 - 1 + lane;
     const bool col = ix <= box.x1 && iy <= box.y1;                 // my column is in the box
-    const bool src = col && zc >= 0 && zc < N;                     // my cell exists: it may hold particles
+    const bool src = col && zc >= 0 && zc < g.nz;                  // my cell exists: it may hold particles
     const bool tgt = col && lane >= 1 && lane <= zt && zc <= box.z1;
     const size_t c = tgt ? g.idx(ix, iy, zc) : 0;
     const bool live = tgt && !(flags[c] & F_SOLID);  // solid cells receive nothing (:288,870)
-    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + zt < N - 1 ? tz0 + zt : N - 1;
+    const int zlo = tz0 > 0 ? tz0 - 1 : 0, zhi = tz0 + zt < g.nz - 1 ? tz0 + zt : g.nz - 1;
     float wf = 0.0f;
     double su = 0, sv_ = 0, sw_ = 0;
     for (int rx = tx0 - 1; rx <= tx0 + P2GT_T; ++rx) {
-        if (rx < 0 || rx >= N) continue;
+        if (rx < 0 || rx >= g.nx) continue;
         for (int ry = ty0 - 1; ry <= ty0 + P2GT_T; ++ry) {
-            if (ry < 0 || ry >= N) continue;
+            if (ry < 0 || ry >= g.ny) continue;
             const int jb = cell_start[g.idx(rx, ry, zlo)];
             const int je = cell_start[g.idx(rx, ry, zhi) + 1];
             if (je == jb) continue;  // block-uniform
@@ -633,9 +631,9 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
     __shared__ double sm[4];
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     double len = 0;
-    if (i < n) {
+    if (i < n && p.pid[i] != PID_DEAD) {   // (dead: a ghost of a decomposed run, already served by P2G)
         const double cx = p.px[i], cy = p.py[i], cz = p.pz[i];
-        const int lo = g.lo, hi = g.hi, wlo = g.lo + 2, whi = g.hi - 2;
+        const int wlo = g.lo + 2, whi = g.hi - 2;
         const int fcx = (int)round(cx), fcy = (int)round(cy), fcz = (int)round(cz);
         // The 27 weights are products of 3 x 3 axis values (same values and association as spline()*spline()*spline()).
         // A cell takes part iff it is on the grid (clamp, :216-221) and within W (:237) — per axis: its coordinate lies in
@@ -643,16 +641,17 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
         // branches: the skipped cells add exactly +0 to every sum.
         double wx[3], wy[3], wz[3];
         int ox[3], oy[3], oz[3];
-        const int N = g.N;
+        const int sxs = (int)g.sx();   // N <= 1024: N^3 fits an int
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int ax = fcx - 1 + d, ay = fcy - 1 + d, az = fcz - 1 + d;
             wx[d] = (ax >= wlo && ax <= whi) ? spline_at(cx, ax, d) : 0.0;
             wy[d] = (ay >= wlo && ay <= whi) ? spline_at(cy, ay, d) : 0.0;
             wz[d] = (az >= wlo && az <= whi) ? spline_at(cz, az, d) : 0.0;
-            ox[d] = (min(max(ax, lo), hi) - lo) * N * N;   // N <= 1024: N^3 fits an int
-            oy[d] = (min(max(ay, lo), hi) - lo) * N;
-            oz[d] = min(max(az, lo), hi) - lo;
+            // clamped to the window (one GPU: the grid, :216-221): a readable index for the cells whose weight is 0
+            ox[d] = (min(max(ax, g.cx0()), g.cx1()) - g.cx0()) * sxs;
+            oy[d] = (min(max(ay, g.cy0()), g.cy1()) - g.cy0()) * g.nz;
+            oz[d] = min(max(az, g.cz0()), g.cz1()) - g.cz0();
         }
         double weight = 0, d0 = 0, d1 = 0, d2 = 0, q0 = 0, q1 = 0, q2 = 0;
 #pragma unroll
@@ -716,7 +715,7 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
     __shared__ double sf[PIC ? 6 : 3][LN];
     __shared__ int srow[NROW][2];
     __shared__ double sm[4];
-    const int tid = threadIdx.x, N = g.N;
+    const int tid = threadIdx.x;
     const int nty = (pb.ny() + G2P_TY - 1) / G2P_TY, ntz = (pb.nz() + G2P_TZ - 1) / G2P_TZ;
     const int tile = blockIdx.x;
     const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
@@ -735,7 +734,7 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
     for (int t = tid; t < LN; t += 256) {
         const int lx = t / (LY * LZ), r = t - lx * (LY * LZ), ly = r / LZ, lz = r - ly * LZ;
         const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gz = z0 - 1 + lz;
-        const bool in = gx >= 0 && gx < N && gy >= 0 && gy < N && gz >= 0 && gz < N;
+        const bool in = gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz;
         const size_t c = in ? g.idx(gx, gy, gz) : 0;
         sf[0][t] = in ? dcx[c] : 0.0;
         sf[1][t] = in ? dcy[c] : 0.0;
@@ -747,7 +746,7 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
         }
     }
     __syncthreads();
-    const int lo = g.lo, wlo = g.lo + 2, whi = g.hi - 2;
+    const int wlo = g.lo + 2, whi = g.hi - 2;
     double len = 0;
     for (int row = 0; row < NROW; ++row) {
         const int a = srow[row][0], b = srow[row][1];
@@ -763,7 +762,7 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
                 wy[d] = (ay >= wlo && ay <= whi) ? spline_at(cy, ay, d) : 0.0;
                 wz[d] = (az >= wlo && az <= whi) ? spline_at(cz, az, d) : 0.0;
             }
-            const int lb = ((fcx - lo - x0) * LY + (fcy - lo - y0)) * LZ + (fcz - lo - z0);  // cell (base-1) in tile coordinates
+            const int lb = ((fcx - g.cx0() - x0) * LY + (fcy - g.cy0() - y0)) * LZ + (fcz - g.cz0() - z0);  // cell (base-1) in tile coordinates
             double weight = 0, d0 = 0, d1 = 0, d2 = 0, q0 = 0, q1 = 0, q2 = 0;
 #pragma unroll
             for (int xi = 0; xi < 3; ++xi)
@@ -813,8 +812,9 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
 __device__ __forceinline__ bool is_solid(const Grid& g, const uint8_t* flags, int x, int y, int z)
 {
     // saccessor.getValue outside the filled box -> background 0 -> not solid (fluid.cc:46-57)
-    if (x < g.lo || x > g.hi || y < g.lo || y > g.hi || z < g.lo || z > g.hi) return false;
-    return flags[g.idx(x - g.lo, y - g.lo, z - g.lo)] & F_SOLID;
+    // (a decomposed run: the window's halo ring holds every cell an owned particle can test)
+    if (x < g.cx0() || x > g.cx1() || y < g.cy0() || y > g.cy1() || z < g.cz0() || z > g.cz1()) return false;
+    return flags[g.idx(x - g.cx0(), y - g.cy0(), z - g.cz0())] & F_SOLID;
 }
 
 // fluid.cc:992-1036: new dt from maxSpeed, move, stuck-particle handling with e = 0.
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, long n, Particles p, con
     if (maxSpeed != 0) timestep = max_dt < dx / maxSpeed ? max_dt : dx / maxSpeed;
     else timestep = max_dt;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
+    if (i < n && p.pid[i] != PID_DEAD) {
         const double e = 0;
         double P0 = p.px[i], P1 = p.py[i], P2 = p.pz[i];
         double V0 = p.vx[i], V1 = p.vy[i], V2 = p.vz[i];
@@ -854,32 +854,7 @@ __global__ void k_publish_dt(double max_dt, double dx, StepState* ss)
     ss->dt = (maxSpeed != 0) ? (max_dt < dx / maxSpeed ? max_dt : dx / maxSpeed) : max_dt;
 }
 
-// ---- multi-GPU: neighbour migration and ghost particles ------------------------------------------
-// A particle whose base cell x left the slab [xs,xe) after advect is appended (7 doubles: pos,
-// vel, id) to the send buffer of that side and marked dead; CFL <= 1 cell/step keeps migrants
-// adjacent, and most waves have none, so the append atomics are rare.
-__global__ __launch_bounds__(256) void k_classify_migrate(Grid g, long n, Particles p, int xs, int xe, int has_lo, int has_hi,
-                                                          double* __restrict__ send_lo, double* __restrict__ send_hi, int cap,
-                                                          int* __restrict__ counters)
-{
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (p.pid[i] == PID_DEAD) return;
-    const int bx = (int)round(p.px[i]) - g.lo;
-    int side = -1;
-    if (bx < xs && has_lo) side = 0;
-    else if (bx >= xe && has_hi) side = 1;
-    if (side < 0) return;
-    const int k = atomicAdd(&counters[side], 1);
-    if (k < cap) {
-        double* d = (side ? send_hi : send_lo) + (size_t)k * 7;
-        d[0] = p.px[i]; d[1] = p.py[i]; d[2] = p.pz[i];
-        d[3] = p.vx[i]; d[4] = p.vy[i]; d[5] = p.vz[i];
-        d[6] = (double)p.pid[i];
-    }
-    p.pid[i] = PID_DEAD;  // (on overflow the host reports the error; the count tells)
-}
-
+// ---- multi-GPU: particle records (7 doubles: pos, vel, id) ----------------------------------------------
 // records (7 doubles) -> SoA at p[off + j]
 __global__ __launch_bounds__(256) void k_unpack_records(long n, const double* __restrict__ rec, Particles p, long off)
 {
@@ -1033,11 +1008,6 @@ void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* f
 {
     if (n > 0) hipLaunchKernelGGL(k_advect, dim3(nblk(n)), dim3(256), 0, st, g, n, p, flags, max_dt, dx, ss);
     hipLaunchKernelGGL(k_publish_dt, dim3(1), dim3(1), 0, st, max_dt, dx, ss);
-}
-void launch_classify_migrate(hipStream_t st, Grid g, long n, Particles p, int xs, int xe, int has_lo, int has_hi, double* send_lo,
-                             double* send_hi, int cap, int* counters)
-{
-    if (n > 0) hipLaunchKernelGGL(k_classify_migrate, dim3(nblk(n)), dim3(256), 0, st, g, n, p, xs, xe, has_lo, has_hi, send_lo, send_hi, cap, counters);
 }
 void launch_unpack_records(hipStream_t st, long n, const double* rec, Particles p, long off)
 {

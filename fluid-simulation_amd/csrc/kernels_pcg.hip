@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
         const uint8_t c = cnt[t];
         T rv = 0;
-        if (c) {
+        if (c && !(c & 0x80)) {   // (bit 7: a ring cell of a decomposed run's local box: another rank's unknown)
             const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
             rv = (T)b[g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0)];
             const T z = rv * sinv[c];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const 
         if (c) {  // unknowns are interior cells: all six neighbours exist in both layouts
             const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
             const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
-            const size_t gx = (size_t)g.N * g.N, gy = (size_t)g.N;
+            const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;
             const T bv = (T)b[gc];
             xv = (T)guess[gc];
             const T nb = (cnt[t - sx] ? (T)guess[gc - gx] : (T)0) + (cnt[t + sx] ? (T)guess[gc + gx] : (T)0) +
@@ -205,9 +205,11 @@ __device__ __forceinline__ bool pcg_head(const double* __restrict__ part_rr, con
 // Thread (ly = tid>>5, kz = tid&31) owns the x-column lx = -1..TX of its (y,z): the x
 // neighbours stay in registers, y/z neighbours go through LDS.  All global loads of the tile
 // are issued BEFORE the partial-sum reduction that yields beta, so both latencies overlap.
-// FUSED = false (multi-GPU): s' was formed by k_pcg_s_l and its x ring planes were received from
-// the neighbour ranks; this kernel then only applies the stencil and forms the partial s'.q.
-template <typename T, bool FUSED>
+// DIST (decomposed run): the local box is the rank's owned cells + a halo; the count byte carries bit 7 on the one ring
+// of halo cells next to the owned ones (z and s are valid there, so s' is formed there too and no exchange of s' is
+// needed) and is 0 beyond; q and the partial s'.q are formed on the owned cells only.  The scalars are single
+// all-reduced values (n_prev = n_rz = 1).
+template <typename T, bool DIST>
 __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
                                                   const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
@@ -247,21 +249,21 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
         for (int m = 0; m < TX + 2; ++m) {
             if (counts) fc[m] = cnt[c0 + m * sx];
             if (values) {
-                rv[m] = FUSED ? r[c0 + m * sx] : (T)0;
-                sv[m] = (FUSED && first) ? (T)0 : s_in[c0 + m * sx];
+                rv[m] = r[c0 + m * sx];
+                sv[m] = first ? (T)0 : s_in[c0 + m * sx];
             }
         }
         {   // y halo: one cell per thread
             const int pl = tid >> 6, side = (tid >> 5) & 1;
             const long cy = ((long)(i0 + pl) * L.Ly + (side ? j0 + TY : j0 - 1)) * L.Lz + k0 + kz;
             if (counts) fy = cnt[cy];
-            if (values) { ry = FUSED ? r[cy] : (T)0; sy = (FUSED && first) ? (T)0 : s_in[cy]; }
+            if (values) { ry = r[cy]; sy = first ? (T)0 : s_in[cy]; }
         }
         if (tid < 64) {  // z halo: 64 cells
             const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
             const long cz = ((long)(i0 + lx) * L.Ly + (j0 + l2)) * L.Lz + (side ? k0 + TZ : k0 - 1);
             if (counts) fz = cnt[cz];
-            if (values) { rz = FUSED ? r[cz] : (T)0; sz = (FUSED && first) ? (T)0 : s_in[cz]; }
+            if (values) { rz = r[cz]; sz = first ? (T)0 : s_in[cz]; }
         }
     };
     if (!sparse && tile < ntiles) issue(tile, true, true);
@@ -270,9 +272,7 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     T beta = 0;
     __syncthreads();  // s_done, coef tables
     if (s_done) return;
-    if (FUSED) {
-        if (!pcg_head<T>(part_rr, part_rz_new, part_rz_old, n_prev, n_rz, ps, first, tol, red, beta)) return;
-    }
+    if (!pcg_head<T>(part_rr, part_rz_new, part_rz_old, n_prev, n_rz, ps, first, tol, red, beta)) return;
 
     double acc = 0;
     while (tile < ntiles) {
@@ -290,16 +290,16 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
         // ---- combine -> LDS ---------------------------------------------------------------------
         T val[TX + 2];
 #pragma unroll
-        for (int m = 0; m < TX + 2; ++m) val[m] = FUSED ? (fc[m] ? (zmode ? rv[m] : rv[m] * sinv[fc[m]]) + beta * sv[m] : (T)0) : sv[m];
+        for (int m = 0; m < TX + 2; ++m) val[m] = fc[m] ? (zmode ? rv[m] : rv[m] * sinv[DIST ? fc[m] & 7 : fc[m]]) + beta * sv[m] : (T)0;
 #pragma unroll
         for (int lx = 0; lx < TX; ++lx) sT[(lx * PY + ly + 1) * PZ + kz + 1] = val[lx + 1];
         {
             const int pl = tid >> 6, side = (tid >> 5) & 1;
-            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = FUSED ? (fy ? (zmode ? ry : ry * sinv[fy]) + beta * sy : (T)0) : sy;
+            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = fy ? (zmode ? ry : ry * sinv[DIST ? fy & 7 : fy]) + beta * sy : (T)0;
         }
         if (tid < 64) {
             const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
-            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = FUSED ? (fz ? (zmode ? rz : rz * sinv[fz]) + beta * sz : (T)0) : sz;
+            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = fz ? (zmode ? rz : rz * sinv[DIST ? fz & 7 : fz]) + beta * sz : (T)0;
         }
         __syncthreads();
         const long cc = c0;
@@ -320,11 +320,11 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
         for (int lx = 0; lx < TX; ++lx) {
             const long c = cc + (lx + 1) * sx;
             T qv = 0;
-            if (fcc[lx]) {
+            if (DIST ? (fcc[lx] && !(fcc[lx] & 0x80)) : (fcc[lx] != 0)) {
                 qv = sdiag[fcc[lx]] * cen[lx] + cf.off * nbv[lx];
                 acc += (double)cen[lx] * (double)qv;
             }
-            if (FUSED) s_out[c] = cen[lx];
+            s_out[c] = cen[lx];
             q[c] = qv;
         }
         tile = next;
@@ -333,49 +333,10 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     if (tid == 0) part_pq[blockIdx.x] = acc;
 }
 
-// S (multi-GPU): s' = invdiag r + beta s, pointwise over the local box (flat, 16-byte vectors).
 template <typename T>
 struct alignas(2 * sizeof(T)) Vec2 {
     T a, b;
 };
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_s_l(long n2, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
-                                                 const T* __restrict__ s_in, T* __restrict__ s_out, Coef<T> cf,
-                                                 const double* __restrict__ g_rr, const double* __restrict__ g_rz_new,
-                                                 const double* __restrict__ g_rz_old, PcgState* ps, int first, double tol, int zmode)
-{
-    // zmode: `r` already holds z = M^-1 r (per-slab multigrid preconditioner)
-    __shared__ double red[16];
-    __shared__ int s_done;
-    __shared__ T sdiag[8], sinv[8];
-    load_coef(sdiag, sinv, cf);
-    if (threadIdx.x == 0) s_done = ps->done;
-    __syncthreads();
-    if (s_done) return;
-    T beta;
-    if (!pcg_head<T>(g_rr, g_rz_new, g_rz_old, 1, 1, ps, first, tol, red, beta)) return;
-    typedef Vec2<T> V2;
-    const V2* r2 = (const V2*)r;
-    const V2* s2 = (const V2*)s_in;
-    const uint16_t* c2 = (const uint16_t*)cnt;
-    const long nth = (long)gridDim.x * 256;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n2; e += nth) {
-        const uint16_t c = c2[e];
-        const int ca = c & 0xff, cb = c >> 8;
-        V2 o;
-        o.a = 0; o.b = 0;
-        if (c) {
-            const V2 rv = r2[e];
-            V2 sv;
-            sv.a = 0; sv.b = 0;
-            if (!first) sv = s2[e];
-            if (ca) o.a = (zmode ? rv.a : rv.a * sinv[ca]) + beta * sv.a;
-            if (cb) o.b = (zmode ? rv.b : rv.b * sinv[cb]) + beta * sv.b;
-        }
-        ((V2*)s_out)[e] = o;
-    }
-}
 
 // out_a[0] = sum a[0..na), out_b[0] = sum b[0..nb)   (one block; fixed order)
 __global__ __launch_bounds__(256) void k_sum2(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
@@ -397,8 +358,9 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
                                                   const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rz_cur, int n_xr, const double* __restrict__ part_pq,
                                                   int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps,
-                                                  int sparse)
+                                                  int sparse, int dist)
 {
+    // dist (decomposed run): count bytes with bit 7 are the ring cells of the local box (another rank's unknowns): skipped
     // sparse (box mostly air): the four vector loads of a pair are issued only if it holds an unknown — one dependent
     // load more on the critical path, a fraction of the traffic; dense boxes keep the unconditional loads
     __shared__ double red[16];
@@ -449,7 +411,8 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
         for (int u = 0; u < U; ++u) {
             const long e = i + u * 256;
             if (cv[u]) {
-                const int ca = cv[u] & 0xff, cb = cv[u] >> 8;
+                int ca = cv[u] & 0xff, cb = cv[u] >> 8;
+                if (dist) { ca = (ca & 0x80) ? 0 : ca; cb = (cb & 0x80) ? 0 : cb; }
                 V2 xo = xv[u], ro = rv[u];
                 if (ca) {
                     xo.a = xo.a + alpha * sv[u].a;
@@ -602,7 +565,7 @@ __global__ __launch_bounds__(256) void k_store_pressure_l(Grid g, LBox L, const 
     const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
     if (i >= 1 && i <= L.nx && j >= 1 && j <= L.ny && k >= LBOX_K0 && k < LBOX_K0 + L.nz) {
         const bool zero = keep && !(ps->bb > 0);
-        const double pv = cnt[t] && !zero ? (double)x[t] : 0.0;
+        const double pv = cnt[t] && !(cnt[t] & 0x80) && !zero ? (double)x[t] : 0.0;
         const size_t c = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
         pressure[c] = pv;
         if (keep) keep[c] = pv;
@@ -631,29 +594,24 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
                    double tol, int n_rz, int zmode, int sparse)
 {
     const int nx = pcg_xr_blocks(L);
-    hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
+    hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
                        part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode, sparse, (const int*)nullptr, 0);
 }
-// multi-GPU pieces: n_* = 1 means "already all-reduced scalar"
+// decomposed run: g_* = single all-reduced scalars; cnt carries the ring bit (k_cnt_pcg); writes pcg_sq_blocks(L) partials of s'.q
 template <typename T>
-void launch_pcg_s(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, Coef<T> cf, const double* g_rr,
-                  const double* g_rz_new, const double* g_rz_old, PcgState* ps, int first, double tol, int zmode)
+void launch_pcg_sq_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf, const double* g_rr,
+                        const double* g_rz_new, const double* g_rz_old, double* part_pq, PcgState* ps, int first, double tol, int zmode)
 {
-    hipLaunchKernelGGL((k_pcg_s_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, r, s_in, s_out, cf, g_rr,
-                       g_rz_new, g_rz_old, ps, first, tol, zmode);
+    hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, g_rr, g_rz_new, g_rz_old,
+                       part_pq, 1, ps, first, tol, 1, zmode, 0, (const int*)nullptr, 0);
 }
+// ... and x += alpha s, r -= alpha q on the owned cells with alpha = g_rz / g_pq; writes pcg_xr_blocks(L) partials of |r|^2 (and r.invdiag r)
 template <typename T>
-void launch_pcg_q(hipStream_t st, LBox L, const uint8_t* cnt, const T* s, T* q, Coef<T> cf, double* part_pq, PcgState* ps)
-{
-    hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, (const T*)nullptr, s, (T*)nullptr, q, cf,
-                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_pq, 0, ps, 0, 0.0, 0, 0, 0, (const int*)nullptr, 0);
-}
-template <typename T>
-void launch_pcg_xr_g(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
-                     const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps)
+void launch_pcg_xr_dist(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
+                        const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps)
 {
     hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, g_rz_cur, 1,
-                       g_pq, 1, part_rr, part_rz_next, ps, 0);
+                       g_pq, 1, part_rr, part_rz_next, ps, 0, 1);
 }
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b)
 {
@@ -664,7 +622,7 @@ void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz, int sparse)
 {
     hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
-                       n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, sparse);
+                       n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, sparse, 0);
 }
 
 int sq_tile_count(const LBox& L) { return sq_tiles(L); }
@@ -683,7 +641,7 @@ void launch_pcg_sq_list(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, 
                         const double* part_rr, int n_prev, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps,
                         int first, double tol, int n_rz, int zmode, const int* tlist, int nlist)
 {
-    hipLaunchKernelGGL((k_pcg_sq_l<T, true>), dim3(pcg_list_blocks(nlist)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
+    hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_list_blocks(nlist)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
                        part_rz_new, part_rz_old, part_pq, n_prev, ps, first, tol, n_rz, zmode, 0, tlist, nlist);
 }
 template <typename T>
@@ -947,11 +905,10 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*, double*, const PcgState*);      \
     template void launch_pcg_init_guess<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, const double*, T*, T*, Coef<T>,      \
                                            double*, double*, PcgState*);                                                               \
-    template void launch_pcg_s<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, Coef<T>, const double*, const double*,     \
-                                  const double*, PcgState*, int, double, int);                                                           \
-    template void launch_pcg_q<T>(hipStream_t, LBox, const uint8_t*, const T*, T*, Coef<T>, double*, PcgState*);                        \
-    template void launch_pcg_xr_g<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,             \
-                                     const double*, double*, double*, PcgState*);
+    template void launch_pcg_sq_dist<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
+                                        const double*, double*, PcgState*, int, double, int);                                            \
+    template void launch_pcg_xr_dist<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,          \
+                                        const double*, double*, double*, PcgState*);
 INST(double)
 INST(float)
 

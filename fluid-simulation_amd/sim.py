@@ -70,7 +70,13 @@ class FluidSim:
             if k == "gravity":
                 p.gravity[0], p.gravity[1], p.gravity[2] = v
             elif k == "preconditioner":
-                p.reserved = {"mg": 0, "jacobi": 1}[v]   # FLUID_PRECOND_*
+                p.preconditioner = {"mg": 0, "jacobi": 1}[v]
+            elif k == "solve_start":
+                p.solve_start = {"warm": 0, "zero": 1}[v]
+            elif k == "mg_precision":
+                p.mg_precision = {"fp32": 0, "fp64": 1}[v]
+            elif k == "dist_solve":
+                p.dist_solve = {"auto": 0, "decomposed": 1, "replicated": 2}[v]
             elif hasattr(p, k):
                 setattr(p, k, v)
             else:

@@ -56,9 +56,23 @@ typedef struct fluid_sim fluid_sim_t;
 #define FLUID_PRECISION_FP64 0    /* fp64 PCG vectors (reference arithmetic: Eigen VectorXd)          */
 #define FLUID_PRECISION_FP32 1    /* fp32 PCG vectors (stencil micro-benchmark / experiments only)    */
 
-/* preconditioner of the PCG (fluid_params.reserved); the reference uses Eigen IncompleteCholesky */
+/* preconditioner of the PCG (fluid_params.preconditioner); the reference uses Eigen IncompleteCholesky */
 #define FLUID_PRECOND_MG 0        /* geometric multigrid V(2,2) cycle; iteration count independent of N  */
-#define FLUID_PRECOND_JACOBI 1    /* Eigen DiagonalPreconditioner arithmetic; used by the multi-GPU path  */
+#define FLUID_PRECOND_JACOBI 1    /* Eigen DiagonalPreconditioner arithmetic, iteration-for-iteration Eigen's Jacobi CG */
+
+/* start of every pressure solve (fluid_params.solve_start) */
+#define FLUID_START_WARM 0        /* x0 = the previous solve's pressure (Eigen's solveWithGuess form of the same loop;
+                                     the converged p is the same within cg_tol, cg_iters is NOT the reference's count) */
+#define FLUID_START_ZERO 1        /* x0 = 0 like the reference's cg.solve(b), fluid.cc:1474: cg_iters comparable        */
+
+/* arithmetic of the multigrid V-cycle inside the fp64 PCG (fluid_params.mg_precision) */
+#define FLUID_MG_FP32 0           /* float cycle (default: M^-1 only has to be a fixed SPD operator)     */
+#define FLUID_MG_FP64 1           /* double cycle                                                        */
+
+/* multi-GPU pressure block (fluid_params.dist_solve; fluid_create_dist only) */
+#define FLUID_DIST_AUTO 0         /* decomposed solve when the active box is large, replicated otherwise */
+#define FLUID_DIST_DECOMPOSED 1   /* domain-decomposed PCG with the globally coupled V-cycle             */
+#define FLUID_DIST_REPLICATED 2   /* P2G fields all-reduced, the pressure block solved on every rank     */
 
 typedef struct fluid_params {
     int32_t n;                /* cells per axis                         fluid.cc:1159 (121)      */
@@ -73,10 +87,14 @@ typedef struct fluid_params {
     int32_t cg_max_iters;     /* 0 = 2*numActive                        IterativeSolverBase.h:362 */
     int32_t max_outer_passes; /* 0 = unlimited (reference)                                       */
     int32_t precision;        /* FLUID_PRECISION_*                                               */
-    int32_t reserved;         /* preconditioner: 0 = multigrid V-cycle (fp64, one GPU), 1 = Jacobi           */
+    int32_t preconditioner;   /* FLUID_PRECOND_*                                                  */
     double flip_blend;        /* 1 = pure FLIP (the reference, fluid.cc:981); b < 1 blends in the PIC gather of
                                  the reference's unused clampedCatmullRom (fluid.cc:125-207):
                                  v' = b (v + delta) + (1-b) v_pic.  Build extension.      */
+    int32_t solve_start;      /* FLUID_START_*                                                   */
+    int32_t mg_precision;     /* FLUID_MG_*                                                      */
+    int32_t dist_solve;       /* FLUID_DIST_*                                                    */
+    int32_t pad_;             /* must be 0                                                       */
 } fluid_params_t;
 
 typedef struct fluid_step_stats {
@@ -183,37 +201,53 @@ int fluid_profile_enable(fluid_sim_t* s, int sample_every);
 int fluid_profile_read(fluid_sim_t* s, int klass, int64_t* n_launches, int64_t* n_sampled, double* total_ms, double* cells);
 int fluid_profile_reset(fluid_sim_t* s);
 
-/* ---- multi-GPU: x-slab domain decomposition (one process per GPU) ------------------------- */
-/* The reference is single-process (no communication backend); this is new design.
- * Rank r owns the x planes [bounds[r], bounds[r+1]); every rank keeps full-size field arrays and
- * computes only its slab (+1-plane halos at their global index).  Exchanges per step: ghost
- * particles and cell counts of the boundary planes (P2G), boundary planes of container/velocity/
- * pressure/FLIP-delta, per PCG iteration one plane of the search vector each way plus two
- * scalar all-reduces, max-speed all-reduce, neighbour particle migration.
+/* ---- multi-GPU: 3-D block decomposition (one process per GPU) --------------------------------
+ * The reference is single-process (no communication backend); this is new design
+ * (SURVEY.md 8e).  The grid is cut into dims[0] x dims[1] x dims[2] blocks by per-axis cut planes;
+ * rank r owns block (bx, by, bz) = (r / (dims[1] dims[2]), (r / dims[2]) % dims[1], r % dims[2]):
+ * its cells, and the particles whose base cell (round(pos), fluid.cc:267) lies in it.
  *
- * Transport is supplied by the caller (RCCL through torch.distributed in bench.py; gloo in the
- * tests; a C++ host would pass ncclSend/ncclRecv/ncclAllReduce wrappers).  All pointers are
- * DEVICE pointers; calls must be ordered after prior work on `stream` and complete (or be
- * stream-ordered) before later work on it.  Return 0 on success. */
+ *   decomposed solve   a rank's field arrays cover its block + a 4-cell halo ring only (the
+ *                      "window").  Per step: particle migration and ghost particles with the
+ *                      <= 26 adjacent blocks, halo exchanges of flags / velocity / pressure /
+ *                      FLIP delta, the unknown numbering from all-reduced row counts, and a
+ *                      domain-decomposed PCG whose multigrid V-cycle is globally coupled: halo
+ *                      exchanges of the residual and of the coarse correction inside the two
+ *                      finest levels, the coarser levels gathered (one all-reduce) and solved
+ *                      redundantly on every rank — the same cycle as on one GPU, so the
+ *                      iteration count does not grow with the number of blocks.
+ *   replicated solve   particles sharded the same way, but every rank keeps full-size arrays;
+ *                      the P2G result of the active box is assembled on every rank by one SUM
+ *                      all-reduce and the pressure block runs identically everywhere (bit-identical
+ *                      to the one-GPU step; fallback for boxes too small to be worth exchanging).
+ *
+ * Transport is supplied by the caller (RCCL inside the library: fluid_rccl_comm_create; gloo in
+ * the tests: the Python callbacks; an in-process transport for several blocks per process:
+ * fluid_local_comm_create).  All pointers are DEVICE pointers; calls must be ordered after prior
+ * work on `stream` and complete (or be stream-ordered) before later work on it.  Return 0 on
+ * success.  Every rank makes the same sequence of allreduce calls; exchange calls are matched
+ * pairwise (rank a lists peer b with the byte counts b lists for a, in both directions). */
 #define FLUID_DT_F64 0
 #define FLUID_DT_I32 1
 #define FLUID_DT_I64 2
+#define FLUID_DT_F32 3
+#define FLUID_DT_U8 4
 #define FLUID_OP_SUM 0
 #define FLUID_OP_MAX 1
 #define FLUID_OP_MIN 2
+#define FLUID_MAX_RANKS 64
 typedef struct fluid_comm {
     int32_t rank, size;
     void* ctx;
-    /* Send send_lo[0..nlo_send) bytes to rank-1 and send_hi to rank+1; receive nlo_recv bytes from
-     * rank-1 into recv_lo and nhi_recv bytes from rank+1 into recv_hi.  A missing neighbour
-     * (rank 0 / size-1) has its sizes passed as 0.  Sizes are known to both sides. */
-    int (*sendrecv)(void* ctx, const void* send_lo, size_t nlo_send, void* recv_lo, size_t nlo_recv,
-                    const void* send_hi, size_t nhi_send, void* recv_hi, size_t nhi_recv, void* stream);
+    /* Neighbour exchange: for i < n send sbytes[i] bytes from sbuf[i] to rank peer[i] and receive
+     * rbytes[i] bytes from the same rank into rbuf[i] (either count may be 0).  Peers are distinct. */
+    int (*exchange)(void* ctx, int32_t n, const int32_t* peer, const void* const* sbuf, const size_t* sbytes,
+                    void* const* rbuf, const size_t* rbytes, void* stream);
     /* In-place all-reduce of `count` elements of dtype FLUID_DT_* with FLUID_OP_*. */
-    int (*allreduce)(void* ctx, void* buf, int32_t count, int32_t dtype, int32_t op, void* stream);
+    int (*allreduce)(void* ctx, void* buf, int64_t count, int32_t dtype, int32_t op, void* stream);
 } fluid_comm_t;
 
-/* Native transport: fluid_comm_t over RCCL (ncclSend/ncclRecv/ncclAllReduce on the solver's stream).
+/* Native transport: fluid_comm_t over RCCL (grouped ncclSend/ncclRecv, ncclAllReduce on the solver's stream).
  * librccl_path: the librccl.so to dlopen ("" = by name); id128: ncclUniqueId made by rank 0 with
  * fluid_rccl_unique_id and handed to the other ranks by the launcher.  Binds to the current HIP device. */
 int fluid_rccl_unique_id(const char* librccl_path, void* id128);
@@ -221,16 +255,35 @@ int fluid_rccl_comm_create(const char* librccl_path, const void* id128, int32_t 
 int fluid_rccl_comm_destroy(fluid_comm_t* comm);
 const char* fluid_rccl_last_error(void);
 
-/* Like fluid_create, for rank comm->rank of comm->size.  bounds[size+1]: bounds[0]=0,
- * bounds[size]=n, strictly increasing (every slab >= 1 plane; >= 3 recommended). */
-int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const int32_t* bounds, fluid_sim_t** out);
-/* Upload THIS rank's particles (base cell x inside its slab) with their global ids (unique
+/* In-process transport: `size` handles driven by `size` host threads of ONE process (several blocks per GPU: the
+ * tests run 2 x 2 x 2 blocks on the one GPU of their box this way; a host that drives several GPUs from one
+ * process can use it too).  Device-to-device copies between the handles' buffers, host-side rendezvous. */
+int fluid_local_group_create(int32_t size, void** group);
+int fluid_local_group_destroy(void* group);
+/* Wakes every rank waiting inside the transport with an error: the driver thread of a rank that failed elsewhere calls it. */
+int fluid_local_group_abort(void* group);
+int fluid_local_comm_create(void* group, int32_t rank, fluid_comm_t* out);
+
+typedef struct fluid_decomp {
+    int32_t dims[3];          /* blocks per axis; dims[0]*dims[1]*dims[2] == comm->size                        */
+    const int32_t* cuts[3];   /* cuts[a][0..dims[a]]: cuts[a][0] = 0, cuts[a][dims[a]] = n, ascending; interior
+                                 cuts are multiples of 4 and every block is >= 8 cells wide (the coupled V-cycle
+                                 coarsens 2 x 2 x 2 twice across block faces)                                  */
+} fluid_decomp_t;
+/* Like fluid_create, for rank comm->rank of comm->size. */
+int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const fluid_decomp_t* decomp, fluid_sim_t** out);
+/* Geometry of this handle's arrays in a decomposed run (one GPU: the whole grid): global index of the window's first
+ * cell, window dims (the shape of fluid_download_field's arrays), owned block [own_lo, own_hi) in global indices. */
+int fluid_window(fluid_sim_t* s, int32_t origin[3], int32_t dims[3], int32_t own_lo[3], int32_t own_hi[3]);
+/* Upload THIS rank's particles (base cell inside its block) with their global ids (unique
  * across ranks; the order of fluid_download_particles_ids is the device order). */
 int fluid_upload_particles_ids(fluid_sim_t* s, int64_t n, const double* pos, const double* vel, const uint32_t* ids);
 /* This rank's current particles and ids; call with NULLs to get the count. */
 int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, uint32_t* ids);
-/* Equal-count split of the x planes for `size` ranks from a host particle set (host-only). */
-int fluid_partition_by_count(int32_t n, int64_t np, const double* pos, int32_t size, int32_t* bounds);
+/* Cut planes for dims[0] x dims[1] x dims[2] blocks of about equal particle count per axis slab, from a host
+ * particle set (host-only); cuts[a] receives dims[a]+1 values that satisfy fluid_decomp's rules. */
+int fluid_partition_blocks(int32_t n, int64_t np, const double* pos, const int32_t dims[3], int32_t* cuts_x, int32_t* cuts_y,
+                           int32_t* cuts_z);
 
 /* ---- OpenVDB file output (replaces file2.write(grids2), fluid.cc:1503-1504,1508) ----------
  * Writes n_grids dense float32 N^3 arrays (z fastest, cell (0,0,0) = index coordinate (lo,lo,lo), lo = -(N/2)) as

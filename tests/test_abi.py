@@ -47,18 +47,6 @@ def test_scene_generator(fs):
     assert (lo, hi) == (-60, 60) and fs.grid_bounds(128) == (-64, 63)
 
 
-def test_partition_by_count(fs):
-    fd = fs.load_dist()
-    pos = fs.water_cube_drop(64, 4, 0)
-    for size in (1, 2, 3, 8):
-        b = fd.partition_by_count(64, pos, size)
-        assert b[0] == 0 and b[-1] == 64 and all(b[i] < b[i + 1] for i in range(size))
-    b = fd.partition_by_count(64, pos, 2)
-    bx = np.floor(np.abs(pos[:, 0]) + 0.5) * np.sign(pos[:, 0]) + 32
-    left = (bx < b[1]).sum()
-    assert abs(left - len(pos) / 2) <= len(pos) * 0.15
-
-
 def test_no_gpu_means_loud_failure(fs):
     import torch
     if torch.cuda.is_available():

@@ -1,9 +1,10 @@
 """CPU (-m "not gpu"): the multi-rank protocol with world_size 2 and 3 over gloo, no GPU.
 
 The transport callbacks of fluid_comm_t (fluid-simulation_amd/dist.py TorchComm, mode "host") are
-driven exactly as the C++ host drives them in its distributed PCG (one plane each way per
+driven as the C++ host drives them in its distributed PCG (one grouped neighbour exchange per
 iteration + scalar all-reduces), on an x-slab decomposed 7-point Poisson problem in numpy, and
-the result is compared with the undivided solve."""
+the result is compared with the undivided solve.  The geometry of the 3-D block decomposition
+(cuts, block of a rank, default dims) is checked on the host as well."""
 import os
 import subprocess
 import sys
@@ -29,10 +30,14 @@ bounds = [round(n * r / world) for r in range(world + 1)]
 xs, xe = bounds[rank], bounds[rank + 1]
 nx = xe - xs
 def P(a): return a.ctypes.data_as(C.c_void_p).value
-def ring(s):   # s: (nx+2, n, n) with ring planes 0 and nx+1
+def ring(s):   # s: (nx+2, n, n) with ring planes 0 and nx+1: one exchange call with both neighbours
     pb = s[0].nbytes
-    rc = comm._sendrecv(None, P(s[1]), pb if rank > 0 else 0, P(s[0]), pb if rank > 0 else 0,
-                        P(s[nx]), pb if rank < world - 1 else 0, P(s[nx + 1]), pb if rank < world - 1 else 0, None)
+    peers, sb, rb = [], [], []
+    if rank > 0: peers.append(rank - 1); sb.append(P(s[1])); rb.append(P(s[0]))
+    if rank < world - 1: peers.append(rank + 1); sb.append(P(s[nx])); rb.append(P(s[nx + 1]))
+    k = len(peers)
+    rc = comm._exchange(None, k, (C.c_int32 * k)(*peers), (C.c_void_p * k)(*sb), (C.c_size_t * k)(*([pb] * k)),
+                        (C.c_void_p * k)(*rb), (C.c_size_t * k)(*([pb] * k)), None)
     assert rc == 0, comm.error
 def allsum(v):
     a = np.array(v, dtype=np.float64)
@@ -87,3 +92,22 @@ def test_slab_protocol_over_gloo(tmp_path, world):
     sp = np.pad(x, 1)
     Ax = 6.5 * x - (sp[:-2, 1:-1, 1:-1] + sp[2:, 1:-1, 1:-1] + sp[1:-1, :-2, 1:-1] + sp[1:-1, 2:, 1:-1] + sp[1:-1, 1:-1, :-2] + sp[1:-1, 1:-1, 2:])
     assert np.linalg.norm(Ax - b) / np.linalg.norm(b) < 1e-10
+
+
+def test_block_partition_rules(fs):
+    fd = fs.load_dist()
+    assert fd.default_dims(8) == [2, 2, 2] and fd.default_dims(4) == [2, 2, 1] and fd.default_dims(2) == [2, 1, 1]
+    assert fd.default_dims(6) == [3, 2, 1] and fd.default_dims(1) == [1, 1, 1]
+    pos = fs.water_cube_drop(64, 4, 0)
+    for dims in ([2, 1, 1], [2, 2, 2], [3, 1, 1], [1, 2, 2]):
+        cuts = fd.partition_blocks(64, pos, dims)
+        for a in range(3):
+            c = cuts[a]
+            assert c[0] == 0 and c[-1] == 64 and len(c) == dims[a] + 1
+            assert all(c[i + 1] - c[i] >= 8 for i in range(dims[a])) or dims[a] == 1
+            assert all(v % 4 == 0 for v in c[1:-1])
+    # the cube is centred: two slabs split it near the middle
+    c = fd.partition_blocks(64, pos, [2, 1, 1])[0]
+    assert 28 <= c[1] <= 36
+    with pytest.raises(fs.FluidError):
+        fd.partition_blocks(16, pos, [4, 1, 1])   # blocks of < 8 cells

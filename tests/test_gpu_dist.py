@@ -1,5 +1,9 @@
-"""-m gpu: the x-slab decomposed step (2 and 3 ranks sharing the one GPU of the box, gloo + host
-staging as transport) against the single-GPU step on the same input."""
+"""-m gpu: the 3-D block decomposed step against the single-GPU step on the same input.
+
+Blocks run as host threads of this process over the in-process transport (2 x 2 x 2 on the one GPU of the box: the box
+allows few processes per card), plus 2 / 3 ranks as separate processes over gloo (torch transport, staged through the host)
+and 1 rank over both RCCL transports.  Integer work (unknown numbering across blocks, outer passes) must be bit-exact;
+the decomposed solve runs the globally coupled V-cycle, so its iteration counts must stay close to the one-GPU counts."""
 import os
 import subprocess
 import sys
@@ -10,6 +14,150 @@ import pytest
 from conftest import rel_l2, ROOT
 
 pytestmark = pytest.mark.gpu
+
+
+def scene(fs, n, ppc, vel=0.0, pile=0):
+    pos = fs.water_cube_drop(n, ppc, seed=0)
+    if pile:  # one cell past the P2G form switch: every rank must take the tile form, like the single GPU does
+        pos = np.concatenate([pos, np.round(pos[0]) + np.random.default_rng(5).uniform(-0.4, 0.4, size=(pile, 3))])
+    v = None
+    if vel:
+        v = np.random.default_rng(1).standard_normal(pos.shape) * vel
+    return pos, v
+
+
+def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, **kw):
+    """dims[0] x dims[1] x dims[2] blocks as threads of this process; returns the assembled result."""
+    fd = fs.load_dist()
+    size = dims[0] * dims[1] * dims[2]
+    cuts = fd.uniform_cuts(n, dims) if uniform else fd.partition_blocks(n, pos, dims)
+    grp = fd.LocalGroup(size)
+    F = fs.FIELD
+    sims = [None] * size
+
+    def work(r):
+        sim = fd.DistFluidSim(n, dims, cuts, grp.comms[r], dist_solve=mode, **kw)
+        sims[r] = sim
+        sim.upload_global(pos, vel)
+        st = [sim.step() for _ in range(steps)]
+        p, v, ids = sim.download_local()
+        return dict(st=st, p=p, v=v, ids=ids, idx=sim.field(F.INDICES), cont=sim.field(F.CONTAINER), pres=sim.field(F.PRESSURE),
+                    vel=sim.field(F.VEL))
+
+    try:
+        res = grp.run(work)
+    finally:
+        for s in sims:
+            if s is not None:
+                s.close()
+        grp.close()
+    ids = np.concatenate([r["ids"] for r in res])
+    o = np.argsort(ids)
+    out = dict(ids=ids[o], pos=np.concatenate([r["p"] for r in res])[o], vel=np.concatenate([r["v"] for r in res])[o],
+               st=res[0]["st"], all_st=[r["st"] for r in res], cuts=cuts, counts=[len(r["ids"]) for r in res])
+    for k, key in (("indices", "idx"), ("container", "cont"), ("pressure", "pres"), ("velgrid", "vel")):
+        out[k] = fd.assemble(n, sims, [r[key] for r in res])
+    return out
+
+
+def single(fs, n, pos, vel, steps, **kw):
+    sim = fs.FluidSim(n=n, **kw)
+    sim.upload_particles(pos, vel)
+    st = [sim.step() for _ in range(steps)]
+    p, v = sim.download_particles()
+    F = fs.FIELD
+    out = dict(st=st, pos=p, vel=v, indices=sim.field(F.INDICES), container=sim.field(F.CONTAINER), pressure=sim.field(F.PRESSURE),
+               velgrid=sim.field(F.VEL))
+    sim.close()
+    return out
+
+
+def compare(d, ref, npart, label, tol_p=1e-9, tol_v=1e-7, tol_pr=1e-8):
+    st, rs = d["st"], ref["st"]
+    # every rank reports the same global scalars
+    for other in d["all_st"]:
+        assert [s["num_active"] for s in other] == [s["num_active"] for s in st]
+        assert [s["cg_iters"] for s in other] == [s["cg_iters"] for s in st]
+        assert [s["outer_passes"] for s in other] == [s["outer_passes"] for s in st]
+    # integer work: bit-exact, including the global unknown numbering across blocks
+    assert [s["num_active"] for s in st] == [s["num_active"] for s in rs]
+    assert [s["outer_passes"] for s in st] == [s["outer_passes"] for s in rs]
+    assert np.array_equal(d["indices"], ref["indices"])
+    assert len(d["ids"]) == npart and np.array_equal(d["ids"], np.arange(npart))
+    # P2G sums have the same order on both paths
+    assert rel_l2(d["container"], ref["container"]) < 1e-12
+    ep, ev = rel_l2(d["pos"], ref["pos"]), rel_l2(d["vel"], ref["vel"])
+    epr = rel_l2(d["pressure"], ref["pressure"])
+    print(f"{label}: cuts={d['cuts']} counts={d['counts']} pos {ep:.2e} vel {ev:.2e} pressure {epr:.2e} "
+          f"iters {[s['cg_iters'] for s in st]} vs {[s['cg_iters'] for s in rs]} passes {[s['outer_passes'] for s in st]}")
+    assert ep < tol_p and ev < tol_v and epr < tol_pr
+    assert rel_l2(d["velgrid"], ref["velgrid"]) < 1e-8
+    assert np.allclose([s["dt_out"] for s in st], [s["dt_out"] for s in rs], rtol=1e-9)
+    return st, rs
+
+
+CASES = [
+    # dims, n, ppc, steps, scene kw, sim kw
+    ((2, 1, 1), 32, 4, 4, {}, {}),
+    ((1, 1, 2), 32, 4, 4, {}, {}),
+    ((3, 1, 1), 40, 4, 3, {}, {}),
+    ((2, 2, 1), 40, 4, 3, {"vel": 1.0}, {}),
+    ((2, 2, 2), 48, 4, 4, {"vel": 2.0}, {}),
+    ((2, 2, 2), 40, 4, 3, {"vel": 1.0}, {"flip_blend": 0.9}),
+    ((2, 1, 1), 32, 4, 3, {"pile": 600}, {}),
+]
+
+
+@pytest.mark.parametrize("mode", ["decomposed", "replicated"])
+@pytest.mark.parametrize("dims,n,ppc,steps,skw,kw", CASES)
+def test_blocks_match_single(fs, mode, dims, n, ppc, steps, skw, kw):
+    pos, vel = scene(fs, n, ppc, **skw)
+    # the decomposed PCG starts every solve from x0 = 0: compare with the one-GPU run that does the same
+    ref = single(fs, n, pos, vel, steps, solve_start="zero" if mode == "decomposed" else "warm", **kw)
+    d = run_blocks(fs, dims, n, pos, vel, steps, mode, **kw)
+    st, rs = compare(d, ref, len(pos), f"{mode} {dims} n={n}")
+    if mode == "replicated":
+        # the same arithmetic on every rank as on one GPU
+        assert rel_l2(d["pos"], ref["pos"]) < 1e-14 and [s["cg_iters"] for s in st] == [s["cg_iters"] for s in rs]
+    else:
+        # globally coupled V-cycle: the iteration count must not grow with the number of blocks (another hierarchy
+        # anchoring than the one-GPU run: a few iterations either way)
+        a, b = sum(s["cg_iters"] for s in st), sum(s["cg_iters"] for s in rs)
+        assert a <= 1.2 * b + 2 * sum(s["outer_passes"] for s in rs), (a, b)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_decomposed_levels_on_blocks(fs, split, monkeypatch):
+    """Both forms of the coupled V-cycle: level 1 gathered (split 1) and level 1 on the blocks with halo exchanges (split 2)."""
+    monkeypatch.setenv("FLUID_DIST_SPLIT", str(split))
+    n, ppc, steps = 64, 4, 3
+    pos, vel = scene(fs, n, ppc, vel=1.0)
+    ref = single(fs, n, pos, vel, steps, solve_start="zero")
+    d = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed")
+    st, rs = compare(d, ref, len(pos), f"split {split}")
+    a, b = sum(s["cg_iters"] for s in st), sum(s["cg_iters"] for s in rs)
+    assert a <= 1.2 * b + 2 * sum(s["outer_passes"] for s in rs), (a, b)
+
+
+def test_decomposed_jacobi_and_uniform_cuts(fs):
+    """Eigen's diagonal preconditioner over the blocks: iteration for iteration the one-GPU Jacobi PCG (the sums differ by rounding only)."""
+    n, ppc, steps = 32, 4, 2
+    pos, vel = scene(fs, n, ppc)
+    ref = single(fs, n, pos, vel, steps, preconditioner="jacobi")
+    d = run_blocks(fs, (2, 2, 1), n, pos, vel, steps, "decomposed", uniform=True, preconditioner="jacobi")
+    st, rs = compare(d, ref, len(pos), "jacobi 2x2x1")
+    assert all(abs(a["cg_iters"] - b["cg_iters"]) <= 2 * b["outer_passes"] for a, b in zip(st, rs))
+
+
+def test_block_empties_and_fills(fs):
+    """A block that holds no particle at first (uniform cuts, the cube in one corner region) and receives them as the fluid falls."""
+    n, steps = 48, 12
+    pos, _ = scene(fs, n, 4)
+    pos = pos + np.array([6.0, 9.0, 0.0])        # off-centre: the low-y blocks start empty
+    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    d = run_blocks(fs, (1, 2, 2), n, pos, None, steps, "decomposed", uniform=True)
+    assert min(d["counts"]) >= 0
+    compare(d, ref, len(pos), "fills", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
 
 
 def run_dist(world, n, ppc, steps, tmp_path, extra=(), mode="staged"):
@@ -24,38 +172,19 @@ def run_dist(world, n, ppc, steps, tmp_path, extra=(), mode="staged"):
     return np.load(out)
 
 
-@pytest.mark.parametrize("world,n,ppc,steps,extra", [(2, 32, 4, 4, ()), (3, 40, 4, 3, ()), (2, 32, 4, 6, ("--uniform", "--vel", "3.0")),
-                                                    (2, 32, 4, 4, ("--vel", "1.0", "--blend", "0.9")),
-                                                    (2, 32, 4, 3, ("--pile", "600"))])
-def test_dist_matches_single(fs, tmp_path, world, n, ppc, steps, extra):
-    d = run_dist(world, n, ppc, steps, tmp_path, extra)
-    pos = fs.water_cube_drop(n, ppc, seed=0)
-    if "--pile" in extra:  # one cell past the P2G form switch: every rank must take the tile form, like the single GPU does
-        k = int(extra[extra.index("--pile") + 1])
-        pos = np.concatenate([pos, np.round(pos[0]) + np.random.default_rng(5).uniform(-0.4, 0.4, size=(k, 3))])
-    vel = None
-    if "--vel" in extra:
-        vel = np.random.default_rng(1).standard_normal(pos.shape) * float(extra[extra.index("--vel") + 1])
-    blend = float(extra[extra.index("--blend") + 1]) if "--blend" in extra else 1.0
-    sim = fs.FluidSim(n=n, flip_blend=blend)
-    sim.upload_particles(pos, vel)
-    st = [sim.step() for _ in range(steps)]
-    p, v = sim.download_particles()
-    F = fs.FIELD
-    # integer work: bit-exact, including the global unknown numbering across ranks
-    assert list(d["num_active"]) == [s["num_active"] for s in st]
-    assert list(d["outer"]) == [s["outer_passes"] for s in st]
-    assert np.array_equal(d["indices"], sim.field(F.INDICES))
-    assert len(d["ids"]) == len(pos) and np.array_equal(d["ids"], np.arange(len(pos)))
-    # P2G sums have the same order on both paths: container and the pre-solve fields agree to rounding of the solve
-    assert rel_l2(d["container"], sim.field(F.CONTAINER)) < 1e-12
-    ep, ev = rel_l2(d["pos"], p), rel_l2(d["vel"], v)
-    epr = rel_l2(d["pressure"], sim.field(F.PRESSURE))
-    print(f"world={world} n={n}: bounds={list(d['bounds'])} counts={list(d['counts'])} pos {ep:.2e} vel {ev:.2e} pressure {epr:.2e} "
-          f"iters {list(d['iters'])} vs {[s['cg_iters'] for s in st]} comm calls {list(d['calls'])}")
-    assert ep < 1e-9 and ev < 1e-7 and epr < 1e-8
-    assert rel_l2(d["velgrid"], sim.field(F.VEL)) < 1e-8
-    assert np.allclose(d["dt"], [s["dt_out"] for s in st], rtol=1e-9)
+@pytest.mark.parametrize("world,solve", [(2, "decomposed"), (3, "decomposed"), (2, "replicated")])
+def test_processes_over_gloo(fs, tmp_path, world, solve):
+    """One process per block over torch.distributed (gloo, staged through the host): the transport bench.py falls back to."""
+    n, ppc, steps = 32, 4, 3
+    d = run_dist(world, n, ppc, steps, tmp_path, ("--solve", solve))
+    pos, _ = scene(fs, n, ppc)
+    ref = single(fs, n, pos, None, steps, solve_start="zero" if solve == "decomposed" else "warm")
+    assert list(d["num_active"]) == [s["num_active"] for s in ref["st"]]
+    assert list(d["outer"]) == [s["outer_passes"] for s in ref["st"]]
+    assert np.array_equal(d["indices"], ref["indices"])
+    assert np.array_equal(d["ids"], np.arange(len(pos)))
+    print(f"gloo world={world} {solve}: comm calls {list(d['calls'])} iters {list(d['iters'])} vs {[s['cg_iters'] for s in ref['st']]}")
+    assert rel_l2(d["pos"], ref["pos"]) < 1e-9 and rel_l2(d["vel"], ref["vel"]) < 1e-7 and rel_l2(d["pressure"], ref["pressure"]) < 1e-8
 
 
 @pytest.mark.parametrize("mode", ["rccl", "device"])
@@ -63,11 +192,9 @@ def test_one_rank_over_rccl(fs, tmp_path, mode):
     """World size 1 over the RCCL transports (native ncclAllReduce / torch nccl): all a 1-GPU box can run of them.
     Exercises dlopen + ncclCommInitRank + stream-ordered all-reduces; the neighbour exchange has no peer here."""
     n, ppc, steps = 32, 4, 3
-    d = run_dist(1, n, ppc, steps, tmp_path, mode=mode)
-    sim = fs.FluidSim(n=n)
-    sim.upload_particles(fs.water_cube_drop(n, ppc, seed=0))
-    st = [sim.step() for _ in range(steps)]
-    p, v = sim.download_particles()
-    assert list(d["num_active"]) == [s["num_active"] for s in st]
-    assert np.array_equal(d["indices"], sim.field(fs.FIELD.INDICES))
-    assert rel_l2(d["pos"], p) < 1e-9 and rel_l2(d["vel"], v) < 1e-7
+    d = run_dist(1, n, ppc, steps, tmp_path, ("--solve", "decomposed"), mode=mode)
+    pos, _ = scene(fs, n, ppc)
+    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    assert list(d["num_active"]) == [s["num_active"] for s in ref["st"]]
+    assert np.array_equal(d["indices"], ref["indices"])
+    assert rel_l2(d["pos"], ref["pos"]) < 1e-9 and rel_l2(d["vel"], ref["vel"]) < 1e-7
