@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--flip-blend", type=float, default=1.0, help="1 = the reference's pure FLIP; BASELINE config 1 names 0.95 (PIC/FLIP blend, build extension)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-micro", action="store_true", help="skip the dense stencil micro-benchmark")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="keep timing oracle steps until this much CPU time is spent")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps timed per cpu_baseline leg (1 thread, all cores)")
+    ap.add_argument("--no-long-run", action="store_true", help="skip the 500-step drop -> splash -> pool run (long_run key)")
+    ap.add_argument("--long-steps", type=int, default=500, help="steps of the long run (the reference's loop runs 500, fluid.cc:1368)")
+    ap.add_argument("--dist-solve", default="auto", choices=["auto", "decomposed", "replicated"], help="multi-GPU pressure block (FLUID_DIST_*)")
     ap.add_argument("--force-dist", action="store_true", help="run the decomposed code path even with one rank (overhead check)")
     ap.add_argument("--sample-every", type=int, default=32, help="bracket every k-th PCG launch (and every k/8-th P2G / sort / G2P / solve) with a hipEvent pair; each record stalls the stream ~5-10 us")
     return ap.parse_args()
@@ -98,9 +101,10 @@ def main():
         sim = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
         sim.upload_particles(pos0)
     else:
-        # ONE simulation: particles in x slabs of equal count, one slab per GPU; the pressure block is replicated (strong scaling)
+        # ONE simulation cut into 3-D blocks (8 ranks: 2 x 2 x 2), one block per GPU (strong scaling)
         fd = fs.load_dist()
-        bounds = fd.partition_by_count(n, pos0, world)
+        dims = fd.default_dims(world)
+        cuts = fd.partition_blocks(n, pos0, dims)
         import torch
         comm, err = None, ""
         try:
@@ -117,8 +121,9 @@ def main():
                 comm.close()
             comm = fd.TorchComm(mode="device", device=torch.device("cuda", local_rank))
             transport = f"torch.distributed nccl callbacks (native RCCL init failed on some rank: {err})"
-        sim = fd.DistFluidSim(n, bounds, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
+        sim = fd.DistFluidSim(n, dims, cuts, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve=a.dist_solve)
         sim.upload_global(pos0)
+        solve_mode = "replicated" if list(sim.wdims) == [n, n, n] and world > 1 else "decomposed"
 
     def barrier():
         if dist is not None:
@@ -219,11 +224,15 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"water_cube_drop {n}^3 grid, {ppc} particles/cell, {len(pos0)} particles, " + ("pure FLIP" if a.flip_blend >= 1 else f"PIC/FLIP blend {a.flip_blend}"),
                    "grid": n, "ppc": ppc, "particles": int(len(pos0)), "cg_tol": a.cg_tol,
-                   "parallelism": "single GPU" if transport is None else f"particles sharded over {world} x slabs (sort, migration, P2G, G2P, advect), P2G fields all-reduced, pressure block replicated on every GPU; transport {transport}"},
+                   "parallelism": "single GPU" if transport is None else
+                   (f"{dims[0]} x {dims[1]} x {dims[2]} blocks, one per GPU (cuts {cuts}); particles sharded (sort, migration, ghosts, P2G, G2P, advect); " +
+                    ("window arrays = block + 4 halo cells, halo exchanges, domain-decomposed PCG with the globally coupled V-cycle" if solve_mode == "decomposed"
+                     else "P2G fields all-reduced, pressure block replicated on every GPU") + f"; transport {transport}")},
         "roofline": roof,
         "roofline_others": roof_others,
         "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),
                        "cg_iters_total": sum(s["cg_iters"] for s in stats), "relres_last": stats[-1]["relres"],
+                       "cg_iters_note": "solves start from the previous pressure (FLUID_START_WARM): not the reference's x0 = 0 count, see cg_iters_total_x0_zero",
                        "box_last": [stats[-1]["box_lo"], stats[-1]["box_hi"]]},
         "kernel_ms": {"mg_up0_avg": per(mgs) if mgs.get("sampled") else None, "pcg_sq_avg": per(sq), "pcg_xr_avg": per(xr), "solve_avg": per(solve), "p2g_avg": per(p2g),
                       "g2p_avg": per(g2p), "sort_avg": per(srt)},
@@ -249,29 +258,75 @@ def main():
     if not a.no_micro and world == 1:
         out["stencil_microbench"] = {"workload": f"dense {n}^3 all-fluid interior, q=A s", **stencil_microbench(fs, n, local_rank)}
 
+    if not a.no_micro and world == 1:
+        # the same timed steps with every solve started from x0 = 0 like the reference's cg.solve(b) (fluid.cc:1474): the
+        # iteration count comparable with the reference's
+        simz = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, solve_start="zero")
+        simz.upload_particles(pos0)
+        for _ in range(a.warmup):
+            simz.step()
+        out["step_stats"]["cg_iters_total_x0_zero"] = sum(simz.step()["cg_iters"] for _ in range(a.steps))
+        simz.close()
+
+    if not a.no_long_run and world == 1:
+        # the reference's whole run: 500 steps (fluid.cc:1368) through drop -> splash -> settled pool; the headline above
+        # times the free fall only
+        siml = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
+        siml.upload_particles(pos0)
+        ts, its, passes = [], 0, 0
+        for _ in range(a.long_steps):
+            c0 = time.perf_counter()
+            st = siml.step()
+            ts.append((time.perf_counter() - c0) * 1e3)
+            its += st["cg_iters"]; passes += st["outer_passes"]
+        ts = np.array(ts)
+        out["long_run"] = {"steps": a.long_steps, "mean_ms": float(ts.mean()), "p95_ms": float(np.percentile(ts, 95)), "max_ms": float(ts.max()),
+                           "total_s": float(ts.sum() / 1e3), "substeps_per_s": float(a.long_steps / (ts.sum() / 1e3)),
+                           "mean_ms_by_100": [float(ts[i:i + 100].mean()) for i in range(0, a.long_steps, 100)],
+                           "cg_iters_total": its, "outer_passes_total": passes, "box_last": [st["box_lo"], st["box_hi"]],
+                           "num_active_last": st["num_active"]}
+        siml.close()
+
     if cpu_state is not None:
         oracle = entry.load_oracle()
-        # The reference's CPU path = serial grid sweeps + Eigen IC-PCG (fluid.cc:1352,1473-1474).  When the build of the
-        # reference's vendored Eigen travelled with the repo (oracle/_ref), the oracle's solves go through it.
+        # The reference's CPU path = TBB particle loops on all cores (fluid.cc:845,978,1126) + serial grid sweeps + serial
+        # Eigen IC-PCG (fluid.cc:1352,1473-1474; run.sh has no -fopenmp).  When the build of the reference's vendored Eigen
+        # travelled with the repo (oracle/_ref), the oracle's solves go through it.
         use_ref = oracle.ref_lib() is not None
-        orc = oracle.Oracle(n=n, use_ref_solver=use_ref)
-        if not use_ref:
-            orc.set_cg_tol(a.cg_tol)
-        if a.flip_blend < 1:
-            orc.set_flip_blend(a.flip_blend)
-        orc.set_particles(cpu_state[0], cpu_state[1])
-        orc.dt = cpu_state[2]
-        csteps, csec = 0, 0.0
-        while csec < a.cpu_seconds and csteps < a.steps:
-            c0 = time.perf_counter()
-            orc.step()
-            csec += time.perf_counter() - c0
-            csteps += 1
+        ncores = len(os.sched_getaffinity(0))
+        cpu_model = ""
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:  # noqa: BLE001
+            pass
         solver = ("pressure solves by the reference's own vendored Eigen 3.3.4 ConjugateGradient<IncompleteCholesky> (oracle/_ref)"
                   if use_ref else "pressure solves by the restated Jacobi-CG (oracle/_ref not present)")
-        out["cpu_baseline"] = {"value": csteps / csec, "unit": "substeps/s", "cores": 1, "kind": "port",
-                               "sample": f"{csteps} oracle step(s) of the same {n}^3 workload from the state at the start of the timed region "
-                                         f"({csec:.1f} s); {solver}"}
+
+        def cpu_leg(threads):
+            orc = oracle.Oracle(n=n, use_ref_solver=use_ref)
+            if not use_ref:
+                orc.set_cg_tol(a.cg_tol)
+            if a.flip_blend < 1:
+                orc.set_flip_blend(a.flip_blend)
+            orc.set_threads(threads)
+            orc.set_particles(cpu_state[0], cpu_state[1])
+            orc.dt = cpu_state[2]
+            csec = 0.0
+            for _ in range(a.cpu_steps):
+                c0 = time.perf_counter()
+                orc.step()
+                csec += time.perf_counter() - c0
+            return orc, csec
+
+        orc1, sec1 = cpu_leg(1)
+        orcn, secn = cpu_leg(ncores)
+        sample = (f"{a.cpu_steps} oracle steps of the same {n}^3 workload from the state at the start of the timed region; {solver}; "
+                  f"host CPU: {cpu_model}, {ncores} cores available")
+        out["cpu_baseline"] = {"value": a.cpu_steps / secn, "unit": "substeps/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model,
+                               "seconds": secn, "sample": sample + " — particle loops on all cores under per-cell locks (the reference's TBB loops), grid sweeps and the Eigen solve serial like the reference's"}
+        out["cpu_baseline_1thread"] = {"value": a.cpu_steps / sec1, "unit": "substeps/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
+                                       "seconds": sec1, "sample": sample + " — one thread"}
+        csteps, orc = a.cpu_steps, orc1
         # full-size parity readout: GPU vs oracle after the same number of steps from the same state
         sim2 = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
         sim2.upload_particles(cpu_state[0], cpu_state[1])

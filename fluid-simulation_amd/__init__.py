@@ -7,7 +7,7 @@ hand-written HIP for gfx950.  There is NO CPU fallback: if the shared library is
 import fails; if no GPU is visible, ``FluidSim(...)`` raises.
 """
 from ._lib import lib, FluidError, Params, StepStats, FIELD, PROF  # noqa: F401
-from .sim import FluidSim, water_cube_drop, reference_scatter, grid_bounds, write_vdb  # noqa: F401
+from .sim import FluidSim, water_cube_drop, reference_scatter, grid_bounds, write_vdb, VdbStream  # noqa: F401
 
 def load_dist():
     """torch is imported only when the multi-GPU path is used."""
@@ -15,4 +15,4 @@ def load_dist():
     return dist
 
 
-__all__ = ["load_dist", "FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "reference_scatter", "grid_bounds", "write_vdb", "lib"]
+__all__ = ["load_dist", "FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "reference_scatter", "grid_bounds", "write_vdb", "VdbStream", "lib"]

@@ -81,7 +81,13 @@ SYMBOLS = [
     ("fluid_profile_enable", C.c_int, [_P, C.c_int]),
     ("fluid_profile_read", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("fluid_profile_reset", C.c_int, [_P]),
+    ("fluid_spline_eval", C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, _P]),
+    ("fluid_dot_eval", C.c_int, [C.c_int32, C.c_int64, _P, _P, _P]),
     ("fluid_write_vdb", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("fluid_write_vdb_ex", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_P), C.c_int32]),
+    ("fluid_vdb_open", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("fluid_vdb_append", C.c_int, [_P, _P]),
+    ("fluid_vdb_close", C.c_int, [_P]),
     # multi-GPU (argtypes with the comm struct are completed in dist.py)
     ("fluid_create_dist", C.c_int, None),
     ("fluid_window", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

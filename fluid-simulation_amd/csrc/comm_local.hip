@@ -81,7 +81,10 @@ int cb_exchange(void* vctx, int32_t n, const int32_t* peer, const void* const* s
         if (g->failed || m.bytes != rbytes[i]) { g->failed = true; g->cv.notify_all(); return 1; }
         const void* src = m.ptr;
         lk.unlock();
-        const hipError_t e = hipMemcpy(rbuf[i], src, rbytes[i], hipMemcpyDefault);
+        // on the receiver's own stream and waited for: a device-to-device hipMemcpy may return before the copy has landed,
+        // and the null stream does not order with the handles' non-blocking streams
+        hipError_t e = hipMemcpyAsync(rbuf[i], src, rbytes[i], hipMemcpyDefault, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
         lk.lock();
         if (e != hipSuccess) { g->failed = true; g->cv.notify_all(); return 1; }
         m.consumed++;
@@ -105,7 +108,9 @@ int cb_allreduce(void* vctx, void* buf, int64_t count, int32_t dtype, int32_t op
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
     std::vector<char>& mine = g->stage[c->rank];
     mine.resize(bytes);
-    if (bytes && hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (bytes && (hipMemcpyAsync(mine.data(), buf, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+                  hipStreamSynchronize((hipStream_t)stream) != hipSuccess))
+        return 1;
     std::unique_lock<std::mutex> lk(g->mu);
     const uint64_t my_gen = g->gen;
     if (++g->arrived == g->size) {
@@ -127,7 +132,9 @@ int cb_allreduce(void* vctx, void* buf, int64_t count, int32_t dtype, int32_t op
     if (g->failed) return 1;
     const std::vector<char>& out = g->result[my_gen & 1];
     lk.unlock();
-    if (bytes && hipMemcpy(buf, out.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    if (bytes && (hipMemcpyAsync(buf, out.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+                  hipStreamSynchronize((hipStream_t)stream) != hipSuccess))
+        return 1;
     return 0;
 }
 

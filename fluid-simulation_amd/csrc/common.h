@@ -271,6 +271,9 @@ void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box);
 void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float* container, double* u, double* v, double* w, double* ub, double* vb,
                        double* wb);
 
+void launch_spline_eval(hipStream_t st, int which, long n, const double* x, double* w);
+void launch_dot(hipStream_t st, long n, const double* a, const double* b, double* part, int nb, double* out);
+
 // pcg (kernels_pcg.hip); T = double or float
 LBox make_lbox(const Box& b);
 size_t lbox_max_cells(int N);

@@ -1170,6 +1170,52 @@ int fluid_stencil_apply(fluid_sim_t* s, int reps, int box_mode, float* avg_ms)
     return FLUID_OK;
 }
 
+static int hook_device(int32_t device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FLUID_ERR_HIP, "no HIP device visible: libfluid_hip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(FLUID_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    return FLUID_OK;
+}
+
+int fluid_spline_eval(int32_t device, int32_t which, int64_t n, const double* x, double* w)
+{
+    if (n < 0 || which < 0 || which > 3 || (n > 0 && (!x || !w))) return fail(FLUID_ERR_ARG, "bad argument");
+    int rc = hook_device(device);
+    if (rc || n == 0) return rc;
+    double *dx = nullptr, *dw = nullptr;
+    HIPCHK(hipMalloc((void**)&dx, n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dw, n * sizeof(double)));
+    HIPCHK(hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice));
+    launch_spline_eval(nullptr, which, (long)n, dx, dw);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(w, dw, n * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dw);
+    return FLUID_OK;
+}
+
+int fluid_dot_eval(int32_t device, int64_t n, const double* a, const double* b, double* out)
+{
+    if (n < 0 || !out || (n > 0 && (!a || !b))) return fail(FLUID_ERR_ARG, "bad argument");
+    int rc = hook_device(device);
+    if (rc) return rc;
+    double *da = nullptr, *db = nullptr, *dp = nullptr;
+    const int nb = 1024;   // partials of one PCG launch
+    HIPCHK(hipMalloc((void**)&da, (n + 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&db, (n + 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dp, (nb + 1) * sizeof(double)));
+    if (n) {
+        HIPCHK(hipMemcpy(da, a, n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(db, b, n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    launch_dot(nullptr, (long)n, da, db, dp, nb, dp + nb);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dp + nb, sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dp);
+    return FLUID_OK;
+}
+
 int fluid_profile_enable(fluid_sim_t* s, int sample_every)
 {
     if (!s || sample_every < 0) return fail(FLUID_ERR_ARG, "bad argument");

@@ -968,6 +968,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
         return bail("alloc of the decomposition's scratch failed");
     if (!d->repl) {
         const int org[3] = {g.ox, g.oy, g.oz};
+        if (hipMemset(s->indices, 0xFF, s->ncell * sizeof(int)) != hipSuccess) return bail("indices fill failed");   // -1: no unknown yet (fluid.cc:1388)
         make_plan(d, d->plan_flags, [&](int r) { return block_of(d, r); }, HALO_W, org, 0, g.sx(), g.nz);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail("device sync failed");

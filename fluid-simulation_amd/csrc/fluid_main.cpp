@@ -59,6 +59,15 @@ int main(int, char**)
     if (!outdir.empty()) mkdir(outdir.c_str(), 0755);  // the reference aborts when simulation/ is missing
     const size_t ncell = (size_t)prm.n * prm.n * prm.n;
     std::vector<float> out(outdir.empty() ? 0 : ncell);
+    // file.write(grids) of fluid.cc:1508: `grids` is declared outside the loop (:1366) and receives every step's grid
+    // (:1450), so the final mygrids.vdb holds all of them — streamed here, one grid appended per step
+    fluid_vdb_writer_t* all = nullptr;
+    std::string fin;
+    if (!outdir.empty() && steps > 0) {
+        const size_t slash = outdir.find_last_of('/');   // beside the output directory: ./mygrids.vdb for the default "simulation"
+        fin = (slash == std::string::npos ? std::string() : outdir.substr(0, slash + 1)) + "mygrids.vdb";
+        if (fluid_vdb_open(fin.c_str(), prm.n, steps, FLUID_VDB_ZIP_ACTIVE_MASK, &all) != FLUID_OK) { std::cerr << "cannot write " << fin << std::endl; return 1; }
+    }
 
     double dt = prm.max_dt;  // fluid.cc:1367
     double simulationTime = 0;
@@ -84,11 +93,12 @@ int main(int, char**)
                 std::cerr << "fluid_download_field: " << fluid_last_error() << std::endl;
                 return 1;
             }
-            // file2.write(grids2) of fluid.cc:1503-1504: simulation/mygrids<i>.vdb.  (The reference's grids2 vector is
-            // never cleared, so its file i also repeats the grids of steps 0..i-1; this driver writes step i only.)
+            // file2.write(grids2) of fluid.cc:1503-1504: simulation/mygrids<i>.vdb.  grids2 is declared inside the loop
+            // (:1373), so each of these files holds exactly the grid of its step.
             const std::string fn = outdir + "/mygrids" + std::to_string(i) + ".vdb";
             const float* gp[1] = {out.data()};
             if (fluid_write_vdb(fn.c_str(), prm.n, 1, gp) != FLUID_OK) { std::cerr << "cannot write " << fn << std::endl; return 1; }
+            if (fluid_vdb_append(all, out.data()) != FLUID_OK) { std::cerr << "cannot write " << fin << std::endl; return 1; }
             if (raw_f32) {  // FLUID_RAW=1: also the bare float32 dump (int32 n, then n^3 floats, z fastest)
                 const std::string fr = outdir + "/mygrids" + std::to_string(i) + ".f32";
                 FILE* f = fopen(fr.c_str(), "wb");
@@ -100,12 +110,7 @@ int main(int, char**)
             }
         }
     }
-    if (!outdir.empty() && steps > 0) {  // file.write(grids) of fluid.cc:1508 (there: every step's grid; here the last)
-        const float* gp[1] = {out.data()};
-        const size_t slash = outdir.find_last_of('/');   // beside the output directory: ./mygrids.vdb for the default "simulation"
-        const std::string fin = (slash == std::string::npos ? std::string() : outdir.substr(0, slash + 1)) + "mygrids.vdb";
-        if (fluid_write_vdb(fin.c_str(), prm.n, 1, gp) != FLUID_OK) { std::cerr << "cannot write " << fin << std::endl; return 1; }
-    }
+    if (all && fluid_vdb_close(all) != FLUID_OK) { std::cerr << "cannot write " << fin << std::endl; return 1; }
     fluid_destroy(sim);
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cout << "Time Taken " << sec / 60 << " minutes" << std::endl;  // fluid.cc:1513 (wall, not clock())

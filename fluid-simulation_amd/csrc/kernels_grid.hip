@@ -406,3 +406,40 @@ void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float
 }
 
 }  // namespace fl
+
+// ---- known-answer hooks (include/fluid_hip.h) ---------------------------------------------------------------
+namespace fl {
+__global__ __launch_bounds__(256) void k_spline_eval(int which, long n, const double* __restrict__ x, double* __restrict__ w)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double p = x[i];
+    if (which == 0) w[i] = spline(p);
+    else w[i] = spline_at(p, (int)round(p) - 1 + (which - 1), which - 1);
+}
+void launch_spline_eval(hipStream_t st, int which, long n, const double* x, double* w)
+{
+    if (n > 0) hipLaunchKernelGGL(k_spline_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, which, n, x, w);
+}
+// per-block partials of a.b (grid-stride, wave shuffles, one value per block), then the fixed-order re-summation of the
+// partials by one block: the reduction scheme of the PCG kernels (k_pcg_sq_l / k_pcg_xr_l partials + block_sum_array)
+__global__ __launch_bounds__(256) void k_dot_partial(long n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double acc = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += a[i] * b[i];
+    acc = block_sum<double, 4>(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_dot_final(const double* __restrict__ part, int nb, double* __restrict__ out)
+{
+    __shared__ double sm[5];
+    const double r = block_sum_array<4>(part, nb, sm);
+    if (threadIdx.x == 0) out[0] = r;
+}
+void launch_dot(hipStream_t st, long n, const double* a, const double* b, double* part, int nb, double* out)
+{
+    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, st, n, a, b, part);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, st, (const double*)part, nb, out);
+}
+}  // namespace fl

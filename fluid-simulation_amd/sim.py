@@ -18,8 +18,12 @@ def grid_bounds(n):
     return lo, lo + n - 1
 
 
-def write_vdb(path, grids):
-    """Write dense float32 (n,n,n) arrays as the unnamed FloatGrids of fluid.cc:1161-1164,1503 (OpenVDB file format 224)."""
+_VDB_COMPRESSION = {"zip": 3, "active_mask": 2}
+
+
+def write_vdb(path, grids, compression="zip"):
+    """Write dense float32 (n,n,n) arrays as the unnamed FloatGrids of fluid.cc:1161-1164,1503 (OpenVDB file format 224);
+    compression "zip" = ZIP | ACTIVE_MASK (the library's default), "active_mask" = ACTIVE_MASK only."""
     import ctypes as C
     if isinstance(grids, np.ndarray) and grids.ndim == 3:
         grids = [grids]
@@ -27,7 +31,27 @@ def write_vdb(path, grids):
     n = arrs[0].shape[0]
     assert all(a.shape == (n, n, n) for a in arrs)
     ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
-    check(lib.fluid_write_vdb(str(path).encode(), n, len(arrs), ptrs))
+    check(lib.fluid_write_vdb_ex(str(path).encode(), n, len(arrs), ptrs, _VDB_COMPRESSION[compression]))
+
+
+class VdbStream:
+    """The final mygrids.vdb of the reference (every step's grid, fluid.cc:1366,1450,1508) written one grid at a time."""
+
+    def __init__(self, path, n, n_grids, compression="zip"):
+        import ctypes as C
+        self._h = C.c_void_p()
+        self.n = n
+        check(lib.fluid_vdb_open(str(path).encode(), n, n_grids, _VDB_COMPRESSION[compression], C.byref(self._h)))
+
+    def append(self, grid):
+        a = np.ascontiguousarray(grid, dtype=np.float32)
+        assert a.shape == (self.n,) * 3
+        check(lib.fluid_vdb_append(self._h, a.ctypes.data))
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            check(lib.fluid_vdb_close(h))
 
 
 def water_cube_drop(n, ppc, seed=0):

@@ -182,6 +182,15 @@ int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
  * box: 0 = dense sweep over all N^3 cells, 1 = active box only. */
 int fluid_stencil_apply(fluid_sim_t* s, int reps, int box, float* avg_ms);
 
+/* ---- known-answer hooks ------------------------------------------------------------------- */
+/* w[i] = spline(x[i]) (fluid.cc:22-37) evaluated by the DEVICE function the P2G / G2P kernels use (which = 0), or the
+ * three-cell form those kernels call per axis, spline_at(p, round(p) - 1 + d, d) with d = which - 1 (which = 1..3: x[i]
+ * is then the particle coordinate p).  Host buffers; tests compare bit for bit with the reference's own function. */
+int fluid_spline_eval(int32_t device, int32_t which, int64_t n, const double* x, double* w);
+/* out[0] = sum_i a[i] * b[i] over n doubles with the block-partial + fixed-order re-summation the PCG kernels use for
+ * their dot products (restates the long dot-product test of openvdb/unittest/TestConjGradient.cc:212-237). */
+int fluid_dot_eval(int32_t device, int64_t n, const double* a, const double* b, double* out);
+
 /* ---- profiling ------------------------------------------------------------------------- */
 /* Kernel classes timed with hipEvent pairs on the handle's stream. */
 #define FLUID_PROF_PCG_SQ 0      /* fused p-update + 7-point apply + dot     */
@@ -285,11 +294,21 @@ int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, u
 int fluid_partition_blocks(int32_t n, int64_t np, const double* pos, const int32_t dims[3], int32_t* cuts_x, int32_t* cuts_y,
                            int32_t* cuts_z);
 
-/* ---- OpenVDB file output (replaces file2.write(grids2), fluid.cc:1503-1504,1508) ----------
- * Writes n_grids dense float32 N^3 arrays (z fastest, cell (0,0,0) = index coordinate (lo,lo,lo), lo = -(N/2)) as
- * unnamed FloatGrids (Tree_float_5_4_3, background 0, voxel size 1, every cell of [lo,hi]^3 active) in OpenVDB's
- * file format 224 — the grids fluid.cc:1161-1164,1434-1451 builds.  Host only: no GPU, no OpenVDB library. */
+/* ---- OpenVDB file output (replaces file2.write(grids2) / file.write(grids), fluid.cc:1503-1504,1508) ----
+ * Dense float32 N^3 arrays (z fastest, cell (0,0,0) = index coordinate (lo,lo,lo), lo = -(N/2)) written as unnamed
+ * FloatGrids (Tree_float_5_4_3, background 0, voxel size 1, every cell of [lo,hi]^3 active) in OpenVDB's file format 224
+ * — the grids fluid.cc:1161-1164,1434-1451 builds.  Host only: no GPU, no OpenVDB library (zlib for the ZIP flag).
+ * The reference writes ONE grid into every simulation/mygrids<i>.vdb (`grids2` lives inside the loop, fluid.cc:1373) and
+ * EVERY step's grid into the final mygrids.vdb (`grids`, :1366,1450,1508): the streaming form appends one grid per step. */
+#define FLUID_VDB_ACTIVE_MASK 2       /* io/Compression.h:80 COMPRESS_ACTIVE_MASK                                  */
+#define FLUID_VDB_ZIP_ACTIVE_MASK 3   /* COMPRESS_ZIP | COMPRESS_ACTIVE_MASK: the library's default (Compression.h:78-81) */
+typedef struct fluid_vdb_writer fluid_vdb_writer_t;
+int fluid_vdb_open(const char* path, int32_t n, int32_t n_grids, int32_t compression, fluid_vdb_writer_t** out);
+int fluid_vdb_append(fluid_vdb_writer_t* w, const float* grid);     /* exactly n_grids times                       */
+int fluid_vdb_close(fluid_vdb_writer_t* w);                         /* FLUID_ERR_ARG if fewer grids were appended  */
+/* n_grids arrays in one call; fluid_write_vdb = ZIP | ACTIVE_MASK. */
 int fluid_write_vdb(const char* path, int32_t n, int32_t n_grids, const float* const* grids);
+int fluid_write_vdb_ex(const char* path, int32_t n, int32_t n_grids, const float* const* grids, int32_t compression);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 namespace {
@@ -51,6 +52,31 @@ inline double spline(double x)
 
 typedef void (*ref_solver_fn)(int n, int nnz, const int* rows, const int* cols, const double* vals,
                               const double* b, double* x, int* iters, double* err);
+
+// nthreads > 1: the particle loops run on host threads the way the reference runs them under tbb::parallel_for
+// (fluid.cc:845,978,1126), the scatters under a lock per cell like its std::mutex cube (fluid.cc:290-294,872-874; striped here).
+// The float32 accumulations then depend on the thread schedule exactly as they do in the reference (SURVEY 8c "determinism
+// caveat"); nthreads = 1 is the serial, bitwise reproducible order every parity test uses.
+template <typename F>
+static void parallel_for(int nthreads, size_t n, F fn)
+{
+    if (nthreads <= 1 || n < 4096) { fn((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        const size_t a = std::min(n, per * t), b = std::min(n, per * (t + 1));
+        if (a < b) th.emplace_back([=] { fn(a, b, t); });
+    }
+    for (auto& x : th) x.join();
+}
+struct CellLocks {
+    static constexpr size_t N = (size_t)1 << 16;
+    std::atomic<unsigned char> l[N];
+    CellLocks() { for (auto& x : l) x.store(0); }
+    void lock(size_t k) { auto& a = l[k & (N - 1)]; while (a.exchange(1, std::memory_order_acquire)) {} }
+    void unlock(size_t k) { l[k & (N - 1)].store(0, std::memory_order_release); }
+};
+static CellLocks g_locks;
 
 struct Oracle {
     int N, lo, hi, wlo, whi;
@@ -122,7 +148,9 @@ void p2g(Oracle& o)
     std::fill(o.vel.begin(), o.vel.end(), 0.0);          // fluid.cc:1378
     std::fill(o.weights.begin(), o.weights.end(), 0.0f);  // fluid.cc:1108
     const size_t np = o.ppos.size() / 3;
-    for (size_t i = 0; i < np; ++i) {
+    const bool mt = o.nthreads > 1;
+    parallel_for(o.nthreads, np, [&](size_t i0, size_t i1, int) {
+    for (size_t i = i0; i < i1; ++i) {
         const double cx = o.ppos[3 * i], cy = o.ppos[3 * i + 1], cz = o.ppos[3 * i + 2];
         const double* vc = &o.pvel[3 * i];
         int minx, maxx, miny, maxy, minz, maxz;
@@ -135,15 +163,19 @@ void p2g(Oracle& o)
                     if (!o.isSolid(x, y, z) && o.withinW(x, y, z)) {  // :288 (bound-2)
                         double cw = spline(cx - x) * spline(cy - y) * spline(cz - z);  // :291
                         size_t k = o.idx(x, y, z);
+                        if (mt) g_locks.lock(k);                     // :290 lockGrid[...]->lock()
                         o.weights[k] = (float)(o.weights[k] + cw);   // :292 FloatGrid narrowing
                         o.vel[3 * k + 0] = o.vel[3 * k + 0] + cw * vc[0];  // :293
                         o.vel[3 * k + 1] = o.vel[3 * k + 1] + cw * vc[1];
                         o.vel[3 * k + 2] = o.vel[3 * k + 2] + cw * vc[2];
+                        if (mt) g_locks.unlock(k);
                     }
                 }
     }
+    });
     // fluid.cc:1130-1146
-    for (size_t k = 0; k < o.ncell; ++k) {
+    parallel_for(o.nthreads, o.ncell, [&](size_t k0, size_t k1, int) {
+    for (size_t k = k0; k < k1; ++k) {
         double w = o.weights[k];
         if (w > 0) {
             o.vel[3 * k + 0] /= w;
@@ -151,6 +183,7 @@ void p2g(Oracle& o)
             o.vel[3 * k + 2] /= w;
         }
     }
+    });
 }
 
 // fluid.cc:1388-1455: indices=-1, container=0, PointList::interpolate (843-882),
@@ -160,7 +193,9 @@ void flags_index(Oracle& o)
     std::fill(o.indices.begin(), o.indices.end(), -1);
     std::fill(o.container.begin(), o.container.end(), 0.0f);
     const size_t np = o.ppos.size() / 3;
-    for (size_t i = 0; i < np; ++i) {
+    const bool mt = o.nthreads > 1;
+    parallel_for(o.nthreads, np, [&](size_t i0, size_t i1, int) {
+    for (size_t i = i0; i < i1; ++i) {
         const double cx = o.ppos[3 * i], cy = o.ppos[3 * i + 1], cz = o.ppos[3 * i + 2];
         int minx, maxx, miny, maxy, minz, maxz;
         support(o, cx, minx, maxx);
@@ -172,10 +207,13 @@ void flags_index(Oracle& o)
                     double cw = spline(cx - x) * spline(cy - y) * spline(cz - z);  // :869
                     if (!o.isSolid(x, y, z) && cw > 0) {                            // :870
                         size_t k = o.idx(x, y, z);
+                        if (mt) g_locks.lock(k);                                    // :872
                         o.container[k] = (float)(o.container[k] + cw);              // :873
+                        if (mt) g_locks.unlock(k);
                     }
                 }
     }
+    });
     int numActive = 0;
     for (int x = o.lo; x <= o.hi; x++)
         for (int y = o.lo; y <= o.hi; y++)
@@ -483,7 +521,10 @@ void flip_advect(Oracle& o)
     const double e = 0;
     const size_t np = o.ppos.size() / 3;
     double maxSpeed = 0.0;
-    for (size_t i = 0; i < np; ++i) {
+    std::vector<double> tmax((size_t)std::max(o.nthreads, 1), 0.0);   // the reference: one mutex-guarded maximum (:977-990)
+    parallel_for(o.nthreads, np, [&](size_t i0, size_t i1, int tid) {
+    double maxSpeed = 0.0;
+    for (size_t i = i0; i < i1; ++i) {
         const double cx = o.ppos[3 * i], cy = o.ppos[3 * i + 1], cz = o.ppos[3 * i + 2];
         int minx, maxx, miny, maxy, minz, maxz;
         support(o, cx, minx, maxx);
@@ -518,12 +559,16 @@ void flip_advect(Oracle& o)
         double len = sqrt(o.pvel[3 * i] * o.pvel[3 * i] + o.pvel[3 * i + 1] * o.pvel[3 * i + 1] + o.pvel[3 * i + 2] * o.pvel[3 * i + 2]);
         if (maxSpeed < len) maxSpeed = len;
     }
+    tmax[tid] = maxSpeed;
+    });
+    for (double m : tmax) if (maxSpeed < m) maxSpeed = m;
     o.maxSpeed = maxSpeed;
     double timestep;
     if (maxSpeed != 0) timestep = o.max_dt < o.dx / maxSpeed ? o.max_dt : o.dx / maxSpeed;  // :992-999
     else timestep = o.max_dt;
     o.dt = timestep;  // written back to the caller's dt (double& timestep)
-    for (size_t i = 0; i < np; ++i) {
+    parallel_for(o.nthreads, np, [&](size_t i0, size_t i1, int) {
+    for (size_t i = i0; i < i1; ++i) {
         double* P = &o.ppos[3 * i];
         double* V = &o.pvel[3 * i];
         double position[3] = {P[0] + timestep * V[0], P[1] + timestep * V[1], P[2] + timestep * V[2]};
@@ -541,6 +586,7 @@ void flip_advect(Oracle& o)
             P[0] = position[0]; P[1] = position[1]; P[2] = position[2];
         }
     }
+    });
 }
 
 // fluid.cc:1378-1490
@@ -599,6 +645,7 @@ void* oracle_create(int N, double dx, double rho, const double* g, double max_dt
 void oracle_destroy(void* h) { delete (Oracle*)h; }
 void oracle_set_ref_solver(void* h, void* fn) { ((Oracle*)h)->ref_solver = (ref_solver_fn)fn; }
 void oracle_set_cg_tol(void* h, double tol) { ((Oracle*)h)->cg_tol = tol; }
+void oracle_set_threads(void* h, int n) { ((Oracle*)h)->nthreads = n < 1 ? 1 : n; }
 void oracle_set_flip_blend(void* h, double b) { ((Oracle*)h)->flip_blend = b; }
 void oracle_set_dt(void* h, double dt) { ((Oracle*)h)->dt = dt; }
 double oracle_get_dt(void* h) { return ((Oracle*)h)->dt; }

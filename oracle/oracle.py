@@ -32,6 +32,7 @@ _lib.oracle_create.argtypes = [C.c_int, C.c_double, C.c_double, _P, C.c_double, 
 _lib.oracle_destroy.argtypes = [_P]
 _lib.oracle_set_ref_solver.argtypes = [_P, _P]
 _lib.oracle_set_cg_tol.argtypes = [_P, C.c_double]
+_lib.oracle_set_threads.argtypes = [_P, C.c_int]
 _lib.oracle_set_flip_blend.argtypes = [_P, C.c_double]
 _lib.oracle_set_dt.argtypes = [_P, C.c_double]
 _lib.oracle_get_dt.restype = C.c_double
@@ -75,6 +76,22 @@ def ref_lib():
 
 def _ptr(a):
     return a.ctypes.data_as(_P)
+
+
+_SPLINE_SO = os.path.join(_HERE, "_ref", "libspline_ref.so")
+
+
+def ref_spline(x):
+    """The reference's own spline() (fluid.cc:22-37 compiled as it is, oracle/_ref/libspline_ref.so) on an array; None if
+    the reference build is not present."""
+    if not os.path.exists(_SPLINE_SO):
+        return None
+    lib = C.CDLL(_SPLINE_SO)
+    lib.ref_spline_n.argtypes = [C.c_long, _P, _P]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    w = np.empty_like(x)
+    lib.ref_spline_n(x.size, x.ctypes.data_as(_P), w.ctypes.data_as(_P))
+    return w
 
 
 def spline(x):
@@ -172,6 +189,11 @@ class Oracle:
 
     def set_cg_tol(self, tol):
         _lib.oracle_set_cg_tol(self._h, tol)
+
+    def set_threads(self, n):
+        """Host threads of the particle loops (1 = the serial, reproducible order of the parity tests; > 1 mirrors the
+        reference's tbb::parallel_for with per-cell locks: float32 sums then depend on the schedule, as in the reference)."""
+        _lib.oracle_set_threads(self._h, int(n))
 
     def set_flip_blend(self, b):
         """1 = the reference's pure FLIP; < 1 = PIC/FLIP blend (build extension, BASELINE config 1)."""

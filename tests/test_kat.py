@@ -1,0 +1,179 @@
+"""Known-answer tests that do NOT come from the repo's own restatement:
+
+  a1  spline()  — the reference's own function (fluid.cc:22-37, compiled as it is into oracle/_ref/libspline_ref.so by
+      oracle/Makefile) against the oracle's restatement (CPU) and against the device function the P2G / G2P kernels call
+      (GPU), bit for bit on a dense sweep.  Pins row a1.
+  a14 the long dot product of openvdb/unittest/TestConjGradient.cc:212-237 through the PCG kernels' reduction scheme.
+  a9-a15 the open-top tank P = -y of openvdb/unittest/TestPoissonSolver.cc:254-309 and a hydrostatic column through the
+      HIP matrix, solver and velocity update.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def sweep():
+    # dense over the support, every branch boundary and its neighbours in ulps, both signs, some far values
+    x = np.concatenate([np.linspace(-1.6, 1.6, 200001), np.random.default_rng(0).uniform(-1.1, 1.1, 200000)])
+    edges = np.array([0.0, 0.5, 1.0, -0.5, -1.0, 1.5])
+    near = np.concatenate([np.nextafter(edges, np.inf), np.nextafter(edges, -np.inf), edges,
+                           np.nextafter(np.nextafter(edges, np.inf), np.inf), [1e-300, -1e-300, 7.0, -7.0, 1e300]])
+    return np.concatenate([x, near])
+
+
+def test_oracle_spline_is_the_references(oracle):
+    x = sweep()
+    ref = oracle.ref_spline(x)
+    if ref is None:
+        pytest.skip("oracle/_ref/libspline_ref.so not built (needs /root/reference at build time)")
+    mine = np.array([oracle.spline(v) for v in x[::7]])
+    assert np.array_equal(mine.view(np.uint64), ref[::7].view(np.uint64))
+    # the published shape: 1.5 x cubic B-spline of 2x, support |x| < 1, spline(0) = 1
+    assert oracle.ref_spline(np.array([0.0]))[0] == 1.0 and oracle.ref_spline(np.array([1.0]))[0] == 0.0
+
+
+@pytest.mark.gpu
+def test_device_spline_is_the_references(fs, oracle):
+    x = sweep()
+    ref = oracle.ref_spline(x)
+    assert ref is not None, "oracle/_ref/libspline_ref.so must travel with the repo"
+    w = np.empty_like(x)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert fs.lib.fluid_spline_eval(0, 0, x.size, P(x), P(w)) == 0
+    assert np.array_equal(w.view(np.uint64), ref.view(np.uint64))
+    # the per-axis form the kernels use: spline_at(p, round(p) - 1 + d, d) == spline(p - (round(p) - 1 + d)) for every particle coordinate
+    p = np.random.default_rng(1).uniform(-60, 60, 300000)
+    p = np.concatenate([p, np.arange(-5, 6) + 0.5, np.arange(-5, 6) - 0.5, np.arange(-5, 6).astype(float)])
+    base = np.floor(np.abs(p) + 0.5) * np.sign(p)   # C round()
+    for d in range(3):
+        wd = np.empty_like(p)
+        assert fs.lib.fluid_spline_eval(0, 1 + d, p.size, P(p), P(wd)) == 0
+        want = oracle.ref_spline(p - (base - 1 + d))
+        assert np.array_equal(wd.view(np.uint64), want.view(np.uint64)), d
+
+
+@pytest.mark.gpu
+def test_long_dot_product(fs):
+    """TestConjGradient.cc:212-237: vectors of 10 034 502 entries, a = 2, b = 3 -> a.b = 6 n to 1e-7 (relative)."""
+    n = 10034502
+    a = np.full(n, 2.0); b = np.full(n, 3.0)
+    out = np.zeros(1)
+    P = lambda v: v.ctypes.data_as(C.c_void_p)
+    assert fs.lib.fluid_dot_eval(0, n, P(a), P(b), P(out)) == 0
+    assert abs(out[0] - 6.0 * n) <= 1e-7 * 6.0 * n
+    assert out[0] == 6.0 * n          # exact here: every partial is an integer below 2^53
+    # an ill-conditioned sum: the fixed-order pairwise scheme against math.fsum
+    import math
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal(3000001) * 10.0 ** rng.integers(-6, 6, 3000001); b = rng.standard_normal(3000001)
+    assert fs.lib.fluid_dot_eval(0, a.size, P(a), P(b), P(out)) == 0
+    exact = math.fsum((a * b).tolist())
+    assert abs(out[0] - exact) <= 1e-12 * np.sum(np.abs(a * b))
+    # run to run reproducible
+    out2 = np.zeros(1)
+    assert fs.lib.fluid_dot_eval(0, a.size, P(a), P(b), P(out2)) == 0
+    assert out2[0] == out[0]
+
+
+def tank(fs, n, lo_cell, hi_cell, top_open):
+    """Solid everywhere except the cavity [lo_cell, hi_cell]^3 (index space); open top: one more empty layer above the fluid."""
+    solid = np.ones((n, n, n), dtype=np.uint8)
+    c = slice(lo_cell, hi_cell + 1)
+    solid[c, lo_cell:hi_cell + (2 if top_open else 1), c] = 0
+    return solid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precond", ["mg", "jacobi"])
+def test_open_top_tank_is_hydrostatic(fs, precond):
+    """TestPoissonSolver.cc:254-309 restated on the HIP path: a cubic tank of N = 9 cells, solid (Neumann) sides and bottom,
+    free surface (Dirichlet p = 0) above the top layer, a unit downward flux through the bottom -> P = -y exactly: here
+    p(depth) = b0 * (depth + 1/2 ... ) in the matrix's own scaling, checked as a LINEAR profile with the analytic slope and
+    as the exact solution of the reference's matrix (setA, fluid.cc:304-412).  Tolerance as there: 10 * 1e-7 relative."""
+    n, N = 24, 9
+    lo_c = 6
+    hi_c = lo_c + N - 1
+    sim = fs.FluidSim(n=n, preconditioner=precond, solve_start="zero")
+    sim.set_solid(tank(fs, n, lo_c, hi_c, True))
+    F = fs.FIELD
+    cont = np.zeros((n, n, n), dtype=np.float32)
+    cont[lo_c:hi_c + 1, lo_c:hi_c + 1, lo_c:hi_c + 1] = 1.0   # fluid fills the cavity; the layer above it is air
+    sim.upload_field(F.CONTAINER, cont)
+    sim.flags_index()
+    st = sim.stats()
+    assert st["num_active"] == N ** 3
+    # rhs: dP/dy = -1 at the bottom wall = a unit source in the bottom layer (the test's boundary functor, :262-283)
+    b = np.zeros((n, n, n), dtype=np.float32)
+    b[lo_c:hi_c + 1, lo_c, lo_c:hi_c + 1] = 1.0
+    sim.upload_field(F.DIVER, b)
+    sim.solve()
+    st = sim.stats()
+    p = sim.field(F.PRESSURE)[lo_c:hi_c + 1, lo_c:hi_c + 1, lo_c:hi_c + 1]
+    scale = sim.dt / 1.0                          # setA: dt / (rho dx^2)
+    # column balance: scale * (p_j - p_{j+1}) = 1 between all layers, scale * p_top = 1 at the free surface (air neighbour: p = 0)
+    col = p[N // 2, :, N // 2]
+    want = (N - np.arange(N)) / np.float32(scale)     # linear in depth below the surface: P = -y up to the scaling
+    assert st["cg_iters_last"] < 60
+    # The matrix is the REFERENCE's (setA, fluid.cc:304-412): Adiag is `scale` accumulated in float32 once per non-solid
+    # neighbour and Aplus = float(-scale), so a diagonal is not exactly the sum of its off-diagonals (float(0.1) six times
+    # != 6 float(0.1)): the analytic profile holds to float32 coefficient rounding, ~1e-6 relative, not to 1e-7.
+    assert np.max(np.abs(p - want[None, :, None])) <= 5e-6 * want.max(), (col, want)
+    assert np.max(np.abs(p - col[None, :, None])) <= 5e-6 * want.max()          # every column alike (Neumann sides)
+    # ... and p solves that float-coefficient system itself to the PCG's tolerance: residual of A p - b with the
+    # coefficients rebuilt here from the same rule
+    acc, diag = np.float32(0), [0.0]
+    for _ in range(6):
+        acc = np.float32(np.float64(acc) + scale)
+        diag.append(float(acc))
+    off = float(np.float32(-scale))
+    P = np.zeros((N + 2, N + 2, N + 2)); P[1:-1, 1:-1, 1:-1] = p
+    cnt = np.full((N, N, N), 6)
+    for ax in (0, 2):                                  # solid walls in x and z on both sides
+        sl = [slice(None)] * 3
+        sl[ax] = 0; cnt[tuple(sl)] -= 1
+        sl[ax] = N - 1; cnt[tuple(sl)] -= 1
+    cnt[:, 0, :] -= 1                                  # solid bottom; the top layer's upper neighbour is air (counts, p = 0)
+    nb = P[:-2, 1:-1, 1:-1] + P[2:, 1:-1, 1:-1] + P[1:-1, :-2, 1:-1] + P[1:-1, 2:, 1:-1] + P[1:-1, 1:-1, :-2] + P[1:-1, 1:-1, 2:]
+    Ap = np.array(diag)[cnt] * p + off * nb
+    rhs = b[lo_c:hi_c + 1, lo_c:hi_c + 1, lo_c:hi_c + 1].astype(np.float64)
+    assert np.linalg.norm(Ap - rhs) <= 1e-12 * np.linalg.norm(rhs) * 10, np.linalg.norm(Ap - rhs)
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_hydrostatic_column_through_the_step_kernels(fs):
+    """A resting block of water in a closed box, through fluid_p2g -> flags -> rhs_div -> solve -> vel_update on the GPU:
+    gravity enters through the wall terms (setRHS, fluid.cc:414-479), the solve must return the linear hydrostatic profile
+    and the update must leave the interior velocity at rest in y up to the dt/10 partial update (fluid.cc:1475)."""
+    n = 32
+    lo, hi = fs.grid_bounds(n)
+    # particles: a regular 2x2x2 lattice per cell filling the bottom half of the box interior
+    cells = np.arange(lo + 2, hi - 1)
+    ys = np.arange(lo + 2, lo + 2 + 10)
+    off = np.array([-0.25, 0.25])
+    gx, gy, gz, ox, oy, oz = np.meshgrid(cells, ys, cells, off, off, off, indexing="ij")
+    pos = np.stack([(gx + ox).ravel(), (gy + oy).ravel(), (gz + oz).ravel()], axis=1)
+    sim = fs.FluidSim(n=n, solve_start="zero")
+    sim.upload_particles(pos)
+    sim.p2g()
+    sim.flags_index()
+    sim.rhs_div(0)
+    sim.solve()
+    F = fs.FIELD
+    p = sim.field(F.PRESSURE)
+    flags = sim.field(F.FLAGS)
+    fluid = (flags & 2) != 0
+    x0 = n // 2
+    col = p[x0, :, x0]
+    fl = fluid[x0, :, x0]
+    depth_cells = np.nonzero(fl)[0]
+    assert len(depth_cells) >= 10
+    # b = rhs - div u with u = 0: only the bottom layer sees the wall term (v + g dt)/dx = -10 * 0.1 = -1 -> a uniform source;
+    # p then rises linearly towards the bottom by |b| / scale per cell
+    d = np.diff(col[depth_cells])
+    assert np.all(d < 0)                                    # pressure falls with height
+    step = d[: len(d) - 2]
+    assert np.max(np.abs(step - step.mean())) <= 1e-6 * abs(step.mean()), step
+    assert abs(abs(step.mean()) - 1.0 / np.float32(sim.dt)) <= 1e-5 / sim.dt   # |g| dt / dx over dt / (rho dx^2): slope = g rho dx
+    sim.close()

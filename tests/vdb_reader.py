@@ -4,7 +4,7 @@ An independent restatement of the READ side of the library the reference links (
 readHeader (:863-935) / readGridDescriptors, io/GridDescriptor.cc:75-104, MetaMap.cc readMeta, math/Maps.h
 ScaleMap::read, tree/RootNode.h readTopology (:2291-2403) / readBuffers, tree/InternalNode.h readTopology
 (:2198-2290), tree/LeafNode.h readTopology / readBuffers (:1331-1441), io/Compression.h readCompressedValues
-(:323-456).  Supports compression flags NONE and ACTIVE_MASK (no ZIP / Blosc payloads), every mask-compression
+(:323-456).  Supports compression flags NONE, ACTIVE_MASK and ZIP (no Blosc payloads), every mask-compression
 metadata code, active tiles at the root and in internal nodes.  Returns per grid: name, metadata, transform and a
 function that densifies a box."""
 import struct
@@ -49,7 +49,7 @@ def _mask(r, log2dim):
 
 def _values(r, count, value_mask, child_mask, background, compression):
     """readCompressedValues for float, file version >= 222."""
-    assert not compression & ~0x2, "ZIP / Blosc payloads are not supported by this test reader"
+    assert not compression & ~0x3, "Blosc payloads are not supported by this test reader"
     meta = r.u("b")
     inactive = [background, background]
     if meta == 1:
@@ -63,7 +63,15 @@ def _values(r, count, value_mask, child_mask, background, compression):
     sel = _mask(r, {512: 3, 4096: 4, 32768: 5}[count]) if meta in (3, 4, 5) else None
     mask_compressed = bool(compression & 0x2) and meta != 6
     nread = int(value_mask.sum()) if mask_compressed else count
-    data = np.frombuffer(r.take(4 * nread), dtype="<f4")
+    if compression & 0x1:
+        # unzipFromStream (io/Compression.cc:103-150): int64 byte count; <= 0: that many raw bytes follow, > 0: zlib stream
+        import zlib
+        nz = r.u("q")
+        raw = r.take(-nz) if nz <= 0 else zlib.decompress(r.take(nz))
+        assert len(raw) == 4 * nread, (len(raw), nread)
+        data = np.frombuffer(raw, dtype="<f4")
+    else:
+        data = np.frombuffer(r.take(4 * nread), dtype="<f4")
     if not mask_compressed:
         return data.copy()
     out = np.empty(count, dtype=np.float32)
