@@ -273,11 +273,13 @@ def test_pressure_pass_and_flip(fs, oracle):
     assert abs(sim.dt - orc.dt) <= 1e-9 * orc.dt
 
 
+@pytest.mark.parametrize("start", ["warm", "zero"])
 @pytest.mark.parametrize("n,ppc,steps", [(24, 4, 12), (32, 8, 10)])
-def test_free_running(fs, oracle, n, ppc, steps):
+def test_free_running(fs, oracle, n, ppc, steps, start):
     """Whole steps, no re-synchronisation: integer results must agree exactly while the float
-    state stays within tolerance; prints the drift."""
-    sim, orc, pos = make_pair(fs, oracle, n, ppc)
+    state stays within tolerance; prints the drift.  Both starts of the solve: from the previous pressure (default) and
+    from x0 = 0 like the reference's cg.solve(b) — the converged pressure is the same within cg_tol."""
+    sim, orc, pos = make_pair(fs, oracle, n, ppc, solve_start=start)
     for i in range(steps):
         sg = sim.step(); so = orc.step()
         assert sg["num_active"] == so["num_active"], (i, sg, so)
@@ -288,6 +290,40 @@ def test_free_running(fs, oracle, n, ppc, steps):
         assert ep < TOL_F and ev < TOL_F, (i, ep, ev)
     print(f"n={n} after {steps} steps: pos drift {ep:.2e} vel drift {ev:.2e}")
     assert np.array_equal(sim.field(fs.FIELD.INDICES), orc.field(4))
+
+
+@pytest.mark.parametrize("n,blend,start", [(128, 0.95, "warm"), (256, 1.0, "warm"), (128, 1.0, "zero")])
+def test_baseline_configs_at_size(fs, oracle, n, blend, start):
+    """BASELINE.json configs[1] (128^3, 8 particles per cell, FLIP blend 0.95) and configs[2] (256^3, 8 per cell) against
+    the oracle AT SIZE: one whole step from a moving state (the free-fall state after two warm-up steps on the GPU handed to
+    both), unknown numbering bit-exact, particle state and fields within the north_star tolerance.  The oracle's solves go
+    through the reference's own Eigen IC-PCG when oracle/_ref travelled with the repo."""
+    ppc = 8
+    pos = fs.water_cube_drop(n, ppc, seed=0)
+    warm = fs.FluidSim(n=n, flip_blend=blend, solve_start=start)
+    warm.upload_particles(pos)
+    warm.step(); warm.step()
+    p0, v0 = warm.download_particles()
+    dt0 = warm.dt
+    warm.close()
+    sim = fs.FluidSim(n=n, flip_blend=blend, solve_start=start)
+    sim.upload_particles(p0, v0); sim.dt = dt0
+    orc = oracle.Oracle(n=n, use_ref_solver=oracle.ref_lib() is not None)
+    if blend < 1:
+        orc.set_flip_blend(blend)
+    orc.set_particles(p0, v0); orc.dt = dt0
+    sg = sim.step(); so = orc.step()
+    F = fs.FIELD
+    assert sg["num_active"] == so["num_active"] and sg["outer_passes"] == so["outer_passes"]
+    assert np.array_equal(sim.field(F.INDICES), orc.field(4))
+    assert rel_l2(sim.field(F.CONTAINER), orc.field(0)) < TOL_W
+    ev, epr = rel_l2(sim.field(F.VEL), orc.field(2)), rel_l2(sim.field(F.PRESSURE), orc.field(7))
+    p, v = sim.download_particles(); po, vo = orc.particles()
+    ep, evp = rel_l2(p, po), rel_l2(v, vo)
+    print(f"n={n} blend={blend} start={start}: unknowns {sg['num_active']} iters {sg['cg_iters']} velgrid {ev:.2e} pressure {epr:.2e} pos {ep:.2e} vel {evp:.2e}")
+    assert ev < TOL_F and epr < TOL_F and ep < TOL_F and evp < TOL_F
+    assert abs(sg["dt_out"] - so["dt_out"]) <= 1e-6 * so["dt_out"]
+    sim.close()
 
 
 @pytest.mark.parametrize("blend", [0.95, 0.0])
@@ -471,7 +507,14 @@ def test_run_sh_fluid_driver(tmp_path):
     assert len(grids) == 1 and grids[0].type == "Tree_float_5_4_3"
     vals, act = grids[0].dense(-16, 15)
     assert np.array_equal(vals, rho) and act.all()
-    assert np.array_equal(vdb_reader.read(tmp_path / "mygrids.vdb")[1][0].dense(-16, 15)[0], rho)
+    # the final file holds EVERY step's grid: `grids` is declared outside the loop (fluid.cc:1366,1450,1508)
+    allg = vdb_reader.read(tmp_path / "mygrids.vdb")[1]
+    assert len(allg) == 3 and [g.unique_name for g in allg] == ["\x1e0", "\x1e1", "\x1e2"]
+    assert all(g.compression == 3 for g in allg)         # ZIP | ACTIVE_MASK, the library's default (io/Compression.h:78-81)
+    assert np.array_equal(allg[2].dense(-16, 15)[0], rho)
+    for i in range(3):
+        ri = np.fromfile(tmp_path / "simulation" / f"mygrids{i}.f32", dtype=np.float32, offset=4).reshape(32, 32, 32)
+        assert np.array_equal(allg[i].dense(-16, 15)[0], ri)
 
 
 def test_long_run_stays_convergent(fs):

@@ -114,7 +114,7 @@ def test_open_top_tank_is_hydrostatic(fs, precond):
     # column balance: scale * (p_j - p_{j+1}) = 1 between all layers, scale * p_top = 1 at the free surface (air neighbour: p = 0)
     col = p[N // 2, :, N // 2]
     want = (N - np.arange(N)) / np.float32(scale)     # linear in depth below the surface: P = -y up to the scaling
-    assert st["cg_iters_last"] < 60
+    assert st["cg_iters_last"] < (60 if precond == "mg" else 100)   # (there: < 60 at 1e-4..1e-7; here to Eigen's 2.2e-16)
     # The matrix is the REFERENCE's (setA, fluid.cc:304-412): Adiag is `scale` accumulated in float32 once per non-solid
     # neighbour and Aplus = float(-scale), so a diagonal is not exactly the sum of its off-diagonals (float(0.1) six times
     # != 6 float(0.1)): the analytic profile holds to float32 coefficient rounding, ~1e-6 relative, not to 1e-7.
