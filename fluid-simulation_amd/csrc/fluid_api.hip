@@ -725,7 +725,7 @@ static int solve_mg(fluid_sim* s)
     // form of the same loop: r0 = b - A x0, same threshold tol^2 |b|^2).  The converged p does not depend on the start
     // beyond the tolerance; a settled pool needs far fewer iterations.  r0.r0 partials travel in part_rz[1] (unused by body 0).
     const bool guess = s->warm && s->have_guess;
-    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, s->p_guess, Q, X, R, cf, s->part_pq, s->part_err, s->part_bb, s->part_rz[1], s->ps);
+    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, s->p_guess, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
     else launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
     long it = 0;
     // Batching of the convergence poll.  Iteration counts barely change from one solve to the next (Eigen's count i means

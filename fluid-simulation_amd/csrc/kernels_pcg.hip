@@ -125,72 +125,35 @@ __global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_
     if (threadIdx.x == 0) { part_bb[blockIdx.x] = abb; part_rz0[blockIdx.x] = arz; }
 }
 
-// Start from a guess (Eigen's solveWithGuess, ConjugateGradient.h:37-43: residual = rhs - mat * x).  The guess is the
-// previous solve's pressure SCALED by the factor that minimises |b - gamma A p_prev|: gamma = (b . A p_prev) / |A p_prev|^2.
-// Inside one step's do..while the passes solve nearly the same system — the dt/10 partial update (fluid.cc:1475) takes a
-// tenth of the pressure gradient out of the divergence, so the next pass's solution is 0.9 x the last one up to the
-// float32 rounding of b — and with gamma the start residual of those passes is ~1e-6 |b| instead of 0.1 |b|: about half
-// the iterations.  Any gamma is a valid guess; the converged p does not depend on it beyond the tolerance.
-//   pass 1 (k_pcg_guess_ax_l):  y = A p_prev on the unknowns (neighbours count only if they are unknowns NOW), partials
-//                               of b.y and y.y;
-//   pass 2 (k_pcg_init_guess_l): gamma from the partials; x0 = gamma p_prev, r0 = b - gamma y, partials of b.b and r0.r0.
+// Start from a guess (Eigen's solveWithGuess, ConjugateGradient.h:37-43: residual = rhs - mat * x): x0 = `guess` (a global
+// field, e.g. the previous solve's pressure) at the unknown cells, r0 = b - A x0, partials of b.b (threshold) and r0.r0.
+// A neighbour contributes only if it is an unknown NOW (its count byte), whatever the guess field holds there.
 template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_guess_ax_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const float* __restrict__ b,
-                                                        const double* __restrict__ guess, T* __restrict__ y, Coef<T> cf,
-                                                        double* __restrict__ part_by, double* __restrict__ part_yy)
+__global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const float* __restrict__ b,
+                                                          const double* __restrict__ guess, T* __restrict__ x, T* __restrict__ r, Coef<T> cf,
+                                                          double* __restrict__ part_bb, double* __restrict__ part_rr0, PcgState* ps)
 {
     __shared__ double red[4];
     __shared__ T sdiag[8], sinv[8];
     load_coef(sdiag, sinv, cf);
     __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ps->done = 0; ps->iters = 0; ps->breakdown = 0; ps->bb = 0; ps->thr = 0; ps->rr = 0; }
     const long n = (long)L.cells();
     const long sx = (long)L.Ly * L.Lz, sy = L.Lz;
-    double aby = 0, ayy = 0;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
-        const uint8_t c = cnt[t];
-        T yv = 0;
-        if (c) {  // unknowns are interior cells: all six neighbours exist in both layouts
-            const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
-            const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
-            const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;
-            const T nb = (cnt[t - sx] ? (T)guess[gc - gx] : (T)0) + (cnt[t + sx] ? (T)guess[gc + gx] : (T)0) +
-                         (cnt[t - sy] ? (T)guess[gc - gy] : (T)0) + (cnt[t + sy] ? (T)guess[gc + gy] : (T)0) +
-                         (cnt[t - 1] ? (T)guess[gc - 1] : (T)0) + (cnt[t + 1] ? (T)guess[gc + 1] : (T)0);
-            yv = sdiag[c] * (T)guess[gc] + cf.off * nb;
-            const double bv = (double)b[gc];
-            aby += bv * (double)yv;
-            ayy += (double)yv * (double)yv;
-        }
-        y[t] = yv;
-    }
-    aby = block_sum<double, 4>(aby, red);
-    ayy = block_sum<double, 4>(ayy, red);
-    if (threadIdx.x == 0) { part_by[blockIdx.x] = aby; part_yy[blockIdx.x] = ayy; }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const float* __restrict__ b,
-                                                          const double* __restrict__ guess, const T* __restrict__ y, T* __restrict__ x,
-                                                          T* __restrict__ r, const double* __restrict__ part_by, const double* __restrict__ part_yy,
-                                                          int n_part, double* __restrict__ part_bb, double* __restrict__ part_rr0, PcgState* ps)
-{
-    __shared__ double red[16];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ps->done = 0; ps->iters = 0; ps->breakdown = 0; ps->bb = 0; ps->thr = 0; ps->rr = 0; }
-    double by, yy, d3;
-    block_sum3(part_by, n_part, part_yy, n_part, part_yy, 0, red, by, yy, d3);   // the same value in every block
-    const T gamma = (yy > 0 && by == by) ? (T)(by / yy) : (T)0;
-    __syncthreads();
-    const long n = (long)L.cells();
     double abb = 0, arr = 0;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
         const uint8_t c = cnt[t];
         T rv = 0, xv = 0;
-        if (c) {
+        if (c) {  // unknowns are interior cells: all six neighbours exist in both layouts
             const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
             const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
+            const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;
             const T bv = (T)b[gc];
-            xv = gamma * (T)guess[gc];
-            rv = bv - gamma * y[t];
+            xv = (T)guess[gc];
+            const T nb = (cnt[t - sx] ? (T)guess[gc - gx] : (T)0) + (cnt[t + sx] ? (T)guess[gc + gx] : (T)0) +
+                         (cnt[t - sy] ? (T)guess[gc - gy] : (T)0) + (cnt[t + sy] ? (T)guess[gc + gy] : (T)0) +
+                         (cnt[t - 1] ? (T)guess[gc - 1] : (T)0) + (cnt[t + 1] ? (T)guess[gc + 1] : (T)0);
+            rv = bv - (sdiag[c] * xv + cf.off * nb);
             abb += (double)bv * (double)bv;
             arr += (double)rv * (double)rv;
         }
@@ -619,15 +582,11 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 {
     hipLaunchKernelGGL((k_pcg_init_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, x, r, cf, part_bb, part_rz0, ps);
 }
-// y = scratch of the local box (the PCG's q vector: not yet in use); part_by / part_yy = scratch partial arrays
 template <typename T>
-void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, T* y, T* x, T* r, Coef<T> cf,
-                           double* part_by, double* part_yy, double* part_bb, double* part_rr0, PcgState* ps)
+void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, T* x, T* r, Coef<T> cf,
+                           double* part_bb, double* part_rr0, PcgState* ps)
 {
-    const int nb = pcg_xr_blocks(L);
-    hipLaunchKernelGGL((k_pcg_guess_ax_l<T>), dim3(nb), dim3(256), 0, st, g, L, cnt, b, guess, y, cf, part_by, part_yy);
-    hipLaunchKernelGGL((k_pcg_init_guess_l<T>), dim3(nb), dim3(256), 0, st, g, L, cnt, b, guess, (const T*)y, x, r, (const double*)part_by,
-                       (const double*)part_yy, nb, part_bb, part_rr0, ps);
+    hipLaunchKernelGGL((k_pcg_init_guess_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, guess, x, r, cf, part_bb, part_rr0, ps);
 }
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
@@ -944,8 +903,8 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*, double*, const PcgState*);      \
-    template void launch_pcg_init_guess<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, const double*, T*, T*, T*, Coef<T>,  \
-                                           double*, double*, double*, double*, PcgState*);                                                               \
+    template void launch_pcg_init_guess<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, const double*, T*, T*, Coef<T>,      \
+                                           double*, double*, PcgState*);                                                               \
     template void launch_pcg_sq_dist<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
                                         const double*, double*, PcgState*, int, double, int);                                            \
     template void launch_pcg_xr_dist<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,          \
