@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps timed per cpu_baseline leg (1 thread, all cores)")
     ap.add_argument("--no-long-run", action="store_true", help="skip the 500-step drop -> splash -> pool run (long_run key)")
     ap.add_argument("--long-steps", type=int, default=500, help="steps of the long run (the reference's loop runs 500, fluid.cc:1368)")
+    ap.add_argument("--no-alt-mode", action="store_true", help="N > 1: do not time the other form of the multi-GPU pressure block as well")
     ap.add_argument("--dist-solve", default="auto", choices=["auto", "decomposed", "replicated"], help="multi-GPU pressure block (FLUID_DIST_*)")
     ap.add_argument("--force-dist", action="store_true", help="run the decomposed code path even with one rank (overhead check)")
     ap.add_argument("--sample-every", type=int, default=32, help="bracket every k-th PCG launch (and every k/8-th P2G / sort / G2P / solve) with a hipEvent pair; each record stalls the stream ~5-10 us")
@@ -129,6 +130,7 @@ def main():
     n, ppc = a.n, a.ppc
     pos0 = fs.water_cube_drop(n, ppc, seed=a.seed)
     transport = None
+    solve_mode = "single"
     if world == 1 and not a.force_dist:
         sim = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
         sim.upload_particles(pos0)
@@ -187,6 +189,31 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N > 1: the same steps with the OTHER form of the multi-GPU pressure block, timed the same way, reported beside the
+    # headline as `alt_mode` (no multi-GPU box is available to the builder: this is how both forms get measured)
+    alt = None
+    if world > 1 and not a.no_alt_mode:
+        other = "replicated" if solve_mode == "decomposed" else "decomposed"
+        try:
+            sim_alt = fd.DistFluidSim(n, dims, cuts, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve=other)
+            sim_alt.upload_global(pos0)
+            for _ in range(a.warmup):
+                sim_alt.step()
+            barrier()
+            c0 = time.perf_counter()
+            st_alt = [sim_alt.step() for _ in range(a.steps)]
+            barrier()
+            el = time.perf_counter() - c0
+            import torch
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            alt = {"pressure_block": other, "value": a.steps / el, "unit": "substeps/s", "ms_per_step": el / a.steps * 1e3,
+                   "cg_iters_total": sum(x["cg_iters"] for x in st_alt), "outer_passes_total": sum(x["outer_passes"] for x in st_alt)}
+            sim_alt.close()
+        except Exception as e:  # noqa: BLE001
+            alt = {"pressure_block": other, "error": str(e)[:300]}
 
     if rank != 0:
         if dist is not None:
@@ -262,6 +289,7 @@ def main():
                      else "P2G fields all-reduced, pressure block replicated on every GPU") + f"; transport {transport}")},
         "roofline": roof,
         "roofline_others": roof_others,
+        **({"pressure_block": solve_mode, "alt_mode": alt} if world > 1 or a.force_dist else {}),
         "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),
                        "cg_iters_total": sum(s["cg_iters"] for s in stats), "relres_last": stats[-1]["relres"],
                        "cg_iters_note": "solves start from the previous pressure (FLUID_START_WARM): not the reference's x0 = 0 count, see cg_iters_total_x0_zero",
