@@ -32,7 +32,7 @@ void launch_row_counts(hipStream_t st, Grid g, Box own, int rx0, int ry0, int RY
 void launch_row_number(hipStream_t st, Grid g, Box own, int rx0, int ry0, int RY, int nseg, int seg, const uint8_t* flags, const int* starts,
                        int* indices);
 void launch_fill_box_int(hipStream_t st, Grid g, Box box, int* a, int v);
-void launch_route(hipStream_t st, Grid g, OwnBox ob, long n, Particles p, int* cnt, double* rec, int pass, bool ghost);
+void launch_route(hipStream_t st, Grid g, OwnBox ob, long n, Particles p, int* cnt, double* rec, int pass);
 void launch_kill_ghosts(hipStream_t st, Grid g, OwnBox ob, long n, Particles p);
 void launch_pack_live(hipStream_t st, long n, Particles p, double* pos, double* vel, uint32_t* ids, int* cursor);
 void launch_cnt_pcg(hipStream_t st, LBox L, Box own, const uint8_t* cnt, uint8_t* out);

@@ -218,15 +218,15 @@ int comm_allreduce(fluid_sim* s, void* buf, long count, int dtype, int op)
 }
 
 // ---- particles: migration + ghosts + sort ----------------------------------------------------------------------------------
-// One routing round (migrants or ghosts): count per direction, exchange the counts, write and exchange the records,
-// append what arrived behind the live particles.
-int route_round(fluid_sim* s, bool ghost)
+// The routing round of a step (k_route: owners-to-be and ghosts in one go): count per direction, exchange the counts, write and
+// exchange the records, append what arrived behind the live particles.
+int route_round(fluid_sim* s)
 {
     DistState* d = s->ds;
     const Grid g = s->g;
     int rc;
     HIPCHK(hipMemsetAsync(d->d_cnt, 0, 64 * sizeof(int), s->st));
-    launch_route(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off), d->d_cnt, nullptr, 0, ghost);
+    launch_route(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off), d->d_cnt, nullptr, 0);
     HIPCHK(hipGetLastError());
     // counts to / from the neighbours
     int np = 0, peer[26], dir[26];
@@ -267,7 +267,7 @@ int route_round(fluid_sim* s, bool ghost)
     for (int dd = 0; dd < 27; ++dd) cur[dd] = (int)soff[dd];
     memcpy(d->h_cnt + 64, cur, sizeof(cur));
     HIPCHK(hipMemcpyAsync(d->d_cnt, d->h_cnt + 64, 27 * sizeof(int), hipMemcpyHostToDevice, s->st));
-    if (stot) launch_route(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off), d->d_cnt, d->mig_s, 1, ghost);
+    if (stot) launch_route(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off), d->d_cnt, d->mig_s, 1);
     HIPCHK(hipGetLastError());
     for (int k = 0; k < np; ++k) {
         const int dd = dir[k];
@@ -280,11 +280,11 @@ int route_round(fluid_sim* s, bool ghost)
     launch_unpack_records(s->st, rtot, d->mig_r, s->pa, s->p_off + s->np);
     HIPCHK(hipGetLastError());
     s->np += rtot;
-    if (!ghost) d->n_routed += stot;
+    d->n_routed += stot;
     return FLUID_OK;
 }
 
-// migration, ghosts, counting sort of everything by window cell, global particle bounding box
+// routing (migration + ghosts), counting sort of everything by window cell, global particle bounding box
 int dist_particles(fluid_sim* s)
 {
     DistState* d = s->ds;
@@ -292,8 +292,7 @@ int dist_particles(fluid_sim* s)
     const long ncell = (long)s->ncell;
     int rc;
     int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
-    if ((rc = route_round(s, false))) return rc;
-    if ((rc = route_round(s, true))) return rc;
+    if ((rc = route_round(s))) return rc;
     // sort: cells of the window, then "off the window" (= off the grid: only an edge block can hold such a particle), then dead
     launch_zero_step_state(s->st, s->ss, std::max(g.nx, std::max(g.ny, g.nz)));
     HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 4) * sizeof(int), s->st));
@@ -371,7 +370,19 @@ int dist_g2p_advect(fluid_sim* s, fluid_step_stats_t* stats)
     int rc;
     launch_kill_ghosts(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off));
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    // the particles are still in the order of the sort (by window cell): where the owned part of the particle box is densely
+    // filled, gather through LDS tiles over exactly the owned cells (the ghosts sit in the halo cells: never touched); the
+    // off-grid bucket at the end of the arrays only has its speeds counted
+    const IBox ownb{{d->ob.lo[0], d->ob.lo[1], d->ob.lo[2]}, {d->ob.hi[0], d->ob.hi[1], d->ob.hi[2]}};
+    const int org[3] = {g.ox, g.oy, g.oz};
+    const Box ownPb = to_box(ib_isect(d->Pg, ownb), org);
+    if (s->p_off == 0 && !box_empty(ownPb) && (double)s->np >= 4.0 * (double)ownPb.cells()) {
+        launch_g2p_tiled(s->st, g, ownPb, s->pa, s->cell_start, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+        if (s->n_out > 0)
+            launch_g2p(s->st, g, s->n_out, s->pa.shifted(s->np - s->n_out), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    } else {
+        launch_g2p(s->st, g, s->np, s->pa.shifted(s->p_off), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    }
     prof_end(s, FLUID_PROF_G2P, tok);
     HIPCHK(hipGetLastError());
     // non-negative doubles order like their bit patterns: MAX over int64

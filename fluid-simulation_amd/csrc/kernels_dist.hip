@@ -130,12 +130,15 @@ void launch_fill_box_int(hipStream_t st, Grid g, Box box, int* a, int v)
     if (box.cells() > 0) hipLaunchKernelGGL(k_fill_box_int, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, a, v);
 }
 
-// ---- particles: migration and ghosts -----------------------------------------------------------------------------------
-// Direction code d = (dx+1)*9 + (dy+1)*3 + (dz+1), 13 = stays.  A particle whose base cell left the owned block goes to
-// the block on that side (CFL: at most one cell per step, fluid.cc:992-999, so the adjacent block); a side without a
-// neighbour block is the edge of the grid, the particle stays (off the grid it is inert).  A particle whose base cell
-// touches an interior face is also a GHOST of the blocks behind that face (edges, corners: up to 7 of them): their
-// P2G sums over the cells next to the face need it (support base-1..base+1, fluid.cc:271-276).
+// ---- particles: migration and ghosts in ONE routing round ---------------------------------------------------------------
+// Direction code d = (dx+1)*9 + (dy+1)*3 + (dz+1), 13 = me.  Every block within one cell of a particle's base cell needs
+// the particle: the block that holds the base cell as its OWNER, the others as a GHOST for their P2G sums over the cells
+// next to the face (support base-1..base+1, fluid.cc:271-276).  At the start of a step every live particle sits in the
+// arrays of the block that owned it last step, and CFL (at most one cell per step, fluid.cc:992-999) keeps its base cell
+// within one cell of that block — so the previous owner sends ONE copy to every adjacent block within one cell of the
+// base cell (up to 7: faces, edges, corner) and keeps the particle itself: as owner if the base cell is still its own, as a
+// ghost if it has just left (the receiver tells owner from ghost by the base cell alone).  A side without a neighbour
+// block is the edge of the grid: nothing is sent there (off the grid a particle is inert and stays with the edge block).
 __device__ __forceinline__ void base_of(const Grid& g, const Particles& p, long i, int b[3])
 {
     b[0] = (int)round(p.px[i]) - g.lo; b[1] = (int)round(p.py[i]) - g.lo; b[2] = (int)round(p.pz[i]) - g.lo;   // GLOBAL index
@@ -146,9 +149,8 @@ __device__ __forceinline__ void put_record(double* d, const Particles& p, long i
     d[3] = p.vx[i]; d[4] = p.vy[i]; d[5] = p.vz[i];
     d[6] = (double)p.pid[i];
 }
-// PASS 0: count per direction into cnt[27]; PASS 1: write the records at cursor[d]++ (cursor preset to the directions'
-// offsets) and, when migrating, mark the particle dead.
-template <int PASS, bool GHOST>
+// PASS 0: count per direction into cnt[27]; PASS 1: write the records at cursor[d]++ (cursors preset to the directions' offsets)
+template <int PASS>
 __global__ __launch_bounds__(256) void k_route(Grid g, OwnBox ob, long n, Particles p, int* __restrict__ cnt, double* __restrict__ rec)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -158,41 +160,27 @@ __global__ __launch_bounds__(256) void k_route(Grid g, OwnBox ob, long n, Partic
     base_of(g, p, i, b);
     int s[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (GHOST) s[a] = (b[a] == ob.lo[a] && ob.has_lo[a]) ? -1 : ((b[a] == ob.hi[a] - 1 && ob.has_hi[a]) ? 1 : 0);
-        else s[a] = (b[a] < ob.lo[a] && ob.has_lo[a]) ? -1 : ((b[a] >= ob.hi[a] && ob.has_hi[a]) ? 1 : 0);
-    }
+    for (int a = 0; a < 3; ++a)   // the neighbour slab of axis a the base cell is within one cell of (blocks are >= 8 wide: at most one)
+        s[a] = (ob.has_lo[a] && b[a] <= ob.lo[a]) ? -1 : ((ob.has_hi[a] && b[a] >= ob.hi[a] - 1) ? 1 : 0);
     if (!(s[0] | s[1] | s[2])) return;
-    if (!GHOST) {
-        const int d = (s[0] + 1) * 9 + (s[1] + 1) * 3 + (s[2] + 1);
+    for (int m = 1; m < 8; ++m) {   // every non-empty sub-selection of the touched sides
+        if (((m & 1) && !s[0]) || ((m & 2) && !s[1]) || ((m & 4) && !s[2])) continue;
+        const int e0 = (m & 1) ? s[0] : 0, e1 = (m & 2) ? s[1] : 0, e2 = (m & 4) ? s[2] : 0;
+        const int d = (e0 + 1) * 9 + (e1 + 1) * 3 + (e2 + 1);
         const int k = atomicAdd(&cnt[d], 1);
-        if (PASS == 1) {
-            put_record(rec + (size_t)k * 7, p, i);
-            p.pid[i] = PID_DEAD;
-        }
-    } else {
-        // every non-empty sub-selection of the touched faces
-        for (int m = 1; m < 8; ++m) {
-            const int e0 = (m & 1) ? s[0] : 0, e1 = (m & 2) ? s[1] : 0, e2 = (m & 4) ? s[2] : 0;
-            if (((m & 1) && !s[0]) || ((m & 2) && !s[1]) || ((m & 4) && !s[2])) continue;
-            const int d = (e0 + 1) * 9 + (e1 + 1) * 3 + (e2 + 1);
-            const int k = atomicAdd(&cnt[d], 1);
-            if (PASS == 1) put_record(rec + (size_t)k * 7, p, i);
-        }
+        if (PASS == 1) put_record(rec + (size_t)k * 7, p, i);
     }
 }
-void launch_route(hipStream_t st, Grid g, OwnBox ob, long n, Particles p, int* cnt, double* rec, int pass, bool ghost)
+void launch_route(hipStream_t st, Grid g, OwnBox ob, long n, Particles p, int* cnt, double* rec, int pass)
 {
     if (n <= 0) return;
     const dim3 gr((unsigned)((n + 255) / 256)), bl(256);
-    if (pass == 0 && !ghost) hipLaunchKernelGGL((k_route<0, false>), gr, bl, 0, st, g, ob, n, p, cnt, rec);
-    else if (pass == 1 && !ghost) hipLaunchKernelGGL((k_route<1, false>), gr, bl, 0, st, g, ob, n, p, cnt, rec);
-    else if (pass == 0) hipLaunchKernelGGL((k_route<0, true>), gr, bl, 0, st, g, ob, n, p, cnt, rec);
-    else hipLaunchKernelGGL((k_route<1, true>), gr, bl, 0, st, g, ob, n, p, cnt, rec);
+    if (pass == 0) hipLaunchKernelGGL((k_route<0>), gr, bl, 0, st, g, ob, n, p, cnt, rec);
+    else hipLaunchKernelGGL((k_route<1>), gr, bl, 0, st, g, ob, n, p, cnt, rec);
 }
 
-// After P2G the ghosts have served: mark every particle whose base cell is not in the owned block dead (the next sort
-// drops the dead bucket).  Sides without a neighbour extend to infinity: off-grid particles belong to the edge block.
+// After P2G the ghosts (copies from the neighbours and own particles that have just left the block) have served: mark
+// every particle whose base cell is not in the owned block dead (G2P / advect skip it, the next sort drops the dead bucket).  Sides without a neighbour extend to infinity: off-grid particles belong to the edge block.
 __global__ __launch_bounds__(256) void k_kill_ghosts(Grid g, OwnBox ob, long n, Particles p)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -863,10 +863,171 @@ static void march_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags
     hipLaunchKernelGGL((k_stencil_march<T, MY, MD>), dim3(nty * ntz * ncx), dim3(MY * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
 }
 
-// variant = MY*100 + MD (0 = default); cxlen = planes per chunk (0 = default)
+// ---- dense sweep, x-marching, 16 bytes per lane ----------------------------------------------------------------------
+// The same march with V = 16 / sizeof(T) cells per lane along z (float: 4, double: 2): a wave covers 64 V cells of a z
+// row with ONE 16-byte load per lane and plane (1 KB per wave instead of 256 B for float), the LDS plane is read and
+// written as 16-byte vectors (y neighbours), the z neighbours inside a lane are registers and across lanes two wave
+// shuffles; lanes 0 / 63 take the cell before / after the wave's z range from a scalar rim load.  Per cell: 1/V LDS
+// write, 2/V LDS reads, 2/V shuffles instead of 1 write + 4 reads — the scalar float kernel was bound by exactly that
+// (54 % of the HBM peak against 75-80 % for double).  Needs N % V == 0 (rows 16-byte aligned); same term order as the scalar
+// kernel (x-, x+, y-, y+, z-, z+), so the results are bit-identical.
+template <typename T, int V>
+struct VecT {
+    typedef T type __attribute__((ext_vector_type(V)));
+};
+template <int V>
+struct FlagT;
+template <>
+struct FlagT<4> { typedef uint32_t type; };
+template <>
+struct FlagT<2> { typedef uint16_t type; };
+
+template <typename T, int MY, int MD>
+__global__ __launch_bounds__(MY * 64) void k_stencil_vec(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
+                                                          const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    typedef typename VecT<T, V>::type vec;
+    typedef typename FlagT<V>::type fvec;
+    __shared__ __attribute__((aligned(16))) T pl[2][MY + 2][MZV];
+    __shared__ T sdiag[8], sinv[8];
+    const int tid = threadIdx.x, wy = tid >> 6, lane = tid & 63;
+    load_coef(sdiag, sinv, cf);
+    const int N = g.N;
+    const long sx = (long)N * N;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tz = vb % ntz, ty = (vb / ntz) % nty, cx = vb / (ntz * nty);
+    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
+    const int y = ty * MY + wy, z0 = tz * MZV + lane * V;
+    const bool cv = y < N && z0 < N;                      // N % V == 0: a lane's cells are all inside or all outside
+    const long col = (long)y * N + z0;
+    // rim rows: waves 0 and 1 also carry the row below / above the footprint
+    const int hy = wy == 0 ? ty * MY - 1 : ty * MY + MY;
+    const bool hduty = wy < 2;
+    const bool hv = hduty && hy >= 0 && hy < N && z0 < N;
+    const long hcol = (long)hy * N + z0;
+    // z rim: lane 0 the cell before the wave's range, lane 63 the cell after it
+    const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
+    const bool rduty = lane == 0 || lane == 63;
+    const bool rv = rduty && y < N && rz >= 0 && rz < N;
+    const long rcol = (long)y * N + rz;
+    auto act = [](uint8_t f) { return (f & F_FLUID) && (f >> F_CNT_SHIFT); };
+    auto ldv = [&](int x, long colx, bool ok, vec& val, fvec& f) {
+        if (ok && x >= 0 && x < N) {
+            const long c = (long)x * sx + colx;
+            f = *reinterpret_cast<const fvec*>(flags + c);
+            val = *reinterpret_cast<const vec*>(s + c);
+        } else {
+            f = 0;
+            val = (vec)(T)0;
+        }
+    };
+    auto lds1 = [&](int x, long colx, bool ok, T& val, uint8_t& f) {
+        if (ok && x >= 0 && x < N) {
+            const long c = (long)x * sx + colx;
+            f = flags[c];
+            val = s[c];
+        } else {
+            f = 0;
+            val = 0;
+        }
+    };
+    auto mkv = [&](vec v, fvec f) {
+        vec o;
+#pragma unroll
+        for (int c = 0; c < V; ++c) o[c] = act((uint8_t)(f >> (8 * c))) ? v[c] : (T)0;
+        return o;
+    };
+    vec vm1, v0, hv0;
+    fvec fm1, f0, hf0;
+    T r0;
+    uint8_t rf0;
+    ldv(xa - 1, col, cv, vm1, fm1);
+    ldv(xa, col, cv, v0, f0);
+    ldv(xa, hcol, hv, hv0, hf0);
+    lds1(xa, rcol, rv, r0, rf0);
+    vec qv[MD], hq[MD];
+    fvec qf[MD], hqf[MD];
+    T rq[MD];
+    uint8_t rqf[MD];
+#pragma unroll
+    for (int d = 0; d < MD; ++d) {
+        ldv(xa + 1 + d, col, cv, qv[d], qf[d]);
+        ldv(xa + 1 + d, hcol, hv, hq[d], hqf[d]);
+        lds1(xa + 1 + d, rcol, rv, rq[d], rqf[d]);
+    }
+    vec sm1 = mkv(vm1, fm1), s0 = mkv(v0, f0), h0 = mkv(hv0, hf0);
+    T rim = act(rf0) ? r0 : (T)0;
+    __syncthreads();  // coef tables
+    for (int xb = xa; xb < xe; xb += MD) {
+#pragma unroll
+        for (int d = 0; d < MD; ++d) {
+            const int x = xb + d;
+            if (x < xe) {  // block-uniform
+                const int buf = x & 1;
+                *reinterpret_cast<vec*>(&pl[buf][wy + 1][lane * V]) = s0;
+                if (hduty) *reinterpret_cast<vec*>(&pl[buf][wy == 0 ? 0 : MY + 1][lane * V]) = h0;
+                __syncthreads();
+                const vec sp1 = mkv(qv[d], qf[d]);
+                if (cv) {
+                    const vec up = *reinterpret_cast<const vec*>(&pl[buf][wy][lane * V]);
+                    const vec dn = *reinterpret_cast<const vec*>(&pl[buf][wy + 2][lane * V]);
+                    T left = __shfl_up(s0[V - 1], 1, 64), right = __shfl_down(s0[0], 1, 64);
+                    if (lane == 0) left = rim;
+                    if (lane == 63) right = rim;
+                    vec out;
+#pragma unroll
+                    for (int c = 0; c < V; ++c) {
+                        const uint8_t fc = (uint8_t)(f0 >> (8 * c));
+                        const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
+                        const T nb = sm1[c] + sp1[c] + up[c] + dn[c] + zl + zr;
+                        out[c] = act(fc) ? sdiag[fc >> F_CNT_SHIFT] * s0[c] + cf.off * nb : (T)0;
+                    }
+                    __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sx + col]));  // streamed once: keep s, not q, in cache
+                }
+                sm1 = s0;
+                s0 = sp1;
+                f0 = qf[d];
+                h0 = mkv(hq[d], hqf[d]);
+                rim = act(rqf[d]) ? rq[d] : (T)0;
+                ldv(x + 1 + MD, col, cv, qv[d], qf[d]);
+                ldv(x + 1 + MD, hcol, hv, hq[d], hqf[d]);
+                lds1(x + 1 + MD, rcol, rv, rq[d], rqf[d]);
+            }
+        }
+    }
+}
+
+template <typename T, int MY, int MD>
+static void vec_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZV - 1) / MZV, ncx = (g.N + cxlen - 1) / cxlen;
+    hipLaunchKernelGGL((k_stencil_vec<T, MY, MD>), dim3(nty * ntz * ncx), dim3(MY * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
+}
+
+// variant = MY*100 + MD (0 = default: the 16-byte form where N allows it); +10000 = the 16-byte form; cxlen = planes per chunk (0 = default)
 template <typename T>
 void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen)
 {
+    constexpr int V = 16 / (int)sizeof(T);
+    const bool can_vec = g.N % V == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)q & 15) == 0;
+    if (can_vec && (variant == 0 || variant >= 10000)) {
+        const int v = variant >= 10000 ? variant - 10000 : 0;
+        if (cxlen <= 0) cxlen = 16;
+        switch (v) {
+        case 404: vec_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 408: vec_launch<T, 4, 8>(st, g, cxlen, flags, s, q, cf); break;
+        case 804: vec_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 808: vec_launch<T, 8, 8>(st, g, cxlen, flags, s, q, cf); break;
+        case 1604: vec_launch<T, 16, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 202: vec_launch<T, 2, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 204: vec_launch<T, 2, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 402: vec_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
+        default: vec_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
+        }
+        return;
+    }
     if (cxlen <= 0) cxlen = 32;
     switch (variant) {
     case 804: march_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;

@@ -360,6 +360,35 @@ def test_particles_roundtrip_order(fs):
     assert np.array_equal(p, pos) and np.array_equal(v, vel)
 
 
+@pytest.mark.parametrize("n", [64, 66, 200])
+def test_marching_stencil_forms_agree(fs, n, monkeypatch):
+    """The dense-sweep kernels of the stencil micro-benchmark: the scalar march, the 16-bytes-per-lane march (4 floats / 2
+    doubles per lane, z neighbours by wave shuffles) in several tile shapes, and the LDS-tiled kernel give the same bits
+    (n = 66: the float form falls back to the scalar march, rows are not 16-byte aligned)."""
+    F = fs.FIELD
+    for prec in ("fp64", "fp32"):
+        sim = fs.FluidSim(n=n, precision=prec)
+        solid = sim.field(F.SOLID)
+        rng = np.random.default_rng(n)
+        cont = ((solid == 0) & (rng.random((n, n, n)) < 0.8)).astype(np.float32)     # holes: air cells inside
+        sim.upload_field(F.CONTAINER, cont)
+        sim.flags_index()
+        s = rng.uniform(-1, 1, size=(n, n, n)).astype(np.float64 if prec == "fp64" else np.float32)   # garbage on non-unknowns too
+        sim.upload_field(F.SEARCH, s)
+        monkeypatch.delenv("FLUID_MARCH_VARIANT", raising=False)
+        sim.stencil_apply(reps=1, box=2)
+        want = sim.field(F.Q)
+        assert np.abs(want).max() > 0
+        for variant, cx in (("10000", "16"), ("10404", "8"), ("11604", "32"), ("10202", "5"), ("1604", "32"), ("804", "7")):
+            monkeypatch.setenv("FLUID_MARCH_VARIANT", variant)
+            monkeypatch.setenv("FLUID_MARCH_CX", cx)
+            sim.upload_field(F.Q if False else F.SEARCH, s)
+            sim.stencil_apply(reps=1, box=0)
+            got = sim.field(F.Q)
+            assert np.array_equal(got, want), (prec, variant, cx)
+        sim.close()
+
+
 def test_stencil_apply_dense(fs, oracle):
     """q = A s alone, all-fluid interior: against a numpy restatement of the setA coefficients."""
     n = 40

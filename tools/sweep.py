@@ -16,8 +16,9 @@ for prec, T in (("fp64", 8), ("fp32", 4)):
     s = np.random.default_rng(1).uniform(-1, 1, size=(n, n, n)) * (solid == 0)
     sim.upload_field(F.SEARCH, s)
     algo = n ** 3 * (2 * T + 1)
-    for var in (404, 804, 1604):
-        for cx in (16, 32, 64):
+    # < 10000: one cell per lane (k_stencil_march); 10000 + MY*100 + MD: 16 bytes per lane (k_stencil_vec)
+    for var in (804, 1604, 10202, 10204, 10402, 10404, 10408, 10804, 10808, 11604):
+        for cx in (8, 16, 32, 64):
             os.environ["FLUID_MARCH_VARIANT"] = str(var); os.environ["FLUID_MARCH_CX"] = str(cx)
             sim.stencil_apply(reps=3, box=0)
             ms = min(sim.stencil_apply(reps=30, box=0) for _ in range(3))
