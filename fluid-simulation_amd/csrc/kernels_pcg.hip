@@ -1006,14 +1006,17 @@ static void vec_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, 
     hipLaunchKernelGGL((k_stencil_vec<T, MY, MD>), dim3(nty * ntz * ncx), dim3(MY * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
 }
 
-// variant = MY*100 + MD (0 = default: the 16-byte form where N allows it); +10000 = the 16-byte form; cxlen = planes per chunk (0 = default)
+// variant = MY*100 + MD of the one-cell-per-lane march, 10000 + MY*100 + MD of the 16-bytes-per-lane march; cxlen = planes per chunk.
+// 0 = the measured best at 256^3 (tools/sweep.py, profiles/r02/stencil_sweep.txt): float: 16 bytes per lane, MY 4, MD 2, 16 planes
+// (5.9 TB/s = 73 % of the HBM peak; one cell per lane: 4.6 TB/s); double: one cell per lane, MY 16, MD 4, 32 planes (6.3 TB/s = 79 %;
+// two cells per lane: 5.6 TB/s — the 8-byte lanes already fill their 512-byte wave loads).
 template <typename T>
 void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen)
 {
     constexpr int V = 16 / (int)sizeof(T);
     const bool can_vec = g.N % V == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)q & 15) == 0;
-    if (can_vec && (variant == 0 || variant >= 10000)) {
-        const int v = variant >= 10000 ? variant - 10000 : 0;
+    if (can_vec && ((variant == 0 && sizeof(T) == 4) || variant >= 10000)) {
+        const int v = variant >= 10000 ? variant - 10000 : 402;
         if (cxlen <= 0) cxlen = 16;
         switch (v) {
         case 404: vec_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
@@ -1024,7 +1027,7 @@ void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T*
         case 202: vec_launch<T, 2, 2>(st, g, cxlen, flags, s, q, cf); break;
         case 204: vec_launch<T, 2, 4>(st, g, cxlen, flags, s, q, cf); break;
         case 402: vec_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
-        default: vec_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
+        default: vec_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
         }
         return;
     }

@@ -160,6 +160,32 @@ def test_block_empties_and_fills(fs):
     compare(d, ref, len(pos), "fills", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
 
 
+def test_decomposed_through_the_splash(fs):
+    """2 x 2 x 2 blocks, 160 free-running steps: the cube falls across the cut planes, hits the floor, splashes into all eight
+    blocks (migration in every direction, ghosts at edges and corners, blocks whose share grows several-fold: buffers grow on
+    demand).  No particle is lost or duplicated, every solve converges, and the run stays on the one-GPU trajectory for as
+    long as two float-identical-to-rounding runs can (the first steps exactly in the integers)."""
+    n, ppc, steps = 48, 4, 160
+    pos, _ = scene(fs, n, ppc)
+    pos = pos + np.array([3.0, 6.0, -2.0])       # off-centre: unequal blocks
+    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    d = run_blocks(fs, (2, 2, 2), n, pos, None, steps, "decomposed", uniform=True)
+    assert np.array_equal(d["ids"], np.arange(len(pos)))                       # nobody lost, nobody twice
+    assert np.isfinite(d["pos"]).all() and np.isfinite(d["vel"]).all()
+    lo, hi = fs.grid_bounds(n)
+    assert d["pos"].min() > lo and d["pos"].max() < hi
+    na, nb = [s["num_active"] for s in d["st"]], [s["num_active"] for s in ref["st"]]
+    same = next((i for i in range(steps) if na[i] != nb[i]), steps)
+    print(f"splash: unknown counts identical for the first {same} of {steps} steps; last {na[-1]} vs {nb[-1]}; "
+          f"iterations {sum(s['cg_iters'] for s in d['st'])} vs {sum(s['cg_iters'] for s in ref['st'])}; counts {d['counts']}")
+    assert same >= 40
+    assert abs(na[-1] - nb[-1]) <= 0.02 * nb[-1]
+    assert all(s["relres"] < 1e-14 for s in d["st"])
+    a, b = sum(s["cg_iters"] for s in d["st"]), sum(s["cg_iters"] for s in ref["st"])
+    assert a <= 1.25 * b, (a, b)
+    assert max(d["counts"]) > 0 and sum(d["counts"]) == len(pos)
+
+
 def run_dist(world, n, ppc, steps, tmp_path, extra=(), mode="staged"):
     out = str(tmp_path / f"dist_{world}_{n}_{mode}.npz")
     port = 29500 + (os.getpid() % 2000) + world
