@@ -84,7 +84,7 @@ def usable_cores():
 
 def pmc_traffic(kernel, n, ppc):
     """HBM/fabric bytes per launch measured by separate rocprofv3 --pmc passes of this workload (see the file's "method")."""
-    tj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
     if n != 256 or ppc != 8 or not os.path.exists(tj):
         return None
     return json.load(open(tj)).get("kernels_final", {}).get(kernel, {}).get("bytes_per_launch")
@@ -247,7 +247,7 @@ def main():
         ach = algo / (avg_ms * 1e-3) / 1e9
         e = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": pmc_traffic(key, n, ppc) if transport is None else None,
-             "traffic_source": "profiles/r01/pmc_traffic.json (kernels_final)", "algorithmic_bytes_per_launch": algo,
+             "traffic_source": "profiles/r02/pmc_traffic.json (kernels_final): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload", "algorithmic_bytes_per_launch": algo,
              "cells_per_launch": cells, "avg_launch_us": avg_ms * 1e3, "launches": prof["launches"], "sampled": prof["sampled"],
              "total_ms_in_timed_region": avg_ms * prof["launches"]}
         if note:
@@ -266,7 +266,7 @@ def main():
               "with 4 blocks per CU), not by bandwidth, DESIGN.md 3"),
         roof_entry("k_mg_up<float, double, double, 8, 8, 16> (level-0 up leg of the V-cycle: prolongation + two damped-Jacobi sweeps + r.z partials)",
               mgs, lambda c: c * 21.5, "k_mg_up<float, double, double, 8, 8, 16>", small),
-        roof_entry("k_pcg_sq_l<double, true> (PCG: s' = z + beta s, q = A s', partial s'.q)", sq, lambda c: c * 33.0, "k_pcg_sq_l<double, true>", small),
+        roof_entry("k_pcg_sq_l<double, false> (PCG: s' = z + beta s, q = A s', partial s'.q)", sq, lambda c: c * 33.0, "k_pcg_sq_l<double, false>", small),
         roof_entry("k_pcg_xr_l<double> (PCG: x += alpha s, r -= alpha q, partial r.r)", xr, lambda c: c * 49.0, "k_pcg_xr_l<double>", small),
     ]
     cands = [c for c in cands if c]
