@@ -39,6 +39,7 @@ void launch_cnt_pcg(hipStream_t st, LBox L, Box own, const uint8_t* cnt, uint8_t
 template <typename T>
 void launch_mask_outside(hipStream_t st, MLevel m, Box own, T* a);
 void launch_mg_type_local(hipStream_t st, Grid g, MLevel m, int w0, int w1, int w2, const uint8_t* flags, const uint8_t* cnt, uint8_t* typ);
+void launch_copy_vel_before(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w, double* ub, double* vb, double* wb);
 void launch_pack_box_own(hipStream_t st, Grid g, Box box, Box own, const float* container, const double* u, const double* v, const double* w, double* buf);
 
 }  // namespace fl

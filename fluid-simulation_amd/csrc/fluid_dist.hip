@@ -99,7 +99,7 @@ struct DistState {
     IBox Pg{}, Rg{}, Sg{};
     Box Rr{0, 0, 0, -1, -1, -1}, Sr{0, 0, 0, -1, -1, -1};   // owned parts, window coordinates
     // plans
-    HaloPlan plan_flags, plan_f1;
+    HaloPlan plan_flags, plan_f1, plan_gather;
     // solver
     int split = 1, split_force = 0;
     IBox dom0{};                      // global level-0 multigrid domain [A, B)
@@ -402,9 +402,8 @@ int dist_g2p_advect(fluid_sim* s, fluid_step_stats_t* stats)
 }
 
 // ---- replicated pressure block ------------------------------------------------------------------------------------
-// Particles sharded by block; the P2G result of the whole active box is assembled on every rank by one SUM all-reduce of
-// [container | u | v | w] (every cell has exactly one owner, the others add exact zeros: bit-identical to a one-GPU
-// P2G), and flags, numbering, the pressure do..while with the single-GPU multigrid PCG and the FLIP delta field run
+// Particles sharded by block; the P2G result of the whole active box is assembled on every rank — an all-gather between
+// the blocks when all of them are adjacent, else one SUM all-reduce: bit-identical to a one-GPU P2G either way — and flags, numbering, the pressure do..while with the single-GPU multigrid PCG and the FLIP delta field run
 // identically on every rank with no communication.
 int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
 {
@@ -422,17 +421,32 @@ int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
             prof_end(s, FLUID_PROF_P2G, tok);
             if (rc) return rc;
         }
-        const size_t need = 4 * (size_t)s->Rb.cells();
-        if (need > d->repl_cap) {
-            if (d->repl_buf) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->repl_buf); d->repl_buf = nullptr; }
-            HIPCHK(hipMalloc((void**)&d->repl_buf, (need + need / 4) * sizeof(double)));
-            d->repl_cap = need + need / 4;
+        if (d->dims[0] <= 2 && d->dims[1] <= 2 && d->dims[2] <= 2) {
+            // every other block is adjacent (<= 2 blocks per axis, e.g. 2 x 2 x 2): ALL-GATHER — each block sends its owned part
+            // of the box straight to every other block (one grouped exchange over all its xGMI links at once, no arithmetic,
+            // half the bytes of the all-reduce below); exact copies, so the fields are bit-identical to a one-GPU P2G
+            const int org[3] = {0, 0, 0};
+            make_plan(d, d->plan_gather, [&](int r) { return ib_isect(block_of(d, r), d->Rg); }, g.N, org, 0, g.sx(), g.nz);
+            if ((rc = halo_exchange1(s, d->plan_gather, 4, s->container))) return rc;
+            void* a[3] = {s->u, s->v, s->w};
+            if ((rc = halo_exchange(s, d->plan_gather, 8, 3, a))) return rc;
+            launch_copy_vel_before(s->st, g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+            HIPCHK(hipGetLastError());
+        } else {
+            // general decomposition: one SUM all-reduce of [container | u | v | w] over the box (every cell has exactly one
+            // owner, the others add exact zeros)
+            const size_t need = 4 * (size_t)s->Rb.cells();
+            if (need > d->repl_cap) {
+                if (d->repl_buf) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->repl_buf); d->repl_buf = nullptr; }
+                HIPCHK(hipMalloc((void**)&d->repl_buf, (need + need / 4) * sizeof(double)));
+                d->repl_cap = need + need / 4;
+            }
+            launch_pack_box_own(s->st, g, s->Rb, d->Rr, s->container, s->u, s->v, s->w, d->repl_buf);
+            HIPCHK(hipGetLastError());
+            if ((rc = comm_allreduce(s, d->repl_buf, (long)need, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            launch_unpack_box(s->st, g, s->Rb, d->repl_buf, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
+            HIPCHK(hipGetLastError());
         }
-        launch_pack_box_own(s->st, g, s->Rb, d->Rr, s->container, s->u, s->v, s->w, d->repl_buf);
-        HIPCHK(hipGetLastError());
-        if ((rc = comm_allreduce(s, d->repl_buf, (long)need, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
-        launch_unpack_box(s->st, g, s->Rb, d->repl_buf, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
-        HIPCHK(hipGetLastError());
     }
     s->have_p2g = true;
     s->have_flags = false;

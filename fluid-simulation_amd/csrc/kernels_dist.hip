@@ -284,6 +284,22 @@ void launch_mg_type_local(hipStream_t st, Grid g, MLevel m, int w0, int w1, int 
     if (n > 0) hipLaunchKernelGGL(k_mg_type_local, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, m, w0, w1, w2, flags, cnt, typ);
 }
 
+// velBeforeUpdate = vels.deepCopy() (fluid.cc:1455) over a box: the cells gathered from the other blocks
+__global__ __launch_bounds__(256) void k_copy_vel_before(Grid g, Box box, const double* __restrict__ u, const double* __restrict__ v,
+                                                         const double* __restrict__ w, double* __restrict__ ub, double* __restrict__ vb,
+                                                         double* __restrict__ wb)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= box.cells()) return;
+    const int nz = box.nz(), ny = box.ny();
+    const size_t c = g.idx((int)(t / ((long)nz * ny)) + box.x0, (int)((t / nz) % ny) + box.y0, (int)(t % nz) + box.z0);
+    ub[c] = u[c]; vb[c] = v[c]; wb[c] = w[c];
+}
+void launch_copy_vel_before(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w, double* ub, double* vb, double* wb)
+{
+    if (box.cells() > 0) hipLaunchKernelGGL(k_copy_vel_before, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, u, v, w, ub, vb, wb);
+}
+
 // P2G result of the owned cells of the active box, packed for the SUM all-reduce of the replicated mode
 // (k_pack_box with a 3-D ownership box; own in window coordinates, inclusive)
 __global__ __launch_bounds__(256) void k_pack_box_own(Grid g, Box box, Box own, const float* __restrict__ container, const double* __restrict__ u,

@@ -105,6 +105,8 @@ CASES = [
     ((2, 2, 2), 48, 4, 4, {"vel": 2.0}, {}),
     ((2, 2, 2), 40, 4, 3, {"vel": 1.0}, {"flip_blend": 0.9}),
     ((2, 1, 1), 32, 4, 3, {"pile": 600}, {}),
+    ((2, 2, 1), 50, 4, 3, {"vel": 0.5}, {}),          # grid sizes that are no multiple of 4 (the reference's own is 121)
+    ((2, 1, 2), 33, 3, 3, {}, {}),
 ]
 
 
