@@ -334,16 +334,13 @@ int mg_up_blocks(const MLevel& m);
 // T = the V-cycle's arithmetic/storage type, F / O = element types of a level's rhs / result (double at level 0)
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
-                    const PcgState* ps, const int* tlist = nullptr, int nlist = 0, const int* nlist_dev = nullptr);
+                    const PcgState* ps, const int* tlist = nullptr, int nlist = 0);
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0, const uint8_t* own = nullptr,
-                  const int* nlist_dev = nullptr);
+                  double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0, const uint8_t* own = nullptr);
 // Active-tile lists of a mostly-air box (level 0 only): flags per tile of the V-cycle legs / of the SQ kernel, and their
 // compaction in ascending tile order (list[0..*count)); the legs, SQ and XR are then launched over the listed tiles only.
-void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags, int mask = 0xff);
-void launch_mg_tile_flags_r(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags, int mask = 0xff);
-int mg_down_r_blocks(const MLevel& m);
+void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags);
 void launch_sq_tile_flags(hipStream_t st, LBox L, const uint8_t* cnt, uint8_t* flags);
 int sq_tile_count(const LBox& L);
 void launch_compact_flags(hipStream_t st, const uint8_t* flags, int n, int* list, int* count);

@@ -172,7 +172,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->tl_lv, s->tl_lv_cnt, s->tl_lv_flags};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -417,7 +417,7 @@ int fl::clear_dirty(fluid_sim* s)
 // fluid.cc:992-999), so the planes of the previous bounding box +- 3 hold every particle and every row a P2G window of
 // this step can touch.  The bounding box read back below tells whether that held; if not (first step, new particles)
 // the sort is simply repeated over the whole grid.
-static int sort_pass(fluid_sim* s, int ax0, int ax1)
+int fl::sort_pass(fluid_sim* s, int ax0, int ax1, int* h_tail)
 {
     const Grid g = s->g;
     const long ncell = (long)s->ncell, n2 = g.sx();
@@ -431,6 +431,7 @@ static int sort_pass(fluid_sim* s, int ax0, int ax1)
     launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->pa.shifted(s->p_off).pid, s->order, s->spid);
     launch_bin_rank(s->st, s->np, 0, s->key, s->cell_start, s->order, s->spid, s->order2);  // every position 0..np (cells, off-grid bucket)
     HIPCHK(hipGetLastError());
+    if (h_tail) HIPCHK(hipMemcpyAsync(h_tail, s->cell_start + ncell, 3 * sizeof(int), hipMemcpyDeviceToHost, s->st));   // bucket starts (decomposed run)
     return read_ss(s);
 }
 
@@ -614,35 +615,6 @@ static int mg_setup(fluid_sim* s)
     launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
     for (int l = 1; l < nl; ++l) launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
     HIPCHK(hipGetLastError());
-    // mostly-air box: the levels 1 .. tail-1 also run over lists of the tiles that hold an unknown (the spray leaves most coarse
-    // tiles empty too); built here on the device, lengths included: no read-back
-    s->lists_lv = false;
-    if (s->lists_on && tail > 1) {
-        size_t need = 0, nflag = 0;
-        for (int l = 1; l < tail; ++l) {
-            const size_t nd = (size_t)mg_down_r_blocks(s->mgl[l]), nu = (size_t)mg_up_blocks(s->mgl[l]);
-            s->tl_lv_off[0][l] = need; need += nd;
-            s->tl_lv_off[1][l] = need; need += nu;
-            nflag = std::max(nflag, std::max(nd, nu));
-        }
-        if (need + nflag > s->tl_lv_cap) {
-            HIPCHK(hipStreamSynchronize(s->st));
-            hipFree(s->tl_lv); hipFree(s->tl_lv_flags);
-            s->tl_lv = nullptr; s->tl_lv_flags = nullptr;
-            s->tl_lv_cap = (need + nflag) * 5 / 4 + 1024;
-            HIPCHK(hipMalloc((void**)&s->tl_lv, s->tl_lv_cap * sizeof(int)));
-            HIPCHK(hipMalloc((void**)&s->tl_lv_flags, s->tl_lv_cap));
-        }
-        if (!s->tl_lv_cnt) HIPCHK(hipMalloc((void**)&s->tl_lv_cnt, 2 * fluid_sim::MG_MAXL * sizeof(int)));
-        for (int l = 1; l < tail; ++l) {
-            launch_mg_tile_flags_r(s->st, s->mgl[l], s->mg_typ[l], s->tl_lv_flags, 2);   // by cell type: covers every coarse unknown under the tile
-            launch_compact_flags(s->st, s->tl_lv_flags, mg_down_r_blocks(s->mgl[l]), s->tl_lv + s->tl_lv_off[0][l], s->tl_lv_cnt + 2 * l);
-            launch_mg_tile_flags(s->st, s->mgl[l], s->mg_typ[l], s->tl_lv_flags, 2);
-            launch_compact_flags(s->st, s->tl_lv_flags, mg_up_blocks(s->mgl[l]), s->tl_lv + s->tl_lv_off[1][l], s->tl_lv_cnt + 2 * l + 1);
-        }
-        HIPCHK(hipGetLastError());
-        s->lists_lv = true;
-    }
     return FLUID_OK;
 }
 
@@ -695,9 +667,6 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         const uint8_t* cc = fold ? s->mg_cnt[l + 1] : nullptr;
         const bool lst = s->lists_on && !fold;
         if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
-        else if (s->lists_lv && fold)
-            launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps,
-                                 s->tl_lv + s->tl_lv_off[0][l], 0, s->tl_lv_cnt + 2 * l);
         else launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps);
         if (!fold) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
     }
@@ -714,9 +683,6 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
             launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0],
                                             s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg);
             prof_end(s, FLUID_PROF_MG_UP0, tok);
-        } else if (s->lists_lv) {
-            launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2],
-                                  s->tl_lv + s->tl_lv_off[1][l], 0, nullptr, s->tl_lv_cnt + 2 * l + 1);
         } else {
             launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
         }

@@ -289,22 +289,25 @@ int dist_particles(fluid_sim* s)
 {
     DistState* d = s->ds;
     const Grid g = s->g;
-    const long ncell = (long)s->ncell;
     int rc;
     int tok = prof_begin(s, FLUID_PROF_SORT, (double)s->np);
     if ((rc = route_round(s))) return rc;
-    // sort: cells of the window, then "off the window" (= off the grid: only an edge block can hold such a particle), then dead
-    launch_zero_step_state(s->st, s->ss, std::max(g.nx, std::max(g.ny, g.nz)));
-    HIPCHK(hipMemsetAsync(s->cell_count, 0, (ncell + 4) * sizeof(int), s->st));
-    launch_bin_count(s->st, g, s->np, s->pa.shifted(s->p_off), s->key, s->slot, s->cell_count, s->ipart, s->ss);
-    launch_exclusive_scan(s->st, s->cell_count, s->cell_start, ncell + 2, s->scan_sums, s->cell_start + ncell + 2);
-    launch_bin_scatter(s->st, s->np, s->key, s->slot, s->cell_start, s->pa.shifted(s->p_off).pid, s->order, s->spid);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(d->h_cnt, s->cell_start + ncell, 3 * sizeof(int), hipMemcpyDeviceToHost, s->st));
-    if ((rc = read_ss(s))) return rc;
+    // sort: cells of the window, then "off the window" (= off the grid: only an edge block can hold such a particle), then dead.
+    // Like the one-GPU sort only the x planes the particles can be in are zeroed, counted into and scanned (the global box of the
+    // previous step + 3: CFL, and what arrived from the neighbours lies inside that box too); if the box read back says otherwise
+    // (first step, new particles) the sort is repeated over the whole window — a local decision, no collective inside.
+    {
+        int ax0 = 0, ax1 = g.nx - 1;
+        const bool guess = s->sort_hint && !box_empty(s->Pb);
+        if (guess) { ax0 = std::max(0, s->Pb.x0 - 3); ax1 = std::min(g.nx - 1, s->Pb.x1 + 3); }
+        if ((rc = sort_pass(s, ax0, ax1, d->h_cnt))) return rc;
+        if (guess && s->h_ss->bbox_max[0] >= 0 && (s->h_ss->bbox_min[0] < std::min(ax0 + 2, s->Pb.x0) || s->h_ss->bbox_max[0] > std::max(ax1 - 2, s->Pb.x1))) {
+            if ((rc = sort_pass(s, 0, g.nx - 1, d->h_cnt))) return rc;
+        }
+        s->sort_hint = true;
+    }
     const long live = d->h_cnt[1];   // cells + off-grid bucket; the dead (last step's ghosts, this step's migrants) are dropped
     s->n_out = d->h_cnt[1] - d->h_cnt[0];
-    launch_bin_rank(s->st, live, 0, s->key, s->cell_start, s->order, s->spid, s->order2);
     launch_reorder(s->st, live, s->order2, s->pa.shifted(s->p_off), s->pb, s->pw, s->cap);   // + the P2G axis weights
     HIPCHK(hipGetLastError());
     std::swap(s->pa, s->pb);

@@ -195,8 +195,7 @@ __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi)
 template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT>
 __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
                                                  T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
-                                                 MgCoef<T> cf, const PcgState* ps, int gx, int gy, const int* __restrict__ tlist,
-                                                 const int* __restrict__ nlist_dev)
+                                                 MgCoef<T> cf, const PcgState* ps, int gx, int gy, const int* __restrict__ tlist)
 {
     constexpr int H = RESTRICT ? 3 : 2;
     constexpr int AX = TX + 2 * H, AY = TY + 2 * H, AZ = TZ + 2 * H;  // u1 and the count bytes
@@ -213,11 +212,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     const int col = threadIdx.x;
     // 1-D launch: virtual tile ids are dealt so that each XCD (own L2) gets a contiguous run of tiles, z fastest;
     // tlist (mostly-air box): only the tiles that hold an unknown are launched, in ascending order (k_mg_tile_flags)
-    // nlist_dev (levels >= 1 of a mostly-air box): the list's length lives on the device — the launch covers every tile and the
-    // blocks beyond the list leave at once, so no host read-back is needed between building the lists and using them
-    const int nlist = nlist_dev ? *nlist_dev : (int)gridDim.x;
-    if ((int)blockIdx.x >= nlist) return;
-    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, nlist)] : xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);
     const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
     const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
     const T w1 = (T)MG_W1, w2 = (T)MG_W2, off = cf.off;
@@ -329,7 +324,7 @@ template <typename T, typename F, typename O, int TX, int TY, int TZ>
 __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
                                                O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
                                                double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
-                                               const int* __restrict__ tlist, const uint8_t* __restrict__ own, const int* __restrict__ nlist_dev)
+                                               const int* __restrict__ tlist, const uint8_t* __restrict__ own)
 {
     // own (decomposed run, level 0): the PCG's count bytes — the partial f.out counts the rank's owned unknowns only
     // (non-zero byte without bit 7); the result itself is written on every unknown of the local box
@@ -347,12 +342,7 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     __shared__ double red[4];
     if (ps && ps->done) return;
     const int col = threadIdx.x;
-    const int nlist = nlist_dev ? *nlist_dev : (int)gridDim.x;   // see k_mg_down
-    if ((int)blockIdx.x >= nlist) {
-        if (part_dot && threadIdx.x == 0) part_dot[blockIdx.x] = 0;
-        return;
-    }
-    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, nlist)] : xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);  // see k_mg_down
     const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
     const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
     const int I0 = i0 / 2 - 2, J0 = j0 / 2 - 2, K0 = k0 / 2 - 2;
@@ -746,10 +736,8 @@ constexpr int MG_TX = 8, MG_TY = 8, MG_TZ = 16;   // down (no restriction) and u
 constexpr int MG_RX = 8, MG_RY = 8, MG_RZ = 8;    // down with the restriction folded in (halo 3)
 // flags[t] = tile t of the level-0 legs (MG_TX x MG_TY x MG_TZ cells, numbered as k_mg_down / k_mg_up decode them) holds an unknown
 template <int TX, int TY, int TZ>
-__global__ __launch_bounds__(256) void k_mg_tile_flags(MLevel m, const uint8_t* __restrict__ cnt, int gx, int gy, uint8_t* __restrict__ flags, int mask)
+__global__ __launch_bounds__(256) void k_mg_tile_flags(MLevel m, const uint8_t* __restrict__ cnt, int gx, int gy, uint8_t* __restrict__ flags)
 {
-    // mask 0xff: `cnt` = count bytes (an unknown has a non-zero count); mask 2: `cnt` = cell types, a tile counts if it holds a
-    // fluid-type cell (2) — a superset of the unknowns that also covers every coarse unknown under the tile
     const int tile = blockIdx.x;
     const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
     const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
@@ -757,7 +745,7 @@ __global__ __launch_bounds__(256) void k_mg_tile_flags(MLevel m, const uint8_t* 
     for (int t = threadIdx.x; t < TX * TY * TZ; t += 256) {
         const int z = t % TZ, y = (t / TZ) % TY, x = t / (TZ * TY);
         const int i = i0 + x, j = j0 + y, k = k0 + z;
-        if (i < m.dx && j < m.dy && k < m.dz) any |= cnt[m.at(i, j, k)] & mask;
+        if (i < m.dx && j < m.dy && k < m.dz) any |= cnt[m.at(i, j, k)];
     }
     any = __syncthreads_or(any);
     if (threadIdx.x == 0) flags[tile] = any != 0;
@@ -777,46 +765,34 @@ int mg_up_blocks(const MLevel& m)
 // both pre-sweeps + residual; with a coarse level (fc != nullptr) the restricted residual goes straight to fc and r is not written
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
-                    const PcgState* ps, const int* tlist, int nlist, const int* nlist_dev)
+                    const PcgState* ps, const int* tlist, int nlist)
 {
     if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return;   // an empty local level (decomposed run)
     if (fc) {
-        // (tlist with nlist_dev: the tiles of THIS shape that hold an unknown, mg_down_r_blocks(m) of them at most)
         const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
         hipLaunchKernelGGL((k_mg_down<T, F, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
-                           ps, (int)g.x, (int)g.y, nlist_dev ? tlist : (const int*)nullptr, nlist_dev);
+                           ps, (int)g.x, (int)g.y, (const int*)nullptr);
     } else {
         const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
-        hipLaunchKernelGGL((k_mg_down<T, F, MG_TX, MG_TY, MG_TZ, false>), dim3(tlist && !nlist_dev ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u,
-                           r, mc, cnt_c, fc, cf, ps, (int)g.x, (int)g.y, tlist, nlist_dev);
+        hipLaunchKernelGGL((k_mg_down<T, F, MG_TX, MG_TY, MG_TZ, false>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u,
+                           r, mc, cnt_c, fc, cf, ps, (int)g.x, (int)g.y, tlist);
     }
-}
-int mg_down_r_blocks(const MLevel& m)
-{
-    const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
-    return (int)(g.x * g.y * g.z);
 }
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps, double wc, const int* tlist, int nlist, const uint8_t* own, const int* nlist_dev)
+                  double* part_dot, const PcgState* ps, double wc, const int* tlist, int nlist, const uint8_t* own)
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
     if (!tlist && g.x * g.y * g.z == 0) return;   // an empty local level (decomposed run: a block outside the active box)
-    hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(tlist && !nlist_dev ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc,
-                       ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist, own, nlist_dev);
+    hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc,
+                       ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist, own);
 }
-// flags of the leg tiles of a level (mg_up_blocks(m) of them), see k_mg_tile_flags
-void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags, int mask)
+// flags of the level-0 leg tiles (mg_up_blocks(m) of them), see k_mg_tile_flags
+void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags)
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
-    hipLaunchKernelGGL((k_mg_tile_flags<MG_TX, MG_TY, MG_TZ>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, (int)g.x, (int)g.y, flags, mask);
-}
-// ... and of the tiles of the down leg with the restriction folded in (mg_down_r_blocks(m) of them)
-void launch_mg_tile_flags_r(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags, int mask)
-{
-    const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
-    hipLaunchKernelGGL((k_mg_tile_flags<MG_RX, MG_RY, MG_RZ>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, (int)g.x, (int)g.y, flags, mask);
+    hipLaunchKernelGGL((k_mg_tile_flags<MG_TX, MG_TY, MG_TZ>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, (int)g.x, (int)g.y, flags);
 }
 
 // LDS footprint of a tail that starts at lv[0] (compact arrays, ring of one cell below and two above — the 4x4x4
@@ -876,17 +852,17 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
 
 #define INSTMG(T)                                                                                                                        \
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*, \
-                                       const int*, int, const int*); \
+                                       const int*, int); \
     template void launch_mg_up<T, T, T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*,  \
-                                        const PcgState*, double, const int*, int, const uint8_t*, const int*);                                                                   \
+                                        const PcgState*, double, const int*, int, const uint8_t*);                                                                               \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                     \
     template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*, double);
 INSTMG(double)
 INSTMG(float)
 // level 0 of a single-precision V-cycle inside the double-precision PCG
 template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
-                                            MgCoef<float>, const PcgState*, const int*, int, const int*);
+                                            MgCoef<float>, const PcgState*, const int*, int);
 template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
-                                                  MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*, const int*);
+                                                  MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*);
 
 }  // namespace fl

@@ -66,13 +66,6 @@ struct fluid_sim {
     uint8_t* tl_flags = nullptr;  // per-tile flags (both tile shapes, one after the other)
     int *tl_mg = nullptr, *tl_sq = nullptr;
     size_t tl_cap = 0;
-    // ... and the same for the levels >= 1 that run as kernels (two tile shapes per level: down leg with the restriction folded in,
-    // up leg); their lengths stay on the device (tl_lv_cnt[2 * l + shape]), the launches cover every tile
-    int *tl_lv = nullptr, *tl_lv_cnt = nullptr;
-    uint8_t* tl_lv_flags = nullptr;
-    size_t tl_lv_cap = 0;
-    size_t tl_lv_off[2][8] = {};
-    bool lists_lv = false;        // this step's V-cycles use them
     int n_tl_mg = 0, n_tl_sq = 0;
     bool lists_hint = false;      // the previous step's box was mostly air: build the lists before this step's flags sync
     bool lists_on = false;        // this step's solves use them
@@ -134,6 +127,7 @@ void prof_end(fluid_sim* s, int k, int tok);
 int alloc_particles(fluid_sim* s, long n);
 int grow_particles(fluid_sim* s, long need);
 int read_ss(fluid_sim* s);
+int sort_pass(fluid_sim* s, int ax0, int ax1, int* h_tail = nullptr);   // counting sort over the x planes [ax0, ax1] of the window
 int clear_dirty(fluid_sim* s);
 int run_p2g(fluid_sim* s, const Box& box);
 template <typename T>
