@@ -1022,11 +1022,13 @@ int fluid_upload_particles_ids(fluid_sim_t* s, int64_t n, const double* pos, con
     if (!s || n < 0 || (n > 0 && (!pos || !ids))) return fail(FLUID_ERR_ARG, "bad particle arguments");
     HIPCHK(hipSetDevice(s->prm.device));
     // some room for ghosts and for particles that migrate in; both the particle arrays and the routing buffers grow on demand
-    int rc = alloc_particles(s, 2 * (long)n + (1L << 16));
+    long slack = 1L << 16;
+    if (const char* e = getenv("FLUID_DIST_SLACK")) slack = std::max(16L, atol(e));   // developer knob: tests force the growth paths with it
+    int rc = alloc_particles(s, 2 * (long)n + slack);
     if (rc) return rc;
     DistState* d = s->ds;
     if (d && !d->mig_s) {
-        d->mig_cap = (long)n / 2 + (1L << 16);
+        d->mig_cap = (long)n / 2 + slack;
         HIPCHK(hipMalloc((void**)&d->mig_s, (size_t)d->mig_cap * 56));
         HIPCHK(hipMalloc((void**)&d->mig_r, (size_t)d->mig_cap * 56));
     }

@@ -47,6 +47,23 @@ int main(int argc, char** argv)
         if (fluid_write_vdb(path, n, n == 8 ? 1 : 2, grids) != FLUID_OK) return fail("fluid_write_vdb");
     }
     if (fluid_write_vdb("/nonexistent-dir/x.vdb", 8, 1, nullptr) == FLUID_OK) return fail("bad path accepted");
+    {   // both compressions, and the streaming form the driver uses for the final mygrids.vdb (one grid appended per step)
+        const int n = 13;
+        std::vector<float> a((size_t)n * n * n);
+        for (size_t i = 0; i < a.size(); ++i) a[i] = (i % 5 == 0) ? 0.f : (float)(i % 11);
+        const float* g1[1] = {a.data()};
+        char path[512];
+        std::snprintf(path, sizeof path, "%s/san_mask.vdb", dir);
+        if (fluid_write_vdb_ex(path, n, 1, g1, FLUID_VDB_ACTIVE_MASK) != FLUID_OK) return fail("fluid_write_vdb_ex");
+        std::snprintf(path, sizeof path, "%s/san_stream.vdb", dir);
+        fluid_vdb_writer_t* w = nullptr;
+        if (fluid_vdb_open(path, n, 3, FLUID_VDB_ZIP_ACTIVE_MASK, &w) != FLUID_OK) return fail("fluid_vdb_open");
+        for (int k = 0; k < 3; ++k)
+            if (fluid_vdb_append(w, a.data()) != FLUID_OK) return fail("fluid_vdb_append");
+        if (fluid_vdb_append(w, a.data()) == FLUID_OK) return fail("a fourth grid accepted");
+        if (fluid_vdb_close(w) != FLUID_OK) return fail("fluid_vdb_close");
+        if (fluid_vdb_open(path, n, 3, 7, &w) == FLUID_OK) return fail("bad compression accepted");
+    }
     std::puts("host sanitizer run: ok");
     return 0;
 }

@@ -151,8 +151,13 @@ def test_decomposed_jacobi_and_uniform_cuts(fs):
     assert all(abs(a["cg_iters"] - b["cg_iters"]) <= 2 * b["outer_passes"] for a, b in zip(st, rs))
 
 
-def test_block_empties_and_fills(fs):
-    """A block that holds no particle at first (uniform cuts, the cube in one corner region) and receives them as the fluid falls."""
+@pytest.mark.parametrize("slack", [None, "64"])
+def test_block_empties_and_fills(fs, slack, monkeypatch):
+    """A block that holds no particle at first (uniform cuts, the cube in one corner region) and receives them as the fluid falls.
+    With almost no spare capacity (FLUID_DIST_SLACK) the particle arrays and the routing buffers must GROW on demand: a rank
+    never fails alone for lack of room (its peers would wait for it in the next exchange)."""
+    if slack:
+        monkeypatch.setenv("FLUID_DIST_SLACK", slack)
     n, steps = 48, 12
     pos, _ = scene(fs, n, 4)
     pos = pos + np.array([6.0, 9.0, 0.0])        # off-centre: the low-y blocks start empty
@@ -160,6 +165,20 @@ def test_block_empties_and_fills(fs):
     d = run_blocks(fs, (1, 2, 2), n, pos, None, steps, "decomposed", uniform=True)
     assert min(d["counts"]) >= 0
     compare(d, ref, len(pos), "fills", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
+
+
+@pytest.mark.parametrize("n,ppc", [(256, 8), (512, 4)])
+def test_baseline_multi_gpu_configs_on_blocks(fs, n, ppc):
+    """BASELINE.json configs[3] (256^3 domain-decomposed 2 x 2 x 2) and configs[4] (512^3, 4 particles per cell, 8 GPUs) AT SIZE,
+    the eight blocks as threads over the in-process transport on this box's one GPU: two whole steps (the 8-pass first step
+    and a steady one) against the one-GPU run — numbering bit-exact, fields to rounding, iteration counts within 20 %."""
+    pos = fs.water_cube_drop(n, ppc, seed=0)
+    steps = 2
+    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    d = run_blocks(fs, (2, 2, 2), n, pos, None, steps, "decomposed")
+    st, rs = compare(d, ref, len(pos), f"decomposed 2x2x2 n={n}")
+    a, b = sum(s["cg_iters"] for s in st), sum(s["cg_iters"] for s in rs)
+    assert a <= 1.2 * b, (a, b)
 
 
 def test_decomposed_through_the_splash(fs):

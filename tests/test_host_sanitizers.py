@@ -15,7 +15,7 @@ def test_scatter_and_vdb_writer_under_asan_ubsan(tmp_path):
     exe = tmp_path / "host_san"
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
            "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "scene_scatter.cpp"), os.path.join(CSRC, "vdb_writer.cpp"),
-           os.path.join(ROOT, "tests", "host_san_main.cpp"), "-o", str(exe)]
+           os.path.join(ROOT, "tests", "host_san_main.cpp"), "-o", str(exe), "-lz"]
     b = subprocess.run(cmd, capture_output=True, text=True)
     if b.returncode != 0 and "asan" in (b.stderr or "").lower() and "cannot find" in b.stderr.lower():
         pytest.skip("sanitizer runtime not installed")
