@@ -334,7 +334,7 @@ int mg_up_blocks(const MLevel& m);
 // T = the V-cycle's arithmetic/storage type, F / O = element types of a level's rhs / result (double at level 0)
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
-                    const PcgState* ps, const int* tlist = nullptr, int nlist = 0, const double* head_rr = nullptr, int n_head = 0);
+                    const PcgState* ps, const int* tlist = nullptr, int nlist = 0);
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
                   double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0, const uint8_t* own = nullptr);

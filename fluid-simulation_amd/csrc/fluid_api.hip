@@ -651,7 +651,7 @@ static MgCoef<V> mg_coef_as(const fluid_sim* s, int level)
     return c;
 }
 template <typename V>
-static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, const double* head_rr, int n_head)
+static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
     const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
@@ -666,7 +666,7 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         V* fc = fold ? F(l + 1) : nullptr;
         const uint8_t* cc = fold ? s->mg_cnt[l + 1] : nullptr;
         const bool lst = s->lists_on && !fold;
-        if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg, head_rr, n_head);
+        if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
         else launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps);
         if (!fold) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
     }
@@ -690,10 +690,9 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
-// head_rr / n_head: the partials of |r|^2 of the previous PCG body — the cycle's first kernel then carries that body's break test
-static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, const double* head_rr = nullptr, int n_head = 0)
+static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
-    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz, head_rr, n_head) : mg_vcycle_t<double>(s, rhs0, z0, part_rz, head_rr, n_head);
+    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz) : mg_vcycle_t<double>(s, rhs0, z0, part_rz);
 }
 
 // PCG loop of ConjugateGradient.h:28-90 with z = V-cycle(r); same start, stopping rule and cap as solve_impl.
@@ -739,7 +738,7 @@ static int solve_mg(fluid_sim* s)
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur], it > 0 ? s->part_rr : nullptr, lists ? n_list : n_init))) return rc;
+            if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur]))) return rc;
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
             if (lists)

@@ -195,8 +195,7 @@ __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi)
 template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT>
 __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
                                                  T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
-                                                 MgCoef<T> cf, PcgState* ps, int gx, int gy, const int* __restrict__ tlist,
-                                                 const double* __restrict__ head_rr, int n_head)
+                                                 MgCoef<T> cf, const PcgState* ps, int gx, int gy, const int* __restrict__ tlist)
 {
     constexpr int H = RESTRICT ? 3 : 2;
     constexpr int AX = TX + 2 * H, AY = TY + 2 * H, AZ = TZ + 2 * H;  // u1 and the count bytes
@@ -247,18 +246,6 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     T fr[XC];
 #pragma unroll
     for (int x = 0; x < XC; ++x) fr[x] = (T)f[qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx)];
-    if (head_rr) {
-        // First kernel of a PCG body (level 0): the break test of the previous body (ConjugateGradient.h:75-76) — every block
-        // re-sums the previous XR launch's partials of |r|^2 (the same value everywhere, the tile's loads above already in flight)
-        // and leaves if the solve has converged, so that the cycle of a body that will not happen is not computed: without this the
-        // test sits at the head of the SQ launch, one whole V-cycle later.  Block 0 records the state exactly as that head would.
-        __shared__ double hsm[5];
-        const double rr = block_sum_array<4>(head_rr, n_head, hsm);
-        if (rr < ps->thr) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) { ps->rr = rr; ps->done = 1; }
-            return;
-        }
-    }
     mg_load_coef(sd, si, cf);
     // ---- u1 = W1 D^-1 f on region A ----
     if (actA) {
@@ -778,17 +765,17 @@ int mg_up_blocks(const MLevel& m)
 // both pre-sweeps + residual; with a coarse level (fc != nullptr) the restricted residual goes straight to fc and r is not written
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
-                    const PcgState* ps, const int* tlist, int nlist, const double* head_rr, int n_head)
+                    const PcgState* ps, const int* tlist, int nlist)
 {
     if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return;   // an empty local level (decomposed run)
     if (fc) {
         const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
         hipLaunchKernelGGL((k_mg_down<T, F, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
-                           (PcgState*)ps, (int)g.x, (int)g.y, (const int*)nullptr, head_rr, n_head);
+                           ps, (int)g.x, (int)g.y, (const int*)nullptr);
     } else {
         const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
         hipLaunchKernelGGL((k_mg_down<T, F, MG_TX, MG_TY, MG_TZ, false>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u,
-                           r, mc, cnt_c, fc, cf, (PcgState*)ps, (int)g.x, (int)g.y, tlist, head_rr, n_head);
+                           r, mc, cnt_c, fc, cf, ps, (int)g.x, (int)g.y, tlist);
     }
 }
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
@@ -865,7 +852,7 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
 
 #define INSTMG(T)                                                                                                                        \
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*, \
-                                       const int*, int, const double*, int); \
+                                       const int*, int); \
     template void launch_mg_up<T, T, T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*,  \
                                         const PcgState*, double, const int*, int, const uint8_t*);                                                                               \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                     \
@@ -874,7 +861,7 @@ INSTMG(double)
 INSTMG(float)
 // level 0 of a single-precision V-cycle inside the double-precision PCG
 template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
-                                            MgCoef<float>, const PcgState*, const int*, int, const double*, int);
+                                            MgCoef<float>, const PcgState*, const int*, int);
 template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
                                                   MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*);
 
