@@ -739,7 +739,11 @@ int dist_solve(fluid_sim* s)
     const double cells = (double)ib_cells(d->lv[0].own);
     int rc;
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
-    launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
+    // start: x0 = 0, or (multigrid path, like the one-GPU solve) the previous pressure — every rank's owned values, its ring from
+    // the owners (the pressure halo exchange carries the guess too), so that r0 = b - A x0 is the same vector on both sides of a cut
+    const bool guess = mg && s->warm && s->have_guess;
+    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, s->p_guess, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
+    else launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
     long it = 0;
     long batch = s->mg_last_iters > 5 ? s->mg_last_iters : 8;   // identical on every rank
     bool done = false;
@@ -756,10 +760,12 @@ int dist_solve(fluid_sim* s)
             } else {
                 launch_sum2(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->part_rz[0], nxr, d->gstage[cur], d->gstage[cur] + 1);
             }
-            if ((rc = comm_allreduce(s, d->gstage[cur], 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            const bool g0 = it == 0 && guess;   // the first body of a warm-started solve also needs |r0|^2 (ConjugateGradient.h:51-56)
+            if (g0) launch_sum2(s->st, s->part_rz[1], nxr, s->part_rz[1], 0, d->gstage[cur] + 2, nullptr);
+            if ((rc = comm_allreduce(s, d->gstage[cur], g0 ? 3 : 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-            launch_pcg_sq_dist<T>(s->st, L, cnt, mg ? Z : R, Sx[prv], Sx[cur], Q, cf, d->gstage[cur], d->gstage[cur] + 1, d->gstage[prv] + 1, s->part_pq, s->ps,
-                                  it == 0, tol, mg ? 1 : 0);
+            launch_pcg_sq_dist<T>(s->st, L, cnt, mg ? Z : R, Sx[prv], Sx[cur], Q, cf, d->gstage[cur], d->gstage[cur] + 1, g0 ? d->gstage[cur] + 2 : d->gstage[prv] + 1,
+                                  s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, mg ? 1 : 0);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             launch_sum2(s->st, s->part_pq, nsq, s->part_pq, 0, d->gpq, nullptr);
             if ((rc = comm_allreduce(s, d->gpq, 1, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
@@ -778,7 +784,8 @@ int dist_solve(fluid_sim* s)
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
     if (!s->h_ps->done) iters = (int)max_it;
-    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, mg && s->warm ? s->p_guess : nullptr, s->ps);
+    s->have_guess = mg && s->warm;
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
@@ -864,7 +871,10 @@ int dist_step_decomposed(fluid_sim* s, fluid_step_stats_t* stats)
                 launch_rhs_div(s->st, g, d->Rr, s->flags, s->u, s->v, s->w, s->rhs, s->diver, s->prm.dx, s->prm.gravity[0] * dt, s->prm.gravity[1] * dt,
                                s->prm.gravity[2] * dt);
             if ((rc = dist_solve(s))) return rc;
-            if ((rc = halo_exchange1(s, d->plan_f1, 8, s->pressure))) return rc;
+            {
+                void* a[2] = {s->pressure, s->p_guess};   // (+ the next solve's starting guess: ring values from their owners)
+                if ((rc = halo_exchange(s, d->plan_f1, 8, s->have_guess ? 2 : 1, a))) return rc;
+            }
             const double dtp = dt * s->prm.update_frac, k = dtp / (s->prm.rho * s->prm.dx);
             if (!box_empty(d->Sr))
                 launch_vel_update(s->st, g, d->Sr, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,
@@ -983,14 +993,13 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
         g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
     }
     fluid_params_t q = *p;
-    if (!d->repl) q.solve_start = FLUID_START_ZERO;   // the decomposed PCG starts from x0 = 0 like the reference's cg.solve(b)
     int rc = fluid_create_window(&q, g, out);
     if (rc) { delete d; return rc; }
     fluid_sim* s = *out;
     s->dist = true;
     s->ds = d;
     auto bail = [&](const std::string& m) { fluid_destroy(s); *out = nullptr; return fail(FLUID_ERR_HIP, m); };
-    if (dalloc(&d->gstage[0], (size_t)2) != hipSuccess || dalloc(&d->gstage[1], (size_t)2) != hipSuccess || dalloc(&d->gpq, (size_t)1) != hipSuccess ||
+    if (dalloc(&d->gstage[0], (size_t)4) != hipSuccess || dalloc(&d->gstage[1], (size_t)4) != hipSuccess || dalloc(&d->gpq, (size_t)1) != hipSuccess ||
         dalloc(&d->d_cnt, (size_t)128) != hipSuccess || dalloc(&d->cnt_pcg, s->lmax + 64) != hipSuccess ||
         hipHostMalloc((void**)&d->h_cnt, 128 * sizeof(int)) != hipSuccess)
         return bail("alloc of the decomposition's scratch failed");

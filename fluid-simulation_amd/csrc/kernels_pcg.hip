@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const 
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
         const uint8_t c = cnt[t];
         T rv = 0, xv = 0;
-        if (c) {  // unknowns are interior cells: all six neighbours exist in both layouts
+        if (c && !(c & 0x80)) {  // unknowns are interior cells: all six neighbours exist in both layouts (bit 7: ring cell of a decomposed run, another rank's unknown — it counts as a neighbour below, not here)
             const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
             const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
             const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;

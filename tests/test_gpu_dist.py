@@ -114,8 +114,7 @@ CASES = [
 @pytest.mark.parametrize("dims,n,ppc,steps,skw,kw", CASES)
 def test_blocks_match_single(fs, mode, dims, n, ppc, steps, skw, kw):
     pos, vel = scene(fs, n, ppc, **skw)
-    # the decomposed PCG starts every solve from x0 = 0: compare with the one-GPU run that does the same
-    ref = single(fs, n, pos, vel, steps, solve_start="zero" if mode == "decomposed" else "warm", **kw)
+    ref = single(fs, n, pos, vel, steps, **kw)      # (both start their solves from the previous pressure by default)
     d = run_blocks(fs, dims, n, pos, vel, steps, mode, **kw)
     st, rs = compare(d, ref, len(pos), f"{mode} {dims} n={n}")
     if mode == "replicated":
@@ -134,9 +133,20 @@ def test_decomposed_levels_on_blocks(fs, split, monkeypatch):
     monkeypatch.setenv("FLUID_DIST_SPLIT", str(split))
     n, ppc, steps = 64, 4, 3
     pos, vel = scene(fs, n, ppc, vel=1.0)
-    ref = single(fs, n, pos, vel, steps, solve_start="zero")
+    ref = single(fs, n, pos, vel, steps)
     d = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed")
     st, rs = compare(d, ref, len(pos), f"split {split}")
+    a, b = sum(s["cg_iters"] for s in st), sum(s["cg_iters"] for s in rs)
+    assert a <= 1.2 * b + 2 * sum(s["outer_passes"] for s in rs), (a, b)
+
+
+def test_decomposed_from_zero_start(fs):
+    """solve_start = zero on both sides: every solve from x0 = 0 like the reference's cg.solve(b) (the iteration counts the reference's)."""
+    n, ppc, steps = 40, 4, 3
+    pos, vel = scene(fs, n, ppc, vel=1.0)
+    ref = single(fs, n, pos, vel, steps, solve_start="zero")
+    d = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed", solve_start="zero")
+    st, rs = compare(d, ref, len(pos), "x0 = 0, 2x2x2")
     a, b = sum(s["cg_iters"] for s in st), sum(s["cg_iters"] for s in rs)
     assert a <= 1.2 * b + 2 * sum(s["outer_passes"] for s in rs), (a, b)
 
@@ -161,7 +171,7 @@ def test_block_empties_and_fills(fs, slack, monkeypatch):
     n, steps = 48, 12
     pos, _ = scene(fs, n, 4)
     pos = pos + np.array([6.0, 9.0, 0.0])        # off-centre: the low-y blocks start empty
-    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    ref = single(fs, n, pos, None, steps)
     d = run_blocks(fs, (1, 2, 2), n, pos, None, steps, "decomposed", uniform=True)
     assert min(d["counts"]) >= 0
     compare(d, ref, len(pos), "fills", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
@@ -174,7 +184,7 @@ def test_baseline_multi_gpu_configs_on_blocks(fs, n, ppc):
     and a steady one) against the one-GPU run — numbering bit-exact, fields to rounding, iteration counts within 20 %."""
     pos = fs.water_cube_drop(n, ppc, seed=0)
     steps = 2
-    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    ref = single(fs, n, pos, None, steps)
     d = run_blocks(fs, (2, 2, 2), n, pos, None, steps, "decomposed")
     st, rs = compare(d, ref, len(pos), f"decomposed 2x2x2 n={n}")
     a, b = sum(s["cg_iters"] for s in st), sum(s["cg_iters"] for s in rs)
@@ -189,7 +199,7 @@ def test_decomposed_through_the_splash(fs):
     n, ppc, steps = 48, 4, 160
     pos, _ = scene(fs, n, ppc)
     pos = pos + np.array([3.0, 6.0, -2.0])       # off-centre: unequal blocks
-    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    ref = single(fs, n, pos, None, steps)
     d = run_blocks(fs, (2, 2, 2), n, pos, None, steps, "decomposed", uniform=True)
     assert np.array_equal(d["ids"], np.arange(len(pos)))                       # nobody lost, nobody twice
     assert np.isfinite(d["pos"]).all() and np.isfinite(d["vel"]).all()
@@ -225,7 +235,7 @@ def test_processes_over_gloo(fs, tmp_path, world, solve):
     n, ppc, steps = 32, 4, 3
     d = run_dist(world, n, ppc, steps, tmp_path, ("--solve", solve))
     pos, _ = scene(fs, n, ppc)
-    ref = single(fs, n, pos, None, steps, solve_start="zero" if solve == "decomposed" else "warm")
+    ref = single(fs, n, pos, None, steps)
     assert list(d["num_active"]) == [s["num_active"] for s in ref["st"]]
     assert list(d["outer"]) == [s["outer_passes"] for s in ref["st"]]
     assert np.array_equal(d["indices"], ref["indices"])
@@ -241,7 +251,7 @@ def test_one_rank_over_rccl(fs, tmp_path, mode):
     n, ppc, steps = 32, 4, 3
     d = run_dist(1, n, ppc, steps, tmp_path, ("--solve", "decomposed"), mode=mode)
     pos, _ = scene(fs, n, ppc)
-    ref = single(fs, n, pos, None, steps, solve_start="zero")
+    ref = single(fs, n, pos, None, steps)
     assert list(d["num_active"]) == [s["num_active"] for s in ref["st"]]
     assert np.array_equal(d["indices"], ref["indices"])
     assert rel_l2(d["pos"], ref["pos"]) < 1e-9 and rel_l2(d["vel"], ref["vel"]) < 1e-7

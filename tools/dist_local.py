@@ -34,7 +34,7 @@ def work(r):
 t0 = time.perf_counter()
 res = grp.run(work)
 print(f"n={n} dims={dims} cuts={cuts} particles={len(pos)} mode={mode}: {steps} steps in {time.perf_counter() - t0:.2f} s (all blocks on one GPU)")
-ref = fs.FluidSim(n=n, solve_start="zero" if mode == "decomposed" else "warm")
+ref = fs.FluidSim(n=n)
 ref.upload_particles(pos)
 rs = []
 for _ in range(steps):
