@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps timed per cpu_baseline leg (1 thread, all cores)")
     ap.add_argument("--no-long-run", action="store_true", help="skip the 500-step drop -> splash -> pool run (long_run key)")
     ap.add_argument("--long-steps", type=int, default=500, help="steps of the long run (the reference's loop runs 500, fluid.cc:1368)")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1: do not run the weak-scaling leg (256 N^(1/3) cells per axis, decomposed solve)")
     ap.add_argument("--no-alt-mode", action="store_true", help="N > 1: do not time the other form of the multi-GPU pressure block as well")
     ap.add_argument("--dist-solve", default="auto", choices=["auto", "decomposed", "replicated"], help="multi-GPU pressure block (FLUID_DIST_*)")
     ap.add_argument("--force-dist", action="store_true", help="run the decomposed code path even with one rank (overhead check)")
@@ -215,6 +216,37 @@ def main():
         except Exception as e:  # noqa: BLE001
             alt = {"pressure_block": other, "error": str(e)[:300]}
 
+    # N > 1: a WEAK-scaling leg beside the strong-scaling headline — the cells per GPU of the 256^3 workload kept fixed, i.e. a grid of
+    # 256 N^(1/3) cells per axis (8 GPUs: BASELINE configs[4], 512^3 with 4 particles per cell; fewer GPUs: 8 per cell), decomposed solve
+    weak = None
+    if world > 1 and not a.no_weak_leg and n == 256:
+        try:
+            nw = int(round(256 * world ** (1.0 / 3.0) / 8.0)) * 8
+            ppcw = 4 if nw >= 512 else 8
+            posw = fs.water_cube_drop(nw, ppcw, seed=a.seed)
+            cutsw = fd.partition_blocks(nw, posw, dims)
+            simw = fd.DistFluidSim(nw, dims, cutsw, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve="decomposed")
+            simw.upload_global(posw)
+            for _ in range(a.warmup):
+                simw.step()
+            barrier()
+            c0 = time.perf_counter()
+            stw = [simw.step() for _ in range(a.steps)]
+            barrier()
+            el = time.perf_counter() - c0
+            import torch
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            weak = {"workload": f"water_cube_drop {nw}^3 grid, {ppcw} particles/cell, {len(posw)} particles, decomposed solve", "grid": nw,
+                    "cells_vs_256": nw ** 3 / 256.0 ** 3, "value": a.steps / el, "unit": "substeps/s", "ms_per_step": el / a.steps * 1e3,
+                    "cg_iters_total": sum(x["cg_iters"] for x in stw), "num_active_last": stw[-1]["num_active"],
+                    "note": "one GPU runs 512^3 / 4 per cell at 72 substeps/s (profiles/r02/bench_512_single_gpu.json)"}
+            simw.close()
+            del posw
+        except Exception as e:  # noqa: BLE001
+            weak = {"error": str(e)[:300]}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -289,7 +321,7 @@ def main():
                      else "P2G fields all-reduced, pressure block replicated on every GPU") + f"; transport {transport}")},
         "roofline": roof,
         "roofline_others": roof_others,
-        **({"pressure_block": solve_mode, "alt_mode": alt} if world > 1 or a.force_dist else {}),
+        **({"pressure_block": solve_mode, "alt_mode": alt, "weak_leg": weak} if world > 1 or a.force_dist else {}),
         "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),
                        "cg_iters_total": sum(s["cg_iters"] for s in stats), "relres_last": stats[-1]["relres"],
                        "cg_iters_note": "solves start from the previous pressure (FLUID_START_WARM): not the reference's x0 = 0 count, see cg_iters_total_x0_zero",
