@@ -194,7 +194,7 @@ def main():
     # N > 1: the same steps with the OTHER form of the multi-GPU pressure block, timed the same way, reported beside the
     # headline as `alt_mode` (no multi-GPU box is available to the builder: this is how both forms get measured)
     alt = None
-    if world > 1 and not a.no_alt_mode:
+    if (world > 1 or a.force_dist) and not a.no_alt_mode:
         other = "replicated" if solve_mode == "decomposed" else "decomposed"
         try:
             sim_alt = fd.DistFluidSim(n, dims, cuts, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve=other)
@@ -219,7 +219,7 @@ def main():
     # N > 1: a WEAK-scaling leg beside the strong-scaling headline — the cells per GPU of the 256^3 workload kept fixed, i.e. a grid of
     # 256 N^(1/3) cells per axis (8 GPUs: BASELINE configs[4], 512^3 with 4 particles per cell; fewer GPUs: 8 per cell), decomposed solve
     weak = None
-    if world > 1 and not a.no_weak_leg and n == 256:
+    if (world > 1 or a.force_dist) and not a.no_weak_leg and n == 256:
         try:
             nw = int(round(256 * world ** (1.0 / 3.0) / 8.0)) * 8
             ppcw = 4 if nw >= 512 else 8
