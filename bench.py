@@ -158,7 +158,6 @@ def main():
             transport = f"torch.distributed nccl callbacks (native RCCL init failed on some rank: {err})"
         sim = fd.DistFluidSim(n, dims, cuts, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve=a.dist_solve)
         sim.upload_global(pos0)
-        solve_mode = "replicated" if list(sim.wdims) == [n, n, n] and world > 1 else "decomposed"
 
     def barrier():
         if dist is not None:
@@ -167,7 +166,9 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        sim.step()
+        st0 = sim.step()
+        if transport is not None:
+            solve_mode = "replicated" if st0["paths"] & 8 else "decomposed"    # FLUID_PATH_DIST_*: what FLUID_DIST_AUTO picked
     # state at the start of the timed region, for the CPU leg
     cpu_state = None
     if rank == 0 and not a.no_cpu and world == 1 and not a.force_dist:
@@ -184,6 +185,8 @@ def main():
     barrier()
     t1 = time.perf_counter()
     sim.profile_enable(0)
+    if transport is not None and stats:
+        solve_mode = "replicated" if stats[0]["paths"] & 8 else "decomposed"
     elapsed = t1 - t0
     if dist is not None:
         import torch

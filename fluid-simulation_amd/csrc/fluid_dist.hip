@@ -357,6 +357,7 @@ void stats_begin(fluid_sim* s)
 {
     DistState* d = s->ds;
     memset(&s->stats, 0, sizeof(s->stats));
+    s->stats.paths = d->repl ? FLUID_PATH_DIST_REPLICATED : FLUID_PATH_DIST_DECOMPOSED;
     s->stats.dt_in = s->dt;
     s->stats.dt_out = s->dt;
     for (int a = 0; a < 3; ++a) {
