@@ -26,7 +26,7 @@ def scene(fs, n, ppc, vel=0.0, pile=0):
     return pos, v
 
 
-def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, **kw):
+def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, solid=None, **kw):
     """dims[0] x dims[1] x dims[2] blocks as threads of this process; returns the assembled result."""
     fd = fs.load_dist()
     size = dims[0] * dims[1] * dims[2]
@@ -38,6 +38,8 @@ def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, **kw):
     def work(r):
         sim = fd.DistFluidSim(n, dims, cuts, grp.comms[r], dist_solve=mode, **kw)
         sims[r] = sim
+        if solid is not None:
+            sim.set_solid(solid)              # the GLOBAL array on every rank; each keeps its window
         sim.upload_global(pos, vel)
         st = [sim.step() for _ in range(steps)]
         p, v, ids = sim.download_local()
@@ -60,8 +62,10 @@ def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, **kw):
     return out
 
 
-def single(fs, n, pos, vel, steps, **kw):
+def single(fs, n, pos, vel, steps, solid=None, **kw):
     sim = fs.FluidSim(n=n, **kw)
+    if solid is not None:
+        sim.set_solid(solid)
     sim.upload_particles(pos, vel)
     st = [sim.step() for _ in range(steps)]
     p, v = sim.download_particles()
@@ -159,6 +163,21 @@ def test_decomposed_jacobi_and_uniform_cuts(fs):
     d = run_blocks(fs, (2, 2, 1), n, pos, vel, steps, "decomposed", uniform=True, preconditioner="jacobi")
     st, rs = compare(d, ref, len(pos), "jacobi 2x2x1")
     assert all(abs(a["cg_iters"] - b["cg_iters"]) <= 2 * b["outer_passes"] for a, b in zip(st, rs))
+
+
+@pytest.mark.parametrize("mode", ["decomposed", "replicated"])
+def test_obstacle_across_the_cuts(fs, mode):
+    """A solid block inside W (the reference's commented 'big wall', fluid.cc:1333-1345) that straddles the cut planes: Neumann
+    faces inside the domain, in every block's window; the cube lands on it."""
+    n, steps = 32, 12
+    sim0 = fs.FluidSim(n=n)
+    solid = sim0.field(fs.FIELD.SOLID).copy()
+    sim0.close()
+    solid[4:28, 2:9, 12:20] = 1
+    pos = fs.water_cube_drop(n, 4, seed=2); pos[:, 1] -= 4.0
+    ref = single(fs, n, pos, None, steps, solid=solid)
+    d = run_blocks(fs, (2, 1, 2), n, pos, None, steps, mode, uniform=True, solid=solid)
+    compare(d, ref, len(pos), f"obstacle {mode}", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
 
 
 @pytest.mark.parametrize("slack", [None, "64"])
