@@ -1,10 +1,10 @@
 // Multi-GPU step: 3-D block decomposition, one process (or host thread) per GPU (include/fluid_hip.h).
 //
 // The reference is single-process (fluid.cc has no communication of any kind): everything here is new design.
-//   particles   a block owns the particles whose base cell lies in it; per step they migrate to the <= 26 adjacent
-//               blocks, and the ones touching an interior face are copied to the blocks behind it as ghosts, so that
-//               every block forms the complete P2G sums of ITS cells in the one-GPU summation order (cell lists
-//               ranked by global id);
+//   particles   a block owns the particles whose base cell lies in it; per step ONE routing round sends a copy of every
+//               particle to each adjacent block (<= 26) within one cell of its base cell — to its new owner if it has
+//               left the block, as a ghost otherwise — so that every block forms the complete P2G sums of ITS cells in
+//               the one-GPU summation order (cell lists ranked by global id);
 //   fields      (decomposed solve) window arrays = block + 4 halo cells; halo exchanges of flags (4 wide), velocity,
 //               pressure and the FLIP delta (1 wide) — one grouped exchange with all neighbours each;
 //   numbering   the reference's x-major unknown numbering from all-reduced row-segment counts;
@@ -13,7 +13,8 @@
 //               the halo what the one-GPU cycle computes there), the levels from `split` on are gathered by one
 //               all-reduce and run redundantly on every rank.  Per cell the arithmetic is the one-GPU cycle's on the
 //               same hierarchy, so the iteration count does not depend on the number of blocks.
-//   replicated  (small boxes) full-size arrays, P2G result all-reduced, pressure block solved identically on every rank.
+//   replicated  (small grids) full-size arrays, the P2G result of the active box gathered from the blocks (all-gather between
+//               adjacent blocks, else one all-reduce), pressure block solved identically on every rank.
 #include "sim.h"
 #include "dist_kernels.h"
 
