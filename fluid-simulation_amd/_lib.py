@@ -41,6 +41,30 @@ class StepStats(C.Structure):
                 "box_lo": list(self.box_lo), "box_hi": list(self.box_hi), "paths": self.paths}
 
 
+class MpmParams(C.Structure):
+    """mpm_params_t (include/mpm_hip.h); defaults = the literals of mpm.cc."""
+    _fields_ = [("B", C.c_int32), ("W", C.c_int32), ("device", C.c_int32), ("cg_max_iters", C.c_int32),
+                ("dx", C.c_double), ("gravity", C.c_double * 3), ("youngs_modulus", C.c_double),
+                ("poisson_ratio", C.c_double), ("beta", C.c_double), ("hardening", C.c_double),
+                ("theta_c", C.c_double), ("theta_s", C.c_double), ("max_dt", C.c_double), ("dt0", C.c_double),
+                ("cg_tol", C.c_double), ("transpose_system", C.c_int32), ("pad_", C.c_int32)]
+
+
+class MpmStepStats(C.Structure):
+    """mpm_step_stats_t."""
+    _fields_ = [("dt_in", C.c_double), ("dt_out", C.c_double), ("cg_error", C.c_double), ("max_speed", C.c_double),
+                ("max_grad", C.c_double), ("max_fp", C.c_double), ("max_fe", C.c_double), ("max_force", C.c_double * 3),
+                ("max_mi", C.c_double), ("max_force_coeff2", C.c_double), ("num_active", C.c_int32),
+                ("cg_iters", C.c_int32), ("any_active", C.c_int32), ("pad_", C.c_int32),
+                ("ms_transfer", C.c_double), ("ms_forces", C.c_double), ("ms_solve", C.c_double),
+                ("ms_deform", C.c_double), ("ms_advect", C.c_double), ("ms_apply_avg", C.c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("max_force", "pad_")}
+        d["max_force"] = list(self.max_force)
+        return d
+
+
 class FIELD:
     CONTAINER, WEIGHTS, VEL, VEL_BEFORE, INDICES, RHS, DIVER, PRESSURE, OUTPUT, SOLID = range(10)
     DIVER2, SEARCH, Q, FLAGS = 14, 15, 16, 17
@@ -88,6 +112,23 @@ SYMBOLS = [
     ("fluid_vdb_open", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("fluid_vdb_append", C.c_int, [_P, _P]),
     ("fluid_vdb_close", C.c_int, [_P]),
+    # the snow-MPM step (include/mpm_hip.h)
+    ("mpm_default_params", C.c_int, [C.POINTER(MpmParams)]),
+    ("mpm_create", C.c_int, [C.POINTER(MpmParams), C.POINTER(_P)]),
+    ("mpm_destroy", C.c_int, [_P]),
+    ("mpm_upload_particles", C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int64)]),
+    ("mpm_num_particles", C.c_int64, [_P]),
+    ("mpm_set_state", C.c_int, [_P, _P, _P, _P, C.c_int32]),
+    ("mpm_set_dt", C.c_int, [_P, C.c_double]),
+    ("mpm_get_dt", C.c_double, [_P]),
+    ("mpm_step", C.c_int, [_P, C.POINTER(MpmStepStats)]),
+    ("mpm_step_solve", C.c_int, [_P, C.POINTER(MpmStepStats)]),
+    ("mpm_step_advance", C.c_int, [_P, C.POINTER(MpmStepStats)]),
+    ("mpm_download_particles", C.c_int, [_P, C.c_int32, _P]),
+    ("mpm_download_field", C.c_int, [_P, C.c_int32, _P]),
+    ("mpm_download_system", C.c_int, [_P, _P, _P]),
+    ("mpm_apply_matrix", C.c_int, [_P, _P, _P]),
+    ("mpm_scene_cone", C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint32, _P]),
     # multi-GPU (argtypes with the comm struct are completed in dist.py)
     ("fluid_create_dist", C.c_int, None),
     ("fluid_window", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

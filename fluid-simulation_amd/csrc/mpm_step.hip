@@ -1,0 +1,1247 @@
+// The snow-MPM step of the reference (`./run.sh mpm`) for gfx950: kernels and host code behind
+// include/mpm_hip.h.  Not a port of mpm.cc: the reference assembles a 3n x 3n sparse matrix through a std::map of 3x3 blocks
+// (729 node pairs per particle, two SVDs and three QR solves per pair, mpm.cc:646-701) and hands it to Eigen's CG; here the
+// matrix never exists.  A v is applied per particle:  dF = (sum_j v_j (x) grad w_jp) F_p,  A_p = d2Psi/dF2 : dF,
+// y_i = v_i + beta dt^2 / m_i * sum_p vol_p A_p F_p^T grad w_ip  — the same linear operator (deformHeader.h:241-272 is
+// linear in dF), one particle pass per CG iteration, with the polar decomposition of a particle computed once per step.
+// M = D^-1 K (D = node masses, K the symmetric energy Hessian) is not symmetric, and the reference's solver object multiplies
+// by the TRANSPOSE of the matrix it is given (Eigen's ConjugateGradient with Lower|Upper on a column-major matrix,
+// ConjugateGradient.h:202-212 — harmless for the symmetric matrices it is meant for): the program's velocities solve
+// (I + beta dt^2 K D^-1) x = b.  That is what this file solves by default (transpose_system = 1); either operator is
+// self-adjoint in a weighted inner product (u^T D^-1 v, or u^T D v for the matrix as assembled), so the CG below uses
+// weighted dot products; the stopping rule stays Eigen's plain |r|^2 <= tol^2 |b|^2.
+//
+// Data: dense node arrays over -B..B (z fastest) and SoA particle arrays in HBM, all fp64 except the float32 node mass
+// (FloatGrid) which is summed in fp64 and rounded once.  Scatter steps use hardware fp64 atomics (global_atomic_add_f64).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpm_hip.h"
+
+int fluid_fail(int code, const std::string& msg);
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return fluid_fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
+
+namespace {
+
+struct MGrid {
+    int B, W, N;
+    __host__ __device__ inline bool in(int x, int y, int z) const { return x >= -B && x <= B && y >= -B && y <= B && z >= -B && z <= B; }
+    __host__ __device__ inline long at(int x, int y, int z) const { return ((long)(x + B) * N + (y + B)) * N + (z + B); }
+    __host__ __device__ inline long cells() const { return (long)N * N * N; }
+};
+
+// per-step device scalars
+struct MpmState {
+    int num_active;
+    int cg_done;
+    int max_cell;                    // first cell attaining max_force_coeff2
+    int any_active;
+    unsigned long long max_speed_bits, max_grad_bits, max_fp_bits, max_fe_bits, max_coeff_bits;
+    double dt;
+    double bb, rho, rho_new, pq, rr; // |b|^2, <r,r>_D, <p,Ap>_D, |r|^2
+    double max_force[3], max_mi;
+};
+
+struct Part {   // SoA, stride = capacity
+    double *pos, *vel, *FE, *FP, *gradV, *volume;
+    // per-step cache for the operator: R, inverse of getDelR's 3x3 matrix, cofactor matrix, F^T applied later
+    double *R, *Minv, *cof, *coef;   // coef: mu_p, lambda_p, J
+    long cap;
+};
+
+__device__ __forceinline__ double ld(const double* a, long cap, int k, long i) { return a[(long)k * cap + i]; }
+__device__ __forceinline__ void stv(double* a, long cap, int k, long i, double v) { a[(long)k * cap + i] = v; }
+
+// mpm.cc:25-41 (half-cell shift, coefficient 1.0)
+__device__ __forceinline__ double mspline(double x)
+{
+    x -= 0.5;
+    if (x < 0) x *= -1.0;
+    if (x < 0.5) return 1.0 * (4.0 * x * x * x - 4.0 * x * x + 2.0 / 3.0);
+    if (x <= 1.0) return 1.0 * ((-8.0 * (x * x * x) / 6.0) + 4.0 * x * x - 4.0 * x + 4.0 / 3.0);
+    return 0;
+}
+// deformHeader.h:38-53
+__device__ __forceinline__ double mspline2(double x)
+{
+    if (x < 0) x *= -1.0;
+    if (x < 0.5) return 1.0 * (4.0 * x * x * x - 4.0 * x * x + 2.0 / 3.0);
+    if (x < 1.0) return 1.0 * ((-8.0 * (x * x * x) / 6.0) + 4.0 * x * x - 4.0 * x + 4.0 / 3.0);
+    return 0;
+}
+// deformHeader.h:54-88
+__device__ __forceinline__ double mspline_grad(double x)
+{
+    if (x >= 0) {
+        if (x < 0.5) return 1.0 * (12.0 * x * x - 8.0 * x);
+        if (x <= 1.0) return 1.0 * ((-8.0 * (x * x) / 2.0) + 8.0 * x - 4.0);
+        return 0;
+    }
+    if (x > -0.5) return 1.0 * (-12.0 * x * x - 8.0 * x);
+    if (x >= -1.0) return 1.0 * ((8.0 * (x * x) / 2.0) + 8.0 * x + 4.0);
+    return 0;
+}
+
+// The 27-node neighbourhood of a particle (base = round(pos), base +- 1 clamped to +-B: mpm.cc:503-513 and every other
+// particle loop) with the separable factors of the weights: w (mpm.cc spline of pos - node), s2 / g (deformHeader.h:99-101).
+struct Nbh {
+    int lo[3], hi[3];
+    double w[3][3], s2[3][3], g[3][3];   // [axis][node - lo]
+};
+__device__ __forceinline__ void neighbourhood(const MGrid& G, const double p[3], Nbh& nb, bool grads)
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int f = (int)round(p[a]);
+        nb.lo[a] = f - 1 > -G.B ? f - 1 : -G.B;
+        nb.hi[a] = f + 1 < G.B ? f + 1 : G.B;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int c = nb.lo[a] + k;
+            nb.w[a][k] = mspline(p[a] - c);
+            if (grads) {
+                nb.s2[a][k] = mspline2(0.5 + c - p[a]);
+                nb.g[a][k] = mspline_grad(p[a] - c - 0.5);
+            }
+        }
+    }
+}
+// getGradW, deformHeader.h:99-103
+__device__ __forceinline__ void grad_w(const Nbh& nb, int i, int j, int k, double g[3])
+{
+    g[0] = -1 * nb.g[0][i] * nb.s2[1][j] * nb.s2[2][k];
+    g[1] = -1 * nb.s2[0][i] * nb.g[1][j] * nb.s2[2][k];
+    g[2] = -1 * nb.s2[0][i] * nb.s2[1][j] * nb.g[2][k];
+}
+
+__device__ __forceinline__ void atomic_max_pos(unsigned long long* slot, double v)
+{
+    if (v > 0) atomicMax(slot, (unsigned long long)__double_as_longlong(v));   // non-negative doubles order like their bits
+}
+
+// ---- 3x3 helpers (row-major double[9]) ----
+__device__ __forceinline__ void mat_mul(const double* a, const double* b, double* r)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+__device__ __forceinline__ void mat_mul_bt(const double* a, const double* b, double* r)   // a * b^T
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = a[3 * i] * b[3 * j] + a[3 * i + 1] * b[3 * j + 1] + a[3 * i + 2] * b[3 * j + 2];
+}
+__device__ __forceinline__ double mat_det(const double* a)
+{
+    return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+}
+// getJFmt, deformHeader.h:227-239: the cofactor matrix J F^-T
+__device__ __forceinline__ void cofactor(const double* F, double* r)
+{
+    r[0] = F[4] * F[8] - F[5] * F[7], r[1] = F[5] * F[6] - F[3] * F[8], r[2] = F[3] * F[7] - F[4] * F[6];
+    r[3] = F[2] * F[7] - F[1] * F[8], r[4] = F[0] * F[8] - F[2] * F[6], r[5] = F[1] * F[6] - F[0] * F[7];
+    r[6] = F[1] * F[5] - F[2] * F[4], r[7] = F[2] * F[3] - F[0] * F[5], r[8] = F[0] * F[4] - F[1] * F[3];
+}
+// F = U diag(s) V^T by one-sided Jacobi (in place of Eigen::JacobiSVD, deformHeader.h:24, mpm.cc:545): the step only ever
+// uses products that do not depend on the order or signs of the factors.
+__device__ void svd3(const double* F, double* U, double* s, double* V)
+{
+    double A[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A[k] = F[k], V[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            double al = 0, be = 0, ga = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                al += A[3 * k + p] * A[3 * k + p];
+                be += A[3 * k + q] * A[3 * k + q];
+                ga += A[3 * k + p] * A[3 * k + q];
+            }
+            if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+            rotated = true;
+            double zeta = (be - al) / (2.0 * ga);
+            double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double ap = A[3 * k + p], aq = A[3 * k + q];
+                A[3 * k + p] = c * ap - sn * aq;
+                A[3 * k + q] = sn * ap + c * aq;
+                double vp = V[3 * k + p], vq = V[3 * k + q];
+                V[3 * k + p] = c * vp - sn * vq;
+                V[3 * k + q] = sn * vp + c * vq;
+            }
+        }
+        if (!rotated) break;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double n = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+        s[j] = n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) U[3 * k + j] = n > 0 ? A[3 * k + j] / n : 0.0;
+    }
+}
+
+// ---- transfer: interpolate (mpm.cc:773-811) + P2Gtransfer's scatter (mpm.cc:218-253,996-999) ----
+__global__ void k_mpm_p2g(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, double* __restrict__ massd,
+                          double* __restrict__ vel /* 3 x cells */)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long C = G.cells();
+    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
+    double v[3] = {ld(P.vel, P.cap, 0, i), ld(P.vel, P.cap, 1, i), ld(P.vel, P.cap, 2, i)};
+    Nbh nb;
+    neighbourhood(G, p, nb, false);
+    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
+        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
+            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+                const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
+                const long k = G.at(x, y, z);
+                if (solid[k]) continue;
+                const double cw = nb.w[0][a] * nb.w[1][b] * nb.w[2][c];
+                if (cw > 0) unsafeAtomicAdd(&massd[k], cw);
+                if (abs(x) <= G.B - 2 && abs(y) <= G.B - 2 && abs(z) <= G.B - 2 && cw != 0) {
+                    unsafeAtomicAdd(&vel[k], v[0] * cw);
+                    unsafeAtomicAdd(&vel[C + k], v[1] * cw);
+                    unsafeAtomicAdd(&vel[2 * C + k], v[2] * cw);
+                }
+            }
+}
+
+// per cell: container = float(mass); vels /= w or 0 (mpm.cc:1000-1015); active flag (mpm.cc:1346-1364); output grid
+// (mpm.cc:1366-1380); velBeforeUpdate (mpm.cc:1390)
+__global__ void k_mpm_cells(MGrid G, const uint8_t* __restrict__ solid, const double* __restrict__ massd, float* __restrict__ container,
+                            float* __restrict__ output, double* __restrict__ vel, double* __restrict__ velb, int* __restrict__ flag)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long C = G.cells();
+    if (k >= C) return;
+    const float cf = (float)massd[k];
+    container[k] = cf;
+    const double w = cf;
+    const int z = (int)(k % G.N) - G.B, y = (int)((k / G.N) % G.N) - G.B, x = (int)(k / ((long)G.N * G.N)) - G.B;
+    const bool act = !solid[k] && abs(x) <= G.W && abs(y) <= G.W && abs(z) <= G.W && w > 0.1;
+    flag[k] = act ? 1 : 0;
+    if (!solid[k] && w > 0.1) output[k] = (float)w;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double v = w > 0.1 ? vel[a * C + k] / w : 0.0;
+        vel[a * C + k] = v;
+        velb[a * C + k] = v;
+    }
+}
+
+// ---- exclusive scan of the active flags in cell order -> indices (mpm.cc:1346-1364) ----
+constexpr int SCAN_T = 256, SCAN_PER = 4, SCAN_BLK = SCAN_T * SCAN_PER;
+__global__ void __launch_bounds__(SCAN_T) k_mpm_scan_sums(long C, const int* __restrict__ flag, int* __restrict__ sums)
+{
+    __shared__ int sh[SCAN_T / 64];
+    long base = (long)blockIdx.x * SCAN_BLK + (long)threadIdx.x * SCAN_PER;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k)
+        if (base + k < C) s += flag[base + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < SCAN_T / 64; ++k) t += sh[k];
+        sums[blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(1024) k_mpm_scan_blocks(int nb, int* __restrict__ sums, MpmState* st)
+{
+    // one block: exclusive scan of the block sums in chunks of 1024
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = i < nb ? sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int incl = sh[threadIdx.x];
+        if (i < nb) sums[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st->num_active = carry;
+}
+__global__ void __launch_bounds__(SCAN_T) k_mpm_scan_final(long C, const int* __restrict__ flag, const int* __restrict__ sums,
+                                                           int* __restrict__ indices, int* __restrict__ active_cell)
+{
+    __shared__ int sh[SCAN_T];
+    long base = (long)blockIdx.x * SCAN_BLK + (long)threadIdx.x * SCAN_PER;
+    int f[SCAN_PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        f[k] = base + k < C ? flag[base + k] : 0;
+        s += f[k];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_T; o <<= 1) {
+        int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sums[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k)
+        if (base + k < C) {
+            if (f[k]) {
+                indices[base + k] = run;
+                active_cell[run] = (int)(base + k);
+                ++run;
+            } else
+                indices[base + k] = -1;
+        }
+}
+
+// ---- findVolume, mpm.cc:739-772 ----
+__global__ void k_mpm_volume(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const float* __restrict__ container)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
+    Nbh nb;
+    neighbourhood(G, p, nb, false);
+    double vol = P.volume[i];
+    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
+        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
+            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+                const long k = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
+                if (!solid[k]) vol += (double)container[k] * nb.w[0][a] * nb.w[1][b] * nb.w[2][c];
+            }
+    P.volume[i] = 1.0 / vol;
+}
+
+// ---- populateGridForces, first loop (mpm.cc:596-644) + the per-particle part of getdPsydx2 (deformHeader.h:253-263) ----
+__global__ void k_mpm_forces(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, double mu0, double lambda0, double eps,
+                             double* __restrict__ forces)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long C = G.cells();
+    double F[9], FP[9], U[9], V[9], sv[3], R[9], S[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) F[k] = ld(P.FE, P.cap, k, i), FP[k] = ld(P.FP, P.cap, k, i);
+    svd3(F, U, sv, V);
+    mat_mul_bt(U, V, R);                       // getR, deformHeader.h:22-28
+    double VD[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) VD[3 * r + c] = V[3 * r + c] * sv[c];
+    mat_mul_bt(VD, V, S);                      // getS, deformHeader.h:29-36
+    const double Jp = mat_det(FP);
+    const double hard = exp(eps * (1 - Jp));
+    const double mu = mu0 * hard, lambda = lambda0 * hard;
+    const double Je = mat_det(F);
+    // getSigma, deformHeader.h:273-307
+    double FmR[9], sigma[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) FmR[k] = F[k] - R[k];
+    mat_mul_bt(FmR, F, sigma);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sigma[k] = 2 * mu * sigma[k] + ((k % 4 == 0) ? lambda * (Je - 1) * Je : 0.0);
+    // cache for the operator: R, inverse of the matrix of getDelR (deformHeader.h:139-141), cofactor matrix, coefficients
+    double m[9] = {S[0] + S[4], S[5], -1 * S[2], S[5], S[0] + S[8], S[1], -1 * S[2], S[1], S[4] + S[8]};
+    double mi[9];
+    cofactor(m, mi);                           // cof(m) = det(m) m^-T; m is symmetric
+    const double dm = mat_det(m);
+    double cf[9];
+    cofactor(F, cf);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        stv(P.R, P.cap, k, i, R[k]);
+        stv(P.Minv, P.cap, k, i, dm != 0 ? mi[k] / dm : 0.0);
+        stv(P.cof, P.cap, k, i, cf[k]);
+    }
+    stv(P.coef, P.cap, 0, i, mu), stv(P.coef, P.cap, 1, i, lambda), stv(P.coef, P.cap, 2, i, Je);
+
+    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
+    const double vol = P.volume[i];
+    Nbh nb;
+    neighbourhood(G, p, nb, true);
+    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
+        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
+            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+                const long k = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
+                if (solid[k]) continue;
+                double g[3];
+                grad_w(nb, a, b, c, g);
+                if (g[0] == 0 && g[1] == 0 && g[2] == 0) continue;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double f = -1 * vol * (sigma[3 * r] * g[0] + sigma[3 * r + 1] * g[1] + sigma[3 * r + 2] * g[2]);
+                    unsafeAtomicAdd(&forces[r * C + k], f);
+                }
+            }
+}
+
+// ---- right-hand side and the "Max Force" line, mpm.cc:383-417 ----
+__global__ void k_mpm_rhs(MGrid G, const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container,
+                          const double* __restrict__ vel, const double* __restrict__ forces, double g0, double g1, double g2,
+                          double* __restrict__ b, double* __restrict__ bb_part, unsigned long long* coeff_bits)
+{
+    __shared__ double sh[4];
+    const int na = st->num_active;
+    const double dt = st->dt;
+    const long C = G.cells();
+    double acc = 0, best = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < na; k += gridDim.x * blockDim.x) {
+        const long c = active_cell[k];
+        const double mi = container[c];
+        const double f[3] = {forces[c], forces[C + c], forces[2 * C + c]};
+        const double gr[3] = {g0, g1, g2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double v = vel[a * C + c] + dt * ((1.0 / mi) * f[a] + gr[a]);
+            b[3 * (long)k + a] = v;
+            acc += v * v;
+        }
+        double maxf = fmax(fabs(f[0]), fmax(fabs(f[1]), fabs(f[2])));
+        best = fmax(best, maxf / mi);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o), best = fmax(best, __shfl_down(best, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc, atomic_max_pos(coeff_bits, best);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < (int)blockDim.x / 64; ++k) t += sh[k];
+        bb_part[blockIdx.x] = t;
+    }
+}
+// first active cell (x-major order) attaining the maximum of maxf / mi: the reference's strict `>` keeps the first
+__global__ void k_mpm_maxforce_cell(MGrid G, const int* __restrict__ active_cell, MpmState* st, const float* __restrict__ container,
+                                    const double* __restrict__ forces)
+{
+    const int na = st->num_active;
+    const long C = G.cells();
+    const double target = __longlong_as_double((long long)st->max_coeff_bits);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < na; k += gridDim.x * blockDim.x) {
+        const long c = active_cell[k];
+        const double mi = container[c];
+        double maxf = fmax(fabs(forces[c]), fmax(fabs(forces[C + c]), fabs(forces[2 * C + c])));
+        if (target > 0 && maxf / mi == target) atomicMin(&st->max_cell, (int)c);
+    }
+}
+__global__ void k_mpm_maxforce_final(MGrid G, MpmState* st, const float* __restrict__ container, const double* __restrict__ forces)
+{
+    const long C = G.cells();
+    st->any_active = st->num_active > 0;   // every cell with mass > 0.1 lies inside the walls: same set as the unknowns
+    const int c = st->max_cell;
+    if (c >= 0 && c < C && st->max_coeff_bits) {
+        const double mi = container[c];
+        for (int a = 0; a < 3; ++a) st->max_force[a] = st->dt * forces[a * C + c] / mi;
+        st->max_mi = mi;
+    } else {
+        st->max_force[0] = st->max_force[1] = st->max_force[2] = 0, st->max_mi = 0;
+    }
+}
+
+// ---- the operator: y = v + beta dt^2 D^-1 K v, one thread per particle (mpm.cc:646-701 + 418-441, matrix-free) ----
+// v, y: 3 * num_active doubles in unknown order; y must hold v on entry (the identity part).
+__global__ void k_mpm_apply(MGrid G, long n, Part P, const int* __restrict__ indices, const float* __restrict__ container,
+                            const MpmState* st, double beta, int transposed, const double* __restrict__ v, double* __restrict__ y)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
+    Nbh nb;
+    neighbourhood(G, p, nb, true);
+    // G = sum_j v_j (x) grad w_j over the unknown nodes
+    double Gm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool any = false;
+    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
+        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
+            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+                const int k = indices[G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c)];
+                if (k < 0) continue;
+                double g[3];
+                grad_w(nb, a, b, c, g);
+                if (g[0] == 0 && g[1] == 0 && g[2] == 0) continue;
+                any = true;
+                // transposed system (what the reference's Eigen solves, see mpm_hip.h): K D^-1 v — the mass divides the input
+                const double wj = transposed ? 1.0 / (double)container[G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c)] : 1.0;
+                const double vx = wj * v[3 * (long)k], vy = wj * v[3 * (long)k + 1], vz = wj * v[3 * (long)k + 2];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) Gm[d] += vx * g[d], Gm[3 + d] += vy * g[d], Gm[6 + d] += vz * g[d];
+            }
+    if (!any) return;
+    double F[9], R[9], Mi[9], cf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) F[k] = ld(P.FE, P.cap, k, i), R[k] = ld(P.R, P.cap, k, i), Mi[k] = ld(P.Minv, P.cap, k, i), cf[k] = ld(P.cof, P.cap, k, i);
+    const double mu = ld(P.coef, P.cap, 0, i), lambda = ld(P.coef, P.cap, 1, i), J = ld(P.coef, P.cap, 2, i);
+    double dF[9];
+    mat_mul(Gm, F, dF);                         // rows of getDelFE (deformHeader.h:107-132), summed over nodes and directions
+    // getDelR, deformHeader.h:133-147
+    double RtdF[9], rhs01, rhs02, rhs12;
+    {
+        double Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+        mat_mul(Rt, dF, RtdF);
+        rhs01 = RtdF[1] - RtdF[3], rhs02 = RtdF[2] - RtdF[6], rhs12 = RtdF[5] - RtdF[7];   // R^T dF - dF^T R
+    }
+    const double x0 = Mi[0] * rhs01 + Mi[1] * rhs02 + Mi[2] * rhs12;
+    const double x1 = Mi[3] * rhs01 + Mi[4] * rhs02 + Mi[5] * rhs12;
+    const double x2 = Mi[6] * rhs01 + Mi[7] * rhs02 + Mi[8] * rhs12;
+    const double rdr[9] = {0, x0, x1, -1 * x0, 0, x2, -1 * x1, -1 * x2, 0};
+    double dR[9];
+    mat_mul(R, rdr, dR);
+    // doubleDot22(JFmt, dF) and doubleDot42(getdJF(F), dF) = the derivative of the cofactor matrix along dF
+    double dd = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dd += cf[k] * dF[k];
+    double dcf[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+            dcf[3 * r + c] = dF[3 * r1 + c1] * F[3 * r2 + c2] + F[3 * r1 + c1] * dF[3 * r2 + c2] - dF[3 * r1 + c2] * F[3 * r2 + c1] -
+                             F[3 * r1 + c2] * dF[3 * r2 + c1];
+        }
+    double Ap[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ap[k] = 2 * mu * dF[k] - 2 * mu * dR[k] + lambda * cf[k] * dd + lambda * (J - 1) * dcf[k];   // deformHeader.h:248
+    double ApFt[9];
+    mat_mul_bt(Ap, F, ApFt);                    // A_p F^T
+    const double dt = st->dt;
+    const double sc = beta * dt * dt * P.volume[i];
+    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
+        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
+            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+                const long cell = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
+                const int k = indices[cell];
+                if (k < 0) continue;
+                double g[3];
+                grad_w(nb, a, b, c, g);
+                if (g[0] == 0 && g[1] == 0 && g[2] == 0) continue;
+                const double f = transposed ? sc : sc * (1.0 / (double)container[cell]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    unsafeAtomicAdd(&y[3 * (long)k + r], f * (ApFt[3 * r] * g[0] + ApFt[3 * r + 1] * g[1] + ApFt[3 * r + 2] * g[2]));
+            }
+}
+
+// ---- CG vector kernels (3 * num_active doubles, weighted dots) ----
+// A = I + c D^-1 K is self-adjoint in <u, v> = u^T D v, its transpose I + c K D^-1 in u^T D^-1 v
+__device__ __forceinline__ double dot_weight(float mass, int transposed) { return transposed ? 1.0 / (double)mass : (double)mass; }
+constexpr int RED_BLOCKS = 256;
+__device__ __forceinline__ void block_sum2(double a, double b, double* pa, double* pb)
+{
+    __shared__ double sh[2][4];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o), b += __shfl_down(b, o);
+    if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = a, sh[1][threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0, tb = 0;
+        for (int k = 0; k < (int)blockDim.x / 64; ++k) ta += sh[0][k], tb += sh[1][k];
+        pa[blockIdx.x] = ta, pb[blockIdx.x] = tb;
+    }
+}
+// sums the partials of the previous kernel; `what`: 0 |b|^2 -> bb (+ rho = <b,b>_D passed in part2), 1 <p,Ap>_D -> pq,
+// 2 after the update: |r|^2 -> rr, <r,r>_D -> rho_new
+__global__ void k_mpm_cg_scalars(int what, int nparts, const double* __restrict__ part1, const double* __restrict__ part2, MpmState* st, double tol)
+{
+    double a = 0, b = 0;
+    for (int k = threadIdx.x; k < nparts; k += 64) a += part1[k], b += part2 ? part2[k] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o), b += __shfl_down(b, o);
+    if (threadIdx.x) return;
+    if (what == 0) {
+        st->bb = a, st->rho = b, st->rr = a;
+        st->cg_done = (a == 0) ? 1 : 0;   // b = 0 => x = 0 (IterativeSolverBase / ConjugateGradient.h:44-50)
+    } else if (what == 1) {
+        st->pq = b;
+    } else {
+        st->rr = a, st->rho_new = b;
+        if (a < tol * tol * st->bb) st->cg_done = 1;
+    }
+}
+// r = p = b, x = 0, y(=Ap) = p; partials of |b|^2 and <b,b>_D
+__global__ void k_mpm_cg_init(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
+                              const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+                              double* __restrict__ q, double* pa, double* pb)
+{
+    const long n3 = 3L * st->num_active;
+    double a = 0, d = 0;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
+        const double v = b[k], m = dot_weight(container[active_cell[k / 3]], transposed);
+        x[k] = 0, r[k] = v, p[k] = v, q[k] = v;
+        a += v * v, d += m * v * v;
+    }
+    block_sum2(a, d, pa, pb);
+}
+__global__ void k_mpm_cg_pq(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
+                            const double* __restrict__ p, const double* __restrict__ q, double* pa, double* pb)
+{
+    const long n3 = 3L * st->num_active;
+    double d = 0;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x)
+        d += dot_weight(container[active_cell[k / 3]], transposed) * p[k] * q[k];
+    block_sum2(0.0, d, pa, pb);
+}
+// x += alpha p; r -= alpha q; partials |r|^2, <r,r>_D
+__global__ void k_mpm_cg_xr(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
+                            double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p, const double* __restrict__ q,
+                            double* pa, double* pb)
+{
+    const long n3 = 3L * st->num_active;
+    const double alpha = st->rho / st->pq;
+    double a = 0, d = 0;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
+        x[k] += alpha * p[k];
+        const double rv = r[k] - alpha * q[k];
+        r[k] = rv;
+        a += rv * rv, d += dot_weight(container[active_cell[k / 3]], transposed) * rv * rv;
+    }
+    block_sum2(a, d, pa, pb);
+}
+// p = r + beta p; q = p (the identity part of the next product); rho = rho_new (by thread 0 of block 0 AFTER everyone read it:
+// done in a separate tiny kernel to stay race-free)
+__global__ void k_mpm_cg_p(const MpmState* st, const double* __restrict__ r, double* __restrict__ p, double* __restrict__ q)
+{
+    const long n3 = 3L * st->num_active;
+    const double beta = st->rho_new / st->rho;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
+        const double v = r[k] + beta * p[k];
+        p[k] = v, q[k] = v;
+    }
+}
+__global__ void k_mpm_cg_roll(MpmState* st) { st->rho = st->rho_new; }
+__global__ void k_mpm_copy(long n, const double* __restrict__ a, double* __restrict__ b)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) b[k] = a[k];
+}
+
+// ---- updateVelocity, mpm.cc:705-737 ----
+__global__ void k_mpm_update_velocity(MGrid G, const uint8_t* __restrict__ solid, const float* __restrict__ container,
+                                      const int* __restrict__ indices, const double* __restrict__ x, double* __restrict__ vel)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long C = G.cells();
+    if (k >= C || solid[k]) return;
+    const int idx = indices[k];
+    const bool on = (double)container[k] > 0.1 && idx >= 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) vel[a * C + k] = on ? x[3 * (long)idx + a] : 0.0;
+}
+
+// ---- updateDeformationGradient, mpm.cc:493-586 ----
+__global__ void k_mpm_deform(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const double* __restrict__ vel, MpmState* st,
+                             double minv, double maxv)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    double t = 0, t2 = 0, t3 = 0;
+    if (i < n) {
+    const long C = G.cells();
+    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
+    Nbh nb;
+    neighbourhood(G, p, nb, true);
+    double gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
+        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
+            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+                const long k = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
+                if (solid[k]) continue;
+                double g[3];
+                grad_w(nb, a, b, c, g);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double vr = vel[r * C + k];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) gv[3 * r + d] += vr * g[d];
+                }
+            }
+    const double dt = st->dt;
+    double FE[9], FP[9], A[9], tFE[9], F[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        stv(P.gradV, P.cap, k, i, gv[k]);
+        FE[k] = ld(P.FE, P.cap, k, i), FP[k] = ld(P.FP, P.cap, k, i);
+        A[k] = ((k % 4 == 0) ? 1.0 : 0.0) + dt * gv[k];
+    }
+    mat_mul(A, FE, tFE);
+    mat_mul(tFE, FP, F);
+    double U[9], V[9], sv[3];
+    svd3(tFE, U, sv, V);
+    double UD[9], VDi[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double s = sv[c] > minv ? sv[c] : minv;
+        s = s < maxv ? s : maxv;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) UD[3 * r + c] = U[3 * r + c] * s, VDi[3 * r + c] = V[3 * r + c] * (1.0 / s);
+    }
+    double nFE[9], T[9], nFP[9];
+    mat_mul_bt(UD, V, nFE);
+    mat_mul_bt(VDi, U, T);
+    mat_mul(T, F, nFP);
+    double mx = gv[0], mn = gv[0];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        stv(P.FE, P.cap, k, i, nFE[k]), stv(P.FP, P.cap, k, i, nFP[k]);
+        mx = fmax(mx, gv[k]), mn = fmin(mn, gv[k]);
+    }
+    t = fmax(mx, -1 * mn), t2 = mat_det(nFP), t3 = mat_det(nFE);
+    }
+    // wave-level maxima (the reference's maxima start at 0: negative values never show), one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) t = fmax(t, __shfl_xor(t, o)), t2 = fmax(t2, __shfl_xor(t2, o)), t3 = fmax(t3, __shfl_xor(t3, o));
+    if ((threadIdx.x & 63) == 0) atomic_max_pos(&st->max_grad_bits, t), atomic_max_pos(&st->max_fp_bits, t2), atomic_max_pos(&st->max_fe_bits, t3);
+}
+
+
+// ---- FLIPadvect, mpm.cc:906-969 with CatmullRomFLIP mpm.cc:163-216 and getVelocity mpm.cc:64-76 ----
+__device__ __forceinline__ double vel_at(const MGrid& G, const double* __restrict__ g, long C, int a, int x, int y, int z)
+{
+    return G.in(x, y, z) ? g[a * C + G.at(x, y, z)] : 0.0;   // reads beyond the grid return the background 0
+}
+__global__ void k_mpm_flip(MGrid G, long n, Part P, const double* __restrict__ vel, const double* __restrict__ velb, MpmState* st)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    double len = 0;
+    if (i < n) {
+        const long C = G.cells();
+        double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
+        Nbh nb;
+        neighbourhood(G, p, nb, false);
+        double weight = 0, delta[3] = {0, 0, 0};
+        for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
+            for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
+                for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+                    const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
+                    if (abs(x) > G.W || abs(y) > G.W || abs(z) > G.W) continue;
+                    const double cw = nb.w[0][a] * nb.w[1][b] * nb.w[2][c];
+                    const double vc[3] = {(vel_at(G, vel, C, 0, x, y, z) + vel_at(G, vel, C, 0, x + 1, y, z)) / 2.0,
+                                          (vel_at(G, vel, C, 1, x, y, z) + vel_at(G, vel, C, 1, x, y + 1, z)) / 2.0,
+                                          (vel_at(G, vel, C, 2, x, y, z) + vel_at(G, vel, C, 2, x, y, z + 1)) / 2.0};
+                    const double vp[3] = {(vel_at(G, velb, C, 0, x, y, z) + vel_at(G, velb, C, 0, x + 1, y, z)) / 2.0,
+                                          (vel_at(G, velb, C, 1, x, y, z) + vel_at(G, velb, C, 1, x, y + 1, z)) / 2.0,
+                                          (vel_at(G, velb, C, 2, x, y, z) + vel_at(G, velb, C, 2, x, y, z + 1)) / 2.0};
+                    weight += cw;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) delta[d] += (vc[d] - vp[d]) * cw;
+                }
+        double v[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            v[d] = ld(P.vel, P.cap, d, i) + (weight == 0 ? 0.0 : delta[d] / weight);
+            stv(P.vel, P.cap, d, i, v[d]);
+        }
+        len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    }
+    for (int o = 32; o > 0; o >>= 1) len = fmax(len, __shfl_xor(len, o));
+    if ((threadIdx.x & 63) == 0) atomic_max_pos(&st->max_speed_bits, len);
+}
+__global__ void k_mpm_timestep(MpmState* st, double max_dt, double dx)
+{
+    const double ms = __longlong_as_double((long long)st->max_speed_bits);
+    st->dt = ms != 0 ? (max_dt < dx / ms ? max_dt : dx / ms) : max_dt;   // mpm.cc:929-936
+}
+__global__ void k_mpm_advect(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const MpmState* st)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ts = st->dt, e = 0.0;
+    double p[3], v[3], q[3];
+    int r[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        p[a] = ld(P.pos, P.cap, a, i), v[a] = ld(P.vel, P.cap, a, i);
+        q[a] = p[a] + ts * v[a];
+        r[a] = (int)(q[a] > 0 ? ceil(q[a]) : floor(q[a]));
+    }
+    auto is_solid = [&](int x, int y, int z) { return G.in(x, y, z) && solid[G.at(x, y, z)] != 0; };
+    if (is_solid(r[0], r[1], r[2])) {
+        // Coord(int, double, double): the doubles become Int32 by truncation (math/Coord.h:61)
+        if (is_solid(r[0], (int)p[1], (int)p[2])) v[0] *= -1.0 * e;
+        if (is_solid((int)p[0], r[1], (int)p[2])) v[1] *= -1.0 * e;
+        if (is_solid((int)p[0], (int)p[1], r[2])) v[2] *= -1.0 * e;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) stv(P.vel, P.cap, a, i, v[a]), stv(P.pos, P.cap, a, i, p[a] + v[a] * ts);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) stv(P.pos, P.cap, a, i, q[a]);
+    }
+}
+
+// AoS <-> SoA of `w` doubles per particle
+__global__ void k_mpm_to_soa(long n, long cap, int w, const double* __restrict__ aos, double* __restrict__ soa)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n * w) soa[(k % w) * cap + k / w] = aos[k];
+}
+__global__ void k_mpm_to_aos(long n, long cap, int w, const double* __restrict__ soa, double* __restrict__ aos)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n * w) aos[k] = soa[(k % w) * cap + k / w];
+}
+__global__ void k_mpm_identity(long n, long cap, double* __restrict__ FE, double* __restrict__ FP, double* __restrict__ volume)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 9; ++k) FE[k * cap + i] = FP[k * cap + i] = (k % 4 == 0) ? 1.0 : 0.0;
+    volume[i] = 0.0;
+}
+__global__ void k_mpm_interleave(long C, const double* __restrict__ soa, double* __restrict__ aos)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < C) aos[3 * k] = soa[k], aos[3 * k + 1] = soa[C + k], aos[3 * k + 2] = soa[2 * C + k];
+}
+
+inline unsigned blocks_for(long n, int t) { return (unsigned)((n + t - 1) / t); }
+inline double bits_to_double(unsigned long long b)
+{
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+
+}  // namespace
+
+struct mpm_sim {
+    mpm_params_t prm;
+    MGrid G;
+    hipStream_t st = nullptr;
+    long C = 0, n = 0;
+    Part P{};
+    uint8_t* solid = nullptr;
+    float *container = nullptr, *output = nullptr;
+    double *massd = nullptr, *vel = nullptr, *velb = nullptr, *forces = nullptr;
+    int *flag = nullptr, *indices = nullptr, *active_cell = nullptr, *sums = nullptr;
+    double *b = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *part = nullptr;
+    double* stage = nullptr;
+    size_t stage_bytes = 0;
+    MpmState* state = nullptr;
+    MpmState* h_state = nullptr;   // pinned
+    int step_no = 0, num_active = 0;
+    bool mid_step = false;
+    mpm_step_stats_t stats{};
+    double dt = 0.001;
+    hipEvent_t ev[8] = {};
+};
+
+namespace {
+
+template <typename T>
+int dalloc(T** p, size_t n)
+{
+    HIPCHK(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+    HIPCHK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
+    return 0;
+}
+int ensure_stage(mpm_sim* s, size_t bytes)
+{
+    if (bytes <= s->stage_bytes) return 0;
+    if (s->stage) HIPCHK(hipFree(s->stage));
+    s->stage = nullptr, s->stage_bytes = 0;
+    HIPCHK(hipMalloc((void**)&s->stage, bytes));
+    s->stage_bytes = bytes;
+    return 0;
+}
+void free_particles(mpm_sim* s)
+{
+    double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.cof, &s->P.coef};
+    for (auto p : a) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    s->P.cap = 0;
+}
+int alloc_particles(mpm_sim* s, long cap)
+{
+    free_particles(s);
+    s->P.cap = cap;
+    if (dalloc(&s->P.pos, 3 * cap) || dalloc(&s->P.vel, 3 * cap) || dalloc(&s->P.FE, 9 * cap) || dalloc(&s->P.FP, 9 * cap) ||
+        dalloc(&s->P.gradV, 9 * cap) || dalloc(&s->P.volume, cap) || dalloc(&s->P.R, 9 * cap) || dalloc(&s->P.Minv, 9 * cap) ||
+        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap))
+        return FLUID_ERR_HIP;
+    return 0;
+}
+
+// y = A v on the device (v in s->p, result in s->q)
+int apply_operator(mpm_sim* s)
+{
+    // q holds p already (the identity part)
+    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, s->indices, s->container, s->state, s->prm.beta, s->prm.transpose_system, s->p, s->q);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int read_state(mpm_sim* s)
+{
+    HIPCHK(hipMemcpyAsync(s->h_state, s->state, sizeof(MpmState), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpm_default_params(mpm_params_t* p)
+{
+    if (!p) return fluid_fail(FLUID_ERR_ARG, "mpm_default_params: null");
+    memset(p, 0, sizeof *p);
+    p->B = 15, p->W = 13, p->device = 0, p->cg_max_iters = 0;
+    p->dx = 1.0, p->gravity[0] = 0, p->gravity[1] = -10, p->gravity[2] = 0;
+    p->youngs_modulus = 48000, p->poisson_ratio = 0.47, p->beta = 0.5, p->hardening = 10;
+    p->theta_c = 0.025, p->theta_s = 0.0075, p->max_dt = 0.001, p->dt0 = 0.001;
+    p->cg_tol = 2.220446049250313e-16;
+    p->transpose_system = 1;
+    return 0;
+}
+
+int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
+{
+    if (!prm || !out) return fluid_fail(FLUID_ERR_ARG, "mpm_create: null argument");
+    if (prm->B < 3 || prm->B > 400 || prm->W < 1 || prm->W > prm->B) return fluid_fail(FLUID_ERR_ARG, "mpm_create: need 3 <= B <= 400 and 1 <= W <= B");
+    if (!(prm->dx > 0) || !(prm->max_dt > 0) || !(prm->dt0 > 0)) return fluid_fail(FLUID_ERR_ARG, "mpm_create: dx, max_dt, dt0 must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fluid_fail(FLUID_ERR_HIP, "mpm_create: no HIP device (this library has no CPU path)");
+    if (prm->device < 0 || prm->device >= ndev) return fluid_fail(FLUID_ERR_ARG, "mpm_create: bad device ordinal");
+    HIPCHK(hipSetDevice(prm->device));
+    mpm_sim* s = new mpm_sim;
+    s->prm = *prm;
+    s->G = MGrid{prm->B, prm->W, 2 * prm->B + 1};
+    s->C = s->G.cells();
+    s->dt = prm->dt0;
+    const long C = s->C;
+    const int nb = (int)blocks_for(C, SCAN_BLK);
+    int rc = 0;
+    if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) rc = FLUID_ERR_HIP;
+    rc = rc || dalloc(&s->solid, C) || dalloc(&s->container, C) || dalloc(&s->output, C) || dalloc(&s->massd, C) || dalloc(&s->vel, 3 * C) ||
+         dalloc(&s->velb, 3 * C) || dalloc(&s->forces, 3 * C) || dalloc(&s->flag, C) || dalloc(&s->indices, C) || dalloc(&s->active_cell, C) ||
+         dalloc(&s->sums, nb) || dalloc(&s->part, 2 * RED_BLOCKS) || dalloc(&s->state, 1);
+    // unknowns live inside the walls only: (2W+1)^3 at most
+    const long maxu = (long)(2 * prm->W + 1) * (2 * prm->W + 1) * (2 * prm->W + 1);
+    rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu);
+    if (!rc && hipHostMalloc((void**)&s->h_state, sizeof(MpmState)) != hipSuccess) rc = FLUID_ERR_HIP;
+    for (int k = 0; k < 8 && !rc; ++k)
+        if (hipEventCreate(&s->ev[k]) != hipSuccess) rc = FLUID_ERR_HIP;
+    if (rc) {
+        mpm_destroy(s);
+        return fluid_fail(FLUID_ERR_HIP, "mpm_create: device allocation failed");
+    }
+    std::vector<uint8_t> h(C);
+    const MGrid& G = s->G;
+    for (int x = -G.B; x <= G.B; ++x)
+        for (int y = -G.B; y <= G.B; ++y)
+            for (int z = -G.B; z <= G.B; ++z) h[G.at(x, y, z)] = (std::abs(x) > G.W || std::abs(y) > G.W || std::abs(z) > G.W) ? 1 : 0;
+    HIPCHK(hipMemcpy(s->solid, h.data(), C, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(s->indices, 0xFF, C * sizeof(int)));
+    *out = s;
+    return 0;
+}
+
+int mpm_destroy(mpm_sim_t* s)
+{
+    if (!s) return 0;
+    free_particles(s);
+    void* a[] = {s->solid, s->container, s->output, s->massd, s->vel, s->velb, s->forces, s->flag, s->indices, s->active_cell, s->sums,
+                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage};
+    for (void* p : a)
+        if (p) (void)hipFree(p);
+    if (s->h_state) (void)hipHostFree(s->h_state);
+    for (int k = 0; k < 8; ++k)
+        if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+    if (s->st) (void)hipStreamDestroy(s->st);
+    delete s;
+    return 0;
+}
+
+int mpm_upload_particles(mpm_sim_t* s, int64_t n, const double* pos, const double* vel, int64_t* kept)
+{
+    if (!s || n < 0 || (n && !pos)) return fluid_fail(FLUID_ERR_ARG, "mpm_upload_particles: bad argument");
+    // PointList::add, mpm.cc:471-491
+    std::vector<double> hp, hv;
+    hp.reserve(3 * (size_t)n), hv.reserve(3 * (size_t)n);
+    const int bd = s->G.B - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const double* p = pos + 3 * i;
+        if (std::fabs(p[0]) < bd && std::fabs(p[1]) < bd && std::fabs(p[2]) < bd) {
+            hp.insert(hp.end(), p, p + 3);
+            if (vel)
+                hv.insert(hv.end(), vel + 3 * i, vel + 3 * i + 3);
+            else
+                hv.push_back(0.0), hv.push_back(-50.0), hv.push_back(0.0);
+        }
+    }
+    const long m = (long)hp.size() / 3;
+    if (m > s->P.cap || !s->P.pos)
+        if (alloc_particles(s, m > 64 ? m : 64)) return FLUID_ERR_HIP;
+    s->n = m;
+    if (kept) *kept = m;
+    s->step_no = 0;
+    s->mid_step = false;
+    s->dt = s->prm.dt0;
+    if (!m) return 0;
+    if (ensure_stage(s, sizeof(double) * 3 * m)) return FLUID_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(s->stage, hp.data(), sizeof(double) * 3 * m, hipMemcpyHostToDevice, s->st));
+    k_mpm_to_soa<<<blocks_for(3 * m, 256), 256, 0, s->st>>>(m, s->P.cap, 3, s->stage, s->P.pos);
+    HIPCHK(hipStreamSynchronize(s->st));
+    HIPCHK(hipMemcpyAsync(s->stage, hv.data(), sizeof(double) * 3 * m, hipMemcpyHostToDevice, s->st));
+    k_mpm_to_soa<<<blocks_for(3 * m, 256), 256, 0, s->st>>>(m, s->P.cap, 3, s->stage, s->P.vel);
+    k_mpm_identity<<<blocks_for(m, 256), 256, 0, s->st>>>(m, s->P.cap, s->P.FE, s->P.FP, s->P.volume);
+    HIPCHK(hipMemsetAsync(s->P.gradV, 0, sizeof(double) * 9 * s->P.cap, s->st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+int64_t mpm_num_particles(const mpm_sim_t* s) { return s ? s->n : -1; }
+
+int mpm_set_state(mpm_sim_t* s, const double* FE, const double* FP, const double* volume, int32_t step_no)
+{
+    if (!s || step_no < 0) return fluid_fail(FLUID_ERR_ARG, "mpm_set_state: bad argument");
+    const long m = s->n;
+    const double* src[3] = {FE, FP, volume};
+    double* dst[3] = {s->P.FE, s->P.FP, s->P.volume};
+    const int w[3] = {9, 9, 1};
+    for (int k = 0; k < 3; ++k) {
+        if (!src[k] || !m) continue;
+        if (ensure_stage(s, sizeof(double) * w[k] * m)) return FLUID_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(s->stage, src[k], sizeof(double) * w[k] * m, hipMemcpyHostToDevice, s->st));
+        k_mpm_to_soa<<<blocks_for((long)w[k] * m, 256), 256, 0, s->st>>>(m, s->P.cap, w[k], s->stage, dst[k]);
+        HIPCHK(hipStreamSynchronize(s->st));
+    }
+    s->step_no = step_no;
+    return 0;
+}
+
+int mpm_set_dt(mpm_sim_t* s, double dt)
+{
+    if (!s || !(dt > 0)) return fluid_fail(FLUID_ERR_ARG, "mpm_set_dt: bad argument");
+    s->dt = dt;
+    return 0;
+}
+double mpm_get_dt(const mpm_sim_t* s) { return s ? s->dt : 0.0; }
+
+// mpm.cc:1313-1404: transfer, numbering, forces, right-hand side, solve, updateVelocity
+int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
+{
+    if (!s) return fluid_fail(FLUID_ERR_ARG, "mpm_step_solve: null handle");
+    if (s->mid_step) return fluid_fail(FLUID_ERR_STATE, "mpm_step_solve: the previous step was not advanced");
+    const MGrid G = s->G;
+    const long C = s->C, n = s->n;
+    const mpm_params_t& pr = s->prm;
+    hipStream_t st = s->st;
+    const unsigned pb = blocks_for(n, 128), cb = blocks_for(C, 256);
+    const int nb = (int)blocks_for(C, SCAN_BLK);
+
+    // step scalars
+    memset(s->h_state, 0, sizeof(MpmState));
+    s->h_state->dt = s->dt;
+    s->h_state->max_cell = 0x7fffffff;
+    HIPCHK(hipMemcpyAsync(s->state, s->h_state, sizeof(MpmState), hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(s->ev[0], st));
+    // mpm.cc:1315-1331,1431: indices = -1, gridForces = 0, container = 0, vels = 0
+    HIPCHK(hipMemsetAsync(s->massd, 0, sizeof(double) * C, st));
+    HIPCHK(hipMemsetAsync(s->vel, 0, sizeof(double) * 3 * C, st));
+    HIPCHK(hipMemsetAsync(s->forces, 0, sizeof(double) * 3 * C, st));
+    if (n) k_mpm_p2g<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, s->massd, s->vel);
+    k_mpm_cells<<<cb, 256, 0, st>>>(G, s->solid, s->massd, s->container, s->output, s->vel, s->velb, s->flag);
+    k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->flag, s->sums);
+    k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, s->state);
+    k_mpm_scan_final<<<nb, SCAN_T, 0, st>>>(C, s->flag, s->sums, s->indices, s->active_cell);
+    if (s->step_no == 0 && n) k_mpm_volume<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, s->container);   // mpm.cc:1343-1346
+    HIPCHK(hipEventRecord(s->ev[1], st));
+    // populateGridForces (mpm.cc:1395): mu = E / (2 (1 + nu)), lambda = E nu / ((1 + nu) (1 - 2 nu))
+    const double mu0 = pr.youngs_modulus / (2 * (1 + pr.poisson_ratio));
+    const double lambda0 = pr.youngs_modulus * pr.poisson_ratio / ((1 + pr.poisson_ratio) * (1 - 2 * pr.poisson_ratio));
+    if (n) k_mpm_forces<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, mu0, lambda0, pr.hardening, s->forces);
+    HIPCHK(hipEventRecord(s->ev[2], st));
+    // populateMatrices' right-hand side (mpm.cc:383-416) and cg.solve (mpm.cc:1401-1403)
+    k_mpm_rhs<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->vel, s->forces, pr.gravity[0], pr.gravity[1], pr.gravity[2],
+                                          s->b, s->part, &s->state->max_coeff_bits);
+    k_mpm_maxforce_cell<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->forces);
+    k_mpm_maxforce_final<<<1, 1, 0, st>>>(G, s->state, s->container, s->forces);
+    k_mpm_cg_init<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->b, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
+    k_mpm_cg_scalars<<<1, 64, 0, st>>>(0, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
+    HIPCHK(hipGetLastError());
+    if (read_state(s)) return FLUID_ERR_HIP;
+    s->num_active = s->h_state->num_active;
+    const long max_iters = pr.cg_max_iters > 0 ? pr.cg_max_iters : 2L * 3 * s->num_active;
+    int iters = 0;
+    float ms_apply = 0;
+    int n_apply = 0;
+    while (!s->h_state->cg_done && iters < max_iters) {
+        HIPCHK(hipEventRecord(s->ev[6], st));
+        if (apply_operator(s)) return FLUID_ERR_HIP;
+        HIPCHK(hipEventRecord(s->ev[7], st));
+        k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, s->part, s->part + RED_BLOCKS);
+        k_mpm_cg_scalars<<<1, 64, 0, st>>>(1, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
+        k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
+        k_mpm_cg_scalars<<<1, 64, 0, st>>>(2, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
+        k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, s->r, s->p, s->q);
+        k_mpm_cg_roll<<<1, 1, 0, st>>>(s->state);
+        HIPCHK(hipGetLastError());
+        if (read_state(s)) return FLUID_ERR_HIP;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s->ev[6], s->ev[7]) == hipSuccess) ms_apply += ms, ++n_apply;
+        if (!std::isfinite(s->h_state->pq) || s->h_state->pq == 0) break;
+        if (s->h_state->cg_done) break;   // Eigen leaves the loop before counting the iteration (ConjugateGradient.h:78-79)
+        ++iters;
+    }
+    const double cg_error = s->h_state->bb > 0 ? std::sqrt(s->h_state->rr / s->h_state->bb) : 0.0;
+    HIPCHK(hipEventRecord(s->ev[3], st));
+    k_mpm_update_velocity<<<cb, 256, 0, st>>>(G, s->solid, s->container, s->indices, s->x, s->vel);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    s->mid_step = true;
+    mpm_step_stats_t& o = s->stats;
+    memset(&o, 0, sizeof o);
+    const MpmState& h = *s->h_state;
+    o.dt_in = s->dt, o.dt_out = s->dt, o.cg_error = cg_error;
+    for (int a = 0; a < 3; ++a) o.max_force[a] = h.max_force[a];
+    o.max_mi = h.max_mi, o.max_force_coeff2 = bits_to_double(h.max_coeff_bits);
+    o.num_active = h.num_active, o.cg_iters = iters, o.any_active = h.any_active;
+    float ms;
+    double* dst[3] = {&o.ms_transfer, &o.ms_forces, &o.ms_solve};
+    for (int k = 0; k < 3; ++k)
+        if (hipEventElapsedTime(&ms, s->ev[k], s->ev[k + 1]) == hipSuccess) *dst[k] = ms;
+    o.ms_apply_avg = n_apply ? ms_apply / n_apply : 0.0;
+    if (out) *out = o;
+    return 0;
+}
+
+// mpm.cc:1410-1431: updateDeformationGradient, FLIPadvect (the grid velocity stays readable until the next step's transfer)
+int mpm_step_advance(mpm_sim_t* s, mpm_step_stats_t* out)
+{
+    if (!s) return fluid_fail(FLUID_ERR_ARG, "mpm_step_advance: null handle");
+    if (!s->mid_step) return fluid_fail(FLUID_ERR_STATE, "mpm_step_advance: call mpm_step_solve first");
+    const MGrid G = s->G;
+    const long n = s->n;
+    const mpm_params_t& pr = s->prm;
+    hipStream_t st = s->st;
+    const unsigned pb = blocks_for(n, 128);
+    HIPCHK(hipEventRecord(s->ev[3], st));
+    if (n) k_mpm_deform<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, s->vel, s->state, 1 - pr.theta_c, 1 + pr.theta_s);
+    HIPCHK(hipEventRecord(s->ev[4], st));
+    if (n) k_mpm_flip<<<pb, 128, 0, st>>>(G, n, s->P, s->vel, s->velb, s->state);
+    k_mpm_timestep<<<1, 1, 0, st>>>(s->state, pr.max_dt, pr.dx);
+    if (n) k_mpm_advect<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, s->state);
+    HIPCHK(hipEventRecord(s->ev[5], st));
+    HIPCHK(hipGetLastError());
+    if (read_state(s)) return FLUID_ERR_HIP;
+    const MpmState& h = *s->h_state;
+    s->dt = h.dt;
+    s->step_no++;
+    s->mid_step = false;
+    mpm_step_stats_t& o = s->stats;
+    o.dt_out = h.dt;
+    o.max_speed = bits_to_double(h.max_speed_bits), o.max_grad = bits_to_double(h.max_grad_bits);
+    o.max_fp = bits_to_double(h.max_fp_bits), o.max_fe = bits_to_double(h.max_fe_bits);
+    float ms;
+    if (hipEventElapsedTime(&ms, s->ev[3], s->ev[4]) == hipSuccess) o.ms_deform = ms;
+    if (hipEventElapsedTime(&ms, s->ev[4], s->ev[5]) == hipSuccess) o.ms_advect = ms;
+    if (out) *out = o;
+    return 0;
+}
+
+int mpm_step(mpm_sim_t* s, mpm_step_stats_t* out)
+{
+    int rc = mpm_step_solve(s, nullptr);
+    if (rc) return rc;
+    return mpm_step_advance(s, out);
+}
+
+int mpm_download_particles(mpm_sim_t* s, int32_t what, double* out)
+{
+    if (!s || !out || what < 0 || what > 5) return fluid_fail(FLUID_ERR_ARG, "mpm_download_particles: bad argument");
+    const double* src[] = {s->P.pos, s->P.vel, s->P.FE, s->P.FP, s->P.gradV, s->P.volume};
+    const int w[] = {3, 3, 9, 9, 9, 1};
+    const long m = s->n;
+    if (!m) return 0;
+    if (ensure_stage(s, sizeof(double) * w[what] * m)) return FLUID_ERR_HIP;
+    k_mpm_to_aos<<<blocks_for((long)w[what] * m, 256), 256, 0, s->st>>>(m, s->P.cap, w[what], src[what], s->stage);
+    HIPCHK(hipMemcpyAsync(out, s->stage, sizeof(double) * w[what] * m, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+int mpm_download_field(mpm_sim_t* s, int32_t field, void* out)
+{
+    if (!s || !out) return fluid_fail(FLUID_ERR_ARG, "mpm_download_field: null argument");
+    const long C = s->C;
+    switch (field) {
+        case MPM_F_CONTAINER: HIPCHK(hipMemcpyAsync(out, s->container, 4 * C, hipMemcpyDeviceToHost, s->st)); break;
+        case MPM_F_OUTPUT: HIPCHK(hipMemcpyAsync(out, s->output, 4 * C, hipMemcpyDeviceToHost, s->st)); break;
+        case MPM_F_INDICES: HIPCHK(hipMemcpyAsync(out, s->indices, 4 * C, hipMemcpyDeviceToHost, s->st)); break;
+        case MPM_F_SOLID: {
+            std::vector<uint8_t> h(C);
+            HIPCHK(hipMemcpyAsync(h.data(), s->solid, C, hipMemcpyDeviceToHost, s->st));
+            HIPCHK(hipStreamSynchronize(s->st));
+            for (long k = 0; k < C; ++k) ((float*)out)[k] = h[k] ? 1.f : 0.f;
+            return 0;
+        }
+        case MPM_F_VEL_BEFORE:
+        case MPM_F_FORCES:
+        case MPM_F_VEL: {
+            const double* src = field == MPM_F_VEL_BEFORE ? s->velb : (field == MPM_F_FORCES ? s->forces : s->vel);
+            if (ensure_stage(s, sizeof(double) * 3 * C)) return FLUID_ERR_HIP;
+            k_mpm_interleave<<<blocks_for(C, 256), 256, 0, s->st>>>(C, src, s->stage);
+            HIPCHK(hipMemcpyAsync(out, s->stage, sizeof(double) * 3 * C, hipMemcpyDeviceToHost, s->st));
+            break;
+        }
+        default: return fluid_fail(FLUID_ERR_ARG, "mpm_download_field: unknown field");
+    }
+    HIPCHK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+int mpm_download_system(mpm_sim_t* s, double* b, double* x)
+{
+    if (!s) return fluid_fail(FLUID_ERR_ARG, "mpm_download_system: null handle");
+    const size_t bytes = sizeof(double) * 3 * (size_t)s->num_active;
+    if (b && bytes) HIPCHK(hipMemcpyAsync(b, s->b, bytes, hipMemcpyDeviceToHost, s->st));
+    if (x && bytes) HIPCHK(hipMemcpyAsync(x, s->x, bytes, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+int mpm_apply_matrix(mpm_sim_t* s, const double* v, double* y)
+{
+    if (!s || !v || !y) return fluid_fail(FLUID_ERR_ARG, "mpm_apply_matrix: null argument");
+    if (!s->mid_step) return fluid_fail(FLUID_ERR_STATE, "mpm_apply_matrix: only between mpm_step_solve and mpm_step_advance");
+    const size_t n3 = 3 * (size_t)s->num_active;
+    if (!n3) return 0;
+    HIPCHK(hipMemcpyAsync(s->p, v, sizeof(double) * n3, hipMemcpyHostToDevice, s->st));
+    k_mpm_copy<<<blocks_for((long)n3, 256), 256, 0, s->st>>>((long)n3, s->p, s->q);
+    if (apply_operator(s)) return FLUID_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(y, s->q, sizeof(double) * n3, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+}  // extern "C"

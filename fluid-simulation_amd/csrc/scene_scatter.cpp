@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "fluid_hip.h"
+#include "mpm_hip.h"
 
 namespace {
 
@@ -65,21 +66,11 @@ inline int32_t floor_to(int32_t v, int32_t dim) { return v & ~(dim - 1); }  // n
 
 }  // namespace
 
-extern "C" int64_t fluid_scene_uniform_scatter(const int32_t lo[3], const int32_t hi[3], float points_per_volume, uint32_t seed,
-                                               int32_t boundary, double* pos)
+namespace {
+
+// The draws of UniformPointScatter::operator() (PointScatter.h:143-185) over the active values `vals` in ValueOn order.
+int64_t scatter_values(const std::vector<Value>& vals, float points_per_volume, uint32_t seed, int32_t boundary, double* pos)
 {
-    if (!lo || !hi || !(points_per_volume > 0)) return -1;
-    BoxI b;
-    for (int a = 0; a < 3; ++a) {
-        if (lo[a] > hi[a] || lo[a] < -(1 << 20) || hi[a] > (1 << 20)) return -1;
-        b.lo[a] = lo[a];
-        b.hi[a] = hi[a];
-    }
-    // root table: std::map ordered by Coord::operator< (x, then y, then z) over the 4096^3 blocks the box touches
-    std::vector<Value> vals;
-    for (int32_t x = floor_to(b.lo[0], 4096); x <= b.hi[0]; x += 4096)
-        for (int32_t y = floor_to(b.lo[1], 4096); y <= b.hi[1]; y += 4096)
-            for (int32_t z = floor_to(b.lo[2], 4096); z <= b.hi[2]; z += 4096) walk(b, x, y, z, 4096, vals);
     uint64_t voxels = 0;
     for (const Value& v : vals) voxels += (uint64_t)v.dim * v.dim * v.dim;
     if (voxels == 0) return 0;
@@ -122,4 +113,59 @@ extern "C" int64_t fluid_scene_uniform_scatter(const int32_t lo[3], const int32_
         }
     }
     return cnt;
+}
+
+}  // namespace
+
+extern "C" int64_t fluid_scene_uniform_scatter(const int32_t lo[3], const int32_t hi[3], float points_per_volume, uint32_t seed,
+                                               int32_t boundary, double* pos)
+{
+    if (!lo || !hi || !(points_per_volume > 0)) return -1;
+    BoxI b;
+    for (int a = 0; a < 3; ++a) {
+        if (lo[a] > hi[a] || lo[a] < -(1 << 20) || hi[a] > (1 << 20)) return -1;
+        b.lo[a] = lo[a];
+        b.hi[a] = hi[a];
+    }
+    // root table: std::map ordered by Coord::operator< (x, then y, then z) over the 4096^3 blocks the box touches
+    std::vector<Value> vals;
+    for (int32_t x = floor_to(b.lo[0], 4096); x <= b.hi[0]; x += 4096)
+        for (int32_t y = floor_to(b.lo[1], 4096); y <= b.hi[1]; y += 4096)
+            for (int32_t z = floor_to(b.lo[2], 4096); z <= b.hi[2]; z += 4096) walk(b, x, y, z, 4096, vals);
+    return scatter_values(vals, points_per_volume, seed, boundary, pos);
+}
+
+// The snow cone of the MPM program (mpm.cc:1037-1052): single active voxels set with setValue, no tiles.  ValueOn order of
+// voxels: root nodes by origin (x, y, z), then the child index inside the 4096^3 node, inside the 128^3 node, then the
+// offset inside the 8^3 leaf — every index x-major, z fastest.
+extern "C" int64_t mpm_scene_cone(int32_t B, int32_t W, int32_t layers, float points_per_voxel, uint32_t seed, double* pos)
+{
+    if (B < 3 || W < 1 || W > B || layers < 1 || layers > 2 * W + 1 || !(points_per_voxel > 0)) return -1;
+    std::vector<Value> vals;
+    for (int32_t i = -W; i <= W; ++i)
+        for (int32_t j = -W; j <= -W + layers - 1; ++j)
+            for (int32_t k = -W; k <= W; ++k) {
+                const double r = (double)(j + W) / 2;
+                if ((double)i * i + (double)k * k <= r * r) vals.push_back(Value{i, j, k, 1});
+            }
+    auto key = [](const Value& v, int64_t out[6]) {
+        const int32_t c[3] = {v.x, v.y, v.z};
+        int64_t root[3], i1 = 0, i2 = 0, i3 = 0;
+        for (int a = 0; a < 3; ++a) {
+            root[a] = floor_to(c[a], 4096);
+            const int32_t in_root = c[a] - (int32_t)root[a];          // 0..4095
+            i1 = i1 * 32 + (in_root >> 7);                            // 32^3 children of 128^3
+            i2 = i2 * 16 + ((in_root & 127) >> 3);                    // 16^3 leaves
+            i3 = i3 * 8 + (in_root & 7);                              // 8^3 voxels
+        }
+        out[0] = root[0], out[1] = root[1], out[2] = root[2], out[3] = i1, out[4] = i2, out[5] = i3;
+    };
+    std::sort(vals.begin(), vals.end(), [&](const Value& a, const Value& b) {
+        int64_t ka[6], kb[6];
+        key(a, ka), key(b, kb);
+        for (int t = 0; t < 6; ++t)
+            if (ka[t] != kb[t]) return ka[t] < kb[t];
+        return false;
+    });
+    return scatter_values(vals, points_per_voxel, seed, B, pos);
 }

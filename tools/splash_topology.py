@@ -28,3 +28,12 @@ for thr in (4, 32, 256):
     keep = np.isin(lab, np.nonzero(sizes > thr)[0] + 1)
     idx = np.argwhere(keep)
     print(f"components > {thr} cells: bbox", idx.min(0), idx.max(0), "cells", int(keep.sum()), "box cells", int(np.prod(idx.max(0) - idx.min(0) + 1)))
+# tiles (8 x 8 x 16 in x, y, z) that hold a fluid cell, with and without the small components
+def tiles(mask):
+    m = np.zeros(((n + 7) // 8 * 8, (n + 7) // 8 * 8, (n + 15) // 16 * 16), bool)
+    m[:n, :n, :n] = mask
+    return int(m.reshape(m.shape[0] // 8, 8, m.shape[1] // 8, 8, m.shape[2] // 16, 16).any(axis=(1, 3, 5)).sum())
+print("active tiles, all fluid cells:", tiles(fluid))
+for thr in (1, 2, 4, 8, 32, 256):
+    keep = np.isin(lab, np.nonzero(sizes > thr)[0] + 1)
+    print(f"  without components <= {thr} cells: tiles {tiles(keep)}  cells dropped {int(fluid.sum() - keep.sum())}  components dropped {int((sizes <= thr).sum())}")
