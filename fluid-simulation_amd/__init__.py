@@ -6,7 +6,7 @@ The reference (Aakash1312/Fluid-Simulation, ``fluid.cc``) is one ``main()`` whos
 hand-written HIP for gfx950.  There is NO CPU fallback: if the shared library is missing,
 import fails; if no GPU is visible, ``FluidSim(...)`` raises.
 """
-from ._lib import lib, FluidError, Params, StepStats, FIELD, PROF  # noqa: F401
+from ._lib import lib, FluidError, Params, StepStats, FIELD, PROF, MpmParams, MpmStepStats  # noqa: F401
 from .mpm import MpmSim, snow_cone, MPM_P, MPM_F  # noqa: F401
 from .sim import FluidSim, water_cube_drop, reference_scatter, grid_bounds, write_vdb, VdbStream  # noqa: F401
 
@@ -16,4 +16,4 @@ def load_dist():
     return dist
 
 
-__all__ = ["MpmSim", "snow_cone", "MPM_P", "MPM_F", "load_dist", "FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "reference_scatter", "grid_bounds", "write_vdb", "VdbStream", "lib"]
+__all__ = ["MpmParams", "MpmStepStats", "MpmSim", "snow_cone", "MPM_P", "MPM_F", "load_dist", "FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "reference_scatter", "grid_bounds", "write_vdb", "VdbStream", "lib"]

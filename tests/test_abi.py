@@ -106,3 +106,24 @@ int main(int argc, char** argv) {
     import vdb_reader
     info, grids = vdb_reader.read(tmp_path / "c.vdb")
     assert np.array_equal(grids[0].dense(-4, 3)[0].ravel(), np.arange(512, dtype=np.float32))
+
+
+def test_mpm_header_symbols_and_literals(fs):
+    """include/mpm_hip.h: every declared entry point is exported; defaults = the literals of mpm.cc."""
+    txt = open(os.path.join(ROOT, "include", "mpm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mpm_[a-z0-9_]+)\s*\(", txt)))
+    assert len(syms) >= 16
+    for s in syms:
+        assert hasattr(fs.lib, s), f"{s} declared in include/mpm_hip.h but not exported by libfluid_hip.so"
+    p = fs.MpmParams()
+    assert fs.lib.mpm_default_params(C.byref(p)) == 0
+    assert (p.B, p.W) == (15, 13) and p.dx == 1.0 and list(p.gravity) == [0.0, -10.0, 0.0]       # mpm.cc:1023,1156,1281-1282
+    assert (p.youngs_modulus, p.poisson_ratio, p.beta, p.hardening) == (48000.0, 0.47, 0.5, 10.0)   # mpm.cc:1391-1395
+    assert (p.theta_c, p.theta_s, p.max_dt, p.dt0) == (0.025, 0.0075, 0.001, 0.001)                # mpm.cc:1410,1417,1295
+    assert p.cg_tol == np.finfo(np.float64).eps and p.transpose_system == 1
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(fs.FluidError) as e:
+            fs.MpmSim()
+        assert e.value.code == 2 and "no CPU path" in str(e.value)

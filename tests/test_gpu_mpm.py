@@ -1,0 +1,170 @@
+"""-m gpu: the snow-MPM step on the HIP path, through the C ABI of include/mpm_hip.h, against the CPU
+restatement oracle/mpm_oracle.cpp on the same seeded inputs.
+
+Bars: unknown numbering and num_active bit-exact; the float32 node mass within the accumulation-order noise of a float sum
+(the oracle adds in particle order in float32 like the serial reference, the kernel sums in fp64 and rounds once: <= 2e-6
+relative at 400 particles per voxel, <= 2e-7 at 8); every fp64 field and particle array <= 1e-4 relative L2 (north_star's
+float tolerance) — the measured margins are orders of magnitude inside and asserted much tighter below.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mo():
+    from oracle import mpm_oracle
+    return mpm_oracle
+
+
+def make_pair(fs, mo, pos, vel=None, **kw):
+    sim = fs.MpmSim(**kw)
+    kept = sim.upload_particles(pos, vel)
+    orc = mo.MpmOracle()
+    if "transpose_system" in kw:
+        orc.set_transposed(kw["transpose_system"])
+    assert orc.set_particles(pos, vel) == kept
+    return sim, orc
+
+
+def scene(fs, ppv=400.0, keep=None, seed=0):
+    pos = fs.snow_cone(points_per_voxel=ppv, seed=seed)
+    if keep:
+        pos = pos[np.random.default_rng(7).choice(len(pos), keep, replace=False)]
+    return pos
+
+
+def compare_step(fs, sim, orc, so, tol_mass, tol=1e-9):
+    F, P = fs.MPM_F, fs.MPM_P
+    assert np.array_equal(sim.field(F.INDICES), orc.field(3))
+    assert rel_l2(sim.field(F.CONTAINER), orc.field(0)) < tol_mass
+    assert rel_l2(sim.field(F.OUTPUT), orc.field(2)) < tol_mass
+    for fid in (F.VEL_BEFORE, F.FORCES, F.VEL):
+        e = rel_l2(sim.field(fid), orc.field(fid))
+        assert e < max(tol, 20 * tol_mass), (fid, e)
+    for what in (P.POS, P.VEL, P.FE, P.FP, P.GRADV, P.VOLUME):
+        e = rel_l2(sim.particles(what), orc.particles(what))
+        assert e < max(tol, 20 * tol_mass), (what, e)
+
+
+def test_reference_scene_step_by_step(fs, mo):
+    """The reference's own scene (6205 particles, 31^3 grid), 4 steps free-running, every array after every step."""
+    sim, orc = make_pair(fs, mo, scene(fs))
+    assert sim.num_particles == orc.num_particles == 6205
+    for i in range(4):
+        sg, so = sim.step(), orc.step()
+        assert sg["num_active"] == so["num_active"] > 0
+        assert sg["any_active"] == so["any_active"] == 1
+        assert sg["cg_error"] < 2.3e-16 and so["cg_error"] < 2.3e-16
+        for k in ("dt_in", "dt_out", "max_speed", "max_grad", "max_fp", "max_fe", "max_mi", "max_force_coeff2"):
+            assert sg[k] == pytest.approx(so[k], rel=1e-5, abs=1e-300), (i, k)
+        assert np.allclose(sg["max_force"], so["max_force"], rtol=1e-5, atol=1e-12)
+        compare_step(fs, sim, orc, so, tol_mass=3e-6)
+    sim.close()
+
+
+def test_solution_solves_the_programs_system(fs, mo):
+    """x solves A^T x = b for the matrix the restatement assembles the reference's way (std::map of 3x3 blocks): the HIP
+    path never forms A, its operator is probed column by column between the two halves of a step."""
+    pos = scene(fs, keep=500)
+    for transposed in (1, 0):
+        sim, orc = make_pair(fs, mo, pos, transpose_system=transposed)
+        sim.step(), orc.step()
+        sg = sim.step_solve()
+        so = orc.step()
+        n = 3 * so["num_active"]
+        assert sg["num_active"] == so["num_active"]
+        rows, cols, vals, b, x = orc.system()
+        A = np.zeros((n, n))
+        np.add.at(A, (rows, cols), vals)
+        Aop = A.T if transposed else A
+        bg, xg = sim.system(sg["num_active"])
+        assert rel_l2(bg, b) < 1e-9
+        assert np.linalg.norm(Aop @ xg - bg) <= 1e-13 * np.linalg.norm(bg)
+        assert rel_l2(xg, x) < 1e-9
+        # the operator itself, all columns
+        cols_g = np.stack([sim.apply_matrix(np.eye(n)[k]) for k in range(n)], axis=1)
+        assert np.abs(cols_g - Aop).max() <= 1e-9 * np.abs(Aop).max()
+        sim.step_advance()
+        compare_step(fs, sim, orc, so, tol_mass=3e-6)
+        sim.close()
+    # the two systems really differ (rows scaled by 1/m_i)
+    assert np.abs(A - A.T).max() > 1e-3
+
+
+@pytest.mark.parametrize("ppv,keep", [(8.0, None), (40.0, None), (400.0, 900)])
+def test_sparser_scenes(fs, mo, ppv, keep):
+    """Fewer particles per node: lighter nodes, a stiffer system (more CG iterations), thresholds (mass > 0.1) in play."""
+    sim, orc = make_pair(fs, mo, scene(fs, ppv=ppv, keep=keep, seed=3))
+    for i in range(3):
+        sg, so = sim.step(), orc.step()
+        assert sg["num_active"] == so["num_active"]
+        assert sg["cg_error"] < 2.3e-16
+        compare_step(fs, sim, orc, so, tol_mass=1e-6, tol=1e-8)
+    sim.close()
+
+
+def test_wall_contact_and_truncated_coordinates(fs, mo):
+    """Particles driven into the floor and the side walls: FLIPadvect's ceil/floor rounding, the Coord(int, double, double)
+    truncation and the restitution e = 0 (mpm.cc:938-966); particles outside |p| < B - 2 are dropped by add()."""
+    rng = np.random.default_rng(11)
+    pos = np.concatenate([rng.uniform(-12.9, 12.9, size=(3000, 3)) * [1, 0.02, 1] + [0, -12.6, 0],
+                          rng.uniform(11.5, 12.95, size=(500, 3)) * rng.choice([-1, 1], size=(500, 3)),
+                          np.array([[13.0, 0, 0], [0, -13.5, 0], [0, 0, 14.9], [12.999, -12.999, 12.999]])])
+    vel = rng.normal(size=pos.shape) * 400.0          # up to ~ a cell per step at dt = 1e-3
+    sim, orc = make_pair(fs, mo, pos, vel)
+    assert sim.num_particles == orc.num_particles == len(pos) - 3
+    for i in range(5):
+        sg, so = sim.step(), orc.step()
+        assert sg["num_active"] == so["num_active"]
+        assert sg["dt_out"] == pytest.approx(so["dt_out"], rel=1e-9)
+        compare_step(fs, sim, orc, so, tol_mass=1e-6, tol=1e-8)
+    v = sim.particles(fs.MPM_P.VEL)
+    assert (v == 0).any()                              # some component was zeroed by a wall
+    sim.close()
+
+
+def test_empty_and_call_order(fs):
+    sim = fs.MpmSim()
+    st = sim.step()                                    # no particles: nothing active, dt stays
+    assert st["num_active"] == 0 and st["any_active"] == 0 and st["dt_out"] == 0.001 and st["cg_iters"] == 0
+    with pytest.raises(fs.FluidError):
+        sim.step_advance()
+    sim.step_solve()
+    with pytest.raises(fs.FluidError):
+        sim.step_solve()
+    sim.step_advance()
+    with pytest.raises(fs.FluidError):
+        sim.apply_matrix(np.zeros(3))
+    with pytest.raises(fs.FluidError):
+        fs.MpmSim(B=2)
+    sim.close()
+
+
+def test_larger_grid_and_restart(fs, mo):
+    """A grid other than the reference's 31^3 (B = 23, W = 21) and a restart from downloaded state (FE, FP, volume, dt)."""
+    B, W = 23, 21
+    pos = fs.snow_cone(B=B, W=W, layers=8, points_per_voxel=6.0, seed=2)
+    sim = fs.MpmSim(B=B, W=W)
+    sim.upload_particles(pos)
+    orc = mo.MpmOracle(B=B, W=W)
+    orc.set_particles(pos)
+    for i in range(2):
+        sg, so = sim.step(), orc.step()
+        assert sg["num_active"] == so["num_active"] > 100
+    F, P = fs.MPM_F, fs.MPM_P
+    assert np.array_equal(sim.field(F.INDICES), orc.field(3))
+    assert rel_l2(sim.particles(P.POS), orc.particles(0)) < 1e-10
+    # restart a second handle from the first one's state: the next step is the same step
+    sim2 = fs.MpmSim(B=B, W=W)
+    sim2.upload_particles(sim.particles(P.POS), sim.particles(P.VEL))
+    sim2.set_state(sim.particles(P.FE), sim.particles(P.FP), sim.particles(P.VOLUME), step_no=2)
+    sim2.dt = sim.dt
+    a, b = sim.step(), sim2.step()
+    assert a["num_active"] == b["num_active"]
+    for what in (P.POS, P.VEL, P.FE, P.FP):
+        assert rel_l2(sim2.particles(what), sim.particles(what)) < 1e-12
+    sim.close(), sim2.close()
