@@ -45,6 +45,8 @@ struct MpmState {
     int cg_done;
     int max_cell;                    // first cell attaining max_force_coeff2
     int any_active;
+    int cg_iters;                    // Eigen's `i` (ConjugateGradient.h:70-88)
+    int pad_;
     unsigned long long max_speed_bits, max_grad_bits, max_fp_bits, max_fe_bits, max_coeff_bits;
     double dt;
     double bb, rho, rho_new, pq, rr; // |b|^2, <r,r>_D, <p,Ap>_D, |r|^2
@@ -199,29 +201,80 @@ __device__ void svd3(const double* F, double* U, double* s, double* V)
     }
 }
 
+
+// ---- wave-level aggregation of the scatters ----
+// Particles arrive grouped by voxel (the scatter emits them in ValueOn order and snow moves coherently), so the lanes of a
+// wave mostly share their base cell and hence their 27 target nodes: with one atomic per lane the same ~150 addresses take
+// thousands of serialised updates (348 us per operator application on the reference scene).  Lanes with equal consecutive
+// keys (base cell) form a segment; values are summed along each segment with 6 shuffle steps and the segment's last lane
+// issues one atomic.  Any particle order stays correct — unsorted input only shortens the segments.
+struct Seg {
+    int start;   // first lane of this lane's segment
+    bool tail;   // this lane is the last of its segment
+};
+__device__ __forceinline__ Seg seg_setup(long key)
+{
+    const int lane = threadIdx.x & 63;
+    const long prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1));
+    Seg sg;
+    sg.start = 63 - __clzll((long long)below);
+    sg.tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    return sg;
+}
+__device__ __forceinline__ double seg_sum(double v, const Seg& sg)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o);
+        if (lane - o >= sg.start) v += t;
+    }
+    return v;   // complete on the tail lane
+}
+__device__ __forceinline__ long base_key(const MGrid& G, const double p[3], bool valid)
+{
+    if (!valid) return -1 - (long)(threadIdx.x & 63);   // a segment of its own
+    const long N = 2L * G.B + 3;                        // round(p) may lie one cell outside the grid on either side
+    return (((long)round(p[0]) + G.B + 1) * N + ((long)round(p[1]) + G.B + 1)) * N + ((long)round(p[2]) + G.B + 1);
+}
+
 // ---- transfer: interpolate (mpm.cc:773-811) + P2Gtransfer's scatter (mpm.cc:218-253,996-999) ----
-__global__ void k_mpm_p2g(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, double* __restrict__ massd,
+__global__ void __launch_bounds__(128) k_mpm_p2g(MGrid G, long n, Part P, const int* __restrict__ order, const uint8_t* __restrict__ solid, double* __restrict__ massd,
                           double* __restrict__ vel /* 3 x cells */)
 {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = j < n;
+    const long ii = order[valid ? j : 0];
     const long C = G.cells();
-    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
-    double v[3] = {ld(P.vel, P.cap, 0, i), ld(P.vel, P.cap, 1, i), ld(P.vel, P.cap, 2, i)};
+    double p[3] = {ld(P.pos, P.cap, 0, ii), ld(P.pos, P.cap, 1, ii), ld(P.pos, P.cap, 2, ii)};
+    double v[3] = {ld(P.vel, P.cap, 0, ii), ld(P.vel, P.cap, 1, ii), ld(P.vel, P.cap, 2, ii)};
     Nbh nb;
     neighbourhood(G, p, nb, false);
-    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
-        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
-            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+    const Seg sg = seg_setup(base_key(G, p, valid));
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
                 const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
-                const long k = G.at(x, y, z);
-                if (solid[k]) continue;
-                const double cw = nb.w[0][a] * nb.w[1][b] * nb.w[2][c];
-                if (cw > 0) unsafeAtomicAdd(&massd[k], cw);
-                if (abs(x) <= G.B - 2 && abs(y) <= G.B - 2 && abs(z) <= G.B - 2 && cw != 0) {
-                    unsafeAtomicAdd(&vel[k], v[0] * cw);
-                    unsafeAtomicAdd(&vel[C + k], v[1] * cw);
-                    unsafeAtomicAdd(&vel[2 * C + k], v[2] * cw);
+                const bool in = valid && x <= nb.hi[0] && y <= nb.hi[1] && z <= nb.hi[2];
+                const long k = in ? G.at(x, y, z) : 0;
+                const bool ok = in && !solid[k];
+                const double cw = ok ? nb.w[0][a] * nb.w[1][b] * nb.w[2][c] : 0.0;
+                const bool mom = ok && abs(x) <= G.B - 2 && abs(y) <= G.B - 2 && abs(z) <= G.B - 2;
+                const double m = seg_sum(cw > 0 ? cw : 0.0, sg);
+                const double m0 = seg_sum(mom ? v[0] * cw : 0.0, sg), m1 = seg_sum(mom ? v[1] * cw : 0.0, sg), m2 = seg_sum(mom ? v[2] * cw : 0.0, sg);
+                if (sg.tail && ok) {
+                    if (m > 0) unsafeAtomicAdd(&massd[k], m);
+                    if (mom) {
+                        if (m0 != 0) unsafeAtomicAdd(&vel[k], m0);
+                        if (m1 != 0) unsafeAtomicAdd(&vel[C + k], m1);
+                        if (m2 != 0) unsafeAtomicAdd(&vel[2 * C + k], m2);
+                    }
                 }
             }
 }
@@ -268,7 +321,7 @@ __global__ void __launch_bounds__(SCAN_T) k_mpm_scan_sums(long C, const int* __r
         sums[blockIdx.x] = t;
     }
 }
-__global__ void __launch_bounds__(1024) k_mpm_scan_blocks(int nb, int* __restrict__ sums, MpmState* st)
+__global__ void __launch_bounds__(1024) k_mpm_scan_blocks(int nb, int* __restrict__ sums, int* __restrict__ total)
 {
     // one block: exclusive scan of the block sums in chunks of 1024
     __shared__ int sh[1024];
@@ -292,7 +345,7 @@ __global__ void __launch_bounds__(1024) k_mpm_scan_blocks(int nb, int* __restric
         if (threadIdx.x == 1023) carry += incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) st->num_active = carry;
+    if (threadIdx.x == 0 && total) *total = carry;
 }
 __global__ void __launch_bounds__(SCAN_T) k_mpm_scan_final(long C, const int* __restrict__ flag, const int* __restrict__ sums,
                                                            int* __restrict__ indices, int* __restrict__ active_cell)
@@ -326,8 +379,59 @@ __global__ void __launch_bounds__(SCAN_T) k_mpm_scan_final(long C, const int* __
         }
 }
 
+// ---- particles in base-cell order (counting sort, every step) ----
+// The scatter kernels run over `order`: lanes of a wave then share their base cell, so the wave-level aggregation above
+// turns thousands of same-address atomics into one per wave and node.  Order inside a cell is whatever the rank atomics
+// give (sums differ in the last bits from run to run, as with any atomic accumulation).
+__global__ void k_mpm_sort_count(MGrid G, long n, Part P, int* __restrict__ cell_count, int* __restrict__ key, int* __restrict__ rank)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int f = (int)round(ld(P.pos, P.cap, a, i));
+        c[a] = f < -G.B ? -G.B : (f > G.B ? G.B : f);
+    }
+    const int k = (int)G.at(c[0], c[1], c[2]);
+    key[i] = k;
+    rank[i] = atomicAdd(&cell_count[k], 1);
+}
+__global__ void __launch_bounds__(SCAN_T) k_mpm_scan_excl(long C, const int* __restrict__ vals, const int* __restrict__ sums, int* __restrict__ out)
+{
+    __shared__ int sh[SCAN_T];
+    long base = (long)blockIdx.x * SCAN_BLK + (long)threadIdx.x * SCAN_PER;
+    int f[SCAN_PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        f[k] = base + k < C ? vals[base + k] : 0;
+        s += f[k];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_T; o <<= 1) {
+        int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sums[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k)
+        if (base + k < C) {
+            out[base + k] = run;
+            run += f[k];
+        }
+}
+__global__ void k_mpm_sort_place(long n, const int* __restrict__ key, const int* __restrict__ rank, const int* __restrict__ cell_start,
+                                 int* __restrict__ order)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[cell_start[key[i]] + rank[i]] = (int)i;
+}
+
 // ---- findVolume, mpm.cc:739-772 ----
-__global__ void k_mpm_volume(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const float* __restrict__ container)
+__global__ void __launch_bounds__(128) k_mpm_volume(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const float* __restrict__ container)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -335,21 +439,27 @@ __global__ void k_mpm_volume(MGrid G, long n, Part P, const uint8_t* __restrict_
     Nbh nb;
     neighbourhood(G, p, nb, false);
     double vol = P.volume[i];
-    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
-        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
-            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
-                const long k = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
-                if (!solid[k]) vol += (double)container[k] * nb.w[0][a] * nb.w[1][b] * nb.w[2][c];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
+                const bool in = x <= nb.hi[0] && y <= nb.hi[1] && z <= nb.hi[2];
+                const long k = in ? G.at(x, y, z) : 0;
+                if (in && !solid[k]) vol += (double)container[k] * nb.w[0][a] * nb.w[1][b] * nb.w[2][c];
             }
     P.volume[i] = 1.0 / vol;
 }
 
 // ---- populateGridForces, first loop (mpm.cc:596-644) + the per-particle part of getdPsydx2 (deformHeader.h:253-263) ----
-__global__ void k_mpm_forces(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, double mu0, double lambda0, double eps,
+__global__ void __launch_bounds__(128) k_mpm_forces(MGrid G, long n, Part P, const int* __restrict__ order, const uint8_t* __restrict__ solid, double mu0, double lambda0, double eps,
                              double* __restrict__ forces)
 {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i0 < n;
+    const long i = order[valid ? i0 : 0];   // idle lanes of the last wave recompute a particle and store nothing
     const long C = G.cells();
     double F[9], FP[9], U[9], V[9], sv[3], R[9], S[9];
 #pragma unroll
@@ -380,30 +490,41 @@ __global__ void k_mpm_forces(MGrid G, long n, Part P, const uint8_t* __restrict_
     const double dm = mat_det(m);
     double cf[9];
     cofactor(F, cf);
+    if (valid) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        stv(P.R, P.cap, k, i, R[k]);
-        stv(P.Minv, P.cap, k, i, dm != 0 ? mi[k] / dm : 0.0);
-        stv(P.cof, P.cap, k, i, cf[k]);
+        for (int k = 0; k < 9; ++k) {
+            stv(P.R, P.cap, k, i, R[k]);
+            stv(P.Minv, P.cap, k, i, dm != 0 ? mi[k] / dm : 0.0);
+            stv(P.cof, P.cap, k, i, cf[k]);
+        }
+        stv(P.coef, P.cap, 0, i, mu), stv(P.coef, P.cap, 1, i, lambda), stv(P.coef, P.cap, 2, i, Je);
     }
-    stv(P.coef, P.cap, 0, i, mu), stv(P.coef, P.cap, 1, i, lambda), stv(P.coef, P.cap, 2, i, Je);
 
     double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
     const double vol = P.volume[i];
     Nbh nb;
     neighbourhood(G, p, nb, true);
-    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
-        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
-            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
-                const long k = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
-                if (solid[k]) continue;
+    const Seg sg = seg_setup(base_key(G, p, valid));
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
+                const bool in = valid && x <= nb.hi[0] && y <= nb.hi[1] && z <= nb.hi[2];
+                const long k = in ? G.at(x, y, z) : 0;
+                const bool ok = in && !solid[k];
                 double g[3];
                 grad_w(nb, a, b, c, g);
-                if (g[0] == 0 && g[1] == 0 && g[2] == 0) continue;
+                double f[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    double f = -1 * vol * (sigma[3 * r] * g[0] + sigma[3 * r + 1] * g[1] + sigma[3 * r + 2] * g[2]);
-                    unsafeAtomicAdd(&forces[r * C + k], f);
+                for (int r = 0; r < 3; ++r)
+                    f[r] = seg_sum(ok ? -1 * vol * (sigma[3 * r] * g[0] + sigma[3 * r + 1] * g[1] + sigma[3 * r + 2] * g[2]) : 0.0, sg);
+                if (sg.tail && ok) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        if (f[r] != 0) unsafeAtomicAdd(&forces[r * C + k], f[r]);
                 }
             }
 }
@@ -471,33 +592,41 @@ __global__ void k_mpm_maxforce_final(MGrid G, MpmState* st, const float* __restr
 
 // ---- the operator: y = v + beta dt^2 D^-1 K v, one thread per particle (mpm.cc:646-701 + 418-441, matrix-free) ----
 // v, y: 3 * num_active doubles in unknown order; y must hold v on entry (the identity part).
-__global__ void k_mpm_apply(MGrid G, long n, Part P, const int* __restrict__ indices, const float* __restrict__ container,
-                            const MpmState* st, double beta, int transposed, const double* __restrict__ v, double* __restrict__ y)
+__global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, const int* __restrict__ order, const int* __restrict__ indices, const float* __restrict__ container,
+                            const MpmState* st, double beta, int transposed, int in_solve, const double* __restrict__ v, double* __restrict__ y)
 {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (in_solve && st->cg_done) return;   // speculative launches past convergence do nothing
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i0 < n;
+    const long i = order[valid ? i0 : 0];
     double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
     Nbh nb;
     neighbourhood(G, p, nb, true);
     // G = sum_j v_j (x) grad w_j over the unknown nodes
     double Gm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool any = false;
-    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
-        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
-            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
-                const int k = indices[G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c)];
-                if (k < 0) continue;
-                double g[3];
-                grad_w(nb, a, b, c, g);
-                if (g[0] == 0 && g[1] == 0 && g[2] == 0) continue;
-                any = true;
+    // one x-plane of 9 nodes at a time (its 9 index loads and 27 value loads are independent and in flight together);
+    // the x factors are picked by selects so that the plane loop stays rolled without indexing registers dynamically
+#pragma unroll 1
+    for (int a = 0; a < 3; ++a) {
+        const double s2x = a == 0 ? nb.s2[0][0] : (a == 1 ? nb.s2[0][1] : nb.s2[0][2]);
+        const double gx = a == 0 ? nb.g[0][0] : (a == 1 ? nb.g[0][1] : nb.g[0][2]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int cx = nb.lo[0] + a, cy = nb.lo[1] + b, cz = nb.lo[2] + c;
+                const bool in = cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
+                const long cell = in ? G.at(cx, cy, cz) : 0;
+                const int k = in ? indices[cell] : -1;
+                const long kk = k >= 0 ? k : 0;
+                const double g[3] = {-1 * gx * nb.s2[1][b] * nb.s2[2][c], -1 * s2x * nb.g[1][b] * nb.s2[2][c], -1 * s2x * nb.s2[1][b] * nb.g[2][c]};
                 // transposed system (what the reference's Eigen solves, see mpm_hip.h): K D^-1 v — the mass divides the input
-                const double wj = transposed ? 1.0 / (double)container[G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c)] : 1.0;
-                const double vx = wj * v[3 * (long)k], vy = wj * v[3 * (long)k + 1], vz = wj * v[3 * (long)k + 2];
+                const double wj = k < 0 ? 0.0 : (transposed ? 1.0 / (double)container[cell] : 1.0);
+                const double vx = wj * v[3 * kk], vy = wj * v[3 * kk + 1], vz = wj * v[3 * kk + 2];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) Gm[d] += vx * g[d], Gm[3 + d] += vy * g[d], Gm[6 + d] += vz * g[d];
             }
-    if (!any) return;
+    }
     double F[9], R[9], Mi[9], cf[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) F[k] = ld(P.FE, P.cap, k, i), R[k] = ld(P.R, P.cap, k, i), Mi[k] = ld(P.Minv, P.cap, k, i), cf[k] = ld(P.cof, P.cap, k, i);
@@ -537,20 +666,32 @@ __global__ void k_mpm_apply(MGrid G, long n, Part P, const int* __restrict__ ind
     mat_mul_bt(Ap, F, ApFt);                    // A_p F^T
     const double dt = st->dt;
     const double sc = beta * dt * dt * P.volume[i];
-    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
-        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
-            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
-                const long cell = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
-                const int k = indices[cell];
-                if (k < 0) continue;
-                double g[3];
-                grad_w(nb, a, b, c, g);
-                if (g[0] == 0 && g[1] == 0 && g[2] == 0) continue;
-                const double f = transposed ? sc : sc * (1.0 / (double)container[cell]);
+    const Seg sg = seg_setup(base_key(G, p, valid));
+#pragma unroll 1
+    for (int a = 0; a < 3; ++a) {
+        const double s2x = a == 0 ? nb.s2[0][0] : (a == 1 ? nb.s2[0][1] : nb.s2[0][2]);
+        const double gx = a == 0 ? nb.g[0][0] : (a == 1 ? nb.g[0][1] : nb.g[0][2]);
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    unsafeAtomicAdd(&y[3 * (long)k + r], f * (ApFt[3 * r] * g[0] + ApFt[3 * r + 1] * g[1] + ApFt[3 * r + 2] * g[2]));
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int cx = nb.lo[0] + a, cy = nb.lo[1] + b, cz = nb.lo[2] + c;
+                const bool in = valid && cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
+                const long cell = in ? G.at(cx, cy, cz) : 0;
+                const int k = in ? indices[cell] : -1;
+                const bool ok = k >= 0;
+                const double g[3] = {-1 * gx * nb.s2[1][b] * nb.s2[2][c], -1 * s2x * nb.g[1][b] * nb.s2[2][c], -1 * s2x * nb.s2[1][b] * nb.g[2][c]};
+                const double f = !ok ? 0.0 : (transposed ? sc : sc * (1.0 / (double)container[cell]));
+                double o[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) o[r] = seg_sum(f * (ApFt[3 * r] * g[0] + ApFt[3 * r + 1] * g[1] + ApFt[3 * r + 2] * g[2]), sg);
+                if (sg.tail && ok) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        if (o[r] != 0) unsafeAtomicAdd(&y[3 * (long)k + r], o[r]);
+                }
             }
+    }
 }
 
 // ---- CG vector kernels (3 * num_active doubles, weighted dots) ----
@@ -581,8 +722,11 @@ __global__ void k_mpm_cg_scalars(int what, int nparts, const double* __restrict_
         st->bb = a, st->rho = b, st->rr = a;
         st->cg_done = (a == 0) ? 1 : 0;   // b = 0 => x = 0 (IterativeSolverBase / ConjugateGradient.h:44-50)
     } else if (what == 1) {
+        if (st->cg_done) return;
         st->pq = b;
+        if (!(b > 0) || !isfinite(b)) st->cg_done = 2;   // breakdown: leave x as it is
     } else {
+        if (st->cg_done) return;
         st->rr = a, st->rho_new = b;
         if (a < tol * tol * st->bb) st->cg_done = 1;
     }
@@ -604,7 +748,7 @@ __global__ void k_mpm_cg_init(const int* __restrict__ active_cell, const MpmStat
 __global__ void k_mpm_cg_pq(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
                             const double* __restrict__ p, const double* __restrict__ q, double* pa, double* pb)
 {
-    const long n3 = 3L * st->num_active;
+    const long n3 = st->cg_done ? 0 : 3L * st->num_active;
     double d = 0;
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x)
         d += dot_weight(container[active_cell[k / 3]], transposed) * p[k] * q[k];
@@ -615,7 +759,7 @@ __global__ void k_mpm_cg_xr(const int* __restrict__ active_cell, const MpmState*
                             double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p, const double* __restrict__ q,
                             double* pa, double* pb)
 {
-    const long n3 = 3L * st->num_active;
+    const long n3 = st->cg_done ? 0 : 3L * st->num_active;
     const double alpha = st->rho / st->pq;
     double a = 0, d = 0;
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
@@ -630,14 +774,19 @@ __global__ void k_mpm_cg_xr(const int* __restrict__ active_cell, const MpmState*
 // done in a separate tiny kernel to stay race-free)
 __global__ void k_mpm_cg_p(const MpmState* st, const double* __restrict__ r, double* __restrict__ p, double* __restrict__ q)
 {
-    const long n3 = 3L * st->num_active;
+    const long n3 = st->cg_done ? 0 : 3L * st->num_active;
     const double beta = st->rho_new / st->rho;
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
         const double v = r[k] + beta * p[k];
         p[k] = v, q[k] = v;
     }
 }
-__global__ void k_mpm_cg_roll(MpmState* st) { st->rho = st->rho_new; }
+__global__ void k_mpm_cg_roll(MpmState* st, long max_iters)
+{
+    if (st->cg_done) return;   // Eigen leaves the loop before counting the iteration (ConjugateGradient.h:78-79)
+    st->rho = st->rho_new;
+    if (++st->cg_iters >= max_iters) st->cg_done = 3;
+}
 __global__ void k_mpm_copy(long n, const double* __restrict__ a, double* __restrict__ b)
 {
     long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -658,7 +807,7 @@ __global__ void k_mpm_update_velocity(MGrid G, const uint8_t* __restrict__ solid
 }
 
 // ---- updateDeformationGradient, mpm.cc:493-586 ----
-__global__ void k_mpm_deform(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const double* __restrict__ vel, MpmState* st,
+__global__ void __launch_bounds__(128) k_mpm_deform(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const double* __restrict__ vel, MpmState* st,
                              double minv, double maxv)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,16 +818,21 @@ __global__ void k_mpm_deform(MGrid G, long n, Part P, const uint8_t* __restrict_
     Nbh nb;
     neighbourhood(G, p, nb, true);
     double gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
-        for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
-            for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
-                const long k = G.at(nb.lo[0] + a, nb.lo[1] + b, nb.lo[2] + c);
-                if (solid[k]) continue;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
+                const bool in = x <= nb.hi[0] && y <= nb.hi[1] && z <= nb.hi[2];
+                const long k = in ? G.at(x, y, z) : 0;
+                const bool ok = in && !solid[k];
                 double g[3];
                 grad_w(nb, a, b, c, g);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const double vr = vel[r * C + k];
+                    const double vr = ok ? vel[r * C + k] : 0.0;
 #pragma unroll
                     for (int d = 0; d < 3; ++d) gv[3 * r + d] += vr * g[d];
                 }
@@ -726,7 +880,7 @@ __device__ __forceinline__ double vel_at(const MGrid& G, const double* __restric
 {
     return G.in(x, y, z) ? g[a * C + G.at(x, y, z)] : 0.0;   // reads beyond the grid return the background 0
 }
-__global__ void k_mpm_flip(MGrid G, long n, Part P, const double* __restrict__ vel, const double* __restrict__ velb, MpmState* st)
+__global__ void __launch_bounds__(128) k_mpm_flip(MGrid G, long n, Part P, const double* __restrict__ vel, const double* __restrict__ velb, MpmState* st)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     double len = 0;
@@ -736,10 +890,14 @@ __global__ void k_mpm_flip(MGrid G, long n, Part P, const double* __restrict__ v
         Nbh nb;
         neighbourhood(G, p, nb, false);
         double weight = 0, delta[3] = {0, 0, 0};
-        for (int a = 0; a <= nb.hi[0] - nb.lo[0]; ++a)
-            for (int b = 0; b <= nb.hi[1] - nb.lo[1]; ++b)
-                for (int c = 0; c <= nb.hi[2] - nb.lo[2]; ++c) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
                     const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
+                    if (x > nb.hi[0] || y > nb.hi[1] || z > nb.hi[2]) continue;
                     if (abs(x) > G.W || abs(y) > G.W || abs(z) > G.W) continue;
                     const double cw = nb.w[0][a] * nb.w[1][b] * nb.w[2][c];
                     const double vc[3] = {(vel_at(G, vel, C, 0, x, y, z) + vel_at(G, vel, C, 0, x + 1, y, z)) / 2.0,
@@ -768,7 +926,7 @@ __global__ void k_mpm_timestep(MpmState* st, double max_dt, double dx)
     const double ms = __longlong_as_double((long long)st->max_speed_bits);
     st->dt = ms != 0 ? (max_dt < dx / ms ? max_dt : dx / ms) : max_dt;   // mpm.cc:929-936
 }
-__global__ void k_mpm_advect(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const MpmState* st)
+__global__ void __launch_bounds__(128) k_mpm_advect(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const MpmState* st)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -839,6 +997,7 @@ struct mpm_sim {
     float *container = nullptr, *output = nullptr;
     double *massd = nullptr, *vel = nullptr, *velb = nullptr, *forces = nullptr;
     int *flag = nullptr, *indices = nullptr, *active_cell = nullptr, *sums = nullptr;
+    int *cell_count = nullptr, *cell_start = nullptr, *key = nullptr, *rank = nullptr, *order = nullptr;   // counting sort by base cell
     double *b = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *part = nullptr;
     double* stage = nullptr;
     size_t stage_bytes = 0;
@@ -871,6 +1030,11 @@ int ensure_stage(mpm_sim* s, size_t bytes)
 }
 void free_particles(mpm_sim* s)
 {
+    int** ia[] = {&s->key, &s->rank, &s->order};
+    for (auto p : ia) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
     double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.cof, &s->P.coef};
     for (auto p : a) {
         if (*p) (void)hipFree(*p);
@@ -884,16 +1048,16 @@ int alloc_particles(mpm_sim* s, long cap)
     s->P.cap = cap;
     if (dalloc(&s->P.pos, 3 * cap) || dalloc(&s->P.vel, 3 * cap) || dalloc(&s->P.FE, 9 * cap) || dalloc(&s->P.FP, 9 * cap) ||
         dalloc(&s->P.gradV, 9 * cap) || dalloc(&s->P.volume, cap) || dalloc(&s->P.R, 9 * cap) || dalloc(&s->P.Minv, 9 * cap) ||
-        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap))
+        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap) || dalloc(&s->key, cap) || dalloc(&s->rank, cap) || dalloc(&s->order, cap))
         return FLUID_ERR_HIP;
     return 0;
 }
 
 // y = A v on the device (v in s->p, result in s->q)
-int apply_operator(mpm_sim* s)
+int apply_operator(mpm_sim* s, int in_solve)
 {
     // q holds p already (the identity part)
-    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, s->indices, s->container, s->state, s->prm.beta, s->prm.transpose_system, s->p, s->q);
+    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, s->order, s->indices, s->container, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p, s->q);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -942,7 +1106,7 @@ int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
     if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) rc = FLUID_ERR_HIP;
     rc = rc || dalloc(&s->solid, C) || dalloc(&s->container, C) || dalloc(&s->output, C) || dalloc(&s->massd, C) || dalloc(&s->vel, 3 * C) ||
          dalloc(&s->velb, 3 * C) || dalloc(&s->forces, 3 * C) || dalloc(&s->flag, C) || dalloc(&s->indices, C) || dalloc(&s->active_cell, C) ||
-         dalloc(&s->sums, nb) || dalloc(&s->part, 2 * RED_BLOCKS) || dalloc(&s->state, 1);
+         dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C) || dalloc(&s->part, 2 * RED_BLOCKS) || dalloc(&s->state, 1);
     // unknowns live inside the walls only: (2W+1)^3 at most
     const long maxu = (long)(2 * prm->W + 1) * (2 * prm->W + 1) * (2 * prm->W + 1);
     rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu);
@@ -969,7 +1133,7 @@ int mpm_destroy(mpm_sim_t* s)
     if (!s) return 0;
     free_particles(s);
     void* a[] = {s->solid, s->container, s->output, s->massd, s->vel, s->velb, s->forces, s->flag, s->indices, s->active_cell, s->sums,
-                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage};
+                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage, s->cell_count, s->cell_start};
     for (void* p : a)
         if (p) (void)hipFree(p);
     if (s->h_state) (void)hipHostFree(s->h_state);
@@ -1069,17 +1233,25 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     HIPCHK(hipMemsetAsync(s->massd, 0, sizeof(double) * C, st));
     HIPCHK(hipMemsetAsync(s->vel, 0, sizeof(double) * 3 * C, st));
     HIPCHK(hipMemsetAsync(s->forces, 0, sizeof(double) * 3 * C, st));
-    if (n) k_mpm_p2g<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, s->massd, s->vel);
+    if (n) {
+        HIPCHK(hipMemsetAsync(s->cell_count, 0, sizeof(int) * C, st));
+        k_mpm_sort_count<<<blocks_for(n, 256), 256, 0, st>>>(G, n, s->P, s->cell_count, s->key, s->rank);
+        k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->cell_count, s->sums);
+        k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, nullptr);
+        k_mpm_scan_excl<<<nb, SCAN_T, 0, st>>>(C, s->cell_count, s->sums, s->cell_start);
+        k_mpm_sort_place<<<blocks_for(n, 256), 256, 0, st>>>(n, s->key, s->rank, s->cell_start, s->order);
+    }
+    if (n) k_mpm_p2g<<<pb, 128, 0, st>>>(G, n, s->P, s->order, s->solid, s->massd, s->vel);
     k_mpm_cells<<<cb, 256, 0, st>>>(G, s->solid, s->massd, s->container, s->output, s->vel, s->velb, s->flag);
     k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->flag, s->sums);
-    k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, s->state);
+    k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, &s->state->num_active);
     k_mpm_scan_final<<<nb, SCAN_T, 0, st>>>(C, s->flag, s->sums, s->indices, s->active_cell);
     if (s->step_no == 0 && n) k_mpm_volume<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, s->container);   // mpm.cc:1343-1346
     HIPCHK(hipEventRecord(s->ev[1], st));
     // populateGridForces (mpm.cc:1395): mu = E / (2 (1 + nu)), lambda = E nu / ((1 + nu) (1 - 2 nu))
     const double mu0 = pr.youngs_modulus / (2 * (1 + pr.poisson_ratio));
     const double lambda0 = pr.youngs_modulus * pr.poisson_ratio / ((1 + pr.poisson_ratio) * (1 - 2 * pr.poisson_ratio));
-    if (n) k_mpm_forces<<<pb, 128, 0, st>>>(G, n, s->P, s->solid, mu0, lambda0, pr.hardening, s->forces);
+    if (n) k_mpm_forces<<<pb, 128, 0, st>>>(G, n, s->P, s->order, s->solid, mu0, lambda0, pr.hardening, s->forces);
     HIPCHK(hipEventRecord(s->ev[2], st));
     // populateMatrices' right-hand side (mpm.cc:383-416) and cg.solve (mpm.cc:1401-1403)
     k_mpm_rhs<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->vel, s->forces, pr.gravity[0], pr.gravity[1], pr.gravity[2],
@@ -1091,28 +1263,31 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     HIPCHK(hipGetLastError());
     if (read_state(s)) return FLUID_ERR_HIP;
     s->num_active = s->h_state->num_active;
-    const long max_iters = pr.cg_max_iters > 0 ? pr.cg_max_iters : 2L * 3 * s->num_active;
-    int iters = 0;
+    const long max_iters = pr.cg_max_iters > 0 ? pr.cg_max_iters : (2L * 3 * s->num_active > 0 ? 2L * 3 * s->num_active : 1);
+    // Iterations are launched in batches without waiting for the convergence test: every kernel of an iteration returns
+    // at once when the device-side flag is set, and the host reads the 100-byte state once per batch.
     float ms_apply = 0;
     int n_apply = 0;
-    while (!s->h_state->cg_done && iters < max_iters) {
-        HIPCHK(hipEventRecord(s->ev[6], st));
-        if (apply_operator(s)) return FLUID_ERR_HIP;
-        HIPCHK(hipEventRecord(s->ev[7], st));
-        k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, s->part, s->part + RED_BLOCKS);
-        k_mpm_cg_scalars<<<1, 64, 0, st>>>(1, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
-        k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
-        k_mpm_cg_scalars<<<1, 64, 0, st>>>(2, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
-        k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, s->r, s->p, s->q);
-        k_mpm_cg_roll<<<1, 1, 0, st>>>(s->state);
+    const int batch = 4;
+    while (!s->h_state->cg_done) {
+        for (int it = 0; it < batch; ++it) {
+            const bool timed = it == 0;
+            if (timed) HIPCHK(hipEventRecord(s->ev[6], st));
+            if (apply_operator(s, 1)) return FLUID_ERR_HIP;
+            if (timed) HIPCHK(hipEventRecord(s->ev[7], st));
+            k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, s->part, s->part + RED_BLOCKS);
+            k_mpm_cg_scalars<<<1, 64, 0, st>>>(1, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
+            k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
+            k_mpm_cg_scalars<<<1, 64, 0, st>>>(2, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
+            k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, s->r, s->p, s->q);
+            k_mpm_cg_roll<<<1, 1, 0, st>>>(s->state, max_iters);
+        }
         HIPCHK(hipGetLastError());
         if (read_state(s)) return FLUID_ERR_HIP;
         float ms = 0;
         if (hipEventElapsedTime(&ms, s->ev[6], s->ev[7]) == hipSuccess) ms_apply += ms, ++n_apply;
-        if (!std::isfinite(s->h_state->pq) || s->h_state->pq == 0) break;
-        if (s->h_state->cg_done) break;   // Eigen leaves the loop before counting the iteration (ConjugateGradient.h:78-79)
-        ++iters;
     }
+    const int iters = s->h_state->cg_iters;
     const double cg_error = s->h_state->bb > 0 ? std::sqrt(s->h_state->rr / s->h_state->bb) : 0.0;
     HIPCHK(hipEventRecord(s->ev[3], st));
     k_mpm_update_velocity<<<cb, 256, 0, st>>>(G, s->solid, s->container, s->indices, s->x, s->vel);
@@ -1238,7 +1413,7 @@ int mpm_apply_matrix(mpm_sim_t* s, const double* v, double* y)
     if (!n3) return 0;
     HIPCHK(hipMemcpyAsync(s->p, v, sizeof(double) * n3, hipMemcpyHostToDevice, s->st));
     k_mpm_copy<<<blocks_for((long)n3, 256), 256, 0, s->st>>>((long)n3, s->p, s->q);
-    if (apply_operator(s)) return FLUID_ERR_HIP;
+    if (apply_operator(s, 0)) return FLUID_ERR_HIP;
     HIPCHK(hipMemcpyAsync(y, s->q, sizeof(double) * n3, hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
     return 0;

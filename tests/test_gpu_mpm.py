@@ -170,3 +170,42 @@ def test_larger_grid_and_restart(fs, mo):
     for what in (P.POS, P.VEL, P.FE, P.FP):
         assert rel_l2(sim2.particles(what), sim.particles(what)) < 1e-12
     sim.close(), sim2.close()
+
+
+def test_run_sh_mpm_driver(fs, tmp_path):
+    """`./run.sh mpm` (reference contract, run.sh:1-7): builds and runs the driver; the reference's stdout lines per step
+    (mpm.cc:1313,1394-1396,417,440-442,1405-1412,584,1418,1427) and its files: simulation/mygrids<i>.vdb with the step's
+    output grid, mygrids.vdb with every step's grid (mpm.cc:1383,1434-1437)."""
+    import os, subprocess
+    from conftest import ROOT
+    import vdb_reader
+    env = dict(os.environ, MPM_STEPS="3", MPM_OUT=str(tmp_path / "simulation"))
+    r = subprocess.run([os.path.join(ROOT, "run.sh"), "mpm"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    per_step = ["DT", "1", "GAH", "DAH", "2", "Max", "GARR", "after", "Error:", "5", "3", "MAX", "4", "DT", "Iteration:"]
+    assert len(lines) == 3 * len(per_step) + 1 and lines[-1].startswith("Time Taken")
+    for i in range(3):
+        blk = lines[len(per_step) * i: len(per_step) * (i + 1)]
+        for got, want in zip(blk, per_step):
+            assert got.split("\t")[0].split(" ")[0] == want, (i, got, want)
+        assert blk[-1] == f"Iteration:\t{i + 1}"
+        assert blk[5].startswith("Max Force [") and blk[5].endswith(" 1")
+        assert float(blk[8].split()[1]) < 2.3e-16
+    assert lines[0] == "DT 0.001"
+    # the same run through the binding: the files hold its output grid
+    sim = fs.MpmSim()
+    sim.upload_particles(fs.snow_cone())
+    outs = []
+    for i in range(3):
+        sim.step()
+        outs.append(sim.field(fs.MPM_F.OUTPUT))
+    allg = vdb_reader.read(tmp_path / "mygrids.vdb")[1]
+    assert len(allg) == 3 and all(g.compression == 3 for g in allg)
+    for i in range(3):
+        info, grids = vdb_reader.read(tmp_path / "simulation" / f"mygrids{i}.vdb")
+        assert len(grids) == 1 and grids[0].type == "Tree_float_5_4_3"
+        vals, act = grids[0].dense(-15, 15)
+        assert rel_l2(vals, outs[i]) < 3e-6 and outs[i].max() > 0.1
+        assert rel_l2(allg[i].dense(-15, 15)[0], outs[i]) < 3e-6
+    sim.close()
