@@ -209,3 +209,25 @@ def test_run_sh_mpm_driver(fs, tmp_path):
         assert rel_l2(vals, outs[i]) < 3e-6 and outs[i].max() > 0.1
         assert rel_l2(allg[i].dense(-15, 15)[0], outs[i]) < 3e-6
     sim.close()
+
+
+def test_long_run_through_the_impact(fs):
+    """400 steps of the reference's scene: the cone falls at 50 cells per time unit, hits the floor and is compacted.  Every
+    solve meets Eigen's stopping rule, the state stays finite and inside the walls, plastic flow shows in det FP."""
+    sim = fs.MpmSim()
+    sim.upload_particles(fs.snow_cone())
+    worst, iters = 0.0, []
+    for i in range(400):
+        st = sim.step()
+        assert st["num_active"] > 0 and np.isfinite(st["max_speed"])
+        worst = max(worst, st["cg_error"])
+        iters.append(st["cg_iters"])
+    assert worst < 2.3e-16 and max(iters) < 200
+    P = fs.MPM_P
+    pos, FE, FP = sim.particles(P.POS), sim.particles(P.FE), sim.particles(P.FP)
+    assert np.isfinite(pos).all() and np.isfinite(FE).all() and np.isfinite(FP).all()
+    assert np.abs(pos).max() < 14.0                          # the solid shell starts at |c| > 13
+    sv = np.linalg.svd(FE, compute_uv=False)
+    assert sv.min() >= 1 - 0.025 - 1e-9 and sv.max() <= 1 + 0.0075 + 1e-9    # the clamp of mpm.cc:548-553 held all along
+    assert np.abs(np.linalg.det(FP) - 1).max() > 1e-3       # plastic deformation happened
+    sim.close()
