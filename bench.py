@@ -401,6 +401,12 @@ def main():
                  "cg_iters_mean": float(np.mean([x["cg_iters"] for x in sts])), "cg_error_max": float(max(x["cg_error"] for x in sts)),
                  "phase_ms": {k[3:]: float(np.mean([x[k] for x in sts])) for k in ("ms_transfer", "ms_forces", "ms_solve", "ms_deform", "ms_advect")},
                  "apply_kernel_us": float(np.mean([x["ms_apply_avg"] for x in sts]) * 1e3)}
+            # dominant kernel k_mpm_apply (one matrix-free operator application): 348 B of particle state per particle
+            # (position, F, R, the 3x3 inverse, the cofactor matrix, coefficients, volume, order entry); node vectors stay in L2
+            ab = 348.0 * sim.num_particles
+            d["roofline"] = {"kernel": "k_mpm_apply", "bound": "hbm", "achieved": ab / (d["apply_kernel_us"] * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                             "frac": ab / (d["apply_kernel_us"] * 1e-6) / 8e12, "traffic": None,
+                             "note": "far from the HBM bound: the kernel is limited by dependent fp64 / shuffle chains (~3300 fp64 operations + 972 ds_bpermute per particle), DESIGN.md 9"}
             sim.close()
             return d, posm
         out["mpm"], posm = mpm_leg(15, 4, 400.0, 100, 5)

@@ -101,6 +101,9 @@ struct DistState {
     Box Rr{0, 0, 0, -1, -1, -1}, Sr{0, 0, 0, -1, -1, -1};   // owned parts, window coordinates
     // plans
     HaloPlan plan_flags, plan_f1, plan_gather;
+    HaloPlan plan_split;              // the first replicated multigrid level: every rank's owned coarse block to every other rank
+    bool split_exchange = false;      // ... used when all ranks are adjacent (dims <= 2 per axis); otherwise a SUM all-reduce
+    int split_exchange_force = -1;    // FLUID_DIST_GATHER=exchange|allreduce
     // solver
     int split = 1, split_force = 0;
     IBox dom0{};                      // global level-0 multigrid domain [A, B)
@@ -551,6 +554,14 @@ int dist_mg_setup(fluid_sim* s)
         make_plan(d, L.plan, [&](int r) { return own_l(l, r); }, HALO_W, L.dom.lo, (long)L.m.at(0, 0, 0), L.m.sx, L.m.sy);
     }
     s->mgl[0] = d->lv[0].m;
+    // The first replicated level is assembled from the blocks' owned coarse cells.  With at most two blocks per axis every
+    // rank is adjacent to every other: each sends its block straight to the 1..7 others (one grouped send/recv round, all
+    // xGMI links in parallel, 7/8 of the level per rank) instead of a ring all-reduce of the zero-padded level (twice the
+    // bytes, 2(n-1) steps).  More blocks per axis: all-reduce.
+    d->split_exchange = d->dims[0] <= 2 && d->dims[1] <= 2 && d->dims[2] <= 2;
+    if (d->split_exchange_force >= 0) d->split_exchange = d->split_exchange && d->split_exchange_force == 1;
+    if (d->split_exchange)
+        make_plan(d, d->plan_split, [&](int r) { return own_l(split, r); }, N, gd[split].lo, (long)s->mgl[split].at(0, 0, 0), s->mgl[split].sx, s->mgl[split].sy);
     // one slab, zeroed by one fill (mg_setup of the single-GPU path does the same)
     size_t total = 0;
     auto take = [&](size_t bytes) { const size_t o = total; total += (bytes + 255) / 256 * 256; return o; };
@@ -614,9 +625,14 @@ int dist_mg_setup(fluid_sim* s)
                 const int off[3] = {(F.dom.lo[0] >> 1) - G.lo[0], (F.dom.lo[1] >> 1) - G.lo[1], (F.dom.lo[2] >> 1) - G.lo[2]};
                 launch_mg_coarsen_types(s->st, F.m, F.typ, coarse_view(s->mgl[l], off), s->mg_typ[l]);
             }
-            launch_mask_outside<uint8_t>(s->st, s->mgl[l], to_box(own_l(l, me), G.lo), s->mg_typ[l]);
             HIPCHK(hipGetLastError());
-            if ((rc = comm_allreduce(s, s->mg_typ[l], (long)s->mgl[l].cells, FLUID_DT_U8, FLUID_OP_SUM))) return rc;
+            if (d->split_exchange) {
+                if ((rc = halo_exchange1(s, d->plan_split, 1, s->mg_typ[l]))) return rc;
+            } else {
+                launch_mask_outside<uint8_t>(s->st, s->mgl[l], to_box(own_l(l, me), G.lo), s->mg_typ[l]);
+                HIPCHK(hipGetLastError());
+                if ((rc = comm_allreduce(s, s->mg_typ[l], (long)s->mgl[l].cells, FLUID_DT_U8, FLUID_OP_SUM))) return rc;
+            }
             launch_mg_counts(s->st, s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
         } else {
             launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
@@ -674,15 +690,20 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
         if (l + 1 < split) {
             if ((rc = halo_exchange1(s, d->lv[l + 1].plan, sizeof(V), F(l + 1)))) return rc;
         } else {
-            // gather of the first replicated level: my coarse cells, zeros elsewhere, one SUM all-reduce
-            int lo[3];
-            for (int a = 0; a < 3; ++a) lo[a] = d->dom0.lo[a] >> (l + 1);
-            IBox gb;
-            for (int a = 0; a < 3; ++a) { gb.lo[a] = lo[a]; gb.hi[a] = lo[a] + (a == 0 ? s->mgl[l + 1].dx : (a == 1 ? s->mgl[l + 1].dy : s->mgl[l + 1].dz)); }
-            const IBox o = ib_isect(block_level(d, d->comm.rank, l + 1, s->g.N), gb);
-            launch_mask_outside<V>(s->st, s->mgl[l + 1], to_box(o, lo), F(l + 1));
-            HIPCHK(hipGetLastError());
-            if ((rc = comm_allreduce(s, F(l + 1), (long)s->mgl[l + 1].cells, sizeof(V) == 4 ? FLUID_DT_F32 : FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            // gather of the first replicated level: the owners' coarse cells to everyone (block exchange), or my coarse
+            // cells, zeros elsewhere, and one SUM all-reduce
+            if (d->split_exchange) {
+                if ((rc = halo_exchange1(s, d->plan_split, sizeof(V), F(l + 1)))) return rc;
+            } else {
+                int lo[3];
+                for (int a = 0; a < 3; ++a) lo[a] = d->dom0.lo[a] >> (l + 1);
+                IBox gb;
+                for (int a = 0; a < 3; ++a) { gb.lo[a] = lo[a]; gb.hi[a] = lo[a] + (a == 0 ? s->mgl[l + 1].dx : (a == 1 ? s->mgl[l + 1].dy : s->mgl[l + 1].dz)); }
+                const IBox o = ib_isect(block_level(d, d->comm.rank, l + 1, s->g.N), gb);
+                launch_mask_outside<V>(s->st, s->mgl[l + 1], to_box(o, lo), F(l + 1));
+                HIPCHK(hipGetLastError());
+                if ((rc = comm_allreduce(s, F(l + 1), (long)s->mgl[l + 1].cells, sizeof(V) == 4 ? FLUID_DT_F32 : FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            }
         }
     }
     // ---- replicated levels: down, tail, up (identical on every rank) ----
@@ -978,6 +999,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
     if (const char* e = getenv("FLUID_DIST_SOLVE")) d->repl = atoi(e) == 0;   // developer knob, overrides the param
     if (const char* e = getenv("FLUID_DIST_SPLIT")) d->split_force = atoi(e);
     if (d->split_force < 0 || d->split_force > 2) d->split_force = 0;
+    if (const char* e = getenv("FLUID_DIST_GATHER")) d->split_exchange_force = !strcmp(e, "exchange") ? 1 : (!strcmp(e, "allreduce") ? 0 : -1);
     Grid g;
     g.N = p->n;
     g.lo = -(p->n / 2);

@@ -49,7 +49,8 @@ struct MpmState {
     int pad_;
     unsigned long long max_speed_bits, max_grad_bits, max_fp_bits, max_fe_bits, max_coeff_bits;
     double dt;
-    double bb, rho, rho_new, pq, rr; // |b|^2, <r,r>_D, <p,Ap>_D, |r|^2
+    double bb, pq, rr;               // |b|^2, <p,Ap>_w, |r|^2
+    double rho2[2];                  // <r,r>_w of the current / next iteration (slot = iteration parity)
     double max_force[3], max_mi;
 };
 
@@ -710,28 +711,29 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* pa, doubl
         pa[blockIdx.x] = ta, pb[blockIdx.x] = tb;
     }
 }
-// sums the partials of the previous kernel; `what`: 0 |b|^2 -> bb (+ rho = <b,b>_D passed in part2), 1 <p,Ap>_D -> pq,
-// 2 after the update: |r|^2 -> rr, <r,r>_D -> rho_new
-__global__ void k_mpm_cg_scalars(int what, int nparts, const double* __restrict__ part1, const double* __restrict__ part2, MpmState* st, double tol)
+// every thread of the block gets the sum of n partials, added in the same order in every block
+__device__ __forceinline__ double block_total(const double* __restrict__ part, int n)
 {
-    double a = 0, b = 0;
-    for (int k = threadIdx.x; k < nparts; k += 64) a += part1[k], b += part2 ? part2[k] : 0.0;
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o), b += __shfl_down(b, o);
-    if (threadIdx.x) return;
-    if (what == 0) {
-        st->bb = a, st->rho = b, st->rr = a;
-        st->cg_done = (a == 0) ? 1 : 0;   // b = 0 => x = 0 (IterativeSolverBase / ConjugateGradient.h:44-50)
-    } else if (what == 1) {
-        if (st->cg_done) return;
-        st->pq = b;
-        if (!(b > 0) || !isfinite(b)) st->cg_done = 2;   // breakdown: leave x as it is
-    } else {
-        if (st->cg_done) return;
-        st->rr = a, st->rho_new = b;
-        if (a < tol * tol * st->bb) st->cg_done = 1;
-    }
+    __shared__ double sh[4];
+    double a = 0;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) a += part[k];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    __syncthreads();   // sh may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double t = 0;
+    for (int k = 0; k < (int)blockDim.x / 64; ++k) t += sh[k];
+    return t;
 }
-// r = p = b, x = 0, y(=Ap) = p; partials of |b|^2 and <b,b>_D
+// start of a solve: |b|^2 and <b,b>_w from the partials of k_mpm_cg_init
+__global__ void k_mpm_cg_start(int nparts, const double* __restrict__ part1, const double* __restrict__ part2, MpmState* st)
+{
+    const double a = block_total(part1, nparts), b = block_total(part2, nparts);
+    if (threadIdx.x) return;
+    st->bb = a, st->rho2[0] = b, st->rr = a;
+    st->cg_done = (a == 0) ? 1 : 0;   // b = 0 => x = 0 (IterativeSolverBase / ConjugateGradient.h:44-50)
+}
+// r = p = b, x = 0, y(=Ap) = p; partials of |b|^2 and <b,b>_w
 __global__ void k_mpm_cg_init(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
                               const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
                               double* __restrict__ q, double* pa, double* pb)
@@ -745,6 +747,10 @@ __global__ void k_mpm_cg_init(const int* __restrict__ active_cell, const MpmStat
     }
     block_sum2(a, d, pa, pb);
 }
+// One CG iteration = k_mpm_apply + the three kernels below.  Scalars are not folded by 1-thread kernels in between: every block
+// of the consumer re-sums the producer's 256 partials from L2 (same order everywhere, so every block takes the same
+// decisions), block 0 records them in the state.  `par` = iteration parity: <r,r>_w lives in two slots so that the kernel that
+// writes the next one never races with readers of the current one.
 __global__ void k_mpm_cg_pq(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
                             const double* __restrict__ p, const double* __restrict__ q, double* pa, double* pb)
 {
@@ -754,13 +760,23 @@ __global__ void k_mpm_cg_pq(const int* __restrict__ active_cell, const MpmState*
         d += dot_weight(container[active_cell[k / 3]], transposed) * p[k] * q[k];
     block_sum2(0.0, d, pa, pb);
 }
-// x += alpha p; r -= alpha q; partials |r|^2, <r,r>_D
-__global__ void k_mpm_cg_xr(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
-                            double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p, const double* __restrict__ q,
-                            double* pa, double* pb)
+// alpha = <r,r>_w / <p,Ap>_w; x += alpha p; r -= alpha q; partials |r|^2, <r,r>_w
+__global__ void k_mpm_cg_xr(const int* __restrict__ active_cell, MpmState* st, const float* __restrict__ container, int transposed, int par,
+                            const double* __restrict__ part_pq, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                            const double* __restrict__ q, double* pa, double* pb)
 {
-    const long n3 = st->cg_done ? 0 : 3L * st->num_active;
-    const double alpha = st->rho / st->pq;
+    __shared__ int s_done;   // one read per block: block 0 of this very launch may set the flag while other blocks start
+    if (threadIdx.x == 0) s_done = st->cg_done;
+    __syncthreads();
+    if (s_done) return;
+    const double pq = block_total(part_pq, RED_BLOCKS);
+    if (!(pq > 0) || !isfinite(pq)) {   // breakdown: leave x as it is (every block sees the same value)
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->pq = pq, st->cg_done = 2;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->pq = pq;
+    const long n3 = 3L * st->num_active;
+    const double alpha = st->rho2[par] / pq;
     double a = 0, d = 0;
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
         x[k] += alpha * p[k];
@@ -770,22 +786,28 @@ __global__ void k_mpm_cg_xr(const int* __restrict__ active_cell, const MpmState*
     }
     block_sum2(a, d, pa, pb);
 }
-// p = r + beta p; q = p (the identity part of the next product); rho = rho_new (by thread 0 of block 0 AFTER everyone read it:
-// done in a separate tiny kernel to stay race-free)
-__global__ void k_mpm_cg_p(const MpmState* st, const double* __restrict__ r, double* __restrict__ p, double* __restrict__ q)
+// convergence test (ConjugateGradient.h:76-79), then p = r + beta p and q = p (the identity part of the next product)
+__global__ void k_mpm_cg_p(MpmState* st, int par, double tol, long max_iters, const double* __restrict__ part_rr, const double* __restrict__ part_rho,
+                           const double* __restrict__ r, double* __restrict__ p, double* __restrict__ q)
 {
-    const long n3 = st->cg_done ? 0 : 3L * st->num_active;
-    const double beta = st->rho_new / st->rho;
+    __shared__ int s_done;
+    if (threadIdx.x == 0) s_done = st->cg_done;
+    __syncthreads();
+    if (s_done) return;
+    const double rr = block_total(part_rr, RED_BLOCKS), rho_new = block_total(part_rho, RED_BLOCKS);
+    const bool conv = rr < tol * tol * st->bb;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rr = rr, st->rho2[par ^ 1] = rho_new;
+        if (conv) st->cg_done = 1;                       // Eigen leaves the loop before counting the iteration
+        else if (++st->cg_iters >= max_iters) st->cg_done = 3;
+    }
+    if (conv) return;
+    const long n3 = 3L * st->num_active;
+    const double beta = rho_new / st->rho2[par];
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
         const double v = r[k] + beta * p[k];
         p[k] = v, q[k] = v;
     }
-}
-__global__ void k_mpm_cg_roll(MpmState* st, long max_iters)
-{
-    if (st->cg_done) return;   // Eigen leaves the loop before counting the iteration (ConjugateGradient.h:78-79)
-    st->rho = st->rho_new;
-    if (++st->cg_iters >= max_iters) st->cg_done = 3;
 }
 __global__ void k_mpm_copy(long n, const double* __restrict__ a, double* __restrict__ b)
 {
@@ -1106,7 +1128,7 @@ int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
     if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) rc = FLUID_ERR_HIP;
     rc = rc || dalloc(&s->solid, C) || dalloc(&s->container, C) || dalloc(&s->output, C) || dalloc(&s->massd, C) || dalloc(&s->vel, 3 * C) ||
          dalloc(&s->velb, 3 * C) || dalloc(&s->forces, 3 * C) || dalloc(&s->flag, C) || dalloc(&s->indices, C) || dalloc(&s->active_cell, C) ||
-         dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C) || dalloc(&s->part, 2 * RED_BLOCKS) || dalloc(&s->state, 1);
+         dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C) || dalloc(&s->part, 4 * RED_BLOCKS) || dalloc(&s->state, 1);
     // unknowns live inside the walls only: (2W+1)^3 at most
     const long maxu = (long)(2 * prm->W + 1) * (2 * prm->W + 1) * (2 * prm->W + 1);
     rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu);
@@ -1259,7 +1281,7 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     k_mpm_maxforce_cell<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->forces);
     k_mpm_maxforce_final<<<1, 1, 0, st>>>(G, s->state, s->container, s->forces);
     k_mpm_cg_init<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->b, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
-    k_mpm_cg_scalars<<<1, 64, 0, st>>>(0, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
+    k_mpm_cg_start<<<1, 256, 0, st>>>(RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state);
     HIPCHK(hipGetLastError());
     if (read_state(s)) return FLUID_ERR_HIP;
     s->num_active = s->h_state->num_active;
@@ -1269,18 +1291,19 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     float ms_apply = 0;
     int n_apply = 0;
     const int batch = 4;
+    long launched = 0;
     while (!s->h_state->cg_done) {
         for (int it = 0; it < batch; ++it) {
             const bool timed = it == 0;
             if (timed) HIPCHK(hipEventRecord(s->ev[6], st));
             if (apply_operator(s, 1)) return FLUID_ERR_HIP;
             if (timed) HIPCHK(hipEventRecord(s->ev[7], st));
-            k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, s->part, s->part + RED_BLOCKS);
-            k_mpm_cg_scalars<<<1, 64, 0, st>>>(1, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
-            k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
-            k_mpm_cg_scalars<<<1, 64, 0, st>>>(2, RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state, pr.cg_tol);
-            k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, s->r, s->p, s->q);
-            k_mpm_cg_roll<<<1, 1, 0, st>>>(s->state, max_iters);
+            double *pa = s->part, *pb = s->part + RED_BLOCKS, *pc = s->part + 2 * RED_BLOCKS, *pd = s->part + 3 * RED_BLOCKS;
+            k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, pa, pb);
+            k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, (int)(launched & 1), pb, s->x, s->r, s->p,
+                                                    s->q, pc, pd);
+            k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, (int)(launched & 1), pr.cg_tol, max_iters, pc, pd, s->r, s->p, s->q);
+            ++launched;
         }
         HIPCHK(hipGetLastError());
         if (read_state(s)) return FLUID_ERR_HIP;

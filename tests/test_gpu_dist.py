@@ -131,15 +131,18 @@ def test_blocks_match_single(fs, mode, dims, n, ppc, steps, skw, kw):
         assert a <= 1.2 * b + 2 * sum(s["outer_passes"] for s in rs), (a, b)
 
 
-@pytest.mark.parametrize("split", [1, 2])
-def test_decomposed_levels_on_blocks(fs, split, monkeypatch):
-    """Both forms of the coupled V-cycle: level 1 gathered (split 1) and level 1 on the blocks with halo exchanges (split 2)."""
+@pytest.mark.parametrize("split,gather", [(1, "exchange"), (2, "exchange"), (1, "allreduce"), (2, "allreduce")])
+def test_decomposed_levels_on_blocks(fs, split, gather, monkeypatch):
+    """Both forms of the coupled V-cycle: level 1 gathered (split 1) and level 1 on the blocks with halo exchanges (split 2);
+    the gathered level assembled by the blocks sending their coarse cells to each other (default up to 2 x 2 x 2) or by a SUM
+    all-reduce of the zero-padded level."""
     monkeypatch.setenv("FLUID_DIST_SPLIT", str(split))
+    monkeypatch.setenv("FLUID_DIST_GATHER", gather)
     n, ppc, steps = 64, 4, 3
     pos, vel = scene(fs, n, ppc, vel=1.0)
     ref = single(fs, n, pos, vel, steps)
     d = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed")
-    st, rs = compare(d, ref, len(pos), f"split {split}")
+    st, rs = compare(d, ref, len(pos), f"split {split} {gather}")
     a, b = sum(s["cg_iters"] for s in st), sum(s["cg_iters"] for s in rs)
     assert a <= 1.2 * b + 2 * sum(s["outer_passes"] for s in rs), (a, b)
 
