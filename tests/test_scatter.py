@@ -25,7 +25,7 @@ def _raw_stream(seed, n):
     return rs.randint(0, 2 ** 32, size=n, dtype=np.uint64)
 
 
-def _values_in_order(lo, hi):
+def _values_in_order(lo, hi, tiles=True):
     """Active values of fill(CoordBBox(lo, hi)) in ValueOn order, for boxes that stay inside the 128^3 blocks next to the
     origin: (x, y, z, dim) with dim 8 for a fully covered leaf (tile) and 1 for a voxel of a partly covered one."""
     assert -128 <= lo and hi <= 127
@@ -39,7 +39,7 @@ def _values_in_order(lo, hi):
                 for bx in [b for b in starts if mine(b, rx)]:
                     for by in [b for b in starts if mine(b, ry)]:
                         for bz in [b for b in starts if mine(b, rz)]:
-                            if lo <= bx and bx + 7 <= hi and lo <= by and by + 7 <= hi and lo <= bz and bz + 7 <= hi:
+                            if tiles and lo <= bx and bx + 7 <= hi and lo <= by and by + 7 <= hi and lo <= bz and bz + 7 <= hi:
                                 out.append((bx, by, bz, 8))
                                 continue
                             for x in range(max(bx, lo), min(bx + 7, hi) + 1):
@@ -49,8 +49,8 @@ def _values_in_order(lo, hi):
     return out
 
 
-def _restated_scatter(lo, hi, ppv, seed, boundary):
-    vals = _values_in_order(lo, hi)
+def _restated_scatter(lo, hi, ppv, seed, boundary, vals=None):
+    vals = _values_in_order(lo, hi) if vals is None else vals
     counts = np.array([v[3] ** 3 for v in vals], dtype=np.int64)
     voxels = int(counts.sum())
     target = int(ppv) * voxels
@@ -137,6 +137,21 @@ def test_box_with_a_whole_128_tile():
     assert pos.min() >= -130.5 and pos.max() < 5.5
     inside = ((pos >= -128.5) & (pos < -0.5)).all(axis=1).mean()
     assert abs(inside - (128 / n) ** 3) < 2e-3       # uniform over the box: the tile gets its share
+
+
+def test_snow_cone_of_the_mpm_program():
+    """mpm_scene_cone (mpm.cc:1037-1052,1274-1278): 16 single voxels set one by one (no tiles), walked in
+    ValueOn order — here taken from the flat leaf-by-leaf enumeration of every voxel of [-16, 15]^3, filtered to the cone."""
+    B, W = 15, 13
+    cone = [(x, y, z, 1) for (x, y, z, d) in _values_in_order(-16, 15, tiles=False)
+            if -W <= y <= -W + 3 and abs(x) <= W and abs(z) <= W and x * x + z * z <= ((y + W) / 2) ** 2]
+    assert len(cone) == 16
+    for ppv, seed in ((400.0, 0), (7.0, 5)):
+        pos = fs.snow_cone(B=B, W=W, layers=4, points_per_voxel=ppv, seed=seed)
+        ref = _restated_scatter(0, 0, ppv, seed, B, vals=cone)
+        assert pos.shape == ref.shape and np.array_equal(pos, ref)
+    assert len(fs.snow_cone()) == 6205
+    assert fs.lib.mpm_scene_cone(15, 13, 0, 400.0, 0, None) < 0 and fs.lib.mpm_scene_cone(2, 1, 1, 400.0, 0, None) < 0
 
 
 def test_bad_arguments():
