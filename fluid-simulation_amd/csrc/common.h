@@ -315,8 +315,8 @@ template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure, double* keep = nullptr,
                            const PcgState* ps = nullptr);
 template <typename T>
-void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, T* x, T* r, Coef<T> cf,
-                           double* part_bb, double* part_rr0, PcgState* ps);
+void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, const double* guess2, double ca,
+                           double cb, T* x, T* r, Coef<T> cf, double* part_bb, double* part_rr0, PcgState* ps);
 
 // multigrid preconditioner (kernels_mg.hip)
 MLevel mg_level0(const LBox& L);

@@ -170,7 +170,7 @@ int fluid_destroy(fluid_sim_t* s)
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
-                    s->dcz, s->pressure, s->p_guess, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
+                    s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
                     s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -238,7 +238,11 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     A(dalloc(&s->ub, n)); A(dalloc(&s->vb, n)); A(dalloc(&s->wb, n));
     A(dalloc(&s->dcx, n)); A(dalloc(&s->dcy, n)); A(dalloc(&s->dcz, n));
     A(dalloc(&s->pressure, n));
-    if (s->warm) { A(dalloc(&s->p_guess, n)); if (hipMemset(s->p_guess, 0, n * sizeof(double)) != hipSuccess) return bail(FLUID_ERR_HIP); }
+    if (s->warm) {
+        A(dalloc(&s->p_guess, n)); A(dalloc(&s->p_guess2, n));
+        if (hipMemset(s->p_guess, 0, n * sizeof(double)) != hipSuccess || hipMemset(s->p_guess2, 0, n * sizeof(double)) != hipSuccess) return bail(FLUID_ERR_HIP);
+        if (const char* e = getenv("FLUID_EXTRAPOLATE")) s->extrapolate = atoi(e) != 0;
+    }
     A(dalloc(&s->indices, n));
     A(dalloc(&s->scan_sums, (n + 2) / 2048 + 16));
     A(dalloc(&s->ipart, (size_t)1024 * 8));
@@ -529,6 +533,7 @@ static int phase_p2g(fluid_sim* s)
         s->dirty = s->Sb;
     }
     s->have_p2g = true;
+    s->step_counter++;
     s->have_flags = false;
     return FLUID_OK;
 }
@@ -726,7 +731,10 @@ static int solve_mg(fluid_sim* s)
     // form of the same loop: r0 = b - A x0, same threshold tol^2 |b|^2).  The converged p does not depend on the start
     // beyond the tolerance; a settled pool needs far fewer iterations.  r0.r0 partials travel in part_rz[1] (unused by body 0).
     const bool guess = s->warm && s->have_guess;
-    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, s->p_guess, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
+    const double *g1, *g2;
+    double gca, gcb;
+    s->start_guess(g1, g2, gca, gcb);
+    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, g1, g2, gca, gcb, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
     else launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rr, s->ps);  // (its Jacobi r.z partials are unused)
     long it = 0;
     // Batching of the convergence poll.  Iteration counts barely change from one solve to the next (Eigen's count i means
@@ -781,7 +789,9 @@ static int solve_mg(fluid_sim* s)
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
     if (!s->h_ps->done) iters = (int)max_it;
-    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, s->warm ? s->p_guess : nullptr, s->ps);
+    // the new solution goes into the buffer of the older guess, which then becomes the latest
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, s->warm ? s->p_guess2 : nullptr, s->ps);
+    if (s->warm) s->rotate_guess();
     s->have_guess = s->warm;
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);

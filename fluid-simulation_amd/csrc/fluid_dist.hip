@@ -457,6 +457,7 @@ int dist_step_replicated(fluid_sim* s, fluid_step_stats_t* stats)
         }
     }
     s->have_p2g = true;
+    s->step_counter++;
     s->have_flags = false;
     if ((rc = phase_flags(s))) return rc;           // whole grid on every rank: global numbering
     double error = NAN;
@@ -765,7 +766,10 @@ int dist_solve(fluid_sim* s)
     // start: x0 = 0, or (multigrid path, like the one-GPU solve) the previous pressure — every rank's owned values, its ring from
     // the owners (the pressure halo exchange carries the guess too), so that r0 = b - A x0 is the same vector on both sides of a cut
     const bool guess = mg && s->warm && s->have_guess;
-    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, s->p_guess, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
+    const double *g1, *g2;
+    double gca, gcb;
+    s->start_guess(g1, g2, gca, gcb);
+    if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, g1, g2, gca, gcb, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
     else launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
     long it = 0;
     long batch = s->mg_last_iters > 5 ? s->mg_last_iters : 8;   // identical on every rank
@@ -807,7 +811,8 @@ int dist_solve(fluid_sim* s)
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
     if (!s->h_ps->done) iters = (int)max_it;
-    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, mg && s->warm ? s->p_guess : nullptr, s->ps);
+    launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, mg && s->warm ? s->p_guess2 : nullptr, s->ps);
+    if (mg && s->warm) s->rotate_guess();   // (the pressure halo exchange that follows carries the new p_guess)
     s->have_guess = mg && s->warm;
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
@@ -829,6 +834,7 @@ int dist_step_decomposed(fluid_sim* s, fluid_step_stats_t* stats)
     if ((rc = dist_particles(s))) return rc;           // fluid.cc:1378-1413, first half: who holds what
     if ((rc = clear_dirty(s))) return rc;
     stats_begin(s);
+    s->step_counter++;
     const int org[3] = {g.ox, g.oy, g.oz};
     const bool any = !ib_empty(d->Rg);
     if (any) s->dirty = s->Sb;

@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256) void k_pcg_init_l(Grid g, LBox L, const uint8_
 // A neighbour contributes only if it is an unknown NOW (its count byte), whatever the guess field holds there.
 template <typename T>
 __global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const uint8_t* __restrict__ cnt, const float* __restrict__ b,
-                                                          const double* __restrict__ guess, T* __restrict__ x, T* __restrict__ r, Coef<T> cf,
+                                                          const double* __restrict__ guess, const double* __restrict__ guess2, double ca, double cb,
+                                                          T* __restrict__ x, T* __restrict__ r, Coef<T> cf,
                                                           double* __restrict__ part_bb, double* __restrict__ part_rr0, PcgState* ps)
 {
+    // x0 = ca * guess (+ cb * guess2 when given: the extrapolation over the last two passes of the step's do..while)
     __shared__ double red[4];
     __shared__ T sdiag[8], sinv[8];
     load_coef(sdiag, sinv, cf);
@@ -149,10 +151,11 @@ __global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const 
             const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
             const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;
             const T bv = (T)b[gc];
-            xv = (T)guess[gc];
-            const T nb = (cnt[t - sx] ? (T)guess[gc - gx] : (T)0) + (cnt[t + sx] ? (T)guess[gc + gx] : (T)0) +
-                         (cnt[t - sy] ? (T)guess[gc - gy] : (T)0) + (cnt[t + sy] ? (T)guess[gc + gy] : (T)0) +
-                         (cnt[t - 1] ? (T)guess[gc - 1] : (T)0) + (cnt[t + 1] ? (T)guess[gc + 1] : (T)0);
+            auto G = [&](size_t q) { return guess2 ? (T)(ca * guess[q] + cb * guess2[q]) : (T)guess[q]; };
+            xv = G(gc);
+            const T nb = (cnt[t - sx] ? G(gc - gx) : (T)0) + (cnt[t + sx] ? G(gc + gx) : (T)0) +
+                         (cnt[t - sy] ? G(gc - gy) : (T)0) + (cnt[t + sy] ? G(gc + gy) : (T)0) +
+                         (cnt[t - 1] ? G(gc - 1) : (T)0) + (cnt[t + 1] ? G(gc + 1) : (T)0);
             rv = bv - (sdiag[c] * xv + cf.off * nb);
             abb += (double)bv * (double)bv;
             arr += (double)rv * (double)rv;
@@ -583,10 +586,11 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
     hipLaunchKernelGGL((k_pcg_init_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, x, r, cf, part_bb, part_rz0, ps);
 }
 template <typename T>
-void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, T* x, T* r, Coef<T> cf,
-                           double* part_bb, double* part_rr0, PcgState* ps)
+void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const float* b, const double* guess, const double* guess2, double ca,
+                           double cb, T* x, T* r, Coef<T> cf, double* part_bb, double* part_rr0, PcgState* ps)
 {
-    hipLaunchKernelGGL((k_pcg_init_guess_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, guess, x, r, cf, part_bb, part_rr0, ps);
+    hipLaunchKernelGGL((k_pcg_init_guess_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, g, L, cnt, b, guess, guess2, ca, cb, x, r, cf, part_bb,
+                       part_rr0, ps);
 }
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
@@ -1067,7 +1071,7 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*, double*, const PcgState*);      \
-    template void launch_pcg_init_guess<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, const double*, T*, T*, Coef<T>,      \
+    template void launch_pcg_init_guess<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, const double*, const double*, double, double, T*, T*, Coef<T>, \
                                            double*, double*, PcgState*);                                                               \
     template void launch_pcg_sq_dist<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
                                         const double*, double*, PcgState*, int, double, int);                                            \

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 int fluid_fail(int code, const std::string& msg);   // sets fluid_last_error() of the calling thread, returns code
@@ -39,6 +40,31 @@ struct fluid_sim {
     double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
     double* p_guess = nullptr;    // last solved pressure, never cleared: the multigrid PCG starts from it (FLUID_WARM_START=0: from 0 like the reference)
     bool warm = true, have_guess = false;
+    // Passes of one step's do..while solve the SAME matrix for right-hand sides b_{k+1} = (1 - f) b_k + c (f = update_frac: the partial
+    // velocity update takes f of the pressure gradient out of the divergence, c = what gravity puts back, the same in every pass), so
+    // p_{k+1} = p_k + (1 - f)(p_k - p_{k-1}) up to the float32 rounding of b: from the third pass on the solve starts from that.
+    double* p_guess2 = nullptr;   // the solution before p_guess
+    long guess_step = -1, guess2_step = -1;   // step counter and pass index at which each was stored
+    int guess_pass = -1, guess2_pass = -1;
+    long step_counter = 0;
+    bool extrapolate = true;      // FLUID_EXTRAPOLATE=0 switches it off
+    // the start of this solve: guess arrays and coefficients (g2 == nullptr: plain warm start); called by both solve paths
+    void start_guess(const double*& g1, const double*& g2, double& ca, double& cb) const
+    {
+        g1 = p_guess, g2 = nullptr, ca = 1.0, cb = 0.0;
+        const int k = stats.outer_passes;   // passes completed in this step = index of this one
+        if (extrapolate && p_guess2 && k >= 2 && guess_step == step_counter && guess2_step == step_counter && guess_pass == k - 1 && guess2_pass == k - 2) {
+            const double f = 1.0 - prm.update_frac;
+            g2 = p_guess2, ca = 1.0 + f, cb = -f;
+        }
+    }
+    // after store_pressure wrote the new solution into p_guess2's buffer: it becomes the latest
+    void rotate_guess()
+    {
+        std::swap(p_guess, p_guess2);
+        guess2_step = guess_step, guess2_pass = guess_pass;
+        guess_step = step_counter, guess_pass = stats.outer_passes;
+    }
     int *indices = nullptr, *scan_sums = nullptr, *ipart = nullptr;
     // pcg
     void *R = nullptr, *S[2] = {nullptr, nullptr}, *Q = nullptr, *X = nullptr, *Zmg = nullptr;

@@ -62,7 +62,9 @@ typedef struct fluid_sim fluid_sim_t;
 
 /* start of every pressure solve (fluid_params.solve_start) */
 #define FLUID_START_WARM 0        /* x0 = the previous solve's pressure (Eigen's solveWithGuess form of the same loop;
-                                     the converged p is the same within cg_tol, cg_iters is NOT the reference's count) */
+                                     the converged p is the same within cg_tol, cg_iters is NOT the reference's count);
+                                     from the third pass of a step's do..while on: x0 = p_k + (1 - update_frac)(p_k - p_{k-1}),
+                                     exact up to the float32 rounding of the right-hand side (same matrix, b_{k+1} = 0.9 b_k + c) */
 #define FLUID_START_ZERO 1        /* x0 = 0 like the reference's cg.solve(b), fluid.cc:1474: cg_iters comparable        */
 
 /* arithmetic of the multigrid V-cycle inside the fp64 PCG (fluid_params.mg_precision) */
