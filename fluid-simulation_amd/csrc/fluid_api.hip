@@ -741,7 +741,8 @@ static int solve_mg(fluid_sim* s)
     // i + 1 bodies ran), so the first batch runs exactly the bodies the previous solve needed without looking — one poll
     // (head-only launch + 40-byte copy + stream sync, ~50 us) per solve when the count repeats; after that every body is
     // polled.  Kernels of a finished solve exit at their first instruction, but each still costs a launch.
-    long batch = s->mg_last_iters > 5 ? s->mg_last_iters + 1 : 4;
+    const int pclass = s->pass_class();
+    long batch = s->mg_last_iters_k[pclass] > 5 ? s->mg_last_iters_k[pclass] + 1 : 4;
     bool done = false;
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
@@ -797,7 +798,7 @@ static int solve_mg(fluid_sim* s)
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
     s->stats.cg_iters += iters;
-    s->mg_last_iters = iters;
+    s->mg_last_iters_k[pclass] = iters;
     s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
     if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
     return FLUID_OK;

@@ -772,7 +772,8 @@ int dist_solve(fluid_sim* s)
     if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, g1, g2, gca, gcb, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
     else launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
     long it = 0;
-    long batch = s->mg_last_iters > 5 ? s->mg_last_iters : 8;   // identical on every rank
+    const int pclass = s->pass_class();
+    long batch = s->mg_last_iters_k[pclass] > 5 ? s->mg_last_iters_k[pclass] : 8;   // identical on every rank
     bool done = false;
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
@@ -818,7 +819,7 @@ int dist_solve(fluid_sim* s)
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
     s->stats.cg_iters += iters;
-    s->mg_last_iters = iters;
+    s->mg_last_iters_k[pclass] = iters;
     s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
     if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
     return FLUID_OK;

@@ -53,7 +53,8 @@ struct fluid_sim {
     {
         g1 = p_guess, g2 = nullptr, ca = 1.0, cb = 0.0;
         const int k = stats.outer_passes;   // passes completed in this step = index of this one
-        if (extrapolate && p_guess2 && k >= 2 && guess_step == step_counter && guess2_step == step_counter && guess_pass == k - 1 && guess2_pass == k - 2) {
+        const bool same_step = p_guess2 && k >= 2 && guess_step == step_counter && guess2_step == step_counter && guess_pass == k - 1 && guess2_pass == k - 2;
+        if (extrapolate && same_step) {
             const double f = 1.0 - prm.update_frac;
             g2 = p_guess2, ca = 1.0 + f, cb = -f;
         }
@@ -114,7 +115,10 @@ struct fluid_sim {
     // multigrid preconditioner (single-GPU fp64 solve)
     static constexpr int MG_MAXL = 8;
     int mg_nl = 0, mg_tail = 0;   // levels; first level handled by the single-block tail kernel
-    long mg_last_iters = 0;       // iteration count of the previous multigrid solve (sizes the first unpolled batch)
+    // iteration count of the previous multigrid solve of the same kind (sizes the first unpolled batch): first pass of a step, second pass,
+    // later passes (those start from the extrapolation and need about half the iterations)
+    long mg_last_iters_k[3] = {0, 0, 0};
+    int pass_class() const { return stats.outer_passes < 2 ? stats.outer_passes : 2; }
     int mg_csweeps = 3;           // red-black sweeps (each direction) on the coarsest level (12 -> 2 changes the PCG count by 1 in 520)
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
