@@ -7,16 +7,20 @@ export TMPDIR=/tmp
 O=gpurun_out/fin
 mkdir -p $O
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --no-cpu --no-long-run > $O/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --no-cpu --no-long-run --no-mpm > $O/trace.log 2>&1
 python tools/step_breakdown.py "$(ls -t $O/trace/*/*_kernel_trace.csv | head -n 1)" 12 > $O/step_breakdown.txt
 cp "$(ls -t $O/trace/*/*_kernel_stats.csv | head -n 1)" $O/kernel_stats.csv
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-micro --no-long-run > $O/fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-micro --no-long-run > $O/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-micro --no-long-run --no-mpm > $O/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-micro --no-long-run --no-mpm > $O/write.log 2>&1
 python tools/pmc_summary.py "$(ls -t $O/fetch/*/*_counter_collection.csv | head -n 1)" "$(ls -t $O/write/*/*_counter_collection.csv | head -n 1)" > $O/pmc.json
-timeout -k 10 300 python bench.py --n 128 --no-long-run > $O/bench128.json 2> /dev/null
-timeout -k 10 300 python bench.py --n 512 --ppc 4 --steps 5 --warmup 2 --no-cpu --no-micro --no-long-run > $O/bench512.json 2> /dev/null
+timeout -k 10 300 python bench.py --n 128 --no-long-run --no-mpm > $O/bench128.json 2> /dev/null
+timeout -k 10 300 python bench.py --n 512 --ppc 4 --steps 5 --warmup 2 --no-cpu --no-micro --no-long-run --no-mpm > $O/bench512.json 2> /dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/splash -- python3 tools/long_run.py 256 200 > $O/splash.log 2>&1
 python tools/step_breakdown.py "$(ls -t $O/splash/*/*_kernel_trace.csv | head -n 1)" 195 > $O/step_breakdown_splash.txt
+rm -f $O/splash/*/*_kernel_trace.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/settled -- python3 tools/long_run.py 256 450 > $O/settled.log 2>&1
+python tools/step_breakdown.py "$(ls -t $O/settled/*/*_kernel_trace.csv | head -n 1)" 445 > $O/step_breakdown_settled.txt
+timeout -k 10 300 python tools/long_run.py 256 500 > $O/long_run.txt 2>&1
 # the raw traces are large: only the summaries travel back
-rm -f $O/trace/*/*_kernel_trace.csv $O/splash/*/*_kernel_trace.csv $O/fetch/*/*_counter_collection.csv $O/write/*/*_counter_collection.csv
+rm -f $O/trace/*/*_kernel_trace.csv $O/splash/*/*_kernel_trace.csv $O/settled/*/*_kernel_trace.csv $O/fetch/*/*_counter_collection.csv $O/write/*/*_counter_collection.csv
 ls -la $O
