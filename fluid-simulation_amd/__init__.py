@@ -7,7 +7,7 @@ hand-written HIP for gfx950.  There is NO CPU fallback: if the shared library is
 import fails; if no GPU is visible, ``FluidSim(...)`` raises.
 """
 from ._lib import lib, FluidError, Params, StepStats, FIELD, PROF, MpmParams, MpmStepStats  # noqa: F401
-from .mpm import MpmSim, snow_cone, MPM_P, MPM_F  # noqa: F401
+from .mpm import MpmSim, snow_cone, mpm_eval, MPM_P, MPM_F  # noqa: F401
 from .sim import FluidSim, water_cube_drop, reference_scatter, grid_bounds, write_vdb, VdbStream  # noqa: F401
 
 def load_dist():
@@ -16,4 +16,4 @@ def load_dist():
     return dist
 
 
-__all__ = ["MpmParams", "MpmStepStats", "MpmSim", "snow_cone", "MPM_P", "MPM_F", "load_dist", "FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "reference_scatter", "grid_bounds", "write_vdb", "VdbStream", "lib"]
+__all__ = ["MpmParams", "MpmStepStats", "MpmSim", "snow_cone", "mpm_eval", "MPM_P", "MPM_F", "load_dist", "FluidSim", "FluidError", "Params", "StepStats", "FIELD", "PROF", "water_cube_drop", "reference_scatter", "grid_bounds", "write_vdb", "VdbStream", "lib"]

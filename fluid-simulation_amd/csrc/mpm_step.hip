@@ -203,6 +203,126 @@ __device__ void svd3(const double* F, double* U, double* s, double* V)
 }
 
 
+// ---- constitutive pieces shared by the step kernels and by mpm_eval (the known-answer hook) ----
+struct Setup {          // per particle, once per step
+    double R[9], S[9], Minv[9], cof[9], sigma[9], mu, lambda, J;
+};
+// getR / getS (deformHeader.h:22-36), getSigma (:273-307), and what getdPsydx2 recomputes for every node pair (:253-263):
+// the hardened coefficients, J, the cofactor matrix (getJFmt, :227-239) and the inverse of getDelR's 3x3 matrix (:139-142)
+__device__ __forceinline__ void particle_setup(const double* F, const double* FP, double mu0, double lambda0, double eps, Setup& o)
+{
+    double U[9], V[9], sv[3];
+    svd3(F, U, sv, V);
+    mat_mul_bt(U, V, o.R);
+    double VD[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) VD[3 * r + c] = V[3 * r + c] * sv[c];
+    mat_mul_bt(VD, V, o.S);
+    const double Jp = mat_det(FP);
+    const double hard = exp(eps * (1 - Jp));
+    o.mu = mu0 * hard, o.lambda = lambda0 * hard;
+    o.J = mat_det(F);
+    double FmR[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) FmR[k] = F[k] - o.R[k];
+    mat_mul_bt(FmR, F, o.sigma);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o.sigma[k] = 2 * o.mu * o.sigma[k] + ((k % 4 == 0) ? o.lambda * (o.J - 1) * o.J : 0.0);
+    const double* S = o.S;
+    const double m[9] = {S[0] + S[4], S[5], -1 * S[2], S[5], S[0] + S[8], S[1], -1 * S[2], S[1], S[4] + S[8]};
+    double mi[9];
+    cofactor(m, mi);                           // cof(m) = det(m) m^-T; m is symmetric
+    const double dm = mat_det(m);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o.Minv[k] = dm != 0 ? mi[k] / dm : 0.0;
+    cofactor(F, o.cof);
+}
+// Ap = d2Psi/dF2 : dF (dPsydFdF, deformHeader.h:241-249, for a general dF): 2 mu dF - 2 mu dR + lambda cof (cof : dF) + lambda (J - 1) dcof,
+// dR from getDelR (:133-147), dcof = the derivative of the cofactor matrix along dF (what getdJF / doubleDot42 tabulate, :148-212)
+__device__ __forceinline__ void hessian_apply(const double* F, const double* R, const double* Mi, const double* cf, double mu, double lambda, double J,
+                                              const double* dF, double* Ap)
+{
+    double RtdF[9];
+    {
+        const double Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+        mat_mul(Rt, dF, RtdF);
+    }
+    const double rhs01 = RtdF[1] - RtdF[3], rhs02 = RtdF[2] - RtdF[6], rhs12 = RtdF[5] - RtdF[7];   // R^T dF - dF^T R
+    const double x0 = Mi[0] * rhs01 + Mi[1] * rhs02 + Mi[2] * rhs12;
+    const double x1 = Mi[3] * rhs01 + Mi[4] * rhs02 + Mi[5] * rhs12;
+    const double x2 = Mi[6] * rhs01 + Mi[7] * rhs02 + Mi[8] * rhs12;
+    const double rdr[9] = {0, x0, x1, -1 * x0, 0, x2, -1 * x1, -1 * x2, 0};
+    double dR[9];
+    mat_mul(R, rdr, dR);
+    double dd = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dd += cf[k] * dF[k];
+    double dcf[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+            dcf[3 * r + c] = dF[3 * r1 + c1] * F[3 * r2 + c2] + F[3 * r1 + c1] * dF[3 * r2 + c2] - dF[3 * r1 + c2] * F[3 * r2 + c1] -
+                             F[3 * r1 + c2] * dF[3 * r2 + c1];
+        }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ap[k] = 2 * mu * dF[k] - 2 * mu * dR[k] + lambda * cf[k] * dd + lambda * (J - 1) * dcf[k];   // deformHeader.h:248
+}
+// the singular-value clamp of updateDeformationGradient, mpm.cc:543-555
+__device__ __forceinline__ void clamp_update(const double* tFE, const double* FP, double minv, double maxv, double* nFE, double* nFP)
+{
+    double F[9], U[9], V[9], sv[3];
+    mat_mul(tFE, FP, F);
+    svd3(tFE, U, sv, V);
+    double UD[9], VDi[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double s = sv[c] > minv ? sv[c] : minv;
+        s = s < maxv ? s : maxv;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) UD[3 * r + c] = U[3 * r + c] * s, VDi[3 * r + c] = V[3 * r + c] * (1.0 / s);
+    }
+    double T[9];
+    mat_mul_bt(UD, V, nFE);
+    mat_mul_bt(VDi, U, T);
+    mat_mul(T, F, nFP);
+}
+// mpm_eval: one thread per item, plain AoS arrays
+__global__ void k_mpm_eval(int what, long n, const double* __restrict__ a, const double* __restrict__ b, double p0, double p1, double p2,
+                           double* __restrict__ out0, double* __restrict__ out1)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double A[9], B[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A[k] = a[9 * i + k], B[k] = b ? b[9 * i + k] : ((k % 4 == 0) ? 1.0 : 0.0);
+    if (what == MPM_EVAL_POLAR || what == MPM_EVAL_SIGMA) {
+        Setup st;
+        particle_setup(A, B, p0, p1, p2, st);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (what == MPM_EVAL_POLAR) out0[9 * i + k] = st.R[k], out1[9 * i + k] = st.S[k];
+            else out0[9 * i + k] = st.sigma[k];
+        }
+    } else if (what == MPM_EVAL_HESSIAN) {   // a = F, b = dF, p0 = lambda, p1 = mu (taken as they are: no hardening)
+        double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        Setup st;
+        particle_setup(A, I, 0.0, 0.0, 0.0, st);
+        double Ap[9];
+        hessian_apply(A, st.R, st.Minv, st.cof, p1, p0, st.J, B, Ap);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out0[9 * i + k] = Ap[k];
+    } else if (what == MPM_EVAL_CLAMP) {     // a = tFE, b = FP, p0 = minv, p1 = maxv
+        double nFE[9], nFP[9];
+        clamp_update(A, B, p0, p1, nFE, nFP);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out0[9 * i + k] = nFE[k], out1[9 * i + k] = nFP[k];
+    }
+}
+
 // ---- wave-level aggregation of the scatters ----
 // Particles arrive grouped by voxel (the scatter emits them in ValueOn order and snow moves coherently), so the lanes of a
 // wave mostly share their base cell and hence their 27 target nodes: with one atomic per lane the same ~150 addresses take
@@ -462,43 +582,21 @@ __global__ void __launch_bounds__(128) k_mpm_forces(MGrid G, long n, Part P, con
     const bool valid = i0 < n;
     const long i = order[valid ? i0 : 0];   // idle lanes of the last wave recompute a particle and store nothing
     const long C = G.cells();
-    double F[9], FP[9], U[9], V[9], sv[3], R[9], S[9];
+    double F[9], FP[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) F[k] = ld(P.FE, P.cap, k, i), FP[k] = ld(P.FP, P.cap, k, i);
-    svd3(F, U, sv, V);
-    mat_mul_bt(U, V, R);                       // getR, deformHeader.h:22-28
-    double VD[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) VD[3 * r + c] = V[3 * r + c] * sv[c];
-    mat_mul_bt(VD, V, S);                      // getS, deformHeader.h:29-36
-    const double Jp = mat_det(FP);
-    const double hard = exp(eps * (1 - Jp));
-    const double mu = mu0 * hard, lambda = lambda0 * hard;
-    const double Je = mat_det(F);
-    // getSigma, deformHeader.h:273-307
-    double FmR[9], sigma[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) FmR[k] = F[k] - R[k];
-    mat_mul_bt(FmR, F, sigma);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) sigma[k] = 2 * mu * sigma[k] + ((k % 4 == 0) ? lambda * (Je - 1) * Je : 0.0);
-    // cache for the operator: R, inverse of the matrix of getDelR (deformHeader.h:139-141), cofactor matrix, coefficients
-    double m[9] = {S[0] + S[4], S[5], -1 * S[2], S[5], S[0] + S[8], S[1], -1 * S[2], S[1], S[4] + S[8]};
-    double mi[9];
-    cofactor(m, mi);                           // cof(m) = det(m) m^-T; m is symmetric
-    const double dm = mat_det(m);
-    double cf[9];
-    cofactor(F, cf);
+    Setup su;
+    particle_setup(F, FP, mu0, lambda0, eps, su);
+    const double* sigma = su.sigma;
+    // cache for the operator
     if (valid) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            stv(P.R, P.cap, k, i, R[k]);
-            stv(P.Minv, P.cap, k, i, dm != 0 ? mi[k] / dm : 0.0);
-            stv(P.cof, P.cap, k, i, cf[k]);
+            stv(P.R, P.cap, k, i, su.R[k]);
+            stv(P.Minv, P.cap, k, i, su.Minv[k]);
+            stv(P.cof, P.cap, k, i, su.cof[k]);
         }
-        stv(P.coef, P.cap, 0, i, mu), stv(P.coef, P.cap, 1, i, lambda), stv(P.coef, P.cap, 2, i, Je);
+        stv(P.coef, P.cap, 0, i, su.mu), stv(P.coef, P.cap, 1, i, su.lambda), stv(P.coef, P.cap, 2, i, su.J);
     }
 
     double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
@@ -634,35 +732,8 @@ __global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, cons
     const double mu = ld(P.coef, P.cap, 0, i), lambda = ld(P.coef, P.cap, 1, i), J = ld(P.coef, P.cap, 2, i);
     double dF[9];
     mat_mul(Gm, F, dF);                         // rows of getDelFE (deformHeader.h:107-132), summed over nodes and directions
-    // getDelR, deformHeader.h:133-147
-    double RtdF[9], rhs01, rhs02, rhs12;
-    {
-        double Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
-        mat_mul(Rt, dF, RtdF);
-        rhs01 = RtdF[1] - RtdF[3], rhs02 = RtdF[2] - RtdF[6], rhs12 = RtdF[5] - RtdF[7];   // R^T dF - dF^T R
-    }
-    const double x0 = Mi[0] * rhs01 + Mi[1] * rhs02 + Mi[2] * rhs12;
-    const double x1 = Mi[3] * rhs01 + Mi[4] * rhs02 + Mi[5] * rhs12;
-    const double x2 = Mi[6] * rhs01 + Mi[7] * rhs02 + Mi[8] * rhs12;
-    const double rdr[9] = {0, x0, x1, -1 * x0, 0, x2, -1 * x1, -1 * x2, 0};
-    double dR[9];
-    mat_mul(R, rdr, dR);
-    // doubleDot22(JFmt, dF) and doubleDot42(getdJF(F), dF) = the derivative of the cofactor matrix along dF
-    double dd = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dd += cf[k] * dF[k];
-    double dcf[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-            dcf[3 * r + c] = dF[3 * r1 + c1] * F[3 * r2 + c2] + F[3 * r1 + c1] * dF[3 * r2 + c2] - dF[3 * r1 + c2] * F[3 * r2 + c1] -
-                             F[3 * r1 + c2] * dF[3 * r2 + c1];
-        }
     double Ap[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Ap[k] = 2 * mu * dF[k] - 2 * mu * dR[k] + lambda * cf[k] * dd + lambda * (J - 1) * dcf[k];   // deformHeader.h:248
+    hessian_apply(F, R, Mi, cf, mu, lambda, J, dF, Ap);
     double ApFt[9];
     mat_mul_bt(Ap, F, ApFt);                    // A_p F^T
     const double dt = st->dt;
@@ -860,7 +931,7 @@ __global__ void __launch_bounds__(128) k_mpm_deform(MGrid G, long n, Part P, con
                 }
             }
     const double dt = st->dt;
-    double FE[9], FP[9], A[9], tFE[9], F[9];
+    double FE[9], FP[9], A[9], tFE[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         stv(P.gradV, P.cap, k, i, gv[k]);
@@ -868,21 +939,8 @@ __global__ void __launch_bounds__(128) k_mpm_deform(MGrid G, long n, Part P, con
         A[k] = ((k % 4 == 0) ? 1.0 : 0.0) + dt * gv[k];
     }
     mat_mul(A, FE, tFE);
-    mat_mul(tFE, FP, F);
-    double U[9], V[9], sv[3];
-    svd3(tFE, U, sv, V);
-    double UD[9], VDi[9];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double s = sv[c] > minv ? sv[c] : minv;
-        s = s < maxv ? s : maxv;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) UD[3 * r + c] = U[3 * r + c] * s, VDi[3 * r + c] = V[3 * r + c] * (1.0 / s);
-    }
-    double nFE[9], T[9], nFP[9];
-    mat_mul_bt(UD, V, nFE);
-    mat_mul_bt(VDi, U, T);
-    mat_mul(T, F, nFP);
+    double nFE[9], nFP[9];
+    clamp_update(tFE, FP, minv, maxv, nFE, nFP);
     double mx = gv[0], mn = gv[0];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -1439,6 +1497,35 @@ int mpm_apply_matrix(mpm_sim_t* s, const double* v, double* y)
     if (apply_operator(s, 0)) return FLUID_ERR_HIP;
     HIPCHK(hipMemcpyAsync(y, s->q, sizeof(double) * n3, hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+int mpm_eval(int32_t what, int64_t n, const double* a, const double* b, double p0, double p1, double p2, double* out0, double* out1)
+{
+    if (n < 0 || !a || !out0 || what < MPM_EVAL_POLAR || what > MPM_EVAL_CLAMP) return fluid_fail(FLUID_ERR_ARG, "mpm_eval: bad argument");
+    if ((what == MPM_EVAL_POLAR || what == MPM_EVAL_CLAMP) && !out1) return fluid_fail(FLUID_ERR_ARG, "mpm_eval: this function has two results");
+    if ((what == MPM_EVAL_HESSIAN || what == MPM_EVAL_CLAMP) && !b) return fluid_fail(FLUID_ERR_ARG, "mpm_eval: this function takes two matrices");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fluid_fail(FLUID_ERR_HIP, "mpm_eval: no HIP device (this library has no CPU path)");
+    if (!n) return 0;
+    const size_t bytes = sizeof(double) * 9 * (size_t)n;
+    double *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
+    auto cleanup = [&]() { for (double* p : {da, db, d0, d1}) if (p) (void)hipFree(p); };
+    if (hipMalloc((void**)&da, bytes) != hipSuccess || (b && hipMalloc((void**)&db, bytes) != hipSuccess) || hipMalloc((void**)&d0, bytes) != hipSuccess ||
+        hipMalloc((void**)&d1, bytes) != hipSuccess) {
+        cleanup();
+        return fluid_fail(FLUID_ERR_HIP, "mpm_eval: device allocation failed");
+    }
+    hipError_t e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_mpm_eval<<<blocks_for(n, 128), 128>>>(what, n, da, db, p0, p1, p2, d0, d1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out0, d0, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out1) e = hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fluid_fail(FLUID_ERR_HIP, std::string("mpm_eval: ") + hipGetErrorString(e));
     return 0;
 }
 

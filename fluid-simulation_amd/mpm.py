@@ -32,6 +32,15 @@ def snow_cone(B=15, W=13, layers=4, points_per_voxel=400.0, seed=0):
     return pos
 
 
+def mpm_eval(what, a, b=None, p0=0.0, p1=0.0, p2=0.0):
+    """mpm_eval of include/mpm_hip.h: a, b (n, 3, 3) -> (out0, out1)."""
+    a = np.ascontiguousarray(a, np.float64).reshape(-1, 3, 3)
+    bb = None if b is None else np.ascontiguousarray(b, np.float64).reshape(-1, 3, 3)
+    o0, o1 = np.empty_like(a), np.empty_like(a)
+    check(lib.mpm_eval(what, len(a), _ptr(a), None if bb is None else _ptr(bb), p0, p1, p2, _ptr(o0), _ptr(o1)))
+    return o0, o1
+
+
 class MpmSim:
     """One simulation = the state of mpm.cc's main(): grids over [-B, B]^3 and a PointList."""
 

@@ -120,6 +120,19 @@ int mpm_download_system(mpm_sim_t* s, double* b, double* x);
  * have moved).  For tests: column k of A is mpm_apply_matrix(e_k). */
 int mpm_apply_matrix(mpm_sim_t* s, const double* v, double* y);
 
+/* Known-answer hook: the device functions the step kernels use, on n independent 3x3 matrices (row-major, 9 doubles each).
+ *   MPM_EVAL_POLAR    a = F                       -> out0 = getR(F), out1 = getS(F)                    deformHeader.h:22-36
+ *   MPM_EVAL_SIGMA    a = FE, b = FP, p0 = mu0, p1 = lambda0, p2 = epsilon -> out0 = getSigma(...)     deformHeader.h:273-307
+ *   MPM_EVAL_HESSIAN  a = F, b = dF, p0 = lambda, p1 = mu -> out0 = d2Psi/dF2 : dF — dPsydFdF (deformHeader.h:241-249) for the
+ *                     dF that getDelFE (:107-132) builds, and for any other dF (the operator is linear in it)
+ *   MPM_EVAL_CLAMP    a = (I + dt gradV) FE, b = FP, p0 = 1 - theta_c, p1 = 1 + theta_s -> out0 = FE', out1 = FP'   mpm.cc:543-555
+ * No handle needed; runs on the current device. */
+#define MPM_EVAL_POLAR 0
+#define MPM_EVAL_SIGMA 1
+#define MPM_EVAL_HESSIAN 2
+#define MPM_EVAL_CLAMP 3
+int mpm_eval(int32_t what, int64_t n, const double* a, const double* b, double p0, double p1, double p2, double* out0, double* out1);
+
 /* The reference's scene (mpm.cc:1037-1052,1274-1278): the cone of voxels {(i, j, k): -W <= j <= -W + layers - 1,
  * i^2 + k^2 <= ((j + W) / 2)^2}, UniformPointScatter with points_per_voxel points per voxel and std::mt19937(seed),
  * filtered by PointList::add with boundary B.  layers = 4, points_per_voxel = 400, seed = 0, B = 15, W = 13 is the

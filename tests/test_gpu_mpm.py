@@ -54,6 +54,10 @@ def test_reference_scene_step_by_step(fs, mo):
     """The reference's own scene (6205 particles, 31^3 grid), 4 steps free-running, every array after every step."""
     sim, orc = make_pair(fs, mo, scene(fs))
     assert sim.num_particles == orc.num_particles == 6205
+    # where oracle/_ref travelled, the oracle's solves go through the reference's own solver object (Eigen CG + IncompleteCholesky,
+    # mpm.cc:1271): the HIP path is then compared with what that object returns for the assembled matrix
+    with_eigen = orc.use_reference_solver()
+    print("oracle solves by the reference's Eigen object:", with_eigen)
     for i in range(4):
         sg, so = sim.step(), orc.step()
         assert sg["num_active"] == so["num_active"] > 0
@@ -231,3 +235,48 @@ def test_long_run_through_the_impact(fs):
     assert sv.min() >= 1 - 0.025 - 1e-9 and sv.max() <= 1 + 0.0075 + 1e-9    # the clamp of mpm.cc:548-553 held all along
     assert np.abs(np.linalg.det(FP) - 1).max() > 1e-3       # plastic deformation happened
     sim.close()
+
+
+def test_device_functions_against_the_references_own_code(fs, mo):
+    """mpm_eval: the device functions of the step kernels (polar factors by one-sided Jacobi, stress, the energy Hessian
+    applied to a dF, the singular-value clamp) against deformHeader.h's own functions compiled from the reference with its
+    vendored Eigen (oracle/_ref/libmpm_ref.so: JacobiSVD, colPivHouseholderQr) — and against the restatement where that
+    library did not travel."""
+    ref = mo.reference_functions() or mo.restated
+    pinned = mo.reference_functions() is not None
+    rng = np.random.default_rng(4)
+
+    def rand_F(spread):
+        q1, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        q2, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        return q1 @ np.diag(np.exp(rng.uniform(-np.log(spread), np.log(spread), 3))) @ q2.T
+
+    n = 300
+    F = np.stack([rand_F(1.03 if k % 2 else 3.0) for k in range(n)] + [np.eye(3), 1.3 * np.eye(3), np.diag([2.0, 2.0, 0.5])])
+    R, S = fs.mpm_eval(0, F)
+    for k in range(len(F)):
+        assert np.abs(R[k] - ref.getR(F[k])).max() < 5e-14 * max(1.0, np.abs(F[k]).max())
+        assert np.abs(S[k] - ref.getS(F[k])).max() < 5e-14 * max(1.0, np.abs(F[k]).max())
+    mu0, lam0, eps = 48000 / (2 * 1.47), 48000 * 0.47 / (1.47 * 0.06), 10.0
+    FE = np.stack([rand_F(1.05) for _ in range(n)])
+    FP = np.stack([rand_F(1.05) for _ in range(n)])
+    sig, _ = fs.mpm_eval(1, FE, FP, mu0, lam0, eps)
+    for k in range(n):
+        r = ref.getSigma(mu0, lam0, eps, FE[k], FP[k])
+        assert np.abs(sig[k] - r).max() < 1e-11 * np.abs(r).max()
+    # the Hessian on the dF of getDelFE: row i = gradW^T F
+    lam, mu = 3.1e4, 1.7e4
+    g = rng.normal(size=(n, 3))
+    for i in range(3):
+        dF = np.zeros((n, 3, 3))
+        dF[:, i, :] = np.einsum("nr,nrc->nc", g, FE)
+        Ap, _ = fs.mpm_eval(2, FE, dF, lam, mu)
+        for k in range(0, n, 7):
+            r = ref.dPsydFdF(g[k], FE[k], lam, mu, i)
+            assert np.abs(Ap[k] - r).max() < 1e-12 * np.abs(r).max()
+    tFE = np.stack([rand_F(1.08) for _ in range(n)])
+    a, b = fs.mpm_eval(3, tFE, FP, 1 - 0.025, 1 + 0.0075)
+    for k in range(n):
+        ra, rb = ref.clamp(tFE[k], FP[k], 1 - 0.025, 1 + 0.0075)
+        assert np.abs(a[k] - ra).max() < 1e-13 and np.abs(b[k] - rb).max() < 1e-13
+    print("device functions pinned by the reference's own code:", pinned)
