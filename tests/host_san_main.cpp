@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "fluid_hip.h"
+#include "mpm_hip.h"
 
 static int fail(const char* what)
 {
@@ -37,6 +38,15 @@ int main(int argc, char** argv)
         if (fluid_scene_uniform_scatter(bad, hi, 1.f, 3, 0, nullptr) >= 0) return fail("lo > hi accepted");
         if (fluid_scene_uniform_scatter(lo, hi, 0.f, 3, 0, nullptr) >= 0) return fail("density 0 accepted");
         if (fluid_scene_uniform_scatter(nullptr, hi, 1.f, 3, 0, nullptr) >= 0) return fail("null box accepted");
+    }
+    {   // the snow cone of the MPM program: single voxels on both sides of the origin (four root nodes), count-only and filled
+        const int64_t n = mpm_scene_cone(15, 13, 4, 400.f, 0, nullptr);
+        if (n != 6205) return fail("cone count");
+        std::vector<double> pos((size_t)3 * n);
+        if (mpm_scene_cone(15, 13, 4, 400.f, 0, pos.data()) != n) return fail("cone fill");
+        std::vector<double> big((size_t)3 * mpm_scene_cone(63, 61, 24, 3.f, 1, nullptr));
+        if (mpm_scene_cone(63, 61, 24, 3.f, 1, big.data()) * 3 != (int64_t)big.size()) return fail("large cone fill");
+        if (mpm_scene_cone(15, 13, 0, 400.f, 0, nullptr) >= 0 || mpm_scene_cone(15, 16, 4, 400.f, 0, nullptr) >= 0) return fail("bad cone accepted");
     }
     for (int n : {8, 21}) {
         std::vector<float> a((size_t)n * n * n), b(a.size());
