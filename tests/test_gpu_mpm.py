@@ -280,3 +280,40 @@ def test_device_functions_against_the_references_own_code(fs, mo):
         ra, rb = ref.clamp(tFE[k], FP[k], 1 - 0.025, 1 + 0.0075)
         assert np.abs(a[k] - ra).max() < 1e-13 and np.abs(b[k] - rb).max() < 1e-13
     print("device functions pinned by the reference's own code:", pinned)
+
+
+def test_device_functions_against_committed_reference_outputs(fs):
+    """The same device functions against tests/golden/mpm_functions.npz — outputs of the reference's own deformHeader.h code
+    (make_mpm_golden.py), committed, so this check does not depend on oracle/_ref having travelled."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpm_functions.npz"))
+    mu0, lam0, eps, lam, mu, minv, maxv = z["params"]
+    R, S = fs.mpm_eval(0, z["F"])
+    scale = np.maximum(1.0, np.abs(z["F"]).max(axis=(1, 2)))[:, None, None]
+    assert (np.abs(R - z["R"]) / scale).max() < 5e-14 and (np.abs(S - z["S"]) / scale).max() < 5e-14
+    sig, _ = fs.mpm_eval(1, z["FE"], z["FP"], mu0, lam0, eps)
+    assert (np.abs(sig - z["sigma"]).max(axis=(1, 2)) / np.abs(z["sigma"]).max(axis=(1, 2))).max() < 1e-11
+    for i in range(3):
+        dF = np.zeros_like(z["FE"])
+        dF[:, i, :] = np.einsum("nr,nrc->nc", z["gradW"], z["FE"])
+        Ap, _ = fs.mpm_eval(2, z["FE"], dF, lam, mu)
+        ref = z["hessian"][:, i]
+        assert (np.abs(Ap - ref).max(axis=(1, 2)) / np.abs(ref).max(axis=(1, 2))).max() < 1e-12
+    a, b = fs.mpm_eval(3, z["tFE"], z["FP"], minv, maxv)
+    assert np.abs(a - z["clampFE"]).max() < 1e-13 and np.abs(b - z["clampFP"]).max() < 1e-13
+
+
+def test_solution_matches_the_references_solver_output(fs, mo):
+    """tests/golden/mpm_solve_ref_scene.npz: what the reference's own Eigen object returned for step 1 of the reference's scene.
+    The HIP path's solution of that step agrees with it to the float32 noise of the node masses."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpm_solve_ref_scene.npz"))
+    sim = fs.MpmSim()
+    sim.upload_particles(fs.snow_cone())
+    sim.step()
+    st = sim.step_solve()
+    assert st["num_active"] == int(z["num_active"])
+    b, x = sim.system(st["num_active"])
+    assert rel_l2(b, z["b"]) < 2e-6 and rel_l2(x, z["x_eigen"]) < 2e-6
+    sim.step_advance()
+    sim.close()

@@ -222,3 +222,48 @@ def test_matrix_is_the_derivative_of_the_grid_forces():
         lhs = M @ u                                     # = -(1/m_i) df_i/dx . u  (the matrix adds the Hessian: A = I + beta dt^2 M)
         rhs = -dfdx / mvec
         assert np.linalg.norm(lhs - rhs) <= 2e-5 * np.linalg.norm(rhs)
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_restatement_against_committed_reference_outputs():
+    """tests/golden/mpm_functions.npz holds outputs of the reference's OWN functions (made by make_mpm_golden.py from
+    oracle/_ref/libmpm_ref.so): the restatement reproduces them wherever this runs, with or without /root/reference."""
+    z = np.load(os.path.join(GOLD, "mpm_functions.npz"))
+    for k, x in enumerate(z["xs"]):
+        assert R.spline(x) == z["spline"][k] and R.spline2(x) == z["spline2"][k] and R.spline_gradient(x) == z["spline_gradient"][k]
+    mu0, lam0, eps, lam, mu, minv, maxv = z["params"]
+    for k in range(len(z["F"])):
+        assert np.abs(R.getR(z["F"][k]) - z["R"][k]).max() < 5e-14 * max(1.0, np.abs(z["F"][k]).max())
+        assert np.abs(R.getS(z["F"][k]) - z["S"][k]).max() < 5e-14 * max(1.0, np.abs(z["F"][k]).max())
+        s = R.getSigma(mu0, lam0, eps, z["FE"][k], z["FP"][k])
+        assert np.abs(s - z["sigma"][k]).max() < 1e-11 * np.abs(z["sigma"][k]).max()
+        for i in range(3):
+            h = R.dPsydFdF(z["gradW"][k], z["FE"][k], lam, mu, i)
+            assert np.abs(h - z["hessian"][k, i]).max() < 1e-12 * np.abs(z["hessian"][k, i]).max()
+        a, b = R.clamp(z["tFE"][k], z["FP"][k], minv, maxv)
+        assert np.abs(a - z["clampFE"][k]).max() < 1e-13 and np.abs(b - z["clampFP"][k]).max() < 1e-13
+
+
+def test_committed_system_shows_the_transposed_solve():
+    """tests/golden/mpm_solve_ref_scene.npz: step 1 of the reference's scene, the solution returned by the reference's own Eigen
+    solver object.  It solves A^T x = b to 3.5e-16 and A x = b only to 2 %: the evidence behind transpose_system = 1."""
+    z = np.load(os.path.join(GOLD, "mpm_solve_ref_scene.npz"))
+    n = len(z["b"])
+    A = np.zeros((n, n))
+    np.add.at(A, (z["rows"], z["cols"]), z["vals"])
+    nb = np.linalg.norm(z["b"])
+    assert np.linalg.norm(A.T @ z["x_eigen"] - z["b"]) < 1e-15 * nb
+    assert np.linalg.norm(A @ z["x_eigen"] - z["b"]) > 1e-2 * nb
+    assert int(z["cg_iters"]) < 30 and float(z["cg_error"]) < 2.3e-16
+    # the restatement on the same scene gives the same system and the same solution
+    fs = importlib.import_module("fluid-simulation_amd")
+    o = mo.MpmOracle()
+    o.set_particles(fs.snow_cone())
+    o.step()
+    o.step()
+    rows, cols, vals, b, x = o.system()
+    assert np.array_equal(rows, z["rows"]) and np.array_equal(cols, z["cols"])
+    assert np.abs(vals - z["vals"]).max() <= 1e-12 * np.abs(z["vals"]).max()
+    assert np.linalg.norm(x - z["x_eigen"]) <= 1e-12 * np.linalg.norm(x)
