@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mpm_hip.h"
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(128) k_mpm_p2g(MGrid G, long n, Part P, const 
 {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = j < n;
-    const long ii = order[valid ? j : 0];
+    const long ii = order ? order[valid ? j : 0] : (valid ? j : 0);
     const long C = G.cells();
     double p[3] = {ld(P.pos, P.cap, 0, ii), ld(P.pos, P.cap, 1, ii), ld(P.pos, P.cap, 2, ii)};
     double v[3] = {ld(P.vel, P.cap, 0, ii), ld(P.vel, P.cap, 1, ii), ld(P.vel, P.cap, 2, ii)};
@@ -506,17 +507,35 @@ __global__ void __launch_bounds__(SCAN_T) k_mpm_scan_final(long C, const int* __
 // give (sums differ in the last bits from run to run, as with any atomic accumulation).
 __global__ void k_mpm_sort_count(MGrid G, long n, Part P, int* __restrict__ cell_count, int* __restrict__ key, int* __restrict__ rank)
 {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c[3];
+    // The arrays are nearly sorted already (last step's order, particles move a fraction of a cell per step): the lanes of a
+    // wave mostly share their cell, and one atomic per lane on the same counter would serialise 64-fold.  Runs of equal cells
+    // take ONE atomic (by their last lane) and number themselves from its result.
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const int lane = threadIdx.x & 63;
+    int k = -1 - lane;
+    if (valid) {
+        int c[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        int f = (int)round(ld(P.pos, P.cap, a, i));
-        c[a] = f < -G.B ? -G.B : (f > G.B ? G.B : f);
+        for (int a = 0; a < 3; ++a) {
+            int f = (int)round(ld(P.pos, P.cap, a, i));
+            c[a] = f < -G.B ? -G.B : (f > G.B ? G.B : f);
+        }
+        k = (int)G.at(c[0], c[1], c[2]);
     }
-    const int k = (int)G.at(c[0], c[1], c[2]);
-    key[i] = k;
-    rank[i] = atomicAdd(&cell_count[k], 1);
+    const int prev = __shfl_up(k, 1);
+    const unsigned long long heads = __ballot(lane == 0 || prev != k);
+    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1));
+    const int start = 63 - __clzll((long long)below);
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int tail = above ? lane + __ffsll((long long)above) - 1 : 63;   // last lane of my run
+    int base = 0;
+    if (valid && lane == tail) base = atomicAdd(&cell_count[k], tail - start + 1);
+    base = __shfl(base, tail);
+    if (valid) {
+        key[i] = k;
+        rank[i] = base + (lane - start);
+    }
 }
 __global__ void __launch_bounds__(SCAN_T) k_mpm_scan_excl(long C, const int* __restrict__ vals, const int* __restrict__ sums, int* __restrict__ out)
 {
@@ -551,6 +570,27 @@ __global__ void k_mpm_sort_place(long n, const int* __restrict__ key, const int*
     if (i < n) order[cell_start[key[i]] + rank[i]] = (int)i;
 }
 
+// The particle arrays themselves are put into that order (double-buffered), so that every per-particle kernel of the step —
+// the operator application runs once per CG iteration — reads them coalesced; `pid` keeps the upload index of each slot.
+__global__ void k_mpm_permute(long n, long cap, const int* __restrict__ order, Part src, Part dst, const int* __restrict__ pid_src,
+                              int* __restrict__ pid_dst)
+{
+    long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long i = order[j];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dst.pos[k * cap + j] = src.pos[k * cap + i], dst.vel[k * cap + j] = src.vel[k * cap + i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst.FE[k * cap + j] = src.FE[k * cap + i], dst.FP[k * cap + j] = src.FP[k * cap + i];
+    dst.volume[j] = src.volume[i];
+    pid_dst[j] = pid_src[i];
+}
+__global__ void k_mpm_iota(long n, int* __restrict__ a)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (int)i;
+}
+
 // ---- findVolume, mpm.cc:739-772 ----
 __global__ void __launch_bounds__(128) k_mpm_volume(MGrid G, long n, Part P, const uint8_t* __restrict__ solid, const float* __restrict__ container)
 {
@@ -580,7 +620,7 @@ __global__ void __launch_bounds__(128) k_mpm_forces(MGrid G, long n, Part P, con
 {
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i0 < n;
-    const long i = order[valid ? i0 : 0];   // idle lanes of the last wave recompute a particle and store nothing
+    const long i = order ? order[valid ? i0 : 0] : (valid ? i0 : 0);   // idle lanes of the last wave recompute a particle and store nothing
     const long C = G.cells();
     double F[9], FP[9];
 #pragma unroll
@@ -697,7 +737,7 @@ __global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, cons
     if (in_solve && st->cg_done) return;   // speculative launches past convergence do nothing
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i0 < n;
-    const long i = order[valid ? i0 : 0];
+    const long i = order ? order[valid ? i0 : 0] : (valid ? i0 : 0);
     double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
     Nbh nb;
     neighbourhood(G, p, nb, true);
@@ -1034,15 +1074,16 @@ __global__ void __launch_bounds__(128) k_mpm_advect(MGrid G, long n, Part P, con
 }
 
 // AoS <-> SoA of `w` doubles per particle
-__global__ void k_mpm_to_soa(long n, long cap, int w, const double* __restrict__ aos, double* __restrict__ soa)
+// host arrays are in upload order: slot j holds the particle uploaded as number pid[j]
+__global__ void k_mpm_to_soa(long n, long cap, int w, const int* __restrict__ pid, const double* __restrict__ aos, double* __restrict__ soa)
 {
     long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n * w) soa[(k % w) * cap + k / w] = aos[k];
+    if (k < n * w) soa[(k % w) * cap + k / w] = aos[(long)pid[k / w] * w + k % w];
 }
-__global__ void k_mpm_to_aos(long n, long cap, int w, const double* __restrict__ soa, double* __restrict__ aos)
+__global__ void k_mpm_to_aos(long n, long cap, int w, const int* __restrict__ pid, const double* __restrict__ soa, double* __restrict__ aos)
 {
     long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n * w) aos[k] = soa[(k % w) * cap + k / w];
+    if (k < n * w) aos[(long)pid[k / w] * w + k % w] = soa[(k % w) * cap + k / w];
 }
 __global__ void k_mpm_identity(long n, long cap, double* __restrict__ FE, double* __restrict__ FP, double* __restrict__ volume)
 {
@@ -1072,7 +1113,8 @@ struct mpm_sim {
     MGrid G;
     hipStream_t st = nullptr;
     long C = 0, n = 0;
-    Part P{};
+    Part P{}, P2{};               // P2: the other buffer of pos, vel, FE, FP, volume (the step starts by sorting P into it)
+    int *pid = nullptr, *pid2 = nullptr;   // upload index of each particle slot
     uint8_t* solid = nullptr;
     float *container = nullptr, *output = nullptr;
     double *massd = nullptr, *vel = nullptr, *velb = nullptr, *forces = nullptr;
@@ -1110,25 +1152,28 @@ int ensure_stage(mpm_sim* s, size_t bytes)
 }
 void free_particles(mpm_sim* s)
 {
-    int** ia[] = {&s->key, &s->rank, &s->order};
+    int** ia[] = {&s->key, &s->rank, &s->order, &s->pid, &s->pid2};
     for (auto p : ia) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.cof, &s->P.coef};
+    double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.cof, &s->P.coef,
+                    &s->P2.pos, &s->P2.vel, &s->P2.FE, &s->P2.FP, &s->P2.volume};
     for (auto p : a) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    s->P.cap = 0;
+    s->P.cap = s->P2.cap = 0;
 }
 int alloc_particles(mpm_sim* s, long cap)
 {
     free_particles(s);
-    s->P.cap = cap;
+    s->P.cap = s->P2.cap = cap;
     if (dalloc(&s->P.pos, 3 * cap) || dalloc(&s->P.vel, 3 * cap) || dalloc(&s->P.FE, 9 * cap) || dalloc(&s->P.FP, 9 * cap) ||
         dalloc(&s->P.gradV, 9 * cap) || dalloc(&s->P.volume, cap) || dalloc(&s->P.R, 9 * cap) || dalloc(&s->P.Minv, 9 * cap) ||
-        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap) || dalloc(&s->key, cap) || dalloc(&s->rank, cap) || dalloc(&s->order, cap))
+        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap) || dalloc(&s->key, cap) || dalloc(&s->rank, cap) || dalloc(&s->order, cap) ||
+        dalloc(&s->pid, cap) || dalloc(&s->pid2, cap) || dalloc(&s->P2.pos, 3 * cap) || dalloc(&s->P2.vel, 3 * cap) || dalloc(&s->P2.FE, 9 * cap) ||
+        dalloc(&s->P2.FP, 9 * cap) || dalloc(&s->P2.volume, cap))
         return FLUID_ERR_HIP;
     return 0;
 }
@@ -1137,7 +1182,7 @@ int alloc_particles(mpm_sim* s, long cap)
 int apply_operator(mpm_sim* s, int in_solve)
 {
     // q holds p already (the identity part)
-    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, s->order, s->indices, s->container, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p, s->q);
+    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, nullptr, s->indices, s->container, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p, s->q);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1251,11 +1296,12 @@ int mpm_upload_particles(mpm_sim_t* s, int64_t n, const double* pos, const doubl
     s->dt = s->prm.dt0;
     if (!m) return 0;
     if (ensure_stage(s, sizeof(double) * 3 * m)) return FLUID_ERR_HIP;
+    k_mpm_iota<<<blocks_for(m, 256), 256, 0, s->st>>>(m, s->pid);
     HIPCHK(hipMemcpyAsync(s->stage, hp.data(), sizeof(double) * 3 * m, hipMemcpyHostToDevice, s->st));
-    k_mpm_to_soa<<<blocks_for(3 * m, 256), 256, 0, s->st>>>(m, s->P.cap, 3, s->stage, s->P.pos);
+    k_mpm_to_soa<<<blocks_for(3 * m, 256), 256, 0, s->st>>>(m, s->P.cap, 3, s->pid, s->stage, s->P.pos);
     HIPCHK(hipStreamSynchronize(s->st));
     HIPCHK(hipMemcpyAsync(s->stage, hv.data(), sizeof(double) * 3 * m, hipMemcpyHostToDevice, s->st));
-    k_mpm_to_soa<<<blocks_for(3 * m, 256), 256, 0, s->st>>>(m, s->P.cap, 3, s->stage, s->P.vel);
+    k_mpm_to_soa<<<blocks_for(3 * m, 256), 256, 0, s->st>>>(m, s->P.cap, 3, s->pid, s->stage, s->P.vel);
     k_mpm_identity<<<blocks_for(m, 256), 256, 0, s->st>>>(m, s->P.cap, s->P.FE, s->P.FP, s->P.volume);
     HIPCHK(hipMemsetAsync(s->P.gradV, 0, sizeof(double) * 9 * s->P.cap, s->st));
     HIPCHK(hipGetLastError());
@@ -1276,7 +1322,7 @@ int mpm_set_state(mpm_sim_t* s, const double* FE, const double* FP, const double
         if (!src[k] || !m) continue;
         if (ensure_stage(s, sizeof(double) * w[k] * m)) return FLUID_ERR_HIP;
         HIPCHK(hipMemcpyAsync(s->stage, src[k], sizeof(double) * w[k] * m, hipMemcpyHostToDevice, s->st));
-        k_mpm_to_soa<<<blocks_for((long)w[k] * m, 256), 256, 0, s->st>>>(m, s->P.cap, w[k], s->stage, dst[k]);
+        k_mpm_to_soa<<<blocks_for((long)w[k] * m, 256), 256, 0, s->st>>>(m, s->P.cap, w[k], s->pid, s->stage, dst[k]);
         HIPCHK(hipStreamSynchronize(s->st));
     }
     s->step_no = step_no;
@@ -1320,8 +1366,11 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
         k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, nullptr);
         k_mpm_scan_excl<<<nb, SCAN_T, 0, st>>>(C, s->cell_count, s->sums, s->cell_start);
         k_mpm_sort_place<<<blocks_for(n, 256), 256, 0, st>>>(n, s->key, s->rank, s->cell_start, s->order);
+        k_mpm_permute<<<blocks_for(n, 256), 256, 0, st>>>(n, s->P.cap, s->order, s->P, s->P2, s->pid, s->pid2);
+        std::swap(s->P.pos, s->P2.pos), std::swap(s->P.vel, s->P2.vel), std::swap(s->P.FE, s->P2.FE), std::swap(s->P.FP, s->P2.FP);
+        std::swap(s->P.volume, s->P2.volume), std::swap(s->pid, s->pid2);
     }
-    if (n) k_mpm_p2g<<<pb, 128, 0, st>>>(G, n, s->P, s->order, s->solid, s->massd, s->vel);
+    if (n) k_mpm_p2g<<<pb, 128, 0, st>>>(G, n, s->P, nullptr, s->solid, s->massd, s->vel);
     k_mpm_cells<<<cb, 256, 0, st>>>(G, s->solid, s->massd, s->container, s->output, s->vel, s->velb, s->flag);
     k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->flag, s->sums);
     k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, &s->state->num_active);
@@ -1331,7 +1380,7 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     // populateGridForces (mpm.cc:1395): mu = E / (2 (1 + nu)), lambda = E nu / ((1 + nu) (1 - 2 nu))
     const double mu0 = pr.youngs_modulus / (2 * (1 + pr.poisson_ratio));
     const double lambda0 = pr.youngs_modulus * pr.poisson_ratio / ((1 + pr.poisson_ratio) * (1 - 2 * pr.poisson_ratio));
-    if (n) k_mpm_forces<<<pb, 128, 0, st>>>(G, n, s->P, s->order, s->solid, mu0, lambda0, pr.hardening, s->forces);
+    if (n) k_mpm_forces<<<pb, 128, 0, st>>>(G, n, s->P, nullptr, s->solid, mu0, lambda0, pr.hardening, s->forces);
     HIPCHK(hipEventRecord(s->ev[2], st));
     // populateMatrices' right-hand side (mpm.cc:383-416) and cg.solve (mpm.cc:1401-1403)
     k_mpm_rhs<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->vel, s->forces, pr.gravity[0], pr.gravity[1], pr.gravity[2],
@@ -1440,7 +1489,7 @@ int mpm_download_particles(mpm_sim_t* s, int32_t what, double* out)
     const long m = s->n;
     if (!m) return 0;
     if (ensure_stage(s, sizeof(double) * w[what] * m)) return FLUID_ERR_HIP;
-    k_mpm_to_aos<<<blocks_for((long)w[what] * m, 256), 256, 0, s->st>>>(m, s->P.cap, w[what], src[what], s->stage);
+    k_mpm_to_aos<<<blocks_for((long)w[what] * m, 256), 256, 0, s->st>>>(m, s->P.cap, w[what], s->pid, src[what], s->stage);
     HIPCHK(hipMemcpyAsync(out, s->stage, sizeof(double) * w[what] * m, hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
     return 0;
