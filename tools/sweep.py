@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Developer sweep of the marching-stencil knobs: python tools_sweep.py [n]"""
-import os, sys, json
-import numpy as np
+"""Developer sweep of the marching-stencil knobs: python tools/sweep.py [n]"""
 import os, sys
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 fs = entry.load_package()
