@@ -67,7 +67,7 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_header_is_plain_c_and_links(fs, tmp_path):
-    """include/fluid_hip.h is the drop-in boundary: it must compile as C99 (no C++ in the signatures) and a C program
+    """include/fluid_hip.h (and include/mpm_hip.h) is the drop-in boundary: it must compile as C99 (no C++ in the signatures) and a C program
     must link against libfluid_hip.so and call its host-only entry points without a GPU."""
     import subprocess
     src = tmp_path / "abi.c"
@@ -75,6 +75,7 @@ def test_header_is_plain_c_and_links(fs, tmp_path):
 #include <stdio.h>
 #include <string.h>
 #include "fluid_hip.h"
+#include "mpm_hip.h"
 int main(int argc, char** argv) {
     fluid_params_t prm;
     fluid_step_stats_t st;
@@ -90,7 +91,17 @@ int main(int argc, char** argv) {
     prm.n = 16;
     int rc = fluid_create(&prm, &sim);           /* no GPU here: must fail loudly, never fall back */
     printf("%d %s\n", rc, fluid_last_error());
-    return rc == FLUID_OK ? 4 : 0;
+    if (rc == FLUID_OK) return 4;
+    /* the second header (the snow-MPM step): C99 too, same error convention */
+    mpm_params_t mp;
+    mpm_step_stats_t ms;
+    memset(&ms, 0, sizeof ms);
+    if (mpm_default_params(&mp) != FLUID_OK || mp.B != 15 || mp.transpose_system != 1) return 5;
+    if (mpm_scene_cone(15, 13, 4, 400.f, 0, NULL) != 6205) return 6;
+    mpm_sim_t* msim = NULL;
+    rc = mpm_create(&mp, &msim);
+    printf("%d %s\n", rc, fluid_last_error());
+    return rc == FLUID_OK ? 7 : 0;
 }
 ''')
     exe = tmp_path / "abi"
