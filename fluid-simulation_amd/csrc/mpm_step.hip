@@ -1126,6 +1126,7 @@ struct mpm_sim {
     MpmState* state = nullptr;
     MpmState* h_state = nullptr;   // pinned
     int step_no = 0, num_active = 0;
+    long last_iters = 0;          // CG iterations of the previous step's solve (sizes the first unpolled batch)
     bool mid_step = false;
     mpm_step_stats_t stats{};
     double dt = 0.001;
@@ -1397,10 +1398,11 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     // at once when the device-side flag is set, and the host reads the 100-byte state once per batch.
     float ms_apply = 0;
     int n_apply = 0;
-    const int batch = 4;
+    // first batch: what the previous step's solve needed (counts change slowly from step to step), then two at a time
+    long batch = s->last_iters > 0 ? s->last_iters + 1 : 4;
     long launched = 0;
     while (!s->h_state->cg_done) {
-        for (int it = 0; it < batch; ++it) {
+        for (long it = 0; it < batch; ++it) {
             const bool timed = it == 0;
             if (timed) HIPCHK(hipEventRecord(s->ev[6], st));
             if (apply_operator(s, 1)) return FLUID_ERR_HIP;
@@ -1416,8 +1418,10 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
         if (read_state(s)) return FLUID_ERR_HIP;
         float ms = 0;
         if (hipEventElapsedTime(&ms, s->ev[6], s->ev[7]) == hipSuccess) ms_apply += ms, ++n_apply;
+        batch = 2;
     }
     const int iters = s->h_state->cg_iters;
+    s->last_iters = iters;
     const double cg_error = s->h_state->bb > 0 ? std::sqrt(s->h_state->rr / s->h_state->bb) : 0.0;
     HIPCHK(hipEventRecord(s->ev[3], st));
     k_mpm_update_velocity<<<cb, 256, 0, st>>>(G, s->solid, s->container, s->indices, s->x, s->vel);
