@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(128) k_mpm_forces(MGrid G, long n, Part P, con
 // ---- right-hand side and the "Max Force" line, mpm.cc:383-417 ----
 __global__ void k_mpm_rhs(MGrid G, const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container,
                           const double* __restrict__ vel, const double* __restrict__ forces, double g0, double g1, double g2,
-                          double* __restrict__ b, double* __restrict__ bb_part, unsigned long long* coeff_bits)
+                          double* __restrict__ b, double* __restrict__ invm, double* __restrict__ bb_part, unsigned long long* coeff_bits)
 {
     __shared__ double sh[4];
     const int na = st->num_active;
@@ -681,6 +681,7 @@ __global__ void k_mpm_rhs(MGrid G, const int* __restrict__ active_cell, const Mp
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < na; k += gridDim.x * blockDim.x) {
         const long c = active_cell[k];
         const double mi = container[c];
+        invm[k] = 1.0 / mi;
         const double f[3] = {forces[c], forces[C + c], forces[2 * C + c]};
         const double gr[3] = {g0, g1, g2};
 #pragma unroll
@@ -731,7 +732,7 @@ __global__ void k_mpm_maxforce_final(MGrid G, MpmState* st, const float* __restr
 
 // ---- the operator: y = v + beta dt^2 D^-1 K v, one thread per particle (mpm.cc:646-701 + 418-441, matrix-free) ----
 // v, y: 3 * num_active doubles in unknown order; y must hold v on entry (the identity part).
-__global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, const int* __restrict__ order, const int* __restrict__ indices, const float* __restrict__ container,
+__global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, const int* __restrict__ order, const int* __restrict__ indices, const double* __restrict__ invm,
                             const MpmState* st, double beta, int transposed, int in_solve, const double* __restrict__ v, double* __restrict__ y)
 {
     if (in_solve && st->cg_done) return;   // speculative launches past convergence do nothing
@@ -741,10 +742,26 @@ __global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, cons
     double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
     Nbh nb;
     neighbourhood(G, p, nb, true);
-    // G = sum_j v_j (x) grad w_j over the unknown nodes
-    double Gm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // one x-plane of 9 nodes at a time (its 9 index loads and 27 value loads are independent and in flight together);
+    // The kernel is a chain of dependent loads (node -> unknown number -> value).  The 27 unknown numbers are fetched first, all
+    // in flight together, and serve the gather and the scatter; everything else a node needs is indexed by that number
+    // (invm = 1 / node mass per unknown).  One array per x-plane so that the rolled plane loops below pick by select.
+    int k0[9], k1[9], k2[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int cx = nb.lo[0] + a, cy = nb.lo[1] + b, cz = nb.lo[2] + c;
+                const bool in = valid && cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
+                const int k = in ? indices[G.at(cx, cy, cz)] : -1;
+                if (a == 0) k0[3 * b + c] = k;
+                else if (a == 1) k1[3 * b + c] = k;
+                else k2[3 * b + c] = k;
+            }
+    // G = sum_j v_j (x) grad w_j over the unknown nodes, one x-plane of 9 nodes at a time (its value loads in flight together);
     // the x factors are picked by selects so that the plane loop stays rolled without indexing registers dynamically
+    double Gm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
     for (int a = 0; a < 3; ++a) {
         const double s2x = a == 0 ? nb.s2[0][0] : (a == 1 ? nb.s2[0][1] : nb.s2[0][2]);
@@ -753,14 +770,11 @@ __global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, cons
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int cx = nb.lo[0] + a, cy = nb.lo[1] + b, cz = nb.lo[2] + c;
-                const bool in = cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
-                const long cell = in ? G.at(cx, cy, cz) : 0;
-                const int k = in ? indices[cell] : -1;
+                const int k = a == 0 ? k0[3 * b + c] : (a == 1 ? k1[3 * b + c] : k2[3 * b + c]);
                 const long kk = k >= 0 ? k : 0;
                 const double g[3] = {-1 * gx * nb.s2[1][b] * nb.s2[2][c], -1 * s2x * nb.g[1][b] * nb.s2[2][c], -1 * s2x * nb.s2[1][b] * nb.g[2][c]};
                 // transposed system (what the reference's Eigen solves, see mpm_hip.h): K D^-1 v — the mass divides the input
-                const double wj = k < 0 ? 0.0 : (transposed ? 1.0 / (double)container[cell] : 1.0);
+                const double wj = k < 0 ? 0.0 : (transposed ? invm[kk] : 1.0);
                 const double vx = wj * v[3 * kk], vy = wj * v[3 * kk + 1], vz = wj * v[3 * kk + 2];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) Gm[d] += vx * g[d], Gm[3 + d] += vy * g[d], Gm[6 + d] += vz * g[d];
@@ -787,13 +801,10 @@ __global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, cons
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int cx = nb.lo[0] + a, cy = nb.lo[1] + b, cz = nb.lo[2] + c;
-                const bool in = valid && cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
-                const long cell = in ? G.at(cx, cy, cz) : 0;
-                const int k = in ? indices[cell] : -1;
+                const int k = a == 0 ? k0[3 * b + c] : (a == 1 ? k1[3 * b + c] : k2[3 * b + c]);
                 const bool ok = k >= 0;
                 const double g[3] = {-1 * gx * nb.s2[1][b] * nb.s2[2][c], -1 * s2x * nb.g[1][b] * nb.s2[2][c], -1 * s2x * nb.s2[1][b] * nb.g[2][c]};
-                const double f = !ok ? 0.0 : (transposed ? sc : sc * (1.0 / (double)container[cell]));
+                const double f = !ok ? 0.0 : (transposed ? sc : sc * invm[k]);
                 double o[3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) o[r] = seg_sum(f * (ApFt[3 * r] * g[0] + ApFt[3 * r + 1] * g[1] + ApFt[3 * r + 2] * g[2]), sg);
@@ -1121,6 +1132,7 @@ struct mpm_sim {
     int *flag = nullptr, *indices = nullptr, *active_cell = nullptr, *sums = nullptr;
     int *cell_count = nullptr, *cell_start = nullptr, *key = nullptr, *rank = nullptr, *order = nullptr;   // counting sort by base cell
     double *b = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *part = nullptr;
+    double* invm = nullptr;       // 1 / node mass per unknown
     double* stage = nullptr;
     size_t stage_bytes = 0;
     MpmState* state = nullptr;
@@ -1183,7 +1195,7 @@ int alloc_particles(mpm_sim* s, long cap)
 int apply_operator(mpm_sim* s, int in_solve)
 {
     // q holds p already (the identity part)
-    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, nullptr, s->indices, s->container, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p, s->q);
+    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, nullptr, s->indices, s->invm, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p, s->q);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1235,7 +1247,7 @@ int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
          dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C) || dalloc(&s->part, 4 * RED_BLOCKS) || dalloc(&s->state, 1);
     // unknowns live inside the walls only: (2W+1)^3 at most
     const long maxu = (long)(2 * prm->W + 1) * (2 * prm->W + 1) * (2 * prm->W + 1);
-    rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu);
+    rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu) || dalloc(&s->invm, maxu);
     if (!rc && hipHostMalloc((void**)&s->h_state, sizeof(MpmState)) != hipSuccess) rc = FLUID_ERR_HIP;
     for (int k = 0; k < 8 && !rc; ++k)
         if (hipEventCreate(&s->ev[k]) != hipSuccess) rc = FLUID_ERR_HIP;
@@ -1259,7 +1271,7 @@ int mpm_destroy(mpm_sim_t* s)
     if (!s) return 0;
     free_particles(s);
     void* a[] = {s->solid, s->container, s->output, s->massd, s->vel, s->velb, s->forces, s->flag, s->indices, s->active_cell, s->sums,
-                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage, s->cell_count, s->cell_start};
+                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage, s->cell_count, s->cell_start, s->invm};
     for (void* p : a)
         if (p) (void)hipFree(p);
     if (s->h_state) (void)hipHostFree(s->h_state);
@@ -1385,7 +1397,7 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     HIPCHK(hipEventRecord(s->ev[2], st));
     // populateMatrices' right-hand side (mpm.cc:383-416) and cg.solve (mpm.cc:1401-1403)
     k_mpm_rhs<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->vel, s->forces, pr.gravity[0], pr.gravity[1], pr.gravity[2],
-                                          s->b, s->part, &s->state->max_coeff_bits);
+                                          s->b, s->invm, s->part, &s->state->max_coeff_bits);
     k_mpm_maxforce_cell<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->forces);
     k_mpm_maxforce_final<<<1, 1, 0, st>>>(G, s->state, s->container, s->forces);
     k_mpm_cg_init<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->b, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
