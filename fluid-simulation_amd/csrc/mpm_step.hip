@@ -1188,6 +1188,7 @@ int alloc_particles(mpm_sim* s, long cap)
         dalloc(&s->pid, cap) || dalloc(&s->pid2, cap) || dalloc(&s->P2.pos, 3 * cap) || dalloc(&s->P2.vel, 3 * cap) || dalloc(&s->P2.FE, 9 * cap) ||
         dalloc(&s->P2.FP, 9 * cap) || dalloc(&s->P2.volume, cap))
         return FLUID_ERR_HIP;
+    HIPCHK(hipDeviceSynchronize());   // dalloc's hipMemset runs on the null stream, which the handle's non-blocking stream does not wait for
     return 0;
 }
 
@@ -1262,6 +1263,7 @@ int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
             for (int z = -G.B; z <= G.B; ++z) h[G.at(x, y, z)] = (std::abs(x) > G.W || std::abs(y) > G.W || std::abs(z) > G.W) ? 1 : 0;
     HIPCHK(hipMemcpy(s->solid, h.data(), C, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(s->indices, 0xFF, C * sizeof(int)));
+    HIPCHK(hipDeviceSynchronize());   // the fills above ran on the null stream; s->st is non-blocking
     *out = s;
     return 0;
 }

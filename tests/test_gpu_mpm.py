@@ -317,3 +317,27 @@ def test_solution_matches_the_references_solver_output(fs, mo):
     assert rel_l2(b, z["b"]) < 2e-6 and rel_l2(x, z["x_eigen"]) < 2e-6
     sim.step_advance()
     sim.close()
+
+
+def test_large_upload_round_trip_and_scaled_scene(fs):
+    """A large particle set on a fresh handle: what was uploaded comes back bit for bit (the device fills of freshly allocated
+    arrays must have finished before the handle's own stream writes them — a race once zeroed 219 k positions now and then),
+    and the scaled cone of bench.py's `mpm_scaled` leg keeps thousands of active nodes."""
+    B = 63
+    pos = fs.snow_cone(B=B, W=B - 2, layers=24, points_per_voxel=64.0, seed=0)
+    vel = np.random.default_rng(0).normal(size=pos.shape)
+    for _ in range(3):                                   # fresh handles, fresh allocations
+        sim = fs.MpmSim(B=B, W=B - 2)
+        assert sim.upload_particles(pos, vel) == len(pos)
+        assert np.array_equal(sim.particles(fs.MPM_P.POS), pos) and np.array_equal(sim.particles(fs.MPM_P.VEL), vel)
+        FE = sim.particles(fs.MPM_P.FE)
+        assert np.array_equal(FE, np.broadcast_to(np.eye(3), FE.shape))
+        sim.close()
+    sim = fs.MpmSim(B=B, W=B - 2)
+    sim.upload_particles(pos)
+    for _ in range(5):
+        st = sim.step()
+    assert st["num_active"] > 2500 and st["cg_iters"] > 10 and st["cg_error"] < 2.3e-16
+    p = sim.particles(fs.MPM_P.POS)
+    assert np.abs(p - pos).max() < 1.0                   # 5 steps at |v| = 50 and dt = 1e-3: a quarter of a cell
+    sim.close()
