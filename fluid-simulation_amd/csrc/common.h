@@ -348,4 +348,30 @@ template <typename T>
 void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps,
                     double wc);
 
+// the coarse levels of the cycle as one persistent launch (k_mg_coarse, float cycle only)
+constexpr int MGC_MAXL = 8;                  // = fluid_sim::MG_MAXL
+constexpr int MGC_MAXPH = 10;                // phases: restrict, down per level (<= 4 levels), tail, up per level
+constexpr int MGC_SLOT = 32 * (MGC_MAXPH + 1);   // ints per counter slot: ticket word + one word per phase, each on its own 128-byte line
+constexpr size_t MGC_SYNC_BYTES = 2 * MGC_SLOT * sizeof(int);
+template <typename T>
+struct MgCoarseArgs {
+    int nl, first, tail;        // levels of the hierarchy; the launch runs [first, tail) as legs and [tail, nl) as the tail
+    bool restrict0;             // first phase: f[first] = restriction of r_prev (the residual of level first-1, from an earlier launch)
+    MLevel m[MGC_MAXL];
+    uint8_t* cnt[MGC_MAXL];
+    T *u[MGC_MAXL], *w[MGC_MAXL], *f[MGC_MAXL];
+    const T* r_prev;
+    MgCoef<T> cf[MGC_MAXL];
+    T off[MGC_MAXL];            // off-diagonals of the tail levels
+    double wc[MGC_MAXL], wc_tail;
+    int sweeps;
+};
+size_t mg_coarse_desc_bytes();
+template <typename T>
+void launch_mg_coarse_store(hipStream_t st, const MgCoarseArgs<T>& a, void* desc, int* sync, long long* dbg, int max_blocks, int tpt, int* nblocks, size_t* lds);
+int mg_coarse_ntasks_max();   // tasks the developer trace buffer holds
+template <typename T>
+void launch_mg_coarse(hipStream_t st, const void* desc, int nblocks, size_t lds, int gen, const PcgState* ps, bool prefetch);
+int mg_coarse_max_levels();   // leg levels one launch can hold
+
 }  // namespace fl

@@ -167,12 +167,24 @@ int fluid_destroy(fluid_sim_t* s)
     if (!s) return FLUID_OK;
     if (s->st) hipStreamSynchronize(s->st);
     if (s->ds) dist_destroy(s);
+    if (s->mgc_dbg) {
+        // developer trace of the persistent coarse-level launch: {ticket taken, phase wait over, body done, stores drained} per task, 10 ns ticks
+        if (const char* path = getenv("FLUID_MGC_TRACE")) {
+            std::vector<long long> h((size_t)4 * mg_coarse_ntasks_max());
+            if (hipMemcpy(h.data(), s->mgc_dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                if (FILE* f = fopen(path, "w")) {
+                    for (size_t t = 0; t < h.size() / 4 && h[4 * t]; ++t) fprintf(f, "%zu %lld %lld %lld %lld\n", t, h[4 * t], h[4 * t + 1], h[4 * t + 2], h[4 * t + 3]);
+                    fclose(f);
+                }
+            }
+        }
+    }
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -227,6 +239,11 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     if (const char* e = getenv("FLUID_TILE_LISTS")) s->lists_force = atoi(e) != 0;
     if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
+    if (const char* e = getenv("FLUID_MG_COARSE")) s->mgc_mode = atoi(e);
+    if (const char* e = getenv("FLUID_MG_COARSE_BLOCKS")) s->mgc_max_blocks = std::max(1, atoi(e));
+    if (const char* e = getenv("FLUID_MG_COARSE_CELLS")) s->mgc_max_cells = atol(e);
+    if (const char* e = getenv("FLUID_MG_COARSE_TPT")) s->mgc_tpt = atoi(e);
+    if (const char* e = getenv("FLUID_MG_COARSE_PREFETCH")) s->mgc_prefetch = atoi(e) != 0;
     *out = nullptr;
     auto bail = [&](int rc) { fluid_destroy(s); return rc; };
 #define A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
@@ -259,6 +276,8 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     A(dalloc(&s->ps, (size_t)1)); A(dalloc(&s->ss, (size_t)1));
     A(dalloc(&s->cell_count, n + 4)); A(dalloc(&s->cell_start, n + 4));
     A(dalloc(&s->d_small, (size_t)32));
+    A(dalloc((char**)&s->mgc_desc, mg_coarse_desc_bytes())); A(dalloc((char**)&s->mgc_sync, MGC_SYNC_BYTES));
+    if (getenv("FLUID_MGC_TRACE")) A(dalloc(&s->mgc_dbg, (size_t)4 * mg_coarse_ntasks_max()));
     A(hipHostMalloc((void**)&s->h_small, 32 * sizeof(int)));
     A(hipHostMalloc((void**)&s->h_ps, 2 * sizeof(PcgState)));
     A(hipEventCreateWithFlags(&s->ev_poll[0], hipEventDisableTiming));
@@ -617,6 +636,17 @@ static int mg_setup(fluid_sim* s)
     }
     s->Zmg = s->mg_slab + o_z;
     HIPCHK(hipMemsetAsync(s->mg_slab, 0, total, s->st));
+    // which levels run inside the persistent coarse-level launch: from the first level of <= mgc_max_cells cells on (bigger
+    // levels are real work for the whole chip and keep their own launches)
+    {
+        auto cells = [&](int l) { return (long)s->mgl[l].dx * s->mgl[l].dy * s->mgl[l].dz; };
+        int first = 1;
+        while (first < tail && (cells(first) > s->mgc_max_cells || tail - first > mg_coarse_max_levels())) ++first;
+        const bool fold0 = cells(0) <= 200000;   // level 0 restricts inside its down kernel (mg_vcycle_t)
+        s->mgc_first = first;
+        s->mgc_restrict0 = s->mgc_mode >= 2 && first == 1 && !fold0;
+        s->mgc_on = s->mgc_mode >= 1 && s->mg_fp32 && !s->dist && cells(first) <= s->mgc_max_cells && (first < tail || s->mgc_restrict0);
+    }
     launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
     for (int l = 1; l < nl; ++l) launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
     HIPCHK(hipGetLastError());
@@ -655,6 +685,29 @@ static MgCoef<V> mg_coef_as(const fluid_sim* s, int level)
     c.off = (V)d.off;
     return c;
 }
+// descriptor of the persistent coarse-level launch for this solve (stream-ordered; the coefficients follow dt)
+static int mg_coarse_prepare(fluid_sim* s)
+{
+    if (!s->mgc_on) return FLUID_OK;
+    typedef float V;
+    MgCoarseArgs<V> a;
+    a.nl = s->mg_nl; a.first = s->mgc_first; a.tail = s->mg_tail; a.restrict0 = s->mgc_restrict0;
+    for (int l = 0; l < MGC_MAXL; ++l) {
+        const int q = l < a.nl ? l : a.nl - 1;
+        a.m[l] = s->mgl[q]; a.cnt[l] = s->mg_cnt[q];
+        a.u[l] = (V*)s->mg_u[q]; a.w[l] = (V*)s->mg_v[q]; a.f[l] = (V*)s->mg_f[q];
+        a.cf[l] = mg_coef_as<V>(s, q);
+        a.off[l] = (V)mg_coef(s, q).off;
+        a.wc[l] = s->mg_wc[q == 1 ? 1 : 2];
+    }
+    a.r_prev = (const V*)s->mg_r[a.first - 1];
+    a.wc_tail = s->mg_wc[3];
+    a.sweeps = s->mg_csweeps;
+    launch_mg_coarse_store<V>(s->st, a, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->mgc_max_blocks, s->mgc_tpt, &s->mgc_blocks, &s->mgc_lds);
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+
 template <typename V>
 static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
@@ -664,7 +717,10 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     auto W = [&](int l) { return (V*)s->mg_v[l]; };
     auto F = [&](int l) { return (V*)s->mg_f[l]; };
     auto R = [&](int l) { return (V*)s->mg_r[l]; };
-    for (int l = 0; l < tail; ++l) {
+    // the levels from `coarse` on run inside ONE persistent launch (float cycle; kernels_mg.hip, k_mg_coarse), the others leg by leg
+    const bool pc = s->mgc_on && sizeof(V) == 4;
+    const int coarse = pc ? s->mgc_first : tail;
+    for (int l = 0; l < coarse; ++l) {
         const MLevel& m = s->mgl[l];
         // restriction inside the down kernel (halo 3): not at a big level 0, where 5x halo reads cost more than a launch
         const bool fold = l > 0 || (long)m.dx * m.dy * m.dz <= 200000;
@@ -673,14 +729,17 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         const bool lst = s->lists_on && !fold;
         if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
         else launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps);
-        if (!fold) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
+        if (!fold && !(pc && s->mgc_restrict0)) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
     }
-    {
+    if (pc) {
+        s->stats.paths |= FLUID_PATH_MG_COARSE;
+        launch_mg_coarse<float>(s->st, s->mgc_desc, s->mgc_blocks, s->mgc_lds, (int)(s->mgc_gen++ & 1), ps, s->mgc_prefetch);
+    } else {
         V off[fluid_sim::MG_MAXL];
         for (int l = tail; l < nl; ++l) off[l] = (V)mg_coef(s, l).off;
         launch_mg_tail<V>(s->st, nl - tail, (const V*)F(tail), s->mgl + tail, s->mg_cnt + tail, U(tail), off + tail, s->mg_csweeps, ps, s->mg_wc[3]);
     }
-    for (int l = tail - 1; l >= 0; --l) {
+    for (int l = coarse - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];
         const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);  // out != u: neighbouring tiles still read u
         if (l == 0) {
@@ -727,6 +786,7 @@ static int solve_mg(fluid_sim* s)
     const int n_rz = fold ? 1 : n_rz_raw;
     int rc;
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
+    if ((rc = mg_coarse_prepare(s))) return rc;
     // Start: x = 0 like the reference's cg.solve(b) — or, by default, the previous solve's pressure (Eigen's solveWithGuess
     // form of the same loop: r0 = b - A x0, same threshold tol^2 |b|^2).  The converged p does not depend on the start
     // beyond the tolerance; a settled pool needs far fewer iterations.  r0.r0 partials travel in part_rz[1] (unused by body 0).

@@ -19,6 +19,7 @@
 // halo) and all levels of <= 4 k cells run inside one block (k_mg_tail); it computes in float inside the
 // double PCG (fluid_api.hip, mg_vcycle_t).
 #include "common.h"
+#include <cstring>
 
 namespace fl {
 
@@ -111,8 +112,23 @@ __global__ __launch_bounds__(256) void k_mg_cnt(MLevel m, const uint8_t* __restr
 
 // Coefficients by neighbour count n: diag = dg[n], 1/diag = iv[n] (tables in LDS), off-diagonal = off.
 
+// How a kernel touches the arrays that other workgroups of the SAME launch produce or consume.  Between launches plain
+// accesses are enough (a kernel boundary publishes everything); inside the persistent coarse-level kernel (k_mg_coarse)
+// every such access is an `sc1` one — stores write through, loads bypass the CU's L1 — paired with one agent-scope
+// counter add per workgroup after its stores have drained and an `sc1` poll on the consumer side (MI355X guide,
+// "Workgroup dispatch, XCD placement & inter-workgroup visibility": placement-independent, no L2 write-back fence).
+struct IoPlain {
+    template <typename X> static __device__ __forceinline__ X ld(const X* p) { return *p; }
+    template <typename X> static __device__ __forceinline__ void st(X* p, X v) { *p = v; }
+};
+struct IoSc1 {
+    template <typename X> static __device__ __forceinline__ X ld(const X* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    template <typename X> static __device__ __forceinline__ void st(X* p, X v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+
+
 // f_c = (1/8) P^T r_f : a coarse cell gathers its 4x4x4 fine neighbourhood, weights (1/4,3/4,3/4,1/4) per axis
-template <typename T>
+template <typename T, typename IO = IoPlain>
 __device__ __forceinline__ void d_restrict(const MLevel& mf, const T* __restrict__ rf, const MLevel& mc, const uint8_t* __restrict__ cnt_c,
                                            T* __restrict__ fc, long t)
 {
@@ -154,7 +170,7 @@ __device__ __forceinline__ void d_restrict(const MLevel& mf, const T* __restrict
         }
         out = acc * (T)0.125;
     }
-    fc[C] = out;
+    IO::st(fc + C, out);
 }
 
 // ---- LDS-tiled legs of the V-cycle -----------------------------------------------------------------------
@@ -192,30 +208,48 @@ __device__ __forceinline__ bool in_level(const MLevel& m, int i, int j, int k)
 // up front into registers from clamped (always readable) addresses, so the in-level tests never delay a load.
 __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
 
-template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT>
-__global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
-                                                 T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
-                                                 MgCoef<T> cf, const PcgState* ps, int gx, int gy, const int* __restrict__ tlist)
+// LDS of one tile of a leg (bytes, 16-byte aligned pieces): the legs are device functions over caller-provided LDS so that
+// the stand-alone kernels (one tile per 256-thread block) and the persistent coarse-level kernel (four tiles per
+// 1024-thread block) run the same code
+template <typename T, int TX, int TY, int TZ, bool RESTRICT>
+struct DownTile {
+    static constexpr int H = RESTRICT ? 3 : 2;
+    static constexpr int AX = TX + 2 * H, AY = TY + 2 * H, AZ = TZ + 2 * H;  // u1 and the count bytes
+    static constexpr int BX = AX - 2, BY = AY - 2, BZ = AZ - 2;              // u2
+    static constexpr int CX = BX - 2, CY = BY - 2, CZ = BZ - 2;              // r (the tile itself unless RESTRICT)
+    static constexpr int nA = AX * AY * AZ, nB = BX * BY * BZ, nR = RESTRICT ? CX * CY * CZ : 4;
+    static constexpr int oA = 0, oB = (oA + nA * (int)sizeof(T) + 15) / 16 * 16, oR = (oB + nB * (int)sizeof(T) + 15) / 16 * 16,
+                         oC = (oR + nR * (int)sizeof(T) + 15) / 16 * 16, bytes = (oC + nA + 15) / 16 * 16;
+};
+template <typename T, int TX, int TY, int TZ>
+struct UpTile {
+    static constexpr int AX = TX + 4, AY = TY + 4, AZ = TZ + 4;              // v0 = u + P e and the count bytes
+    static constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2;              // v1
+    static constexpr int EX = TX / 2 + 4, EY = TY / 2 + 4, EZ = TZ / 2 + 4;  // coarse correction under the v0 region
+    static constexpr int nA = AX * AY * AZ, nB = BX * BY * BZ, nE = EX * EY * EZ;
+    static constexpr int oA = 0, oB = (oA + nA * (int)sizeof(T) + 15) / 16 * 16, oE = (oB + nB * (int)sizeof(T) + 15) / 16 * 16,
+                         oC = (oE + nE * (int)sizeof(T) + 15) / 16 * 16, bytes = (oC + nA + 15) / 16 * 16;
+};
+
+// One tile of the down leg by 256 threads (`col` = thread within the tile's group).  sd / si: coefficient tables in LDS; with
+// `cf` the body fills them itself (after issuing its loads), else the caller has, behind a barrier.  `live` = false: a
+// group without a tile of its own walks a valid one for the barriers' sake and stores nothing.
+template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, typename IO>
+__device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
+                                             T* __restrict__ r, const MLevel& mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
+                                             const MgCoef<T>* cf, T off, int tile, int gx, int gy, bool live, int col, char* lds, T* sd, T* si)
 {
-    constexpr int H = RESTRICT ? 3 : 2;
-    constexpr int AX = TX + 2 * H, AY = TY + 2 * H, AZ = TZ + 2 * H;  // u1 and the count bytes
-    constexpr int BX = AX - 2, BY = AY - 2, BZ = AZ - 2;              // u2
-    constexpr int CX = BX - 2, CY = BY - 2, CZ = BZ - 2;              // r (the tile itself unless RESTRICT)
+    typedef DownTile<T, TX, TY, TZ, RESTRICT> D;
+    constexpr int H = D::H, AX = D::AX, AY = D::AY, AZ = D::AZ, BX = D::BX, BY = D::BY, BZ = D::BZ, CX = D::CX, CY = D::CY, CZ = D::CZ;
     constexpr int NHC = 256 / (CY * CZ), XC = (CX + NHC - 1) / NHC;   // the r columns are few: NHC threads share one, XC planes each
     static_assert(AY * AZ <= 256 && NHC >= 1 && TX % 2 == 0 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
-    __shared__ T sA[AX * AY * AZ];
-    __shared__ T sB[BX * BY * BZ];
-    __shared__ T sR[RESTRICT ? CX * CY * CZ : 1];
-    __shared__ uint8_t sC[AX * AY * AZ];
-    __shared__ T sd[8], si[8];
-    if (ps && ps->done) return;
-    const int col = threadIdx.x;
-    // 1-D launch: virtual tile ids are dealt so that each XCD (own L2) gets a contiguous run of tiles, z fastest;
-    // tlist (mostly-air box): only the tiles that hold an unknown are launched, in ascending order (k_mg_tile_flags)
-    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);
+    T* sA = (T*)(lds + D::oA);
+    T* sB = (T*)(lds + D::oB);
+    T* sR = (T*)(lds + D::oR);
+    uint8_t* sC = (uint8_t*)(lds + D::oC);
     const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
     const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
-    const T w1 = (T)MG_W1, w2 = (T)MG_W2, off = cf.off;
+    const T w1 = (T)MG_W1, w2 = (T)MG_W2;
     const long sx = m.sx;
     // ---- every global load of the block ----
     const int ya = col / AZ, za = col - ya * AZ;
@@ -229,7 +263,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
         const int i = i0 - H + x;
         const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
         const int c = cnt[q];
-        fa[x] = (T)f[q];  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
+        fa[x] = (T)IO::ld(f + q);  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
         ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
     const int yb = col / BZ, zb = col - yb * BZ;
@@ -237,7 +271,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     const size_t qb = m.at(0, clampi(j0 - H + 1 + yb, m.dy - 1), clampi(k0 - H + 1 + zb, m.dz - 1));
     T fb[BX];
 #pragma unroll
-    for (int x = 0; x < BX; ++x) fb[x] = (T)f[qb + (size_t)((long)clampi(i0 - H + 1 + x, m.dx - 1) * sx)];
+    for (int x = 0; x < BX; ++x) fb[x] = (T)IO::ld(f + qb + (size_t)((long)clampi(i0 - H + 1 + x, m.dx - 1) * sx));
     const int hc = col / (CY * CZ), cc = col - hc * (CY * CZ);
     const int yc = cc / CZ, zc = cc - yc * CZ;
     const bool actC = hc < NHC;
@@ -245,8 +279,8 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     const size_t qc = m.at(0, clampi(j0 - H + 2 + yc, m.dy - 1), clampi(k0 - H + 2 + zc, m.dz - 1));
     T fr[XC];
 #pragma unroll
-    for (int x = 0; x < XC; ++x) fr[x] = (T)f[qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx)];
-    mg_load_coef(sd, si, cf);
+    for (int x = 0; x < XC; ++x) fr[x] = (T)IO::ld(f + qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx));
+    if (cf) mg_load_coef(sd, si, *cf);
     // ---- u1 = W1 D^-1 f on region A ----
     if (actA) {
 #pragma unroll
@@ -260,7 +294,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     if (actB) {
         const int a0 = (yb + 1) * AZ + zb + 1;
         T cm = sA[a0], c0 = sA[a0 + AY * AZ];
-        const bool in_yz = (unsigned)(yb - (H - 1)) < (unsigned)TY && (unsigned)(zb - (H - 1)) < (unsigned)TZ;
+        const bool in_yz = live && (unsigned)(yb - (H - 1)) < (unsigned)TY && (unsigned)(zb - (H - 1)) < (unsigned)TZ;
 #pragma unroll
         for (int x = 0; x < BX; ++x) {
             const int a = a0 + (x + 1) * AY * AZ;
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
             const T nb = cm + cp + sA[a - AZ] + sA[a + AZ] + sA[a - 1] + sA[a + 1];
             const T v = c0 + w2 * si[n] * (fb[x] - (sd[n] * c0 + off * nb));
             sB[(x * BY + yb) * BZ + zb] = v;
-            if (n && in_yz && x >= H - 1 && x < H - 1 + TX) u[qb + (size_t)((long)(i0 - H + 1 + x) * sx)] = v;  // n != 0: in the level, no clamp
+            if (n && in_yz && x >= H - 1 && x < H - 1 + TX) IO::st(u + qb + (size_t)((long)(i0 - H + 1 + x) * sx), v);  // n != 0: in the level, no clamp
             cm = c0;
             c0 = cp;
         }
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
                 const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
                 const T v = n ? fr[x] - (sd[n] * c0 + off * nb) : (T)0;
                 if (RESTRICT) sR[((xc0 + x) * CY + yc) * CZ + zc] = v;
-                else if (n) r[qc + (size_t)((long)(i0 + xc0 + x) * sx)] = v;
+                else if (n && live) IO::st(r + qc + (size_t)((long)(i0 + xc0 + x) * sx), v);
                 cm = c0;
                 c0 = cp;
             }
@@ -297,11 +331,11 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     if (RESTRICT) {
         __syncthreads();
         constexpr int QX = TX / 2, QY = TY / 2, QZ = TZ / 2;
-        for (int t = threadIdx.x; t < QX * QY * QZ; t += 256) {
+        for (int t = col; t < QX * QY * QZ; t += 256) {
             int X, Y, Z;
             region_cell<QY, QZ>(t, X, Y, Z);
             const int I = i0 / 2 + X, J = j0 / 2 + Y, K = k0 / 2 + Z;
-            if (!in_level(mc, I, J, K)) continue;
+            if (!live || !in_level(mc, I, J, K)) continue;
             const size_t C = mc.at(I, J, K);
             if (!cnt_c[C]) continue;
             auto w = [](int a) { return (a == 0 || a == 3) ? (T)0.25 : (T)0.75; };
@@ -315,49 +349,57 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
                     acc += w(a) * w(b) * ((T)0.25 * (q[0] + q[3]) + (T)0.75 * (q[1] + q[2]));
                 }
             }
-            fc[C] = acc * (T)0.125;
+            IO::st(fc + C, acc * (T)0.125);
         }
     }
 }
 
-template <typename T, typename F, typename O, int TX, int TY, int TZ>
-__global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
-                                               O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
-                                               double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
-                                               const int* __restrict__ tlist, const uint8_t* __restrict__ own)
+template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT>
+__global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
+                                                 T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
+                                                 MgCoef<T> cf, const PcgState* ps, int gx, int gy, const int* __restrict__ tlist)
+{
+    __shared__ __attribute__((aligned(16))) char lds[DownTile<T, TX, TY, TZ, RESTRICT>::bytes];
+    __shared__ T sd[8], si[8];
+    if (ps && ps->done) return;
+    // 1-D launch: virtual tile ids are dealt so that each XCD (own L2) gets a contiguous run of tiles, z fastest;
+    // tlist (mostly-air box): only the tiles that hold an unknown are launched, in ascending order (k_mg_tile_flags)
+    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);
+    mg_down_body<T, F, TX, TY, TZ, RESTRICT, IoPlain>(m, cnt, f, u, r, mc, cnt_c, fc, &cf, cf.off, tile, gx, gy, true, threadIdx.x, lds, sd, si);
+}
+
+// One tile of the up leg by 256 threads; see mg_down_body for col / lds / sd / si / cf / live.  red: 4 doubles (part_dot only).
+template <typename T, typename F, typename O, int TX, int TY, int TZ, typename IO>
+__device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
+                                           O* __restrict__ out, const MLevel& mc, const T* __restrict__ ec, const MgCoef<T>* cf, T off,
+                                           double* __restrict__ part_dot, int tile, int gx, int gy, T wc, const uint8_t* __restrict__ own, bool live,
+                                           int col, char* lds, T* sd, T* si, double* red)
 {
     // own (decomposed run, level 0): the PCG's count bytes — the partial f.out counts the rank's owned unknowns only
     // (non-zero byte without bit 7); the result itself is written on every unknown of the local box
-    constexpr int AX = TX + 4, AY = TY + 4, AZ = TZ + 4;              // v0 = u + P e and the count bytes
-    constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2;              // v1
-    constexpr int EX = TX / 2 + 4, EY = TY / 2 + 4, EZ = TZ / 2 + 4;  // coarse correction under the v0 region
+    typedef UpTile<T, TX, TY, TZ> D;
+    constexpr int AX = D::AX, AY = D::AY, AZ = D::AZ, BX = D::BX, BY = D::BY, BZ = D::BZ, EX = D::EX, EY = D::EY, EZ = D::EZ;
     constexpr int NE = (EX * EY * EZ + 255) / 256;
     constexpr int NHT = 256 / (TY * TZ), XT = TX / NHT;               // NHT threads share a tile column, XT planes each
     static_assert(AY * AZ <= 256 && 256 % (TY * TZ) == 0 && TX % NHT == 0 && TX % 2 == 0 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
-    __shared__ T sA[AX * AY * AZ];
-    __shared__ T sB[BX * BY * BZ];
-    __shared__ T sE[EX * EY * EZ];
-    __shared__ uint8_t sC[AX * AY * AZ];
-    __shared__ T sd[8], si[8];
-    __shared__ double red[4];
-    if (ps && ps->done) return;
-    const int col = threadIdx.x;
-    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);  // see k_mg_down
+    T* sA = (T*)(lds + D::oA);
+    T* sB = (T*)(lds + D::oB);
+    T* sE = (T*)(lds + D::oE);
+    uint8_t* sC = (uint8_t*)(lds + D::oC);
     const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
     const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
     const int I0 = i0 / 2 - 2, J0 = j0 / 2 - 2, K0 = k0 / 2 - 2;
-    const T off = cf.off;
     const long sx = m.sx;
     // ---- every global load of the block ----
     T ee[NE];
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
         int x, y, z;
-        region_cell<EY, EZ>(threadIdx.x + 256 * it, x, y, z);
+        region_cell<EY, EZ>(col + 256 * it, x, y, z);
         const int I = I0 + x, J = J0 + y, K = K0 + z;
         // the coarse arrays carry a ring of zeros (indices -1 and d*), nothing beyond it
         const bool ok = I >= -1 && I <= mc.dx && J >= -1 && J <= mc.dy && K >= -1 && K <= mc.dz;
-        const T v = ec[mc.at(min(max(I, -1), mc.dx), min(max(J, -1), mc.dy), min(max(K, -1), mc.dz))];
+        const T v = IO::ld(ec + mc.at(min(max(I, -1), mc.dx), min(max(J, -1), mc.dy), min(max(K, -1), mc.dz)));
         ee[it] = ok ? v : (T)0;
     }
     const int ya = col / AZ, za = col - ya * AZ;
@@ -371,7 +413,7 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
         const int i = i0 - 2 + x;
         const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
         const int c = cnt[q];
-        ua[x] = u[q];
+        ua[x] = IO::ld(u + q);
         ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
     const int yb = col / BZ, zb = col - yb * BZ;
@@ -379,18 +421,18 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
     const size_t qb = m.at(0, clampi(j0 - 1 + yb, m.dy - 1), clampi(k0 - 1 + zb, m.dz - 1));
     T fb[BX];
 #pragma unroll
-    for (int x = 0; x < BX; ++x) fb[x] = (T)f[qb + (size_t)((long)clampi(i0 - 1 + x, m.dx - 1) * sx)];
+    for (int x = 0; x < BX; ++x) fb[x] = (T)IO::ld(f + qb + (size_t)((long)clampi(i0 - 1 + x, m.dx - 1) * sx));
     const int ht = col / (TY * TZ), ct = col - ht * (TY * TZ);
     const int yt = ct / TZ, zt = ct - yt * TZ;
     const int xt0 = ht * XT;
     const size_t qt = m.at(0, clampi(j0 + yt, m.dy - 1), clampi(k0 + zt, m.dz - 1));
     F ft[XT];  // the rhs in its own precision: level 0 dots it with the result (r.z of PCG)
 #pragma unroll
-    for (int x = 0; x < XT; ++x) ft[x] = f[qt + (size_t)((long)clampi(i0 + xt0 + x, m.dx - 1) * sx)];
-    mg_load_coef(sd, si, cf);
+    for (int x = 0; x < XT; ++x) ft[x] = IO::ld(f + qt + (size_t)((long)clampi(i0 + xt0 + x, m.dx - 1) * sx));
+    if (cf) mg_load_coef(sd, si, *cf);
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
-        const int t = threadIdx.x + 256 * it;
+        const int t = col + 256 * it;
         if (t < EX * EY * EZ) sE[t] = ee[it];
     }
     __syncthreads();
@@ -443,9 +485,9 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
             const int n = sC[((xt0 + x + 2) * AY + yt + 2) * AZ + zt + 2];
             const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
             const T o = c0 + (T)MG_W1 * si[n] * ((T)ft[x] - (sd[n] * c0 + off * nb));
-            if (n) {
+            if (n && live) {
                 const size_t qo = qt + (size_t)((long)(i0 + xt0 + x) * sx);
-                out[qo] = (O)o;  // n != 0: in the level, no clamp
+                IO::st(out + qo, (O)o);  // n != 0: in the level, no clamp
                 if (!own || (own[qo] && !(own[qo] & 0x80))) acc += (double)ft[x] * (double)o;
             }
             cm = c0;
@@ -456,6 +498,21 @@ __global__ __launch_bounds__(256) void k_mg_up(MLevel m, const uint8_t* __restri
         acc = block_sum<double, 4>(acc, red);
         if (threadIdx.x == 0) part_dot[blockIdx.x] = acc;
     }
+}
+
+template <typename T, typename F, typename O, int TX, int TY, int TZ>
+__global__ __launch_bounds__(256, 5) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
+                                               O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
+                                               double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
+                                               const int* __restrict__ tlist, const uint8_t* __restrict__ own)
+{
+    __shared__ __attribute__((aligned(16))) char lds[UpTile<T, TX, TY, TZ>::bytes];
+    __shared__ T sd[8], si[8];
+    __shared__ double red[4];
+    if (ps && ps->done) return;
+    const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);  // see k_mg_down
+    mg_up_body<T, F, O, TX, TY, TZ, IoPlain>(m, cnt, f, u, out, mc, ec, &cf, cf.off, part_dot, tile, gx, gy, wc, own, true, threadIdx.x, lds, sd, si,
+                                             red);
 }
 
 // ---- restriction of the level-0 residual (its down kernel has no room for a halo of 3) -----------------
@@ -520,13 +577,10 @@ __device__ __forceinline__ T tail_nb(const T* p, int c, int sx, int sy)
     return p[c - sx] + p[c + sx] + p[c - sy] + p[c + sy] + p[c - 1] + p[c + 1];
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* ps)
+// the whole tail by the 1024 threads of one block; tail_lds: a.lds_bytes of LDS, sd / si: [MG_TAIL_MAX][8] in LDS
+template <typename T, typename IO>
+__device__ __forceinline__ void mg_tail_body(const MgTail<T>& a, double* tail_lds, T (*sd)[8], T (*si)[8], int tid)
 {
-    extern __shared__ double tail_lds[];
-    __shared__ T sd[MG_TAIL_MAX][8], si[MG_TAIL_MAX][8];
-    if (ps && ps->done) return;
-    const int tid = threadIdx.x;
     char* base = (char*)tail_lds;
 #define TU(lv) ((T*)(base + a.o_u[lv]))
 #define TV(lv) ((T*)(base + a.o_v[lv]))
@@ -546,7 +600,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
             mg_cell(a.mg[0], tid + 1024 * q, i, j, k);
             zg[q] = (int)a.mg[0].at(i, j, k);
             z[q].n = a.cnt[0][zg[q]];
-            zf[q] = a.f0[zg[q]];
+            zf[q] = IO::ld(a.f0 + zg[q]);
         }
     }
     TailCell w[MG_TAIL_MAX];  // deeper levels: one cell per thread (w[0] unused)
@@ -678,12 +732,21 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* p
     }
 #pragma unroll
     for (int q = 0; q < MG_TAIL_Q0; ++q)
-        if (z[q].c >= 0 && z[q].n) a.u0[zg[q]] = TU(0)[z[q].c];
+        if (z[q].c >= 0 && z[q].n) IO::st(a.u0 + zg[q], TU(0)[z[q].c]);
 #undef OWN
 #undef TU
 #undef TV
 #undef TF
 #undef TC
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_mg_tail(MgTail<T> a, const PcgState* ps)
+{
+    extern __shared__ double tail_lds[];
+    __shared__ T sd[MG_TAIL_MAX][8], si[MG_TAIL_MAX][8];
+    if (ps && ps->done) return;
+    mg_tail_body<T, IoPlain>(a, tail_lds, sd, si, threadIdx.x);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -820,8 +883,7 @@ size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem)
 }
 // levels[0..nl) of the tail, f0 = rhs of lv[0] (global layout); result (the correction of lv[0]) in u0
 template <typename T>
-void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps,
-                    double wc)
+static MgTail<T> make_mg_tail(int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, double wc)
 {
     MgTail<T> a;
     a.wc = wc;
@@ -842,13 +904,234 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
     }
     a.lds_bytes = (int)o;
     a.sweeps = sweeps;
+    return a;
+}
+template <typename T>
+void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps,
+                    double wc)
+{
+    const MgTail<T> a = make_mg_tail<T>(nl, f0, lv, cnt, u0, off, sweeps, wc);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)k_mg_tail<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_TAIL_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_mg_tail<T>), dim3(1), dim3(1024), o, st, a, ps);
+    hipLaunchKernelGGL((k_mg_tail<T>), dim3(1), dim3(1024), (size_t)a.lds_bytes, st, a, ps);
 }
+
+// ---- the coarse levels of the cycle as ONE persistent launch ----------------------------------------------------------
+// At bench size the levels under level 0 hold <= 91 k cells: each of their legs (restrict, down, down, tail, up, up) was a
+// launch of 5-10 us that computes for a fraction of that — 41 of the 86 us of a PCG iteration (profiles/r02).  k_mg_coarse
+// runs them as PHASES of one launch: 1024-thread workgroups (a 256-thread leg tile by the first four waves, or the whole
+// tail by all sixteen) pull TASKS (a leg tile / 1024 restriction cells / the tail) from one ticket counter, in phase
+// order; a task of phase p starts once the done-counter of phase p-1 has reached that phase's task count.
+//   * hand-off between workgroups: every array a later phase reads is written with sc1 (write-through) stores and read
+//     with sc1 loads (IoSc1); after its stores a workgroup drains them (s_waitcnt vmcnt(0) in every wave, barrier) and ONE
+//     lane adds 1 to the phase counter (agent-scope atomic); the consumer's lane 0 polls that counter with sc1 loads and
+//     the workgroup passes a barrier before its first load.  No L2 write-back / invalidate fence anywhere (a device-scope
+//     __threadfence per workgroup is what made the earlier grid-barrier attempt lose), and nothing depends on
+//     where a workgroup runs.
+//   * progress: tickets are handed out in task order, a workgroup only ever waits for tasks with smaller tickets, and
+//     those are held by workgroups that are running — so the launch finishes with any number >= 1 of resident
+//     workgroups, and every workgroup leaves as soon as the tickets run out (each prefetches one ticket ahead; that
+//     changes nothing in the argument).
+//   * the counters live in two slots used by alternate launches (`gen`): workgroup 0 clears the slot of the NEXT launch,
+//     which nobody touches during this one, also when the solve is already done and everybody leaves at once.
+// Same arithmetic, cell for cell, as the separate launches (the legs are the same device functions).
+enum { MGC_RESTRICT = 0, MGC_DOWN = 1, MGC_TAIL = 2, MGC_UP = 3 };
+// everything a task of one phase needs, in one record: a task reads it with ONE batch of scalar loads once its ticket has
+// told it the phase (chains of dependent descriptor reads — phase table -> level -> level record -> pointers — cost a
+// task more than its arithmetic)
+template <typename T>
+struct MgcPhase {
+    int kind, level, ntasks, first;   // first = ticket of its first task
+    int gx, gy, ntiles, need;         // need = tasks of the phase before (what its counter must reach)
+    MLevel m, mc;                     // the level and the one under it (RESTRICT: the finer level and the level)
+    const uint8_t *cnt, *cnt_c;
+    const T *f, *u, *ec;              // rhs, (UP) pre-smoothed u and the coarse correction; RESTRICT: f = the finer level's residual
+    T* out;                           // DOWN: u; UP: the corrected, post-smoothed result; RESTRICT: this level's rhs
+    T* fc;                            // DOWN: rhs of the level under it
+    T diag[7], inv[7], off, wc;
+};
+template <typename T>
+struct MgCoarseDesc {
+    int nphase, ntasks, tpt, pad;
+    MgcPhase<T> ph[MGC_MAXPH];
+    MgTail<T> tail;
+    int* sync;
+    long long* dbg;   // developer trace (FLUID_MGC_TRACE): 4 wall-clock stamps per task of the last launch, else nullptr
+};
+size_t mg_coarse_desc_bytes() { return sizeof(MgCoarseDesc<double>) > sizeof(MgCoarseDesc<float>) ? sizeof(MgCoarseDesc<double>) : sizeof(MgCoarseDesc<float>); }
+int mg_coarse_max_levels() { return (MGC_MAXPH - 2) / 2; }
+
+constexpr int MGC_RX = 8, MGC_RY = 8, MGC_RZ = 8;     // down tiles (restriction folded in)
+constexpr int MGC_TX = 8, MGC_TY = 8, MGC_TZ = 16;    // up tiles
+template <typename T>
+constexpr int mgc_leg_bytes()
+{
+    return DownTile<T, MGC_RX, MGC_RY, MGC_RZ, true>::bytes > UpTile<T, MGC_TX, MGC_TY, MGC_TZ>::bytes ? DownTile<T, MGC_RX, MGC_RY, MGC_RZ, true>::bytes
+                                                                                                        : UpTile<T, MGC_TX, MGC_TY, MGC_TZ>::bytes;
+}
+
+template <typename T, bool PREFETCH>
+__global__ __launch_bounds__(1024) void k_mg_coarse(const MgCoarseDesc<T>* __restrict__ D, int gen, const PcgState* ps)
+{
+    extern __shared__ double mgc_lds[];
+    __shared__ T tsd[MG_TAIL_MAX][8], tsi[MG_TAIL_MAX][8];
+    __shared__ T sd[8], si[8];
+    __shared__ int s_task;
+    const int tid0 = threadIdx.x;
+    int* const sync = D->sync;
+    int* const slot = sync + (gen & 1) * MGC_SLOT;
+    if (blockIdx.x == 0 && tid0 <= MGC_MAXPH) sync[((gen + 1) & 1) * MGC_SLOT + 32 * tid0] = 0;
+    if (ps && ps->done) return;
+    int nxt = 0, cur = -1;
+    if (tid0 == 0) nxt = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ntasks = D->ntasks, tpt = D->tpt;
+    long long* const dbg = D->dbg;
+    int first[MGC_MAXPH];   // ticket ranges of the phases, in scalar registers for the whole launch (unused ones: INT_MAX)
+#pragma unroll
+    for (int i = 0; i < MGC_MAXPH; ++i) first[i] = D->ph[i].first;
+    for (;;) {
+        if (tid0 == 0) s_task = nxt;
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(s_task);   // wave-uniform by construction: everything read from the descriptor stays scalar
+        if (t >= ntasks) break;
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));   // opaque per task: the legs' thread -> cell arithmetic stays inside their branches (hoisted out of the loop it spills)
+        // the next ticket: asked for now (its answer is not needed before the next round) or, without PREFETCH, when this task is
+        // done — a prefetched ticket is one a faster workgroup cannot take (measured: half the workgroups ran two tiles of the
+        // first phase each while the others sat on tickets of later phases)
+        if (PREFETCH && tid == 0) nxt = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dbg && tid == 0) dbg[4 * t] = wall_clock64();
+        int p = 0;
+#pragma unroll
+        for (int i = 1; i < MGC_MAXPH; ++i) p += t >= first[i];
+        const MgcPhase<T>& P = D->ph[p];
+        const int kind = P.kind, local = t - P.first;
+        if (p != cur) {
+            // the phase before must be complete: lane 0 polls, the barrier holds everybody's loads back
+            if (tid == 0 && p > 0) {
+                const int need = P.need;
+                while (__hip_atomic_load(slot + 32 * p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+            }
+            if (tid < 7 && (kind == MGC_DOWN || kind == MGC_UP)) {
+                sd[tid] = P.diag[tid];
+                si[tid] = P.inv[tid];
+            }
+            __syncthreads();
+            cur = p;
+        }
+        if (dbg && tid == 0) dbg[4 * t + 1] = wall_clock64();
+        if (kind == MGC_RESTRICT) {
+            d_restrict<T, IoSc1>(P.m, P.f, P.mc, P.cnt_c, P.out, (long)local * 1024 + tid);
+        } else if (kind == MGC_TAIL) {
+            mg_tail_body<T, IoSc1>(D->tail, mgc_lds, tsd, tsi, tid);
+        } else {
+            // `tpt` tiles per task, one per group of 4 waves.  The legs are LDS-bound: four tiles side by side on a CU run
+            // each at a quarter of the speed, so by default a task is ONE tile and waves 4-15 only keep the barriers company
+            // (both legs pass exactly three)
+            const int grp = __builtin_amdgcn_readfirstlane(tid >> 8), col = tid & 255, ntiles = P.ntiles;
+            int tile = local * tpt + grp;
+            const bool live = tile < ntiles;
+            tile = live ? tile : ntiles - 1;
+            char* lds = (char*)mgc_lds + grp * mgc_leg_bytes<T>();
+            if (grp >= tpt) {
+                __syncthreads();
+                __syncthreads();
+                __syncthreads();
+            } else if (kind == MGC_DOWN)
+                mg_down_body<T, T, MGC_RX, MGC_RY, MGC_RZ, true, IoSc1>(P.m, P.cnt, P.f, P.out, (T*)nullptr, P.mc, P.cnt_c, P.fc, nullptr, P.off, tile, P.gx,
+                                                                        P.gy, live, col, lds, sd, si);
+            else
+                mg_up_body<T, T, T, MGC_TX, MGC_TY, MGC_TZ, IoSc1>(P.m, P.cnt, P.f, P.u, P.out, P.mc, P.ec, nullptr, P.off, nullptr, tile, P.gx, P.gy, P.wc,
+                                                                   nullptr, live, col, lds, sd, si, nullptr);
+        }
+        // publish: every wave's stores have left, then one add to the phase's counter
+        if (dbg && tid == 0) dbg[4 * t + 2] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (dbg && tid == 0) dbg[4 * t + 3] = wall_clock64();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(slot + 32 * (p + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!PREFETCH) nxt = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int mg_coarse_ntasks_max() { return 4096; }
+
+template <typename T>
+__global__ void k_mgc_store(MgCoarseDesc<T> d, MgCoarseDesc<T>* dst)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = d;
+}
+
+// Phases and tasks of the launch for levels [a.first, a.tail) + the tail; the descriptor goes to `desc` (device) by a
+// one-thread kernel on the stream (constant for a solve: the coefficients follow dt).  Returns workgroups and LDS bytes.
+template <typename T>
+void launch_mg_coarse_store(hipStream_t st, const MgCoarseArgs<T>& a, void* desc, int* sync, long long* dbg, int max_blocks, int tpt, int* nblocks, size_t* lds)
+{
+    static_assert(sizeof(MgCoarseDesc<T>) <= 4096, "the descriptor travels as a kernel argument");
+    tpt = tpt >= 4 ? 4 : (tpt >= 2 ? 2 : 1);
+    MgCoarseDesc<T> d;
+    std::memset((void*)&d, 0, sizeof d);
+    int np = 0, tk = 0, most = 1;
+    auto add = [&](int kind, int level, int ntasks, int gx, int gy, int ntiles) -> MgcPhase<T>& {
+        MgcPhase<T>& q = d.ph[np];
+        q.kind = kind; q.level = level; q.ntasks = ntasks; q.first = tk; q.gx = gx; q.gy = gy; q.ntiles = ntiles;
+        q.need = np ? d.ph[np - 1].ntasks : 0;
+        for (int k = 0; k < 7; ++k) { q.diag[k] = a.cf[level].diag[k]; q.inv[k] = a.cf[level].inv[k]; }
+        q.off = a.cf[level].off; q.wc = (T)a.wc[level];
+        ++np;
+        tk += ntasks;
+        if (ntasks > most) most = ntasks;
+        return q;
+    };
+    if (a.restrict0) {
+        const MLevel& mc = a.m[a.first];
+        MgcPhase<T>& q = add(MGC_RESTRICT, a.first, (int)(((long)mc.dx * mc.dy * mc.dz + 1023) / 1024), 0, 0, 0);
+        q.m = a.m[a.first - 1]; q.mc = mc; q.f = a.r_prev; q.cnt_c = a.cnt[a.first]; q.out = a.f[a.first];
+    }
+    for (int l = a.first; l < a.tail; ++l) {
+        const dim3 g = mg_tiles(a.m[l], MGC_RX, MGC_RY, MGC_RZ);
+        const int nt = (int)(g.x * g.y * g.z);
+        MgcPhase<T>& q = add(MGC_DOWN, l, (nt + tpt - 1) / tpt, (int)g.x, (int)g.y, nt);
+        q.m = a.m[l]; q.mc = a.m[l + 1]; q.cnt = a.cnt[l]; q.cnt_c = a.cnt[l + 1]; q.f = a.f[l]; q.out = a.u[l]; q.fc = a.f[l + 1];
+    }
+    add(MGC_TAIL, a.tail, 1, 0, 0, 0);
+    for (int l = a.tail - 1; l >= a.first; --l) {
+        const dim3 g = mg_tiles(a.m[l], MGC_TX, MGC_TY, MGC_TZ);
+        const int nt = (int)(g.x * g.y * g.z);
+        MgcPhase<T>& q = add(MGC_UP, l, (nt + tpt - 1) / tpt, (int)g.x, (int)g.y, nt);
+        q.m = a.m[l]; q.mc = a.m[l + 1]; q.cnt = a.cnt[l]; q.f = a.f[l]; q.u = a.u[l]; q.out = a.w[l];
+        q.ec = l + 1 == a.tail ? a.u[l + 1] : a.w[l + 1];   // out != u: neighbouring tiles still read u
+    }
+    for (int i = np; i < MGC_MAXPH; ++i) d.ph[i].first = 0x7fffffff;
+    d.nphase = np; d.ntasks = tk; d.tpt = tpt;
+    d.tail = make_mg_tail<T>(a.nl - a.tail, (const T*)a.f[a.tail], a.m + a.tail, a.cnt + a.tail, a.u[a.tail], a.off + a.tail, a.sweeps, a.wc_tail);
+    d.sync = sync;
+    d.dbg = tk <= mg_coarse_ntasks_max() ? dbg : nullptr;
+    hipLaunchKernelGGL((k_mgc_store<T>), dim3(1), dim3(64), 0, st, d, (MgCoarseDesc<T>*)desc);
+    *nblocks = most < max_blocks ? most : max_blocks;
+    const size_t legs = a.first < a.tail ? tpt * (size_t)mgc_leg_bytes<T>() : 0;
+    *lds = legs > (size_t)d.tail.lds_bytes ? legs : (size_t)d.tail.lds_bytes;
+}
+template <typename T>
+void launch_mg_coarse(hipStream_t st, const void* desc, int nblocks, size_t lds, int gen, const PcgState* ps, bool prefetch)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_mg_coarse<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_TAIL_LDS);
+        hipFuncSetAttribute((const void*)k_mg_coarse<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_TAIL_LDS);
+        attr_set = true;
+    }
+    if (prefetch) hipLaunchKernelGGL((k_mg_coarse<T, true>), dim3(nblocks), dim3(1024), lds, st, (const MgCoarseDesc<T>*)desc, gen, ps);
+    else hipLaunchKernelGGL((k_mg_coarse<T, false>), dim3(nblocks), dim3(1024), lds, st, (const MgCoarseDesc<T>*)desc, gen, ps);
+}
+template void launch_mg_coarse_store<float>(hipStream_t, const MgCoarseArgs<float>&, void*, int*, long long*, int, int, int*, size_t*);
+
+template void launch_mg_coarse<float>(hipStream_t, const void*, int, size_t, int, const PcgState*, bool);
 
 #define INSTMG(T)                                                                                                                        \
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*, \

@@ -126,6 +126,19 @@ struct fluid_sim {
     double mg_wc[4] = {1.25, 1.1, 1.0, 1.0};   // weight of the coarse correction at level 0 / level 1 / deeper kernel levels / inside the tail (FLUID_MG_WC=a,b,c,d)
     bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (FLUID_MG_FP64=1: double)
     double* mg_part = nullptr;    // per-block partials of r.z when a level-0 launch has more blocks than the PCG kernels re-sum
+    // the coarse levels of the cycle as one persistent launch (k_mg_coarse): levels [mgc_first, mg_tail) + the tail, optionally
+    // starting with the restriction of level 0's residual.  FLUID_MG_COARSE=0 (separate launches, the default: measured faster) |
+    // 1 (legs + tail) | 2 (+ restriction)
+    int mgc_mode = 0, mgc_max_blocks = 256, mgc_tpt = 1;   // FLUID_MG_COARSE_BLOCKS, FLUID_MG_COARSE_TPT (leg tiles per task: 1, 2, 4)
+    long mgc_max_cells = 150000;            // a level with more cells keeps its own launches (FLUID_MG_COARSE_CELLS)
+    void* mgc_desc = nullptr;     // device: MgCoarseDesc, rewritten at the start of every solve (the coefficients follow dt)
+    int* mgc_sync = nullptr;      // device: two counter slots, used by alternate launches
+    long long* mgc_dbg = nullptr; // device: per-task clock stamps of the last launch (FLUID_MGC_TRACE=file: written out by fluid_destroy)
+    unsigned mgc_gen = 0;         // launches so far (its parity picks the slot)
+    bool mgc_prefetch = false;    // FLUID_MG_COARSE_PREFETCH=1: every workgroup asks for its next ticket before it runs the current one
+    bool mgc_on = false, mgc_restrict0 = false;   // this step's plan (mg_setup)
+    int mgc_first = 0, mgc_blocks = 0;
+    size_t mgc_lds = 0;
     char* mg_slab = nullptr;      // one allocation behind every mg_* array and Zmg (re-carved each step)
     size_t mg_slab_cap = 0;
     // multi-GPU (3-D block decomposition, fluid_dist.hip)

@@ -117,6 +117,7 @@ typedef struct fluid_step_stats {
 #define FLUID_PATH_TILE_LISTS 2  /* level-0 solver kernels over the lists of tiles that hold an unknown (mostly-air box) */
 #define FLUID_PATH_DIST_DECOMPOSED 4  /* multi-GPU: window arrays, domain-decomposed PCG with the globally coupled V-cycle  */
 #define FLUID_PATH_DIST_REPLICATED 8  /* multi-GPU: particles sharded, pressure block replicated on every rank              */
+#define FLUID_PATH_MG_COARSE 16       /* the V-cycle's coarse levels ran as one persistent launch (FLUID_MG_COARSE=1|2; off by default) */
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 /* Reference defaults (N=121, g=(0,-10,0), dx=1, rho=1, max_dt=0.1, outer_tol=0.1,

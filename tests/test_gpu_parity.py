@@ -634,6 +634,32 @@ def test_forms_switch_by_themselves(fs, monkeypatch):
     assert rel_l2(pra, prb) < 1e-6 and rel_l2(pa, pb) < 1e-9 and rel_l2(va, vb) < 1e-6
 
 
+@pytest.mark.parametrize("mode,tpt", [("1", "1"), ("2", "1"), ("2", "4")])
+def test_persistent_coarse_launch_is_bit_identical(fs, mode, tpt, monkeypatch):
+    """The V-cycle's coarse levels as ONE persistent launch (k_mg_coarse: phases handed from workgroup to workgroup through
+    sc1 stores / loads and agent-scope counters, FLUID_MG_COARSE) run the same device functions as the separate launches:
+    iteration counts equal and every array bit for bit, over several steps and solves (the counter slots alternate)."""
+    n = 96   # box 33^3 -> levels 35, 18, 9, 5: a folded level 0, one leg level, a two-level tail; 176: an unfolded level 0 (box 64^3), so mode 2 restricts inside the launch
+    outs = []
+    for env in ({"FLUID_MG_COARSE": "0"}, {"FLUID_MG_COARSE": mode, "FLUID_MG_COARSE_TPT": tpt}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res = []
+        for nn in (n, 176):
+            sim = fs.FluidSim(n=nn); sim.upload_particles(fs.water_cube_drop(nn, 4, seed=3))
+            st = [sim.step() for _ in range(3)]
+            p, v = sim.download_particles()
+            res.append((st, p, v, sim.field(fs.FIELD.PRESSURE)))
+            sim.close()
+        outs.append(res)
+        for k in env:
+            monkeypatch.delenv(k)
+    for (sa, pa, va, pra), (sb, pb, vb, prb) in zip(*outs):
+        assert all(s["paths"] & 16 == 0 for s in sa) and all(s["paths"] & 16 for s in sb)
+        assert [s["cg_iters"] for s in sa] == [s["cg_iters"] for s in sb]
+        assert np.array_equal(pra, prb) and np.array_equal(pa, pb) and np.array_equal(va, vb)
+
+
 def test_edge_no_particles(fs, oracle):
     """Empty PointList: nothing is fluid, b = 0, the do..while ends on NaN after one pass (fluid.cc:1483-1484)."""
     sim = fs.FluidSim(n=24)
