@@ -86,15 +86,19 @@ def usable_cores():
 
 def pmc_traffic(kernel, n, ppc):
     """HBM/fabric bytes per launch measured by separate rocprofv3 --pmc passes of this workload (see the file's "method")."""
-    tj = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-    if n != 256 or ppc != 8 or not os.path.exists(tj):
+    tj = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r03", "r02")) if os.path.exists(q)), None)
+    if n != 256 or ppc != 8 or tj is None:
         return None
     return json.load(open(tj)).get("kernels_final", {}).get(kernel, {}).get("bytes_per_launch")
 
 
 def stencil_microbench(fs, n, device):
-    """Dense sweep q = A s over all n^3 cells, all-fluid interior (SURVEY.md 8d micro-benchmark)."""
-    out = {}
+    """Dense sweep q = A s over all n^3 cells, all-fluid interior (SURVEY.md 8d micro-benchmark), timed two ways:
+    `cache_resident` = 50 back-to-back launches over ONE (s, q, flags) set (151 MB for fp32 at 256^3: it fits the 256 MiB
+    Infinity Cache, so this is not an HBM figure), `hbm` = launches rotating over enough separate sets to exceed 1 GiB
+    (every operand byte comes from HBM and goes back to it).  The roofline evidence for the north star's
+    ">= 70 % of HBM on the pressure-stencil kernel" is the `hbm` leg."""
+    out = {"footprint_hbm_leg_bytes": 1 << 30}
     for prec, T in (("fp64", 8), ("fp32", 4)):
         sim = fs.FluidSim(n=n, precision=prec, device=device)
         F = fs.FIELD
@@ -105,13 +109,37 @@ def stencil_microbench(fs, n, device):
         s = rng.uniform(-1, 1, size=(n, n, n)) * (solid == 0)
         sim.upload_field(F.SEARCH, s)
         algo = n ** 3 * (2 * T + 1)
-        res = {"bytes_per_cell": 2 * T + 1}
+        res = {"bytes_per_cell": 2 * T + 1, "bytes_per_launch": algo}
+        rate = lambda ms: {"ms": ms, "achieved_GBs": algo / (ms * 1e-3) / 1e9, "frac_of_peak": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         for name, mode in (("march", 0), ("tiled", 2)):
             sim.stencil_apply(reps=5, box=mode)
-            ms = sim.stencil_apply(reps=50, box=mode)
-            res[name] = {"ms": ms, "achieved_GBs": algo / (ms * 1e-3) / 1e9, "frac_of_peak": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            leg = {"cache_resident": rate(sim.stencil_apply(reps=50, box=mode))}
+            ms, nsets = sim.stencil_apply_hbm(reps=56, box=mode, footprint_bytes=out["footprint_hbm_leg_bytes"])
+            leg["hbm"] = rate(ms)
+            leg["hbm"]["sets"] = nsets
+            res[name] = leg
         out[prec] = res
         sim.close()
+    return out
+
+
+def long_run_phases(ts, boxes, its_by_step):
+    """Split the drop -> splash -> pool run by what the active box does: `free_fall` until the box first widens in x or z
+    (the cube keeps its footprint while it falls), `settled` from the first step after which the box never changes
+    again, `splash` in between; per phase: steps, mean / max ms per step, substeps/s, PCG iterations and outer passes."""
+    n = len(ts)
+    ext = [(b[1][0] - b[0][0], b[1][2] - b[0][2]) for b in boxes]
+    fall_end = next((i for i in range(1, n) if ext[i][0] > ext[0][0] + 2 or ext[i][1] > ext[0][1] + 2), n)
+    settle = n
+    while settle > fall_end and boxes[settle - 1] == boxes[n - 1]:
+        settle -= 1
+    out = {}
+    for name, lo, hi in (("free_fall", 0, fall_end), ("splash", fall_end, settle), ("settled", settle, n)):
+        if hi > lo:
+            seg = np.asarray(ts[lo:hi])
+            out[name] = {"steps": [lo, hi], "mean_ms": float(seg.mean()), "max_ms": float(seg.max()), "substeps_per_s": float(1e3 / seg.mean()),
+                         "share_of_time": float(seg.sum() / np.sum(ts)), "cg_iters": int(sum(x[0] for x in its_by_step[lo:hi])),
+                         "outer_passes": int(sum(x[1] for x in its_by_step[lo:hi]))}
     return out
 
 
@@ -283,7 +311,7 @@ def main():
         ach = algo / (avg_ms * 1e-3) / 1e9
         e = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": pmc_traffic(key, n, ppc) if transport is None else None,
-             "traffic_source": "profiles/r02/pmc_traffic.json (kernels_final): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload", "algorithmic_bytes_per_launch": algo,
+             "traffic_source": "profiles/r0N/pmc_traffic.json (kernels_final; newest round present): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload", "algorithmic_bytes_per_launch": algo,
              "cells_per_launch": cells, "avg_launch_us": avg_ms * 1e3, "launches": prof["launches"], "sampled": prof["sampled"],
              "total_ms_in_timed_region": avg_ms * prof["launches"]}
         if note:
@@ -355,6 +383,9 @@ def main():
 
         if not a.no_micro and world == 1:
             out["stencil_microbench"] = {"workload": f"dense {n}^3 all-fluid interior, q=A s", **stencil_microbench(fs, n, local_rank)}
+            if n != 128:
+                # the metric names 128^3 as well: 2.1 M cells, 19 / 36 MB per set — one launch is ~5-10 us, launch-latency-bound
+                out["stencil_microbench"]["at_128"] = {"workload": "dense 128^3 all-fluid interior, q=A s", **stencil_microbench(fs, 128, local_rank)}
 
         if not a.no_micro and world == 1:
             # the same timed steps with every solve started from x0 = 0 like the reference's cg.solve(b) (fluid.cc:1474): the
@@ -371,13 +402,17 @@ def main():
             # times the free fall only
             siml = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
             siml.upload_particles(pos0)
-            ts, its, passes = [], 0, 0
+            ts, its, passes, boxes, its_by_step = [], 0, 0, [], []
             for _ in range(a.long_steps):
                 c0 = time.perf_counter()
                 st = siml.step()
                 ts.append((time.perf_counter() - c0) * 1e3)
                 its += st["cg_iters"]; passes += st["outer_passes"]
+                boxes.append((tuple(st["box_lo"]), tuple(st["box_hi"]))); its_by_step.append((st["cg_iters"], st["outer_passes"]))
             ts = np.array(ts)
+            # phases of the run by the active box: free fall (the cube has not reached the floor: the box is still the cube's), splash (the box
+            # grows), settled (from the step after which the box no longer changes)
+            out["long_run_phases"] = long_run_phases(ts, boxes, its_by_step)
             out["long_run"] = {"steps": a.long_steps, "mean_ms": float(ts.mean()), "p95_ms": float(np.percentile(ts, 95)), "max_ms": float(ts.max()),
                                "total_s": float(ts.sum() / 1e3), "substeps_per_s": float(a.long_steps / (ts.sum() / 1e3)),
                                "mean_ms_by_100": [float(ts[i:i + 100].mean()) for i in range(0, a.long_steps, 100)],
@@ -425,8 +460,14 @@ def main():
                     for _ in range(3):
                         orc.step()
                     sec = (time.perf_counter() - c0) / 3
-                    out["mpm"]["cpu_baseline"] = {"value": 1.0 / sec, "unit": "steps/s", "cores": 1, "kind": "port",
-                                                  "sample": "3 steps of the restatement (oracle/mpm_oracle.cpp) on the same scene after one warm-up step"}
+                    try:
+                        mpm_cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+                    except Exception:  # noqa: BLE001
+                        mpm_cpu = ""
+                    out["mpm"]["cpu_baseline"] = {"value": 1.0 / sec, "unit": "steps/s", "cores": 1, "cores_usable": usable_cores(), "kind": "port",
+                                                  "cpu_model": mpm_cpu, "seconds": sec * 3,
+                                                  "sample": "3 steps of the restatement (oracle/mpm_oracle.cpp; serial like mpm.cc, whose only threads are "
+                                                            "the TBB particle loops it inherits from fluid.cc) on the reference's scene after one warm-up step"}
             except Exception as e:  # noqa: BLE001 — an auxiliary leg must not cost the headline line
                 out.setdefault("mpm", {})["error"] = str(e)[:300]
 

@@ -574,6 +574,8 @@ Coef<T> fl::make_coef(const fluid_sim* s)
     c.off = (T)(float)(-1 * scale);
     return c;
 }
+template Coef<double> fl::make_coef<double>(const fluid_sim*);   // fluid_dist.hip links against these
+template Coef<float> fl::make_coef<float>(const fluid_sim*);
 
 // Both search vectors of this step, zeroed by one fill (padding and non-unknowns must read 0).
 hipError_t fl::zero_search(fluid_sim* s, size_t lb)
@@ -1204,11 +1206,10 @@ int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
     return FLUID_OK;
 }
 
-int fluid_stencil_apply(fluid_sim_t* s, int reps, int box_mode, float* avg_ms)
+// reps launches of q = A s, timed with HIP events; with nsets > 1 the launches rotate over `nsets` separate copies of
+// (s, q, flags) so that no launch finds its operands in the 256 MiB Infinity Cache (sets[i] = {s, q, flags} of copy i)
+static int stencil_run(fluid_sim* s, int reps, int box_mode, int nsets, void* const (*sets)[3], float* avg_ms)
 {
-    if (!s || reps < 1) return fail(FLUID_ERR_ARG, "bad argument");
-    if (!s->have_flags) return fail(FLUID_ERR_STATE, "stencil_apply before flags_index");
-    HIPCHK(hipSetDevice(s->prm.device));
     const int N = s->g.N;
     const Box box = box_mode == 1 ? s->Rb : Box{0, 0, 0, N - 1, N - 1, N - 1};
     if (box_empty(box)) return fail(FLUID_ERR_STATE, "empty active box");
@@ -1221,14 +1222,17 @@ int fluid_stencil_apply(fluid_sim_t* s, int reps, int box_mode, float* avg_ms)
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, s->st));
     for (int i = 0; i < reps; ++i) {
+        const void* S = nsets > 1 ? sets[i % nsets][0] : s->S[0];
+        void* Q = nsets > 1 ? sets[i % nsets][1] : s->Q;
+        const uint8_t* fl = nsets > 1 ? (const uint8_t*)sets[i % nsets][2] : s->flags;
         // box_mode 0: dense sweep (x-marching kernel; grids under 192^3 cannot fill 256 CUs with 32-plane chunks -> tiled);
         // 1: active box, tiled kernel; 2: dense sweep, tiled kernel
         if (s->prm.precision == FLUID_PRECISION_FP32) {
-            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<float>(s->st, s->g, s->flags, (const float*)s->S[0], (float*)s->Q, make_coef<float>(s), mv, mc);
-            else launch_stencil_apply<float>(s->st, s->g, box, s->flags, (const float*)s->S[0], (float*)s->Q, make_coef<float>(s));
+            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<float>(s->st, s->g, fl, (const float*)S, (float*)Q, make_coef<float>(s), mv, mc);
+            else launch_stencil_apply<float>(s->st, s->g, box, fl, (const float*)S, (float*)Q, make_coef<float>(s));
         } else {
-            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<double>(s->st, s->g, s->flags, (const double*)s->S[0], (double*)s->Q, make_coef<double>(s), mv, mc);
-            else launch_stencil_apply<double>(s->st, s->g, box, s->flags, (const double*)s->S[0], (double*)s->Q, make_coef<double>(s));
+            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<double>(s->st, s->g, fl, (const double*)S, (double*)Q, make_coef<double>(s), mv, mc);
+            else launch_stencil_apply<double>(s->st, s->g, box, fl, (const double*)S, (double*)Q, make_coef<double>(s));
         }
     }
     HIPCHK(hipEventRecord(e1, s->st));
@@ -1240,6 +1244,46 @@ int fluid_stencil_apply(fluid_sim_t* s, int reps, int box_mode, float* avg_ms)
     hipEventDestroy(e1);
     if (avg_ms) *avg_ms = ms / reps;
     return FLUID_OK;
+}
+
+int fluid_stencil_apply(fluid_sim_t* s, int reps, int box_mode, float* avg_ms)
+{
+    if (!s || reps < 1) return fail(FLUID_ERR_ARG, "bad argument");
+    if (!s->have_flags) return fail(FLUID_ERR_STATE, "stencil_apply before flags_index");
+    HIPCHK(hipSetDevice(s->prm.device));
+    return stencil_run(s, reps, box_mode, 1, nullptr, avg_ms);
+}
+
+int fluid_stencil_apply_hbm(fluid_sim_t* s, int reps, int box_mode, int64_t footprint_bytes, int32_t* nsets_out, float* avg_ms)
+{
+    if (!s || reps < 1 || footprint_bytes < 0) return fail(FLUID_ERR_ARG, "bad argument");
+    if (!s->have_flags) return fail(FLUID_ERR_STATE, "stencil_apply before flags_index");
+    HIPCHK(hipSetDevice(s->prm.device));
+    // one set = s + q + flags of the whole grid; as many sets as the requested footprint needs (at least 2: the handle's own arrays are not used)
+    const size_t se = solver_elem(s), n = s->ncell;
+    const size_t set_bytes = 2 * n * se + n;
+    int nsets = (int)((footprint_bytes + (int64_t)set_bytes - 1) / (int64_t)set_bytes);
+    nsets = std::max(2, std::min(nsets, 256));
+    std::vector<void*> mem((size_t)3 * nsets, nullptr);
+    std::vector<void*> flat(mem.size());
+    auto release = [&]() { for (void* p : mem) if (p) hipFree(p); };
+    for (int i = 0; i < nsets; ++i) {
+        hipError_t e = hipMalloc(&mem[3 * i], n * se);
+        if (e == hipSuccess) e = hipMalloc(&mem[3 * i + 1], n * se);
+        if (e == hipSuccess) e = hipMalloc(&mem[3 * i + 2], n);
+        if (e == hipSuccess) e = hipMemcpyAsync(mem[3 * i], s->S[0], n * se, hipMemcpyDeviceToDevice, s->st);
+        if (e == hipSuccess) e = hipMemsetAsync(mem[3 * i + 1], 0, n * se, s->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(mem[3 * i + 2], s->flags, n, hipMemcpyDeviceToDevice, s->st);
+        if (e != hipSuccess) { release(); return fail(FLUID_ERR_HIP, std::string("stencil_apply_hbm: ") + hipGetErrorString(e)); }
+    }
+    int rc = stencil_run(s, std::min(reps, nsets), box_mode, nsets, (void* const (*)[3])mem.data(), nullptr);   // first touch of every set, untimed
+    if (!rc) rc = stencil_run(s, reps, box_mode, nsets, (void* const (*)[3])mem.data(), avg_ms);
+    // the result of the last launch, where fluid_download_field(FLUID_FIELD_Q) finds it
+    if (!rc && hipMemcpyAsync(s->Q, mem[3 * ((reps - 1) % nsets) + 1], n * se, hipMemcpyDeviceToDevice, s->st) != hipSuccess) rc = fail(FLUID_ERR_HIP, "stencil_apply_hbm: copy back");
+    hipStreamSynchronize(s->st);
+    release();
+    if (nsets_out) *nsets_out = nsets;
+    return rc;
 }
 
 static int hook_device(int32_t device)

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(MY * 64) void k_stencil_march(Grid g, int cxlen, in
     const bool hv = hduty && hy >= 0 && hy < N && hz >= 0 && hz < N;
     const long hcol = (long)hy * N + hz;
     auto ld = [&](int x, long colx, bool ok, T& val, uint8_t& f) {
-        if (ok && x >= 0 && x < N) {
+        if (ok && x >= 0 && x < N && x <= xe) {   // plane xe is the last one this chunk reads (x+ neighbour of its last plane)
             const long c = (long)x * sx + colx;
             f = flags[c];
             val = s[c];
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(MY * 64) void k_stencil_vec(Grid g, int cxlen, int 
     const long rcol = (long)y * N + rz;
     auto act = [](uint8_t f) { return (f & F_FLUID) && (f >> F_CNT_SHIFT); };
     auto ldv = [&](int x, long colx, bool ok, vec& val, fvec& f) {
-        if (ok && x >= 0 && x < N) {
+        if (ok && x >= 0 && x < N && x <= xe) {   // plane xe is the last one this chunk reads
             const long c = (long)x * sx + colx;
             f = *reinterpret_cast<const fvec*>(flags + c);
             val = *reinterpret_cast<const vec*>(s + c);
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(MY * 64) void k_stencil_vec(Grid g, int cxlen, int 
         }
     };
     auto lds1 = [&](int x, long colx, bool ok, T& val, uint8_t& f) {
-        if (ok && x >= 0 && x < N) {
+        if (ok && x >= 0 && x < N && x <= xe) {
             const long c = (long)x * sx + colx;
             f = flags[c];
             val = s[c];
@@ -1010,16 +1010,428 @@ static void vec_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, 
     hipLaunchKernelGGL((k_stencil_vec<T, MY, MD>), dim3(nty * ntz * ncx), dim3(MY * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
 }
 
-// variant = MY*100 + MD of the one-cell-per-lane march, 10000 + MY*100 + MD of the 16-bytes-per-lane march; cxlen = planes per chunk.
-// 0 = the measured best at 256^3 (tools/sweep.py, profiles/r02/stencil_sweep.txt): float: 16 bytes per lane, MY 4, MD 2, 16 planes
-// (5.9 TB/s = 73 % of the HBM peak; one cell per lane: 4.6 TB/s); double: one cell per lane, MY 16, MD 4, 32 planes (6.3 TB/s = 79 %;
-// two cells per lane: 5.6 TB/s — the 8-byte lanes already fill their 512-byte wave loads).
+// ---- dense sweep, x-marching, independent waves ("rows") ---------------------------------------------------------------
+// Measured from HBM (launches rotating over > 1 GiB of operands, fluid_stencil_apply_hbm) the LDS-plane marches above reach
+// 53-59 % of the peak where a plain copy of the same arrays with the flag stream reaches 72-75 %: a block's waves are
+// coupled by one barrier per plane (the slowest load of 16 waves sets the pace, and HBM latency varies far more than the
+// Infinity Cache's), and every block re-reads a rim that its neighbours own.  Here a WAVE is the unit: it owns R
+// consecutive z rows (V = 16 / sizeof(T) cells per lane, 64 V cells per row segment) and marches them through a chunk
+// of x planes; per plane it loads rows y0-1 .. y0+R itself, 16 bytes per lane each — the two outer rows are some other
+// wave's own rows, fetched at about the same time, so they come from L2 — keeps the x neighbours in registers and takes
+// the z neighbours inside a lane from registers, across lanes from two shuffles.  No LDS plane, no barrier in the loop:
+// every wave streams like a copy loop with MD planes in flight.  Same term order as the other forms (bit-identical).
+template <typename T, int R, int MD>
+__global__ __launch_bounds__(256) void k_stencil_rows(Grid g, int cxlen, int nyg, int ntz, const uint8_t* __restrict__ flags,
+                                                      const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    typedef typename VecT<T, V>::type vec;
+    typedef typename FlagT<V>::type fvec;
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int N = g.N;
+    const long sx = (long)N * N;
+    // wave id: blocks dealt XCD-contiguously, the 4 waves of a block are neighbours in (z, y)
+    const int w = xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    const int tz = w % ntz, yg = (w / ntz) % nyg, cx = w / (ntz * nyg);
+    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
+    if (xa >= N) return;
+    const int y0 = yg * R, z0 = tz * MZV + lane * V;
+    const bool zin = z0 < N;   // N % V == 0: a lane's cells are all inside or all outside
+    // z rim of the wave's segment: lane 0 the cell before it, lane 63 the cell after it
+    const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
+    const bool rduty = (lane == 0 || lane == 63) && rz >= 0 && rz < N;
+    auto act = [](uint8_t f) { return (f & F_FLUID) && (f >> F_CNT_SHIFT); };
+    auto mkv = [&](vec v, fvec f) {
+        vec o;
+#pragma unroll
+        for (int c = 0; c < V; ++c) o[c] = act((uint8_t)(f >> (8 * c))) ? v[c] : (T)0;
+        return o;
+    };
+    struct Plane {
+        vec v[R + 2];     // rows y0-1 .. y0+R
+        fvec f[R + 2];
+        T rv[R];          // rim cells of the own rows
+        uint8_t rf[R];
+    };
+    auto load = [&](int x, Plane& P) {
+        const bool xok = x >= 0 && x < N && x <= xe;
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) {
+            const int y = y0 - 1 + j;
+            if (xok && zin && y >= 0 && y < N) {
+                const long c = (long)x * sx + (long)y * N + z0;
+                P.f[j] = *reinterpret_cast<const fvec*>(flags + c);
+                P.v[j] = *reinterpret_cast<const vec*>(s + c);
+            } else {
+                P.f[j] = 0;
+                P.v[j] = (vec)(T)0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int y = y0 + j;
+            if (xok && rduty && y < N) {
+                const long c = (long)x * sx + (long)y * N + rz;
+                P.rf[j] = flags[c];
+                P.rv[j] = s[c];
+            } else {
+                P.rf[j] = 0;
+                P.rv[j] = 0;
+            }
+        }
+    };
+    Plane A[MD];
+    vec sm1[R], cen[R + 2];
+    fvec f0[R];
+    T rim[R];
+    {
+        Plane P;
+        load(xa - 1, P);
+#pragma unroll
+        for (int j = 0; j < R; ++j) sm1[j] = mkv(P.v[j + 1], P.f[j + 1]);
+        load(xa, P);
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) cen[j] = mkv(P.v[j], P.f[j]);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            f0[j] = P.f[j + 1];
+            rim[j] = act(P.rf[j]) ? P.rv[j] : (T)0;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < MD; ++d) load(xa + 1 + d, A[d]);
+    for (int xb = xa; xb < xe; xb += MD) {
+#pragma unroll
+        for (int d = 0; d < MD; ++d) {
+            const int x = xb + d;
+            if (x < xe) {  // wave-uniform
+                vec nxt[R + 2];
+#pragma unroll
+                for (int j = 0; j < R + 2; ++j) nxt[j] = mkv(A[d].v[j], A[d].f[j]);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const vec s0 = cen[j + 1], up = cen[j], dn = cen[j + 2], sp1 = nxt[j + 1];
+                    T left = __shfl_up(s0[V - 1], 1, 64), right = __shfl_down(s0[0], 1, 64);
+                    if (lane == 0) left = rim[j];
+                    if (lane == 63) right = rim[j];
+                    vec out;
+#pragma unroll
+                    for (int c = 0; c < V; ++c) {
+                        const uint8_t fc = (uint8_t)(f0[j] >> (8 * c));
+                        const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
+                        const T nb = sm1[j][c] + sp1[c] + up[c] + dn[c] + zl + zr;
+                        out[c] = act(fc) ? sdiag[fc >> F_CNT_SHIFT] * s0[c] + cf.off * nb : (T)0;
+                    }
+                    if (zin && y0 + j < N) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sx + (long)(y0 + j) * N + z0]));
+                    sm1[j] = s0;
+                    f0[j] = A[d].f[j + 1];
+                    rim[j] = act(A[d].rf[j]) ? A[d].rv[j] : (T)0;
+                }
+#pragma unroll
+                for (int j = 0; j < R + 2; ++j) cen[j] = nxt[j];
+                load(x + 1 + MD, A[d]);
+            }
+        }
+    }
+}
+
+template <typename T, int R, int MD>
+static void rows_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    const int nyg = (g.N + R - 1) / R, ntz = (g.N + MZV - 1) / MZV, ncx = (g.N + cxlen - 1) / cxlen;
+    const long waves = (long)nyg * ntz * ncx;
+    hipLaunchKernelGGL((k_stencil_rows<T, R, MD>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, cxlen, nyg, ntz, flags, s, q, cf);
+}
+
+// ---- dense sweep, x-marching, lean ("lean") -----------------------------------------------------------------------------
+// The marches above spend ~70 instructions per cell, half of them scalar branches (every guarded load and every
+// `active ? .. : 0` became a branch): from HBM they stop at 53-59 % of the peak where a copy of the same bytes reaches
+// 72-75 % (tools/sweep.py 256 hbm).  Same data flow as k_stencil_vec — one row of 64 V cells per wave and plane, x
+// neighbours in registers, y neighbours through one double-buffered LDS plane, one barrier per plane — rebuilt for a
+// short instruction stream:
+//   * loads are unconditional, from clamped addresses; what lies outside the grid is masked, planes outside the
+//     chunk's reach are skipped by ONE wave-uniform branch;
+//   * the "unknown" predicate of the V flag bytes of a lane is formed on the packed word (SWAR) and expanded to one
+//     all-ones / zero word per cell (v_bfe_i32); values are masked by AND, results too: no per-cell branch;
+//   * the rim rows (y0 - 1, y0 + MY) belong to two EXTRA waves that only load, mask and publish them, so no wave of the
+//     block carries two rows to the barrier;
+//   * z neighbours across lanes by DPP wave shifts (zero fill at the wave's ends = the grid's edge when a row is one
+//     wave's width; else lanes 0 / 63 load the two rim cells).
+// Same term order as the other forms: bit-identical results.
+template <typename T>
+__device__ __forceinline__ T dpp_wave_shr1(T v)   // lane i <- lane i-1, lane 0 <- 0
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+    } else {
+        const long long b = __builtin_bit_cast(long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, true);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | lo);
+    }
+}
+template <typename T>
+__device__ __forceinline__ T dpp_wave_shl1(T v)   // lane i <- lane i+1, lane 63 <- 0
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+    } else {
+        const long long b = __builtin_bit_cast(long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x130, 0xf, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x130, 0xf, 0xf, true);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | lo);
+    }
+}
+// v where the mask word is all ones, +0 where it is zero
+template <typename T>
+__device__ __forceinline__ T and_mask(T v, int m)
+{
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_bit_cast(int, v) & m);
+    else return __builtin_bit_cast(T, __builtin_bit_cast(long long, v) & (long long)m);   // m sign-extends
+}
+
+// AXIS = the axis of the march: 0 = x (a wave steps from plane to plane: successive loads of a wave lie N^2 elements apart),
+// 1 = y (a wave owns one z row segment of ONE x plane and walks it row by row: its loads are one contiguous stream of N-element
+// rows; the waves of a block are MY neighbouring x planes and exchange the x neighbours through the LDS plane, the y neighbours
+// stay in registers).  The sum keeps the order x-, x+, y-, y+, z-, z+ either way.
+// MODE 1 (probe): q = masked s with the same loads, stores and march, no LDS, barrier or arithmetic.
+template <typename T, int MY, int MD, int MODE = 0, int AXIS = 0>
+__global__ __launch_bounds__((MY + 2) * 64) void k_stencil_lean(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
+                                                                const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    typedef typename VecT<T, V>::type vec;
+    typedef typename FlagT<V>::type fvec;
+    __shared__ __attribute__((aligned(16))) T pl[2][MY + 2][MZV];
+    __shared__ T sdiag[8], sinv[8];
+    const int tid = threadIdx.x, wy = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    load_coef(sdiag, sinv, cf);
+    const int N = g.N;
+    const long sm = AXIS == 0 ? (long)N * N : (long)N;   // stride of the march axis (index m below)
+    const long sr = AXIS == 0 ? (long)N : (long)N * N;   // stride of the row axis (index r: the waves of a block)
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tz = vb % ntz, ty = (vb / ntz) % nty, cx = vb / (ntz * nty);
+    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
+    const int xlast = xe < N ? xe : N - 1;          // last march index anybody of this chunk reads
+    const bool own = wy < MY;                       // waves MY, MY+1: the rim rows
+    const int y = own ? ty * MY + wy : (wy == MY ? ty * MY - 1 : ty * MY + MY);
+    const int lrow = own ? wy + 1 : (wy == MY ? 0 : MY + 1);
+    const int z0 = tz * MZV + lane * V;
+    const bool cv = y >= 0 && y < N && z0 < N;      // N % V == 0: a lane's cells are all inside or all outside
+    const unsigned cvm = cv ? 0xFFFFFFFFu : 0u;
+    const long col = (long)min(max(y, 0), N - 1) * sr + min(z0, N - V);
+    // z rim (only when a row is wider than one wave): lane 0 the cell before the wave's range, lane 63 the cell after it
+    const bool rims = ntz > 1;
+    const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
+    const bool rv = own && (lane == 0 || lane == 63) && y < N && rz >= 0 && rz < N;
+    const long rcol = (long)min(max(y, 0), N - 1) * sr + min(max(rz, 0), N - 1);
+    // per-cell masks (all ones / zero) of a packed flag word: unknown = fluid and at least one non-solid neighbour
+    auto active_bits = [](unsigned w) { return (w >> 1) & ((((w >> 2) & 0x07070707u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u; };
+    auto mkv = [&](vec v, unsigned a) {
+        vec o;
+#pragma unroll
+        for (int c = 0; c < V; ++c) o[c] = and_mask<T>(v[c], __builtin_amdgcn_sbfe((int)a, 8 * c, 1));
+        return o;
+    };
+    auto ldp = [&](int x, vec& v, unsigned& w) {   // one step of this wave's row: x is wave-uniform
+        if (x >= 0 && x <= xlast) {
+            const long c = (long)x * sm + col;
+            w = (unsigned)*reinterpret_cast<const fvec*>(flags + c) & cvm;
+            v = *reinterpret_cast<const vec*>(s + c);
+        } else {
+            w = 0;
+            v = (vec)(T)0;
+        }
+    };
+    auto ldr = [&](int x, T& v, unsigned& f) {     // the rim cell of lanes 0 / 63
+        v = 0;
+        f = 0;
+        if (rims && x >= 0 && x <= xlast) {
+            const long c = (long)x * sm + rcol;
+            f = rv ? flags[c] : 0;
+            v = s[c];
+        }
+    };
+    vec vm1, v0;
+    unsigned wm1, w0, rf0;
+    T r0;
+    ldp(xa - 1, vm1, wm1);
+    ldp(xa, v0, w0);
+    ldr(xa, r0, rf0);
+    vec qv[MD];
+    unsigned qw[MD], rqf[MD];
+    T rq[MD];
+#pragma unroll
+    for (int d = 0; d < MD; ++d) {
+        ldp(xa + 1 + d, qv[d], qw[d]);
+        ldr(xa + 1 + d, rq[d], rqf[d]);
+    }
+    vec sm1 = mkv(vm1, active_bits(wm1)), s0 = mkv(v0, active_bits(w0));
+    T rim = and_mask<T>(r0, __builtin_amdgcn_sbfe((int)active_bits(rf0), 0, 1));
+    const T off = cf.off;
+    __syncthreads();  // coef table
+    for (int xb = xa; xb < xe; xb += MD) {
+#pragma unroll
+        for (int d = 0; d < MD; ++d) {
+            const int x = xb + d;
+            if (x < xe) {  // block-uniform
+                const int buf = x & 1;
+                if (MODE == 1) {
+                    if (own && cv) __builtin_nontemporal_store(s0, reinterpret_cast<vec*>(&q[(long)x * sm + col]));
+                    s0 = mkv(qv[d], active_bits(qw[d]));
+                    ldp(x + 1 + MD, qv[d], qw[d]);
+                    continue;
+                }
+                *reinterpret_cast<vec*>(&pl[buf][lrow][lane * V]) = s0;
+                __syncthreads();
+                const unsigned an = active_bits(qw[d]);
+                const vec sp1 = mkv(qv[d], an);
+                if (own) {   // wave-uniform
+                    const vec up = *reinterpret_cast<const vec*>(&pl[buf][lrow - 1][lane * V]);
+                    const vec dn = *reinterpret_cast<const vec*>(&pl[buf][lrow + 1][lane * V]);
+                    T left = dpp_wave_shr1<T>(s0[V - 1]), right = dpp_wave_shl1<T>(s0[0]);
+                    if (rims) {
+                        left = lane == 0 ? rim : left;
+                        right = lane == 63 ? rim : right;
+                    }
+                    const unsigned a0 = active_bits(w0);
+                    vec out;
+#pragma unroll
+                    for (int c = 0; c < V; ++c) {
+                        const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
+                        const T nb = AXIS == 0 ? sm1[c] + sp1[c] + up[c] + dn[c] + zl + zr : up[c] + dn[c] + sm1[c] + sp1[c] + zl + zr;
+                        const T r = sdiag[__builtin_amdgcn_ubfe(w0, 8 * c + F_CNT_SHIFT, 3)] * s0[c] + off * nb;
+                        out[c] = and_mask<T>(r, __builtin_amdgcn_sbfe((int)a0, 8 * c, 1));
+                    }
+                    if (cv) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sm + col]));  // streamed once: keep s, not q, in cache
+                }
+                sm1 = s0;
+                s0 = sp1;
+                w0 = qw[d];
+                rim = and_mask<T>(rq[d], __builtin_amdgcn_sbfe((int)active_bits(rqf[d]), 0, 1));
+                ldp(x + 1 + MD, qv[d], qw[d]);
+                ldr(x + 1 + MD, rq[d], rqf[d]);
+            }
+        }
+    }
+}
+
+template <typename T, int MY, int MD, int MODE = 0, int AXIS = 0>
+static void lean_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZV - 1) / MZV, ncx = (g.N + cxlen - 1) / cxlen;
+    hipLaunchKernelGGL((k_stencil_lean<T, MY, MD, MODE, AXIS>), dim3(nty * ntz * ncx), dim3((MY + 2) * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
+}
+
+// ---- streaming probes (developer: FLUID_MARCH_VARIANT=20001 / 20002): what a plain copy of the same arrays reaches ----
+// 20001: q = s, 16 bytes per lane, non-temporal stores; 20002: q = active(flag) ? s : 0 (adds the 1-byte-per-cell flag stream).
+// They bound what the stencil sweep can reach from HBM on this part (tools/sweep.py ... hbm).
+template <typename T, bool FLAGS>
+__global__ __launch_bounds__(256) void k_stream_probe(long n16, const uint8_t* __restrict__ flags, const T* __restrict__ s, T* __restrict__ q)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef typename VecT<T, V>::type vec;
+    typedef typename FlagT<V>::type fvec;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        vec v = reinterpret_cast<const vec*>(s)[i];
+        if (FLAGS) {
+            const fvec f = reinterpret_cast<const fvec*>(flags)[i];
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+                const uint8_t fc = (uint8_t)(f >> (8 * c));
+                v[c] = ((fc & F_FLUID) && (fc >> F_CNT_SHIFT)) ? v[c] : (T)0;
+            }
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<vec*>(q) + i);
+    }
+}
+
+// variant = MY*100 + MD of the one-cell-per-lane march, 10000 + ... of the 16-bytes-per-lane march, 30000 + R*100 + MD of the
+// barrier-free rows form, 40000 / 60000 + MY*100 + MD of the lean march along x / y, 20001 / 20002 / 5xxxx / 7xxxx: copy probes;
+// cxlen = planes per chunk.  0 = the measured best at 256^3 FROM HBM (tools/sweep.py 256 hbm ..., profiles/r03/stencil_sweep_hbm.txt):
+// the lean march along x, 4 rows + 2 rim waves per block, 2 planes in flight, chunks of 16 (float) / 32 (double) planes —
+// 4.4 TB/s (float) and 4.9 TB/s (double) where a copy of the same arrays with the flag stream reaches 5.8 / 5.9 TB/s.  Every
+// form of the march measured lands within 5 % of that — one cell or 16 bytes per lane, with or without the LDS plane and its
+// barrier, 70 or 15 instructions per cell, along x or along y (each wave one contiguous stream), and the march run as a plain
+// copy (no LDS, no arithmetic) as well: the gap to the linear copy is not in the kernel's arithmetic or synchronisation.
 template <typename T>
 void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen)
 {
     constexpr int V = 16 / (int)sizeof(T);
     const bool can_vec = g.N % V == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)q & 15) == 0;
-    if (can_vec && ((variant == 0 && sizeof(T) == 4) || variant >= 10000)) {
+    if (variant >= 60000 && can_vec) {   // 60000 + MY*100 + MD: the lean march along y (every wave one contiguous stream); 70000 + ...: as a copy (probe)
+        if (cxlen <= 0) cxlen = 32;
+        switch (variant - 60000) {
+        case 402: lean_launch<T, 4, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 403: lean_launch<T, 4, 3, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 404: lean_launch<T, 4, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 602: lean_launch<T, 6, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 604: lean_launch<T, 6, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 802: lean_launch<T, 8, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 804: lean_launch<T, 8, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 1402: lean_launch<T, 14, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 1404: lean_launch<T, 14, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 10402: lean_launch<T, 4, 2, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 10804: lean_launch<T, 8, 4, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
+        default: lean_launch<T, 8, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        }
+        return;
+    }
+    if (variant >= 40000 && can_vec) {   // 40000 + MY*100 + MD: the lean LDS-plane march, MY rows (+ 2 rim waves), MD planes in flight
+        if (cxlen <= 0) cxlen = 32;
+        switch (variant - 40000) {
+        case 402: lean_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 403: lean_launch<T, 4, 3>(st, g, cxlen, flags, s, q, cf); break;
+        case 404: lean_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 602: lean_launch<T, 6, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 604: lean_launch<T, 6, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 802: lean_launch<T, 8, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 803: lean_launch<T, 8, 3>(st, g, cxlen, flags, s, q, cf); break;
+        case 804: lean_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 806: lean_launch<T, 8, 6>(st, g, cxlen, flags, s, q, cf); break;
+        case 1402: lean_launch<T, 14, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 1404: lean_launch<T, 14, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 10402: lean_launch<T, 4, 2, 1>(st, g, cxlen, flags, s, q, cf); break;   // probe: the march as a copy
+        case 10802: lean_launch<T, 8, 2, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 10804: lean_launch<T, 8, 4, 1>(st, g, cxlen, flags, s, q, cf); break;
+        default: lean_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
+        }
+        return;
+    }
+    if (variant >= 30000 && can_vec) {   // 30000 + R*100 + MD: independent waves, R rows each, MD planes in flight
+        if (cxlen <= 0) cxlen = 32;
+        switch (variant - 30000) {
+        case 101: rows_launch<T, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 102: rows_launch<T, 1, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 103: rows_launch<T, 1, 3>(st, g, cxlen, flags, s, q, cf); break;
+        case 104: rows_launch<T, 1, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 201: rows_launch<T, 2, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 202: rows_launch<T, 2, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 203: rows_launch<T, 2, 3>(st, g, cxlen, flags, s, q, cf); break;
+        case 401: rows_launch<T, 4, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 402: rows_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
+        default: rows_launch<T, 1, 2>(st, g, cxlen, flags, s, q, cf); break;
+        }
+        return;
+    }
+    if (variant >= 20000 && can_vec) {
+        const long n16 = (long)g.cells() / V;
+        const int nb = cxlen > 0 ? cxlen * 256 : 2048;
+        if (variant == 20001) hipLaunchKernelGGL((k_stream_probe<T, false>), dim3(nb), dim3(256), 0, st, n16, flags, s, q);
+        else hipLaunchKernelGGL((k_stream_probe<T, true>), dim3(nb), dim3(256), 0, st, n16, flags, s, q);
+        return;
+    }
+    if (variant == 0 && can_vec) {
+        if (sizeof(T) == 4) lean_launch<T, 4, 2>(st, g, 16, flags, s, q, cf);
+        else lean_launch<T, 4, 2>(st, g, 32, flags, s, q, cf);
+        return;
+    }
+    if (can_vec && variant >= 10000) {
         const int v = variant >= 10000 ? variant - 10000 : 402;
         if (cxlen <= 0) cxlen = 16;
         switch (v) {

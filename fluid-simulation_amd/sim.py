@@ -220,6 +220,13 @@ class FluidSim:
         check(lib.fluid_stencil_apply(self._h, reps, box, C.byref(ms)))
         return ms.value
 
+    def stencil_apply_hbm(self, reps=1, box=0, footprint_bytes=1 << 30):
+        """The same sweep rotating over separate copies of (s, q, flags) that together exceed `footprint_bytes`
+        (well above the 256 MiB Infinity Cache): returns (ms per launch, sets used)."""
+        ms, ns = C.c_float(), C.c_int32()
+        check(lib.fluid_stencil_apply_hbm(self._h, reps, box, footprint_bytes, C.byref(ns), C.byref(ms)))
+        return ms.value, ns.value
+
     # ---- profiling -----------------------------------------------------------------------
     def profile_enable(self, sample_every):
         check(lib.fluid_profile_enable(self._h, sample_every))

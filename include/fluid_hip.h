@@ -186,6 +186,11 @@ int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
  * timed with HIP events on the handle's stream; avg_ms = mean duration of one launch.
  * box: 0 = dense sweep over all N^3 cells, 1 = active box only. */
 int fluid_stencil_apply(fluid_sim_t* s, int reps, int box, float* avg_ms);
+/* The same, HBM-proof: the launches rotate over `nsets` separate copies of (s, q, flags), as many as `footprint_bytes` needs
+ * (one set = (2 T + 1) N^3 bytes; at least 2), so that with a footprint well above the 256 MiB Infinity Cache no launch
+ * finds its operands cached — fluid_stencil_apply's back-to-back launches over ONE set of 151 MB (fp32, 256^3) do.
+ * nsets_out: the number of sets used.  q of the last launch is left in the handle's FLUID_FIELD_Q. */
+int fluid_stencil_apply_hbm(fluid_sim_t* s, int reps, int box, int64_t footprint_bytes, int32_t* nsets_out, float* avg_ms);
 
 /* ---- known-answer hooks ------------------------------------------------------------------- */
 /* w[i] = spline(x[i]) (fluid.cc:22-37) evaluated by the DEVICE function the P2G / G2P kernels use (which = 0), or the

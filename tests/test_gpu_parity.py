@@ -363,8 +363,9 @@ def test_particles_roundtrip_order(fs):
 @pytest.mark.parametrize("n", [64, 66, 200])
 def test_marching_stencil_forms_agree(fs, n, monkeypatch):
     """The dense-sweep kernels of the stencil micro-benchmark: the scalar march, the 16-bytes-per-lane march (4 floats / 2
-    doubles per lane, z neighbours by wave shuffles) in several tile shapes, and the LDS-tiled kernel give the same bits
-    (n = 66: the float form falls back to the scalar march, rows are not 16-byte aligned)."""
+    doubles per lane, z neighbours by wave shuffles) in several tile shapes, and the LDS-tiled kernel give the same bits, and so does
+    the barrier-free form in which every wave marches R rows of its own (n = 66: the float forms fall back to the scalar march, rows
+    are not 16-byte aligned)."""
     F = fs.FIELD
     for prec in ("fp64", "fp32"):
         sim = fs.FluidSim(n=n, precision=prec)
@@ -379,7 +380,9 @@ def test_marching_stencil_forms_agree(fs, n, monkeypatch):
         sim.stencil_apply(reps=1, box=2)
         want = sim.field(F.Q)
         assert np.abs(want).max() > 0
-        for variant, cx in (("10000", "16"), ("10404", "8"), ("11604", "32"), ("10202", "5"), ("1604", "32"), ("804", "7")):
+        for variant, cx in (("10000", "16"), ("10404", "8"), ("11604", "32"), ("10202", "5"), ("1604", "32"), ("804", "7"),
+                            ("30102", "32"), ("30103", "7"), ("30202", "16"), ("30401", "9"), ("40402", "16"), ("40804", "32"), ("41402", "5"), ("40603", "9"), ("60402", "32"), ("60804", "7"), ("61402", "256"),
+                            ("0", "0")):   # 3xxxx: independent waves, R rows each
             monkeypatch.setenv("FLUID_MARCH_VARIANT", variant)
             monkeypatch.setenv("FLUID_MARCH_CX", cx)
             sim.upload_field(F.Q if False else F.SEARCH, s)
@@ -408,6 +411,10 @@ def test_stencil_apply_dense(fs, oracle):
         sim.stencil_apply(reps=1, box=0)      # x-marching kernel
         q = sim.field(F.Q)
         assert np.array_equal(q, q_tiled), "marching and tiled stencil kernels disagree"
+        # the HBM-proof form of the micro-benchmark (launches rotating over separate copies of s, q, flags): same result
+        for mode in (0, 2):
+            ms, nsets = sim.stencil_apply_hbm(reps=5, box=mode, footprint_bytes=4 * s.nbytes * 3)
+            assert nsets >= 4 and ms > 0 and np.array_equal(sim.field(F.Q), q)
         # numpy reference: diag count = non-solid neighbours, off = float32(-scale)
         scale = np.float64(sim.dt)
         acc = np.float32(0); table = [np.float32(0)]
