@@ -44,9 +44,15 @@ def parse():
     ap.add_argument("--no-long-run", action="store_true", help="skip the 500-step drop -> splash -> pool run (long_run key)")
     ap.add_argument("--long-steps", type=int, default=500, help="steps of the long run (the reference's loop runs 500, fluid.cc:1368)")
     ap.add_argument("--no-mpm", action="store_true", help="skip the snow-MPM leg (`mpm` key; SURVEY 8(f) f4)")
-    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1: do not run the weak-scaling leg (256 N^(1/3) cells per axis, decomposed solve)")
-    ap.add_argument("--no-alt-mode", action="store_true", help="N > 1: do not time the other form of the multi-GPU pressure block as well")
-    ap.add_argument("--dist-solve", default="auto", choices=["auto", "decomposed", "replicated"], help="multi-GPU pressure block (FLUID_DIST_*)")
+    # N > 1 extras are OFF unless asked for: they run collectives after the timed region, and a rank that fails inside one (an
+    # out-of-memory while building a second handle) must not be able to cost the run its headline line
+    ap.add_argument("--weak-leg", action="store_true", help="N > 1: also run the weak-scaling leg (256 N^(1/3) cells per axis, decomposed solve)")
+    ap.add_argument("--alt-mode", action="store_true", help="N > 1: also time the other form of the multi-GPU pressure block")
+    ap.add_argument("--no-weak-leg", action="store_true", help=argparse.SUPPRESS)   # (accepted for older command lines: the legs are off by default)
+    ap.add_argument("--no-alt-mode", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-solve", default="decomposed", choices=["auto", "decomposed", "replicated"],
+                    help="multi-GPU pressure block (FLUID_DIST_*).  Default: the domain-decomposed solve, the one BASELINE configs[3] names; "
+                         "auto = the library's own choice (replicates the pressure block below 384^3)")
     ap.add_argument("--force-dist", action="store_true", help="run the decomposed code path even with one rank (overhead check)")
     ap.add_argument("--sample-every", type=int, default=32, help="bracket every k-th PCG launch (and every k/8-th P2G / sort / G2P / solve) with a hipEvent pair; each record stalls the stream ~5-10 us")
     return ap.parse_args()
@@ -214,6 +220,13 @@ def main():
     barrier()
     t1 = time.perf_counter()
     sim.profile_enable(0)
+    per_rank_particles = None
+    if transport is not None:
+        import torch
+        cnt = torch.zeros(world, device="cuda", dtype=torch.int64)
+        cnt[rank] = sim.num_live()
+        dist.all_reduce(cnt)
+        per_rank_particles = [int(x) for x in cnt.tolist()]
     if transport is not None and stats:
         solve_mode = "replicated" if stats[0]["paths"] & 8 else "decomposed"
     elapsed = t1 - t0
@@ -225,12 +238,36 @@ def main():
 
     # N > 1: the same steps with the OTHER form of the multi-GPU pressure block, timed the same way, reported beside the
     # headline as `alt_mode` (no multi-GPU box is available to the builder: this is how both forms get measured)
-    alt = None
-    if (world > 1 or a.force_dist) and not a.no_alt_mode:
-        other = "replicated" if solve_mode == "decomposed" else "decomposed"
+    def all_ok(flag):
+        """Every rank takes a leg or none does: MIN over the ranks of `this rank built its handle`."""
+        import torch
+        t = torch.tensor([1 if flag else 0], device="cuda", dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def build_leg(make):
+        """Construct and upload a leg's handle; (handle or None, error text).  No collective inside a rank-local try."""
         try:
-            sim_alt = fd.DistFluidSim(n, dims, cuts, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve=other)
-            sim_alt.upload_global(pos0)
+            return make(), ""
+        except Exception as e:  # noqa: BLE001
+            return None, str(e)[:300]
+
+    alt = None
+    if (world > 1 or a.force_dist) and a.alt_mode:
+        other = "replicated" if solve_mode == "decomposed" else "decomposed"
+        def make_alt():
+            h = fd.DistFluidSim(n, dims, cuts, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve=other)
+            h.upload_global(pos0)
+            return h
+        sim_alt, err_alt = build_leg(make_alt)
+        if not all_ok(sim_alt is not None):
+            if sim_alt is not None:
+                sim_alt.close()
+            alt = {"pressure_block": other, "error": err_alt or "another rank could not build the handle"}
+            sim_alt = None
+        try:
+            if sim_alt is None:
+                raise StopIteration
             for _ in range(a.warmup):
                 sim_alt.step()
             barrier()
@@ -245,20 +282,32 @@ def main():
             alt = {"pressure_block": other, "value": a.steps / el, "unit": "substeps/s", "ms_per_step": el / a.steps * 1e3,
                    "cg_iters_total": sum(x["cg_iters"] for x in st_alt), "outer_passes_total": sum(x["outer_passes"] for x in st_alt)}
             sim_alt.close()
+        except StopIteration:
+            pass
         except Exception as e:  # noqa: BLE001
             alt = {"pressure_block": other, "error": str(e)[:300]}
 
     # N > 1: a WEAK-scaling leg beside the strong-scaling headline — the cells per GPU of the 256^3 workload kept fixed, i.e. a grid of
     # 256 N^(1/3) cells per axis (8 GPUs: BASELINE configs[4], 512^3 with 4 particles per cell; fewer GPUs: 8 per cell), decomposed solve
     weak = None
-    if (world > 1 or a.force_dist) and not a.no_weak_leg and n == 256:
-        try:
-            nw = int(round(256 * world ** (1.0 / 3.0) / 8.0)) * 8
-            ppcw = 4 if nw >= 512 else 8
-            posw = fs.water_cube_drop(nw, ppcw, seed=a.seed)
+    if (world > 1 or a.force_dist) and a.weak_leg and n == 256:
+        nw = int(round(256 * world ** (1.0 / 3.0) / 8.0)) * 8
+        ppcw = 4 if nw >= 512 else 8
+        posw = fs.water_cube_drop(nw, ppcw, seed=a.seed)
+        def make_weak():
             cutsw = fd.partition_blocks(nw, posw, dims)
-            simw = fd.DistFluidSim(nw, dims, cutsw, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve="decomposed")
-            simw.upload_global(posw)
+            h = fd.DistFluidSim(nw, dims, cutsw, comm, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend, dist_solve="decomposed")
+            h.upload_global(posw)
+            return h
+        simw, err_w = build_leg(make_weak)
+        if not all_ok(simw is not None):
+            if simw is not None:
+                simw.close()
+            weak = {"error": err_w or "another rank could not build the handle"}
+            simw = None
+        try:
+            if simw is None:
+                raise StopIteration
             for _ in range(a.warmup):
                 simw.step()
             barrier()
@@ -275,9 +324,11 @@ def main():
                     "cg_iters_total": sum(x["cg_iters"] for x in stw), "num_active_last": stw[-1]["num_active"],
                     "note": "one GPU runs 512^3 / 4 per cell at 72 substeps/s (profiles/r02/bench_512_single_gpu.json)"}
             simw.close()
-            del posw
+        except StopIteration:
+            pass
         except Exception as e:  # noqa: BLE001
             weak = {"error": str(e)[:300]}
+        del posw
 
     if rank != 0:
         if dist is not None:
@@ -353,7 +404,10 @@ def main():
                      else "P2G fields all-reduced, pressure block replicated on every GPU") + f"; transport {transport}")},
         "roofline": roof,
         "roofline_others": roof_others,
-        **({"pressure_block": solve_mode, "alt_mode": alt, "weak_leg": weak} if world > 1 or a.force_dist else {}),
+        **({"pressure_block": solve_mode,
+            "pressure_block_note": "value = ONE simulation on N GPUs with the pressure block in this form; decomposed (the default with N > 1) is the domain "
+                                   "decomposition BASELINE configs[3] names; --dist-solve replicated / auto and --alt-mode time the other form",
+            "particles_per_rank_last": per_rank_particles, "alt_mode": alt, "weak_leg": weak} if world > 1 or a.force_dist else {}),
         "step_stats": {"num_active_last": stats[-1]["num_active"], "outer_passes_total": sum(s["outer_passes"] for s in stats),
                        "cg_iters_total": sum(s["cg_iters"] for s in stats), "relres_last": stats[-1]["relres"],
                        "cg_iters_note": "solves start from the previous pressure (FLUID_START_WARM): not the reference's x0 = 0 count, see cg_iters_total_x0_zero",

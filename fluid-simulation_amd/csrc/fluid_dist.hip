@@ -221,6 +221,29 @@ int comm_allreduce(fluid_sim* s, void* buf, long count, int dtype, int op)
     return FLUID_OK;
 }
 
+// Every rank learns whether ANY rank failed since the last agreement, and all of them leave the step with the same code:
+// MAX over the ranks of a local flag (stream-ordered all-reduce of one int + the read-back).  A rank that hits an error
+// between two communication calls must not simply return — its peers would wait for it in the next exchange for ever
+// (RCCL has no timeout) — so the few places where a step can still fail on ONE rank (growing the particle arrays for
+// what migrates in) bring their result here BEFORE the next data exchange.  Everything else a step needs is sized for
+// the whole block when the handle is created (fluid_create_dist), so that no step allocates.
+int dist_agree(fluid_sim* s, int local_rc)
+{
+    DistState* d = s->ds;
+    int* flag = d->h_cnt + 96;
+    *flag = local_rc ? 1 : 0;
+    hipError_t e = hipMemcpyAsync(d->d_cnt + 96, flag, sizeof(int), hipMemcpyHostToDevice, s->st);
+    // (a failure of these two copies or of the stream leaves no way to tell the peers: that is a dead device, not a full one)
+    if (e == hipSuccess && d->comm.allreduce(d->comm.ctx, d->d_cnt + 96, 1, FLUID_DT_I32, FLUID_OP_MAX, (void*)s->st) != 0)
+        return fail(FLUID_ERR_HIP, "comm callback failed: agreement all-reduce");
+    if (e == hipSuccess) e = hipMemcpyAsync(flag, d->d_cnt + 96, sizeof(int), hipMemcpyDeviceToHost, s->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+    if (e != hipSuccess) return fail(FLUID_ERR_HIP, std::string("agreement: ") + hipGetErrorString(e));
+    if (local_rc) return local_rc;   // (fluid_last_error() already says what failed here)
+    if (*flag) return fail(FLUID_ERR_PEER, "another rank failed in this step (fluid_last_error() there says why); the step was abandoned on every rank");
+    return FLUID_OK;
+}
+
 // ---- particles: migration + ghosts + sort ----------------------------------------------------------------------------------
 // The routing round of a step (k_route: owners-to-be and ghosts in one go): count per direction, exchange the counts, write and
 // exchange the records, append what arrived behind the live particles.
@@ -256,17 +279,24 @@ int route_round(fluid_sim* s)
         stot += d->h_cnt[dd];
         rtot += d->h_cnt[32 + dd];
     }
-    // room for what arrives (a block's share grows as the fluid spreads into it): grown on demand, never a per-rank failure
-    // that would leave the peers waiting in the next exchange
-    if (stot > d->mig_cap || rtot > d->mig_cap) {
-        HIPCHK(hipStreamSynchronize(s->st));
-        hipFree(d->mig_s); hipFree(d->mig_r);
-        d->mig_s = d->mig_r = nullptr;
-        d->mig_cap = std::max(stot, rtot) * 3 / 2 + 4096;
-        HIPCHK(hipMalloc((void**)&d->mig_s, (size_t)d->mig_cap * 56));
-        HIPCHK(hipMalloc((void**)&d->mig_r, (size_t)d->mig_cap * 56));
-    }
-    if ((rc = grow_particles(s, s->p_off + s->np + rtot))) return rc;
+    // room for what arrives (a block's share grows as the fluid spreads into it): grown on demand — the one allocation a
+    // step can still need.  The peers are about to send: whether every rank has the room is agreed before anybody does.
+    auto grow = [&]() -> int {
+        if (stot > d->mig_cap || rtot > d->mig_cap) {
+            HIPCHK(hipStreamSynchronize(s->st));
+            hipFree(d->mig_s); hipFree(d->mig_r);
+            d->mig_s = d->mig_r = nullptr;
+            d->mig_cap = 0;
+            const long cap = std::max(stot, rtot) * 3 / 2 + 4096;
+            if (getenv("FLUID_DIST_FAIL_GROW") && atoi(getenv("FLUID_DIST_FAIL_GROW")) == d->comm.rank)   // (tests: a rank that cannot grow)
+                return fail(FLUID_ERR_HIP, "migration buffers: allocation refused (FLUID_DIST_FAIL_GROW)");
+            HIPCHK(hipMalloc((void**)&d->mig_s, (size_t)cap * 56));
+            HIPCHK(hipMalloc((void**)&d->mig_r, (size_t)cap * 56));
+            d->mig_cap = cap;
+        }
+        return grow_particles(s, s->p_off + s->np + rtot);
+    };
+    if ((rc = dist_agree(s, grow()))) return rc;
     int cur[27];
     for (int dd = 0; dd < 27; ++dd) cur[dd] = (int)soff[dd];
     memcpy(d->h_cnt + 64, cur, sizeof(cur));
@@ -1038,6 +1068,42 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
         const int org[3] = {g.ox, g.oy, g.oz};
         if (hipMemset(s->indices, 0xFF, s->ncell * sizeof(int)) != hipSuccess) return bail("indices fill failed");   // -1: no unknown yet (fluid.cc:1388)
         make_plan(d, d->plan_flags, [&](int r) { return block_of(d, r); }, HALO_W, org, 0, g.sx(), g.nz);
+    }
+    // Every buffer whose size follows the active box is sized NOW for a box that fills the whole block: a step then never
+    // allocates (except for particles that migrate in, dist_agree), so no rank can fail alone between two exchanges.
+    {
+        const long N = p->n;
+        const long on[3] = {d->ob.hi[0] - d->ob.lo[0], d->ob.hi[1] - d->ob.lo[1], d->ob.hi[2] - d->ob.lo[2]};
+        auto shell = [&](int w) { return (on[0] + 2 * w) * (on[1] + 2 * w) * (on[2] + 2 * w) - on[0] * on[1] * on[2]; };
+        size_t stage = 0;
+        if (d->repl) {
+            stage = (size_t)24 * N * N * N;                                  // the all-gather of u, v, w over the whole box
+            d->repl_cap = 4 * (size_t)N * N * N;
+            if (!(d->dims[0] <= 2 && d->dims[1] <= 2 && d->dims[2] <= 2) && hipMalloc((void**)&d->repl_buf, d->repl_cap * sizeof(double)) != hipSuccess)
+                return bail("replicated mode: gather buffer");
+        } else {
+            stage = std::max((size_t)48 * shell(1), (size_t)8 * shell(HALO_W));   // six doubles, 1 wide; one double, HALO_W wide
+            const long lsplit = std::max(300000L, (N / 4 + 2) * (N / 4 + 2) * (N / 4 + 2));   // the gathered level (level 1 while small, else level 2)
+            stage = std::max(stage, (size_t)8 * lsplit);
+            d->rows_cap = (size_t)N * N * d->dims[2] + 1024;
+            if (hipMalloc((void**)&d->rows, d->rows_cap * sizeof(int)) != hipSuccess || hipMalloc((void**)&d->row_starts, d->rows_cap * sizeof(int)) != hipSuccess)
+                return bail("row numbering tables");
+            // multigrid slab: the level-0 arrays never exceed the solver vectors' capacity (lmax); the deeper local levels add 1/7
+            // of that, the gathered ones the level counted above; types + counts + u, v, f, r (the cycle's own precision) + z
+            const size_t es = s->mg_fp32 ? 4 : 8;
+            const size_t cap = (size_t)((double)(s->lmax + 4096) * 1.2 * (2 + 4 * es)) + 8 * (s->lmax + 4096) + (size_t)lsplit * 2 * (2 + 4 * es) + (1 << 20);
+            if (hipMalloc((void**)&s->mg_slab, cap) != hipSuccess) return bail("multigrid slab");
+            s->mg_slab_cap = cap;
+        }
+        if (ensure_stage(s, stage + 4096, stage + 4096)) return bail("halo staging buffers");
+        const Box ownW = to_box(IBox{{d->ob.lo[0], d->ob.lo[1], d->ob.lo[2]}, {d->ob.hi[0], d->ob.hi[1], d->ob.hi[2]}}, (const int[3]){g.ox, g.oy, g.oz});
+        const size_t need = (size_t)12 * ownW.cells(), ni = 4 + 4 * (size_t)p2g_max_items(ownW);
+        if (hipMalloc((void**)&s->p2g_part, need * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->p2g_items, ni * sizeof(int)) != hipSuccess ||
+            hipMemset(s->p2g_items, 0, 4 * sizeof(int)) != hipSuccess)
+            return bail("P2G partials / work list");
+        s->p2g_part_cap = need; s->p2g_items_cap = ni;
+        s->stats.outer_passes = 0;
+        if (pic_fields(s)) return bail("PIC fields");
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail("device sync failed");
     return FLUID_OK;

@@ -342,6 +342,10 @@ class DistFluidSim(FluidSim):
         assert got == n
         return pos, vel, ids
 
+    def num_live(self):
+        """Particles this rank owns now (after a step: without the ghosts it served)."""
+        return int(lib.fluid_download_particles_ids(self._h, None, None, None))
+
     def window_field(self, fid):
         """The handle's whole array (block + halo; the whole grid in replicated mode)."""
         from .sim import _FIELD_DTYPE

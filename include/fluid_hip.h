@@ -35,6 +35,7 @@ typedef struct fluid_sim fluid_sim_t;
 #define FLUID_ERR_HIP 2      /* HIP runtime error (no device, OOM, launch)     */
 #define FLUID_ERR_STATE 3    /* call order (e.g. step before upload_particles) */
 #define FLUID_ERR_SOLVER 4   /* PCG hit the iteration cap / broke down         */
+#define FLUID_ERR_PEER 5     /* multi-GPU: another rank failed in this step; every rank returns together */
 
 /* field ids for fluid_download_field / fluid_upload_field */
 #define FLUID_FIELD_CONTAINER 0   /* float32 N^3  particle weight density (fluid.cc:1157,1413)        */

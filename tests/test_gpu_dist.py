@@ -199,6 +199,53 @@ def test_block_empties_and_fills(fs, slack, monkeypatch):
     compare(d, ref, len(pos), "fills", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
 
 
+def test_a_rank_that_cannot_grow_fails_every_rank(fs, monkeypatch):
+    """The one allocation a step can still need is room for particles that migrate in.  When ONE rank cannot get it
+    (FLUID_DIST_FAIL_GROW names the rank), every rank must leave that step with an error — the one that failed with its own,
+    the others with FLUID_ERR_PEER — instead of waiting for it in the next exchange for ever.  The threads here do NOT wake
+    each other (no fluid_local_group_abort): each has to return by itself."""
+    import threading
+    monkeypatch.setenv("FLUID_DIST_SLACK", "64")
+    monkeypatch.setenv("FLUID_DIST_FAIL_GROW", "1")
+    fd = fs.load_dist()
+    n, steps, dims = 48, 12, (1, 2, 2)
+    pos, _ = scene(fs, n, 4)
+    pos = pos + np.array([6.0, 9.0, 0.0])        # off-centre: the low-y blocks start empty and must grow when the water arrives
+    cuts = fd.uniform_cuts(n, dims)
+    grp = fd.LocalGroup(4)
+    sims, result = [None] * 4, [None] * 4
+
+    def work(r):
+        sim = fd.DistFluidSim(n, dims, cuts, grp.comms[r], dist_solve="decomposed")
+        sims[r] = sim
+        sim.upload_global(pos)
+        for i in range(steps):
+            try:
+                sim.step()
+            except Exception as e:  # noqa: BLE001
+                result[r] = (i, getattr(e, "code", None), str(e))
+                return
+        result[r] = (steps, 0, "")
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=180)
+    hung = [r for r, x in enumerate(th) if x.is_alive()]
+    if hung:
+        fd.lib.fluid_local_group_abort(grp.handle)     # let the stuck threads go before failing
+    assert not hung, f"ranks {hung} are still waiting for a peer that has returned"
+    print(result)
+    assert len({res[0] for res in result}) == 1 and result[0][0] < steps       # all of them, in the same step
+    assert result[1][1] == 2 and "refused" in result[1][2]                      # FLUID_ERR_HIP where it happened
+    assert all(result[r][1] == 5 and "another rank failed" in result[r][2] for r in (0, 2, 3))   # FLUID_ERR_PEER elsewhere
+    for s in sims:
+        if s is not None:
+            s.close()
+    grp.close()
+
+
 @pytest.mark.parametrize("n,ppc", [(256, 8), (512, 4)])
 def test_baseline_multi_gpu_configs_on_blocks(fs, n, ppc):
     """BASELINE.json configs[3] (256^3 domain-decomposed 2 x 2 x 2) and configs[4] (512^3, 4 particles per cell, 8 GPUs) AT SIZE,
@@ -277,3 +324,27 @@ def test_one_rank_over_rccl(fs, tmp_path, mode):
     assert list(d["num_active"]) == [s["num_active"] for s in ref["st"]]
     assert np.array_equal(d["indices"], ref["indices"])
     assert rel_l2(d["pos"], ref["pos"]) < 1e-9 and rel_l2(d["vel"], ref["vel"]) < 1e-7
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("mode", ["rccl", "device"])
+@pytest.mark.parametrize("world,solve", [(2, "decomposed"), (2, "replicated"), (4, "decomposed"), (8, "decomposed")])
+def test_real_peers_over_rccl(fs, tmp_path, world, solve, mode):
+    """One process per GPU with real peers: grouped ncclSend / ncclRecv between blocks and ncclAllReduce over xGMI, through the
+    library's own RCCL transport (`rccl`) and through torch's (`device`).  Skipped on a box with fewer GPUs than ranks (the
+    builder's boxes have one): it wakes up on the first multi-GPU box and checks the run against one GPU before bench.py does."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs, {_gpus()} visible")
+    n, ppc, steps = (64, 4, 4) if world <= 2 else (96, 4, 4)
+    d = run_dist(world, n, ppc, steps, tmp_path, ("--solve", solve), mode=mode)
+    pos, _ = scene(fs, n, ppc)
+    ref = single(fs, n, pos, None, steps)
+    assert list(d["num_active"]) == [s["num_active"] for s in ref["st"]]
+    assert list(d["outer"]) == [s["outer_passes"] for s in ref["st"]]
+    assert np.array_equal(d["indices"], ref["indices"])
+    assert np.array_equal(d["ids"], np.arange(len(pos)))
+    assert rel_l2(d["pos"], ref["pos"]) < 1e-9 and rel_l2(d["vel"], ref["vel"]) < 1e-7 and rel_l2(d["pressure"], ref["pressure"]) < 1e-8
