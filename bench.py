@@ -160,6 +160,9 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
+        if world == 1:   # --force-dist outside a launcher: a rendezvous of one
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(29600 + os.getpid() % 300))):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     fs = entry.load_package()
 

@@ -111,6 +111,14 @@ struct DistState {
     uint8_t* cnt_pcg = nullptr;
     double *gstage[2] = {nullptr, nullptr}, *gpq = nullptr;
     long n_routed = 0;                // particles sent away so far (statistics)
+    // overlap of the residual's halo exchange with the interior tiles of the level-0 down leg (FLUID_DIST_OVERLAP=0: off)
+    bool overlap = true;
+    hipStream_t st2 = nullptr;        // the exchange runs here while the solver's stream sweeps the tiles that read no halo cell
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+    int *tl_int = nullptr, *tl_bnd = nullptr;   // level-0 down-leg tiles (k_mg_down numbering): those that read no received cell / the others
+    size_t tl_cap = 0;
+    int n_int = 0, n_bnd = 0;
+    std::vector<int> h_tl;            // host copy behind the (stream-ordered) upload
 };
 
 namespace {
@@ -207,6 +215,42 @@ int halo_exchange(fluid_sim* s, HaloPlan& p, int elem, int narr, void* const* ar
     COMMCHK(d->comm.exchange(d->comm.ctx, p.n, p.peer, sb, sn, rb, rn, (void*)s->st));
     launch_halo_copy(s->st, p.rcv, elem, d->hr, false);
     HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+// The same exchange with the transfer and the unpack on the second stream: returns once the pack is queued on the solver's
+// stream; the caller queues work that reads no received cell and then makes its stream wait for ev_halo (halo_wait).
+int halo_exchange_begin(fluid_sim* s, HaloPlan& p, int elem, void* a)
+{
+    DistState* d = s->ds;
+    if (p.n == 0) return FLUID_OK;
+    int rc = ensure_stage(s, p.stotal * elem, p.rtotal * elem);
+    if (rc) return rc;
+    p.snd.narr = p.rcv.narr = 1;
+    for (int k = 0; k < HALO_MAX_ARR; ++k) p.snd.arr[k] = p.rcv.arr[k] = a;
+    launch_halo_copy(s->st, p.snd, elem, d->hs, true);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(d->ev_pack, s->st));
+    HIPCHK(hipStreamWaitEvent(d->st2, d->ev_pack, 0));
+    return FLUID_OK;
+}
+int halo_exchange_end(fluid_sim* s, HaloPlan& p, int elem)
+{
+    DistState* d = s->ds;
+    if (p.n == 0) return FLUID_OK;
+    const void* sb[HALO_MAX_BOX];
+    void* rb[HALO_MAX_BOX];
+    size_t sn[HALO_MAX_BOX], rn[HALO_MAX_BOX];
+    for (int k = 0; k < p.n; ++k) {
+        sb[k] = d->hs + (size_t)p.snd.off[k] * elem;
+        rb[k] = d->hr + (size_t)p.rcv.off[k] * elem;
+        sn[k] = p.scount[k] * elem;
+        rn[k] = p.rcount[k] * elem;
+    }
+    COMMCHK(d->comm.exchange(d->comm.ctx, p.n, p.peer, sb, sn, rb, rn, (void*)d->st2));
+    launch_halo_copy(d->st2, p.rcv, elem, d->hr, false);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(d->ev_halo, d->st2));
+    HIPCHK(hipStreamWaitEvent(s->st, d->ev_halo, 0));
     return FLUID_OK;
 }
 int halo_exchange1(fluid_sim* s, HaloPlan& p, int elem, void* a)
@@ -585,6 +629,38 @@ int dist_mg_setup(fluid_sim* s)
         make_plan(d, L.plan, [&](int r) { return own_l(l, r); }, HALO_W, L.dom.lo, (long)L.m.at(0, 0, 0), L.m.sx, L.m.sy);
     }
     s->mgl[0] = d->lv[0].m;
+    // Level-0 down-leg tiles by what they read (k_mg_down<..., 8, 8, 16, false>: the tile + 2 cells): the tiles that touch no cell
+    // the residual's halo exchange writes can be swept while that exchange is in flight
+    d->n_int = d->n_bnd = 0;
+    if (d->overlap && !ib_empty(d->lv[0].dom) && d->lv[0].plan.n > 0) {
+        const MLevel& m0 = d->lv[0].m;
+        const HaloPlan& hp = d->lv[0].plan;
+        constexpr int TX = 8, TY = 8, TZ = 16, H = 2;   // = MG_TX, MG_TY, MG_TZ of kernels_mg.hip
+        const int gx = (m0.dz + TZ - 1) / TZ, gy = (m0.dy + TY - 1) / TY, gz = (m0.dx + TX - 1) / TX, nt = gx * gy * gz;
+        d->h_tl.assign((size_t)2 * nt, 0);
+        int* li = d->h_tl.data();
+        int* lb = li + nt;
+        for (int t = 0; t < nt; ++t) {
+            const int tbx = t % gx, tby = (t / gx) % gy, tbz = t / (gx * gy);
+            const int lo[3] = {tbz * TX - H, tby * TY - H, tbx * TZ - H}, hi[3] = {tbz * TX + TX + H, tby * TY + TY + H, tbx * TZ + TZ + H};
+            bool touches = false;
+            for (int k = 0; k < hp.n && !touches; ++k) {
+                if (!hp.rcount[k]) continue;
+                bool hit = true;
+                for (int a = 0; a < 3; ++a) hit = hit && lo[a] < hp.rcv.lo[k][a] + hp.rcv.n[k][a] && hi[a] > hp.rcv.lo[k][a];
+                touches = hit;
+            }
+            if (touches) lb[d->n_bnd++] = t; else li[d->n_int++] = t;
+        }
+        if ((size_t)nt > d->tl_cap) {
+            if (d->tl_int) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->tl_int); hipFree(d->tl_bnd); d->tl_int = d->tl_bnd = nullptr; }
+            d->tl_cap = (size_t)nt + nt / 4 + 64;
+            HIPCHK(hipMalloc((void**)&d->tl_int, d->tl_cap * sizeof(int)));
+            HIPCHK(hipMalloc((void**)&d->tl_bnd, d->tl_cap * sizeof(int)));
+        }
+        if (d->n_int) HIPCHK(hipMemcpyAsync(d->tl_int, li, d->n_int * sizeof(int), hipMemcpyHostToDevice, s->st));
+        if (d->n_bnd) HIPCHK(hipMemcpyAsync(d->tl_bnd, lb, d->n_bnd * sizeof(int), hipMemcpyHostToDevice, s->st));
+    }
     // The first replicated level is assembled from the blocks' owned coarse cells.  With at most two blocks per axis every
     // rank is adjacent to every other: each sends its block straight to the 1..7 others (one grouped send/recv round, all
     // xGMI links in parallel, 7/8 of the level per rank) instead of a ring all-reduce of the zero-padded level (twice the
@@ -686,7 +762,7 @@ MgCoef<V> coef_as(const fluid_sim* s, int level)
 // z0 = M^-1 rhs0: the V(2,2) cycle of kernels_mg.hip over the decomposed hierarchy.  rhs0 (the PCG residual) must be
 // valid on the whole local level-0 domain (its halo exchanged by the caller); z0 is valid on the owned cells + 1 ring.
 template <typename V>
-int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, bool halo_pending)
 {
     DistState* d = s->ds;
     const int nl = s->mg_nl, tail = s->mg_tail, split = d->split;
@@ -711,7 +787,14 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
         const uint8_t* cc = l + 1 < split ? d->lv[l + 1].cnt : s->mg_cnt[l + 1];
         if (!ib_empty(L.dom)) {
             if (l == 0) {
-                launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps);
+                if (halo_pending) {
+                    // interior tiles while the residual's halo is in flight on the second stream, the rest once it has landed
+                    if (d->n_int) launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps, d->tl_int, d->n_int);
+                    if ((rc = halo_exchange_end(s, L.plan, sizeof(double)))) return rc;
+                    if (d->n_bnd) launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps, d->tl_bnd, d->n_bnd);
+                } else {
+                    launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps);
+                }
                 launch_mg_restrict<V>(s->st, L.m, (const V*)R(0), mc, cc, F(1), ps);
             } else {
                 launch_mg_down<V, V>(s->st, L.m, L.cnt, (const V*)F(l), U(l), R(l), mc, cc, F(l + 1), coef_as<V>(s, l), ps);
@@ -808,11 +891,16 @@ int dist_solve(fluid_sim* s)
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = halo_exchange1(s, d->lv[0].plan, sizeof(T), R))) return rc;
+            // the residual's halo: exchanged on the second stream behind the interior tiles of the level-0 down leg (every rank takes
+            // the same branch: the switch is a parameter of the run, and a rank without a level-0 domain has an empty plan)
+            const bool ovl = mg && d->overlap && d->lv[0].plan.n > 0 && !ib_empty(d->lv[0].dom);
+            if (ovl) rc = halo_exchange_begin(s, d->lv[0].plan, sizeof(T), R);
+            else rc = halo_exchange1(s, d->lv[0].plan, sizeof(T), R);
+            if (rc) return rc;
             // gstage[cur] = {|r|^2 of the previous body (|b|^2 before the first), r.z of this one}
             if (mg) {
-                if (s->mg_fp32) rc = dist_vcycle_t<float>(s, R, Z, s->mg_part);
-                else rc = dist_vcycle_t<double>(s, R, Z, s->mg_part);
+                if (s->mg_fp32) rc = dist_vcycle_t<float>(s, R, Z, s->mg_part, ovl);
+                else rc = dist_vcycle_t<double>(s, R, Z, s->mg_part, ovl);
                 if (rc) return rc;
                 launch_sum2(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->mg_part, n_rz, d->gstage[cur], d->gstage[cur] + 1);
             } else {
@@ -984,8 +1072,11 @@ void fl::dist_destroy(fluid_sim* s)
 {
     DistState* d = s->ds;
     if (!d) return;
-    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq};
+    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq, d->tl_int, d->tl_bnd};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (d->st2) { hipStreamSynchronize(d->st2); hipStreamDestroy(d->st2); }
+    if (d->ev_pack) hipEventDestroy(d->ev_pack);
+    if (d->ev_halo) hipEventDestroy(d->ev_halo);
     if (d->h_cnt) hipHostFree(d->h_cnt);
     delete d;
     s->ds = nullptr;
@@ -1036,6 +1127,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
     if (const char* e = getenv("FLUID_DIST_SOLVE")) d->repl = atoi(e) == 0;   // developer knob, overrides the param
     if (const char* e = getenv("FLUID_DIST_SPLIT")) d->split_force = atoi(e);
     if (d->split_force < 0 || d->split_force > 2) d->split_force = 0;
+    if (const char* e = getenv("FLUID_DIST_OVERLAP")) d->overlap = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DIST_GATHER")) d->split_exchange_force = !strcmp(e, "exchange") ? 1 : (!strcmp(e, "allreduce") ? 0 : -1);
     Grid g;
     g.N = p->n;
@@ -1064,6 +1156,9 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
         dalloc(&d->d_cnt, (size_t)128) != hipSuccess || dalloc(&d->cnt_pcg, s->lmax + 64) != hipSuccess ||
         hipHostMalloc((void**)&d->h_cnt, 128 * sizeof(int)) != hipSuccess)
         return bail("alloc of the decomposition's scratch failed");
+    if (hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->ev_pack, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming) != hipSuccess)
+        return bail("second stream / events");
     if (!d->repl) {
         const int org[3] = {g.ox, g.oy, g.oz};
         if (hipMemset(s->indices, 0xFF, s->ncell * sizeof(int)) != hipSuccess) return bail("indices fill failed");   // -1: no unknown yet (fluid.cc:1388)

@@ -199,6 +199,23 @@ def test_block_empties_and_fills(fs, slack, monkeypatch):
     compare(d, ref, len(pos), "fills", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
 
 
+def test_overlapped_halo_exchange_changes_nothing(fs, monkeypatch):
+    """The residual's halo exchange runs on a second stream behind the level-0 down-leg tiles that read no received cell
+    (FLUID_DIST_OVERLAP, on by default): same tiles, same arithmetic — bit-identical to the serial order, iteration for
+    iteration, and both equal to one GPU."""
+    n, steps = 72, 5
+    pos, vel = scene(fs, n, 4, vel=0.5)
+    ref = single(fs, n, pos, vel, steps)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FLUID_DIST_OVERLAP", flag)
+        out[flag] = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed")
+    a, b = out["1"], out["0"]
+    assert [s["cg_iters"] for s in a["st"]] == [s["cg_iters"] for s in b["st"]]
+    assert np.array_equal(a["pressure"], b["pressure"]) and np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["vel"], b["vel"])
+    compare(a, ref, len(pos), "overlap", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
+
+
 def test_a_rank_that_cannot_grow_fails_every_rank(fs, monkeypatch):
     """The one allocation a step can still need is room for particles that migrate in.  When ONE rank cannot get it
     (FLUID_DIST_FAIL_GROW names the rank), every rank must leave that step with an error — the one that failed with its own,
