@@ -321,6 +321,7 @@ int fluid_set_solid(fluid_sim_t* s, const uint8_t* solid)
         for (int y = 0; y < g.ny; ++y)
             for (int z = 0; z < g.nz; ++z)
                 sol[g.idx(x, y, z)] = solid[((size_t)(x + g.ox) * N + (y + g.oy)) * N + (z + g.oz)] ? 1 : 0;
+    dist_keep_solid(s, solid);   // (a decomposed handle keeps the global array: re-balancing builds new windows from it)
     HIPCHK(hipStreamSynchronize(s->st));
     HIPCHK(hipMemcpy(s->solid, sol.data(), s->ncell, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->flags, sol.data(), s->ncell, hipMemcpyHostToDevice));

@@ -20,6 +20,7 @@
 
 using namespace fl;
 #define fail fluid_fail
+int cuts_from_hist(int n, const int64_t* hist, int P, int32_t* cuts);
 
 #define COMMCHK(expr)                                                                              \
     do {                                                                                           \
@@ -111,6 +112,13 @@ struct DistState {
     uint8_t* cnt_pcg = nullptr;
     double *gstage[2] = {nullptr, nullptr}, *gpq = nullptr;
     long n_routed = 0;                // particles sent away so far (statistics)
+    // re-balancing of the cut planes (fluid_dist_set_rebalance / FLUID_DIST_REBALANCE): every `rb_every` steps the particle
+    // counts of the blocks are compared; beyond `rb_ratio` x the mean the planes are placed anew by particle count
+    int rb_every = 0;
+    double rb_ratio = 2.0;
+    int n_rebalanced = 0;
+    int* rb_buf = nullptr;            // device: 3 N axis histograms + one count per rank
+    std::vector<uint8_t> solid_global;   // what fluid_set_solid was given (empty: the default shell): a new window needs it again
     // overlap of the residual's halo exchange with the interior tiles of the level-0 down leg (FLUID_DIST_OVERLAP=0: off)
     bool overlap = true;
     hipStream_t st2 = nullptr;        // the exchange runs here while the solver's stream sweeps the tiles that read no halo cell
@@ -1062,17 +1070,218 @@ int dist_step_decomposed(fluid_sim* s, fluid_step_stats_t* stats)
 
 }  // namespace
 
+// Cut planes of one axis from the histogram of the particles' base cells: slabs of about equal count, interior cuts multiples
+// of 4, every block >= 8 cells (fluid_decomp's rules).  The running count is taken from the histogram's prefix at the plane
+// actually chosen (a plane moved by the rounding or the width rules used to leave the count where the search had stopped).
+int cuts_from_hist(int n, const int64_t* hist, int P, int32_t* cuts)
+{
+    if (P < 1 || (P > 1 && n < 8 * P + 8)) return fail(FLUID_ERR_ARG, "too many blocks along an axis (each needs >= 8 cells)");
+    std::vector<int64_t> prefix(n + 1, 0);
+    for (int x = 0; x < n; ++x) prefix[x + 1] = prefix[x] + hist[x];
+    const int64_t np = prefix[n];
+    cuts[0] = 0;
+    for (int r = 1; r < P; ++r) {
+        const int64_t target = np * r / P;
+        int x = cuts[r - 1];
+        while (x < n && prefix[x + 1] <= target) ++x;
+        int b = (x + 2) & ~3;                                          // nearest multiple of 4
+        const int lo_b = cuts[r - 1] + 8, hi_b = ((n - 8 * (P - r)) & ~3);   // >= 8 cells for this block and for the ones above
+        if (b < lo_b) b = (lo_b + 3) & ~3;
+        if (b > hi_b) b = hi_b;
+        cuts[r] = b;
+    }
+    cuts[P] = n;
+    for (int r = 0; r < P; ++r)
+        if (P > 1 && cuts[r + 1] - cuts[r] < 8) return fail(FLUID_ERR_ARG, "grid too small for this many blocks");
+    return FLUID_OK;
+}
+
+namespace {
+
+// Re-balancing ("load imbalance ... slab-by-fluid-count split").  The cut planes of a run are placed by the particle
+// counts at upload; the water then falls and spreads, and in the settled pool of the drop scene the upper blocks hold nothing
+// (profiles/r02: particles per block [148010, 157256, 0, 0, 159910, 170880, 0, 0]).  Between two steps nothing but the particles
+// and dt is state (every field is rebuilt by the next step), so the planes can be moved by building the windows anew:
+//   1. SUM all-reduce of the three axis histograms of the live particles' base cells + one count per rank;
+//   2. if the fullest block holds more than `rb_ratio` x the mean and the histograms give other planes: every rank computes the
+//      same new planes;
+//   3. all-to-all of the particles by their new owner (one grouped exchange of counts, one of 56-byte records, staged through the
+//      host — this runs once in many steps);
+//   4. a handle for the new window is created beside the old one and receives the particles; whether EVERY rank got that far is
+//      agreed (dist_agree) — if not, all of them drop the new handle and go on with the old planes — then the new handle's
+//      contents take the place of the old one's.
+// The next solve starts from x = 0 (the stored pressure belongs to the old windows); results do not depend on the planes
+// beyond the tolerance of the solve (tests/test_gpu_dist.py).
+int dist_rebalance(fluid_sim* s)
+{
+    DistState* d = s->ds;
+    const int N = s->g.N, R = d->comm.size, me = d->comm.rank;
+    int rc;
+    const int64_t live = fluid_download_particles_ids(s, nullptr, nullptr, nullptr);
+    if (live < 0) return fail(FLUID_ERR_HIP, "rebalance: counting the live particles failed");
+    std::vector<double> pos(3 * (size_t)live), vel(3 * (size_t)live);
+    std::vector<uint32_t> ids((size_t)live);
+    if (live && fluid_download_particles_ids(s, pos.data(), vel.data(), ids.data()) != live) return fail(FLUID_ERR_HIP, "rebalance: download failed");
+    // 1. histograms of the base cells (fluid.cc:267: round half away from zero) and the per-rank counts, summed over the ranks
+    std::vector<int> h(3 * (size_t)N + R, 0);
+    const int lo = s->g.lo;
+    for (int64_t i = 0; i < live; ++i)
+        for (int a = 0; a < 3; ++a) {
+            long b = std::lround(pos[3 * i + a]) - lo;
+            b = b < 0 ? 0 : (b > N - 1 ? N - 1 : b);
+            h[(size_t)a * N + b]++;
+        }
+    h[3 * (size_t)N + me] = (int)live;
+    HIPCHK(hipMemcpyAsync(d->rb_buf, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+    if ((rc = comm_allreduce(s, d->rb_buf, (long)h.size(), FLUID_DT_I32, FLUID_OP_SUM))) return rc;
+    HIPCHK(hipMemcpyAsync(h.data(), d->rb_buf, h.size() * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    // 2. the same decision on every rank
+    int64_t total = 0, most = 0;
+    for (int r = 0; r < R; ++r) { total += h[3 * (size_t)N + r]; most = std::max<int64_t>(most, h[3 * (size_t)N + r]); }
+    if (total == 0 || (double)most * R <= d->rb_ratio * (double)total) return FLUID_OK;
+    std::vector<int32_t> nc[3];
+    bool same = true;
+    for (int a = 0; a < 3; ++a) {
+        std::vector<int64_t> hist(N);
+        for (int x = 0; x < N; ++x) hist[x] = h[(size_t)a * N + x];
+        nc[a].assign(d->dims[a] + 1, 0);
+        if (cuts_from_hist(N, hist.data(), d->dims[a], nc[a].data())) return FLUID_OK;   // (cannot happen: the current planes satisfy the rules)
+        for (int b = 0; b <= d->dims[a]; ++b) same = same && nc[a][b] == d->cuts[a][b];
+    }
+    if (same) return FLUID_OK;
+    // 3. particles to their new owners
+    auto owner = [&](const double* p) {
+        int b[3];
+        for (int a = 0; a < 3; ++a) {
+            long c = std::lround(p[a]) - lo;
+            c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
+            int k = 0;
+            while (k + 1 < d->dims[a] && c >= nc[a][k + 1]) ++k;
+            b[a] = k;
+        }
+        return rank_of(d, b[0], b[1], b[2]);
+    };
+    std::vector<int> dest((size_t)live), scount(R, 0), rcount(R, 0);
+    for (int64_t i = 0; i < live; ++i) { dest[i] = owner(&pos[3 * i]); scount[dest[i]]++; }
+    int np = 0, peer[FLUID_MAX_RANKS];
+    const void* sb[FLUID_MAX_RANKS];
+    void* rb[FLUID_MAX_RANKS];
+    size_t sn[FLUID_MAX_RANKS], rn[FLUID_MAX_RANKS];
+    for (int r = 0; r < R; ++r) if (r != me) peer[np++] = r;
+    if (np) {
+        HIPCHK(hipMemcpyAsync(d->rb_buf, scount.data(), R * sizeof(int), hipMemcpyHostToDevice, s->st));
+        for (int k = 0; k < np; ++k) { sb[k] = d->rb_buf + peer[k]; rb[k] = d->rb_buf + FLUID_MAX_RANKS + peer[k]; sn[k] = rn[k] = sizeof(int); }
+        COMMCHK(d->comm.exchange(d->comm.ctx, np, peer, sb, sn, rb, rn, (void*)s->st));
+        HIPCHK(hipMemcpyAsync(rcount.data(), d->rb_buf + FLUID_MAX_RANKS, R * sizeof(int), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+    }
+    rcount[me] = 0;
+    std::vector<long> soff(R + 1, 0), roff(R + 1, 0);
+    for (int r = 0; r < R; ++r) { soff[r + 1] = soff[r] + (r == me ? 0 : scount[r]); roff[r + 1] = roff[r] + rcount[r]; }
+    const long stot = soff[R], rtot = roff[R];
+    std::vector<double> srec(7 * (size_t)stot), rrec(7 * (size_t)rtot);
+    {
+        std::vector<long> cur(soff.begin(), soff.end() - 1);
+        for (int64_t i = 0; i < live; ++i) {
+            if (dest[i] == me) continue;
+            double* q = &srec[7 * (size_t)cur[dest[i]]++];
+            for (int a = 0; a < 3; ++a) { q[a] = pos[3 * i + a]; q[3 + a] = vel[3 * i + a]; }
+            q[6] = (double)ids[i];
+        }
+    }
+    auto room = [&]() -> int {
+        if (stot > d->mig_cap || rtot > d->mig_cap) {
+            HIPCHK(hipStreamSynchronize(s->st));
+            hipFree(d->mig_s); hipFree(d->mig_r);
+            d->mig_s = d->mig_r = nullptr;
+            d->mig_cap = 0;
+            const long cap = std::max(stot, rtot) * 5 / 4 + 4096;
+            HIPCHK(hipMalloc((void**)&d->mig_s, (size_t)cap * 56));
+            HIPCHK(hipMalloc((void**)&d->mig_r, (size_t)cap * 56));
+            d->mig_cap = cap;
+        }
+        return FLUID_OK;
+    };
+    if ((rc = dist_agree(s, room()))) return rc;
+    if (np) {
+        if (stot) HIPCHK(hipMemcpyAsync(d->mig_s, srec.data(), srec.size() * sizeof(double), hipMemcpyHostToDevice, s->st));
+        for (int k = 0; k < np; ++k) {
+            const int r = peer[k];
+            sb[k] = d->mig_s + 7 * (size_t)soff[r]; sn[k] = (size_t)scount[r] * 56;
+            rb[k] = d->mig_r + 7 * (size_t)roff[r]; rn[k] = (size_t)rcount[r] * 56;
+        }
+        COMMCHK(d->comm.exchange(d->comm.ctx, np, peer, sb, sn, rb, rn, (void*)s->st));
+        if (rtot) HIPCHK(hipMemcpyAsync(rrec.data(), d->mig_r, rrec.size() * sizeof(double), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+    }
+    const long mine = scount[me] + rtot;
+    std::vector<double> npos(3 * (size_t)mine), nvel(3 * (size_t)mine);
+    std::vector<uint32_t> nids((size_t)mine);
+    long k = 0;
+    for (int64_t i = 0; i < live; ++i)
+        if (dest[i] == me) {
+            for (int a = 0; a < 3; ++a) { npos[3 * k + a] = pos[3 * i + a]; nvel[3 * k + a] = vel[3 * i + a]; }
+            nids[k++] = ids[i];
+        }
+    for (long j = 0; j < rtot; ++j, ++k) {
+        for (int a = 0; a < 3; ++a) { npos[3 * k + a] = rrec[7 * j + a]; nvel[3 * k + a] = rrec[7 * j + 3 + a]; }
+        nids[k] = (uint32_t)rrec[7 * j + 6];
+    }
+    // 4. the new window beside the old one
+    fluid_sim* t = nullptr;
+    auto build = [&]() -> int {
+        fluid_decomp_t dc;
+        for (int a = 0; a < 3; ++a) { dc.dims[a] = d->dims[a]; dc.cuts[a] = nc[a].data(); }
+        int r2 = fluid_create_dist(&s->prm, &d->comm, &dc, &t);
+        if (r2) return r2;
+        if (!d->solid_global.empty() && (r2 = fluid_set_solid(t, d->solid_global.data()))) return r2;
+        return fluid_upload_particles_ids(t, mine, npos.data(), nvel.data(), nids.data());
+    };
+    if ((rc = dist_agree(s, build()))) {
+        if (t) fluid_destroy(t);
+        return rc == FLUID_ERR_PEER || rc == FLUID_ERR_HIP ? FLUID_OK : rc;   // no room for a second window somewhere: go on with the old planes
+    }
+    DistState* nd = t->ds;
+    nd->rb_every = d->rb_every; nd->rb_ratio = d->rb_ratio; nd->n_rebalanced = d->n_rebalanced + 1; nd->n_routed = d->n_routed;
+    nd->solid_global.swap(d->solid_global);
+    t->dt = s->dt;
+    t->step_counter = s->step_counter;
+    t->stats = s->stats;
+    for (int c = 0; c < 3; ++c) t->mg_last_iters_k[c] = s->mg_last_iters_k[c];
+    t->prof_every = s->prof_every;
+    for (int c = 0; c < FLUID_PROF_COUNT; ++c) std::swap(t->prof[c], s->prof[c]);
+    std::swap(*s, *t);      // the caller's handle now holds the new window
+    fluid_destroy(t);       // ... and this one the old
+    return FLUID_OK;
+}
+
+}  // namespace
+
 int fl::dist_step(fluid_sim* s, fluid_step_stats_t* stats)
 {
     HIPCHK(hipSetDevice(s->prm.device));
-    return s->ds->repl ? dist_step_replicated(s, stats) : dist_step_decomposed(s, stats);
+    int rc = s->ds->repl ? dist_step_replicated(s, stats) : dist_step_decomposed(s, stats);
+    if (rc) return rc;
+    DistState* d = s->ds;
+    if (d->rb_every > 0 && d->comm.size > 1 && s->step_counter % d->rb_every == 0) {
+        const int before = d->n_rebalanced;
+        if ((rc = dist_rebalance(s))) return rc;
+        if (s->ds->n_rebalanced != before && stats) stats->paths |= FLUID_PATH_DIST_REBALANCED;
+    }
+    return FLUID_OK;
+}
+
+void fl::dist_keep_solid(fluid_sim* s, const uint8_t* solid_global)
+{
+    if (s->ds) s->ds->solid_global.assign(solid_global, solid_global + (size_t)s->g.N * s->g.N * s->g.N);
 }
 
 void fl::dist_destroy(fluid_sim* s)
 {
     DistState* d = s->ds;
     if (!d) return;
-    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq, d->tl_int, d->tl_bnd};
+    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq, d->tl_int, d->tl_bnd, d->rb_buf};
     for (void* p : ptrs) if (p) hipFree(p);
     if (d->st2) { hipStreamSynchronize(d->st2); hipStreamDestroy(d->st2); }
     if (d->ev_pack) hipEventDestroy(d->ev_pack);
@@ -1128,6 +1337,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
     if (const char* e = getenv("FLUID_DIST_SPLIT")) d->split_force = atoi(e);
     if (d->split_force < 0 || d->split_force > 2) d->split_force = 0;
     if (const char* e = getenv("FLUID_DIST_OVERLAP")) d->overlap = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_DIST_REBALANCE")) d->rb_every = std::max(0, atoi(e));
     if (const char* e = getenv("FLUID_DIST_GATHER")) d->split_exchange_force = !strcmp(e, "exchange") ? 1 : (!strcmp(e, "allreduce") ? 0 : -1);
     Grid g;
     g.N = p->n;
@@ -1156,6 +1366,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
         dalloc(&d->d_cnt, (size_t)128) != hipSuccess || dalloc(&d->cnt_pcg, s->lmax + 64) != hipSuccess ||
         hipHostMalloc((void**)&d->h_cnt, 128 * sizeof(int)) != hipSuccess)
         return bail("alloc of the decomposition's scratch failed");
+    if (dalloc(&d->rb_buf, (size_t)3 * p->n + 2 * FLUID_MAX_RANKS + 64) != hipSuccess) return bail("rebalance scratch");
     if (hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->ev_pack, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming) != hipSuccess)
         return bail("second stream / events");
@@ -1278,31 +1489,33 @@ int fluid_partition_blocks(int32_t n, int64_t np, const double* pos, const int32
     int32_t* cuts[3] = {cuts_x, cuts_y, cuts_z};
     const int lo = -(n / 2);
     for (int a = 0; a < 3; ++a) {
-        const int P = dims[a];
-        if (P < 1 || (P > 1 && n < 8 * P + 8)) return fail(FLUID_ERR_ARG, "too many blocks along an axis (each needs >= 8 cells)");
         std::vector<int64_t> hist(n, 0);
         for (int64_t i = 0; i < np; ++i) {
             long b = std::lround(pos[3 * i + a]) - lo;  // C round(): half away from zero, like the base cell (fluid.cc:267)
             b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
             hist[b]++;
         }
-        cuts[a][0] = 0;
-        int64_t acc = 0;
-        int x = 0;
-        for (int r = 1; r < P; ++r) {
-            const int64_t target = np * r / P;
-            while (x < n && acc + hist[x] <= target) acc += hist[x++];
-            int b = (x + 2) & ~3;                                          // nearest multiple of 4
-            const int lo_b = cuts[a][r - 1] + 8, hi_b = ((n - 8 * (P - r)) & ~3);   // >= 8 cells for this block and for the ones above
-            if (b < lo_b) b = (lo_b + 3) & ~3;
-            if (b > hi_b) b = hi_b;
-            while (x < b) acc += hist[x++];
-            cuts[a][r] = b;
-        }
-        cuts[a][P] = n;
-        for (int r = 0; r < P; ++r)
-            if (P > 1 && cuts[a][r + 1] - cuts[a][r] < 8) return fail(FLUID_ERR_ARG, "grid too small for this many blocks");
+        int rc = cuts_from_hist(n, hist.data(), dims[a], cuts[a]);
+        if (rc) return rc;
     }
+    return FLUID_OK;
+}
+
+int fluid_dist_set_rebalance(fluid_sim_t* s, int32_t every, double ratio)
+{
+    if (!s || !s->ds || every < 0 || !(ratio >= 1.0)) return fail(FLUID_ERR_ARG, "not a decomposed handle, or bad every / ratio");
+    s->ds->rb_every = every;
+    s->ds->rb_ratio = ratio;
+    return FLUID_OK;
+}
+
+int fluid_dist_get_cuts(fluid_sim_t* s, int32_t* cuts_x, int32_t* cuts_y, int32_t* cuts_z, int32_t* n_rebalanced)
+{
+    if (!s || !s->ds) return fail(FLUID_ERR_ARG, "not a decomposed handle");
+    int32_t* c[3] = {cuts_x, cuts_y, cuts_z};
+    for (int a = 0; a < 3; ++a)
+        if (c[a]) for (size_t i = 0; i < s->ds->cuts[a].size(); ++i) c[a][i] = s->ds->cuts[a][i];
+    if (n_rebalanced) *n_rebalanced = s->ds->n_rebalanced;
     return FLUID_OK;
 }
 

@@ -186,4 +186,5 @@ int fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t** ou
 int dist_step(fluid_sim* s, fluid_step_stats_t* stats);
 void dist_destroy(fluid_sim* s);
 int dist_download_field(fluid_sim* s, int field, void* dst, size_t bytes, bool* handled);
+void dist_keep_solid(fluid_sim* s, const uint8_t* solid_global);
 }  // namespace fl

@@ -35,6 +35,10 @@ class FluidDecomp(C.Structure):
 
 lib.fluid_create_dist.restype = C.c_int
 lib.fluid_create_dist.argtypes = [C.POINTER(Params), C.POINTER(FluidComm), C.POINTER(FluidDecomp), C.POINTER(C.c_void_p)]
+lib.fluid_dist_set_rebalance.restype = C.c_int
+lib.fluid_dist_set_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+lib.fluid_dist_get_cuts.restype = C.c_int
+lib.fluid_dist_get_cuts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 lib.fluid_local_comm_create.restype = C.c_int
 lib.fluid_local_comm_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FluidComm)]
 lib.fluid_rccl_unique_id.restype = C.c_int
@@ -303,9 +307,24 @@ class DistFluidSim(FluidSim):
             dc.cuts[a] = C.cast(self._cut_arrays[a], C.POINTER(C.c_int32))
         self._h = C.c_void_p()
         check(lib.fluid_create_dist(C.byref(p), C.byref(comm.struct), C.byref(dc), C.byref(self._h)))
+        self.n_rebalanced = 0
+        self._refresh_window()
+
+    def _refresh_window(self):
         o, d, l, h = ((C.c_int32 * 3)() for _ in range(4))
         check(lib.fluid_window(self._h, o, d, l, h))
         self.origin, self.wdims, self.own_lo, self.own_hi = list(o), list(d), list(l), list(h)
+
+    def set_rebalance(self, every, ratio=2.0):
+        """Every `every` steps compare the blocks' particle counts and move the cut planes when the fullest block holds more than
+        `ratio` x the mean (collective: the same call on every rank; 0 = never)."""
+        check(lib.fluid_dist_set_rebalance(self._h, every, ratio))
+
+    def current_cuts(self):
+        arr = [(C.c_int32 * (self.dims[a] + 1))() for a in range(3)]
+        nr = C.c_int32()
+        check(lib.fluid_dist_get_cuts(self._h, arr[0], arr[1], arr[2], C.byref(nr)))
+        return [list(c) for c in arr], nr.value
 
     def _check(self, rc):
         if rc != 0 and getattr(self.comm, "error", None) is not None:
@@ -364,6 +383,9 @@ class DistFluidSim(FluidSim):
     def step(self):
         st = StepStats()
         self._check(lib.fluid_step(self._h, C.byref(st)))
+        if st.paths & 32:   # FLUID_PATH_DIST_REBALANCED: the cut planes moved, this handle covers another window now
+            self._refresh_window()
+            self.cuts, self.n_rebalanced = self.current_cuts()
         return st.as_dict()
 
 

@@ -118,6 +118,7 @@ typedef struct fluid_step_stats {
 #define FLUID_PATH_TILE_LISTS 2  /* level-0 solver kernels over the lists of tiles that hold an unknown (mostly-air box) */
 #define FLUID_PATH_DIST_DECOMPOSED 4  /* multi-GPU: window arrays, domain-decomposed PCG with the globally coupled V-cycle  */
 #define FLUID_PATH_DIST_REPLICATED 8  /* multi-GPU: particles sharded, pressure block replicated on every rank              */
+#define FLUID_PATH_DIST_REBALANCED 32 /* multi-GPU: the cut planes were moved at the end of this step (the window changed)      */
 #define FLUID_PATH_MG_COARSE 16       /* the V-cycle's coarse levels ran as one persistent launch (FLUID_MG_COARSE=1|2; off by default) */
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -304,6 +305,13 @@ int64_t fluid_download_particles_ids(fluid_sim_t* s, double* pos, double* vel, u
  * particle set (host-only); cuts[a] receives dims[a]+1 values that satisfy fluid_decomp's rules. */
 int fluid_partition_blocks(int32_t n, int64_t np, const double* pos, const int32_t dims[3], int32_t* cuts_x, int32_t* cuts_y,
                            int32_t* cuts_z);
+/* Re-balancing of the cut planes of a decomposed run: every `every` steps (0 = never, the default) the blocks' particle counts
+ * are compared and, when the fullest holds more than `ratio` x the mean (>= 1), the planes are placed anew by particle count and
+ * the particles handed to their new owners; collective — every rank of the run sets the same values.  The window of this handle
+ * then changes (fluid_window), fields downloaded afterwards have the new shape, and the step that did it reports
+ * FLUID_PATH_DIST_REBALANCED.  fluid_dist_get_cuts: the current planes (dims[a] + 1 values per axis) and how often they moved. */
+int fluid_dist_set_rebalance(fluid_sim_t* s, int32_t every, double ratio);
+int fluid_dist_get_cuts(fluid_sim_t* s, int32_t* cuts_x, int32_t* cuts_y, int32_t* cuts_z, int32_t* n_rebalanced);
 
 /* ---- OpenVDB file output (replaces file2.write(grids2) / file.write(grids), fluid.cc:1503-1504,1508) ----
  * Dense float32 N^3 arrays (z fastest, cell (0,0,0) = index coordinate (lo,lo,lo), lo = -(N/2)) written as unnamed

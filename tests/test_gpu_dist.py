@@ -26,7 +26,7 @@ def scene(fs, n, ppc, vel=0.0, pile=0):
     return pos, v
 
 
-def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, solid=None, **kw):
+def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, solid=None, rebalance=None, **kw):
     """dims[0] x dims[1] x dims[2] blocks as threads of this process; returns the assembled result."""
     fd = fs.load_dist()
     size = dims[0] * dims[1] * dims[2]
@@ -41,10 +41,12 @@ def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, solid=None, **
         if solid is not None:
             sim.set_solid(solid)              # the GLOBAL array on every rank; each keeps its window
         sim.upload_global(pos, vel)
+        if rebalance:
+            sim.set_rebalance(*rebalance)
         st = [sim.step() for _ in range(steps)]
         p, v, ids = sim.download_local()
         return dict(st=st, p=p, v=v, ids=ids, idx=sim.field(F.INDICES), cont=sim.field(F.CONTAINER), pres=sim.field(F.PRESSURE),
-                    vel=sim.field(F.VEL))
+                    vel=sim.field(F.VEL), cuts=sim.cuts, moved=sim.n_rebalanced)
 
     try:
         res = grp.run(work)
@@ -56,7 +58,8 @@ def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, solid=None, **
     ids = np.concatenate([r["ids"] for r in res])
     o = np.argsort(ids)
     out = dict(ids=ids[o], pos=np.concatenate([r["p"] for r in res])[o], vel=np.concatenate([r["v"] for r in res])[o],
-               st=res[0]["st"], all_st=[r["st"] for r in res], cuts=cuts, counts=[len(r["ids"]) for r in res])
+               st=res[0]["st"], all_st=[r["st"] for r in res], cuts=res[0]["cuts"], counts=[len(r["ids"]) for r in res],
+               moved=[r["moved"] for r in res], all_cuts=[r["cuts"] for r in res])
     for k, key in (("indices", "idx"), ("container", "cont"), ("pressure", "pres"), ("velgrid", "vel")):
         out[k] = fd.assemble(n, sims, [r[key] for r in res])
     return out
@@ -214,6 +217,28 @@ def test_overlapped_halo_exchange_changes_nothing(fs, monkeypatch):
     assert [s["cg_iters"] for s in a["st"]] == [s["cg_iters"] for s in b["st"]]
     assert np.array_equal(a["pressure"], b["pressure"]) and np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["vel"], b["vel"])
     compare(a, ref, len(pos), "overlap", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
+
+
+@pytest.mark.parametrize("mode", ["decomposed", "replicated"])
+def test_cut_planes_follow_the_water(fs, mode):
+    """Re-balancing: uniform cuts through an off-centre cube leave some blocks with nothing; with fluid_dist_set_rebalance the
+    planes are placed anew by particle count (every rank the same planes, every particle to its new owner, a new window per
+    rank) and the run goes on to the same answer as one GPU — with an obstacle (the new windows need the global solid array again)
+    and a moving state."""
+    n, steps = 64, 12
+    pos, vel = scene(fs, n, 4, vel=0.3)
+    pos = pos + np.array([7.0, 9.0, -5.0])
+    solid = np.zeros((n, n, n), dtype=np.uint8)
+    solid[:2] = solid[-2:] = 1; solid[:, :2] = solid[:, -2:] = 1; solid[:, :, :2] = solid[:, :, -2:] = 1
+    solid[20:30, 2:10, 24:40] = 1                    # a block on the floor
+    ref = single(fs, n, pos, vel, steps, solid=solid)
+    before = run_blocks(fs, (2, 2, 2), n, pos, vel, 1, mode, uniform=True, solid=solid)
+    d = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, mode, uniform=True, solid=solid, rebalance=(4, 1.3))
+    print(f"rebalance {mode}: counts {before['counts']} -> {d['counts']}, cuts {before['cuts']} -> {d['cuts']}, moved {d['moved']}")
+    assert all(m >= 1 for m in d["moved"]) and len(set(d["moved"])) == 1          # every rank, equally often
+    assert all(c == d["all_cuts"][0] for c in d["all_cuts"]) and d["cuts"] != before["cuts"]
+    assert max(d["counts"]) < max(before["counts"])                                # the fullest block got lighter
+    compare(d, ref, len(pos), f"rebalance {mode}", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
 
 
 def test_a_rank_that_cannot_grow_fails_every_rank(fs, monkeypatch):
