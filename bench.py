@@ -495,12 +495,22 @@ def main():
                      "cg_iters_mean": float(np.mean([x["cg_iters"] for x in sts])), "cg_error_max": float(max(x["cg_error"] for x in sts)),
                      "phase_ms": {k[3:]: float(np.mean([x[k] for x in sts])) for k in ("ms_transfer", "ms_forces", "ms_solve", "ms_deform", "ms_advect")},
                      "apply_kernel_us": float(np.mean([x["ms_apply_avg"] for x in sts]) * 1e3)}
-                # dominant kernel k_mpm_apply (one matrix-free operator application): 348 B of particle state per particle
-                # (position, F, R, the 3x3 inverse, the cofactor matrix, coefficients, volume, order entry); node vectors stay in L2
-                ab = 348.0 * sim.num_particles
-                d["roofline"] = {"kernel": "k_mpm_apply", "bound": "hbm", "achieved": ab / (d["apply_kernel_us"] * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                 "frac": ab / (d["apply_kernel_us"] * 1e-6) / 8e12, "traffic": None,
-                                 "note": "far from the HBM bound: the kernel is limited by dependent fp64 / shuffle chains (~3300 fp64 operations + 972 ds_bpermute per particle), DESIGN.md 9"}
+                # One operator application = k_mpm_apply_particles (per particle: gather of G from the unknown vector, energy Hessian,
+                # A_p F_p^T: fp64 arithmetic) + k_mpm_apply_gather (per unknown node: the sum over the particles of the 8 cells that reach
+                # it).  Neither is an HBM kernel: the particle state (104 B read by the gather per particle visit, 8 visits per particle;
+                # 348 B read + 80 B written by the particle kernel) stays in L2 / Infinity Cache, so the honest roofline is the fp64
+                # VECTOR peak for the arithmetic and the aggregate L2 rate for the gather (MI355X guide: 78.6 TFLOP/s fp64 vector, 34.5 TB/s L2).
+                # flops per particle, counted from the source (27 nodes x (3 gradient components x 2 mul + 9 FMA-pairs) + Hessian + 3 3x3 products): ~1300
+                flops = 1300.0 * sim.num_particles
+                us = d["apply_kernel_us"]
+                d["roofline"] = {"kernel": "k_mpm_apply_particles + k_mpm_apply_gather (one application of the matrix-free operator; time = HIP events around both)",
+                                 "bound": "fp64-valu", "achieved": flops / (us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / (us * 1e-6) / 78.6e12,
+                                 "traffic": None,
+                                 "l2_bytes_per_application": 104.0 * 8 * sim.num_particles + 428.0 * sim.num_particles,
+                                 "l2_rate_TBs": (104.0 * 8 + 428.0) * sim.num_particles / (us * 1e-6) / 1e12,
+                                 "note": "latency-bound: ~1300 fp64 operations per particle in dependent chains at 2 waves per SIMD (154 VGPRs), then a node gather "
+                                         "whose waves make one round trip of 13 loads per particle; per-kernel times and the PMC traffic: profiles/r03/mpm_*; "
+                                         "sums are gathers in a fixed order (no atomics): two runs give the same bits"}
                 sim.close()
                 return d, posm
             try:

@@ -12,9 +12,12 @@
 // weighted dot products; the stopping rule stays Eigen's plain |r|^2 <= tol^2 |b|^2.
 //
 // Data: dense node arrays over -B..B (z fastest) and SoA particle arrays in HBM, all fp64 except the float32 node mass
-// (FloatGrid) which is summed in fp64 and rounded once.  Scatter steps use hardware fp64 atomics (global_atomic_add_f64).
+// (FloatGrid) which is summed in fp64 and rounded once.  The three particle -> node sums (transfer, forces, operator) are GATHERS
+// per node over the cell lists of the sorted particles (k_mpm_gather): no atomics, the order of every sum is a function of the
+// input alone — two runs give the same bits.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -24,6 +27,11 @@
 #include "../../include/mpm_hip.h"
 
 int fluid_fail(int code, const std::string& msg);
+namespace fl {
+// kernels_particles.hip: order2 = every cell's list re-ranked by ascending id, 256 sorted positions per block with the ids of
+// their cells staged through LDS (cell_start needs its one-past-the-end entry)
+void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, const int* cell_start, const int* order, const uint32_t* spid, int* order2);
+}
 #define HIPCHK(expr)                                                                                              \
     do {                                                                                                          \
         hipError_t e_ = (expr);                                                                                   \
@@ -47,6 +55,8 @@ struct MpmState {
     int max_cell;                    // first cell attaining max_force_coeff2
     int any_active;
     int cg_iters;                    // Eigen's `i` (ConjugateGradient.h:70-88)
+    int num_touched;                 // nodes within one cell of a particle (the nodes the transfer and the force gather visit)
+    int num_cells;                   // non-empty cells
     int pad_;
     unsigned long long max_speed_bits, max_grad_bits, max_fp_bits, max_fe_bits, max_coeff_bits;
     double dt;
@@ -59,6 +69,8 @@ struct Part {   // SoA, stride = capacity
     double *pos, *vel, *FE, *FP, *gradV, *volume;
     // per-step cache for the operator: R, inverse of getDelR's 3x3 matrix, cofactor matrix, F^T applied later
     double *R, *Minv, *cof, *coef;   // coef: mu_p, lambda_p, J
+    double* node9;                   // 10 doubles per particle for the node gathers: the stress (forces) / A_p F_p^T (operator) + its scale
+    double* wfac;                    // 12 doubles per particle, once per step: s2 and grad factors (deformHeader.h:99-101) of the nodes base-1, base per axis
     long cap;
 };
 
@@ -324,81 +336,224 @@ __global__ void k_mpm_eval(int what, long n, const double* __restrict__ a, const
     }
 }
 
-// ---- wave-level aggregation of the scatters ----
-// Particles arrive grouped by voxel (the scatter emits them in ValueOn order and snow moves coherently), so the lanes of a
-// wave mostly share their base cell and hence their 27 target nodes: with one atomic per lane the same ~150 addresses take
-// thousands of serialised updates (348 us per operator application on the reference scene).  Lanes with equal consecutive
-// keys (base cell) form a segment; values are summed along each segment with 6 shuffle steps and the segment's last lane
-// issues one atomic.  Any particle order stays correct — unsorted input only shortens the segments.
-struct Seg {
-    int start;   // first lane of this lane's segment
-    bool tail;   // this lane is the last of its segment
-};
-__device__ __forceinline__ Seg seg_setup(long key)
+// ---- particle -> node sums as gathers over cell lists ----
+// The reference scatters from particles to their 27 nodes (mpm.cc:218-253, 596-644, 646-701).  The first version here did the
+// same with fp64 atomics (aggregated along runs of equal base cell inside a wave): fast enough, but the order of an atomic sum
+// is whatever the hardware makes it, so two runs differed in the last bits, and the aggregation cost the operator kernel 972
+// ds_bpermute per particle and 186 VGPRs.  Now every step sorts the particles by base cell AND, inside a cell, by their upload
+// index (k_mpm_sort_rank), the per-particle part of a sum (stress, A_p F_p^T) is written to `node9`, and one workgroup per NODE
+// walks the particle lists of the 27 cells around it: wave w takes the cells w, w+4, ..., lanes stride the particles of a cell,
+// every lane adds in list order, lanes and waves are folded in a fixed order.  The weights are evaluated at the node itself:
+// nb.w[a][node - lo] of the scatter form IS mspline(p[a] - node[a]).
+template <int NQ>
+__device__ __forceinline__ void gather_fold(double (&acc)[NQ], double (*sh)[4])
 {
-    const int lane = threadIdx.x & 63;
-    const long prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key;
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1));
-    Seg sg;
-    sg.start = 63 - __clzll((long long)below);
-    sg.tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-    return sg;
-}
-__device__ __forceinline__ double seg_sum(double v, const Seg& sg)
-{
-    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_up(v, o);
-        if (lane - o >= sg.start) v += t;
+    for (int q = 0; q < NQ; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        acc[q] = v;
     }
-    return v;   // complete on the tail lane
+    __syncthreads();   // the LDS words may still be read by the previous node's epilogue
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) sh[q][threadIdx.x >> 6] = acc[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = ((sh[q][0] + sh[q][1]) + sh[q][2]) + sh[q][3];
 }
-__device__ __forceinline__ long base_key(const MGrid& G, const double p[3], bool valid)
+// does particle position p reach node c along one axis (mpm.cc:503-513: nodes base-1 .. base+1, clamped to the grid), and the slot rule of
+// the 3-wide loops (node - lo <= 2)
+__device__ __forceinline__ bool reaches(const MGrid& G, double p, int c)
 {
-    if (!valid) return -1 - (long)(threadIdx.x & 63);   // a segment of its own
-    const long N = 2L * G.B + 3;                        // round(p) may lie one cell outside the grid on either side
-    return (((long)round(p[0]) + G.B + 1) * N + ((long)round(p[1]) + G.B + 1)) * N + ((long)round(p[2]) + G.B + 1);
+    const int f = (int)round(p);
+    const int lo = f - 1 > -G.B ? f - 1 : -G.B, hi = f + 1 < G.B ? f + 1 : G.B;
+    return c >= lo && c <= hi && c - lo <= 2;
 }
 
-// ---- transfer: interpolate (mpm.cc:773-811) + P2Gtransfer's scatter (mpm.cc:218-253,996-999) ----
-__global__ void __launch_bounds__(128) k_mpm_p2g(MGrid G, long n, Part P, const int* __restrict__ order, const uint8_t* __restrict__ solid, double* __restrict__ massd,
-                          double* __restrict__ vel /* 3 x cells */)
+// MODE 0: interpolate + P2Gtransfer (mpm.cc:773-811, 218-253, 996-999) over the touched nodes: massd, vel (3 x cells)
+// MODE 1: populateGridForces' node sums (mpm.cc:596-644) over the touched nodes: forces (3 x cells); node9 = sigma, scale = volume
+// MODE 2: the operator's node sums over the unknowns: y = v + sum; node9 = A_p F_p^T, scale = beta dt^2 vol_p
+template <int MODE>
+__global__ void __launch_bounds__(256) k_mpm_gather(MGrid G, Part P, const int* __restrict__ cell_start, const int* __restrict__ cell_count,
+                                                    const int* __restrict__ list, const int* __restrict__ n_list, const MpmState* st, int in_solve,
+                                                    int transposed, const double* __restrict__ invm, const double* __restrict__ v,
+                                                    double* __restrict__ out0, double* __restrict__ out1)
 {
-    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = j < n;
-    const long ii = order ? order[valid ? j : 0] : (valid ? j : 0);
+    constexpr int NQ = MODE == 0 ? 4 : 3;
+    __shared__ double sh[NQ][4];
+    if (MODE == 2 && in_solve && st->cg_done) return;   // speculative launches past convergence do nothing
+    const int nn = *n_list;
     const long C = G.cells();
-    double p[3] = {ld(P.pos, P.cap, 0, ii), ld(P.pos, P.cap, 1, ii), ld(P.pos, P.cap, 2, ii)};
-    double v[3] = {ld(P.vel, P.cap, 0, ii), ld(P.vel, P.cap, 1, ii), ld(P.vel, P.cap, 2, ii)};
-    Nbh nb;
-    neighbourhood(G, p, nb, false);
-    const Seg sg = seg_setup(base_key(G, p, valid));
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = blockIdx.x; q < nn; q += gridDim.x) {
+        const long k = list[q];
+        const int nz = (int)(k % G.N) - G.B, ny = (int)((k / G.N) % G.N) - G.B, nx = (int)(k / ((long)G.N * G.N)) - G.B;
+        const bool mom = abs(nx) <= G.B - 2 && abs(ny) <= G.B - 2 && abs(nz) <= G.B - 2;
+        double acc[NQ];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
-                const bool in = valid && x <= nb.hi[0] && y <= nb.hi[1] && z <= nb.hi[2];
-                const long k = in ? G.at(x, y, z) : 0;
-                const bool ok = in && !solid[k];
-                const double cw = ok ? nb.w[0][a] * nb.w[1][b] * nb.w[2][c] : 0.0;
-                const bool mom = ok && abs(x) <= G.B - 2 && abs(y) <= G.B - 2 && abs(z) <= G.B - 2;
-                const double m = seg_sum(cw > 0 ? cw : 0.0, sg);
-                const double m0 = seg_sum(mom ? v[0] * cw : 0.0, sg), m1 = seg_sum(mom ? v[1] * cw : 0.0, sg), m2 = seg_sum(mom ? v[2] * cw : 0.0, sg);
-                if (sg.tail && ok) {
-                    if (m > 0) unsafeAtomicAdd(&massd[k], m);
+        for (int i = 0; i < NQ; ++i) acc[i] = 0;
+        // Which cells can reach this node: base cells n-1 .. n+1 per axis.  For the gradient weights (MODE 1, 2) the node one ABOVE the
+        // base cell never carries weight — mspline2(0.5 + c - p) needs c - p < 0.5 and mspline_grad(p - c - 0.5) vanishes at and below
+        // -1, while p < base + 0.5 — so only the cells n and n+1 are walked (8 lists instead of 27); the transfer keeps all 27 (its
+        // spline evaluates to 2.2e-16, not 0, at the closed end of its support: mpm.cc:25-41)
+        constexpr int NC = MODE == 0 ? 27 : 8;
+        for (int ci = wv; ci < NC; ci += 4) {
+            const int fx = MODE == 0 ? nx + ci / 9 - 1 : nx + (ci >> 2), fy = MODE == 0 ? ny + (ci / 3) % 3 - 1 : ny + ((ci >> 1) & 1),
+                      fz = MODE == 0 ? nz + ci % 3 - 1 : nz + (ci & 1);
+            if (!G.in(fx, fy, fz)) continue;
+            const long c = G.at(fx, fy, fz);
+            const int cnt = cell_count[c];
+            if (!cnt) continue;
+            const long j0 = cell_start[c];
+            for (long j = j0 + lane; j < j0 + cnt; j += 64) {
+                const double p[3] = {ld(P.pos, P.cap, 0, j), ld(P.pos, P.cap, 1, j), ld(P.pos, P.cap, 2, j)};
+                if (!(reaches(G, p[0], nx) && reaches(G, p[1], ny) && reaches(G, p[2], nz))) continue;
+                if (MODE == 0) {
+                    const double cw = mspline(p[0] - nx) * mspline(p[1] - ny) * mspline(p[2] - nz);
+                    if (cw == 0) continue;   // (adds nothing: the velocity loads can stay away)
+                    acc[0] += cw > 0 ? cw : 0.0;
                     if (mom) {
-                        if (m0 != 0) unsafeAtomicAdd(&vel[k], m0);
-                        if (m1 != 0) unsafeAtomicAdd(&vel[C + k], m1);
-                        if (m2 != 0) unsafeAtomicAdd(&vel[2 * C + k], m2);
+                        acc[1] += ld(P.vel, P.cap, 0, j) * cw;
+                        acc[2] += ld(P.vel, P.cap, 1, j) * cw;
+                        acc[3] += ld(P.vel, P.cap, 2, j) * cw;
                     }
+                } else {
+                    // getGradW (deformHeader.h:99-103) at this node
+                    const double s2x = mspline2(0.5 + nx - p[0]), s2y = mspline2(0.5 + ny - p[1]), s2z = mspline2(0.5 + nz - p[2]);
+                    const double gx = mspline_grad(p[0] - nx - 0.5), gy = mspline_grad(p[1] - ny - 0.5), gz = mspline_grad(p[2] - nz - 0.5);
+                    if ((s2x == 0 && gx == 0) || (s2y == 0 && gy == 0) || (s2z == 0 && gz == 0)) continue;   // grad w = 0: adds nothing
+                    const double g[3] = {-1 * gx * s2y * s2z, -1 * s2x * gy * s2z, -1 * s2x * s2y * gz};
+                    double m[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) m[i] = ld(P.node9, P.cap, i, j);
+                    const double sc = ld(P.node9, P.cap, 9, j);
+                    const double f = MODE == 1 ? -1 * sc : (transposed ? sc : sc * invm[q]);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) acc[r] += f * (m[3 * r] * g[0] + m[3 * r + 1] * g[1] + m[3 * r + 2] * g[2]);
                 }
             }
+        }
+        gather_fold<NQ>(acc, sh);
+        if (threadIdx.x == 0) {
+            if (MODE == 0) {
+                if (acc[0] > 0) out0[k] = acc[0];
+                if (mom) out1[k] = acc[1], out1[C + k] = acc[2], out1[2 * C + k] = acc[3];
+            } else if (MODE == 1) {
+                out0[k] = acc[0], out0[C + k] = acc[1], out0[2 * C + k] = acc[2];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) out0[3 * (long)q + r] = v[3 * (long)q + r] + acc[r];
+            }
+        }
+    }
+}
+// The operator's node sums run once per CG iteration.  A particle of base cell f carries gradient weight on the nodes f-1 and f of
+// every axis only (k_mpm_gather), so a CELL's particles feed exactly its 8 corner nodes f - 1 + (a, b, c): one workgroup per
+// non-empty cell stages the cell's list (position, A_p F_p^T, scale: 13 doubles per particle, read ONCE) in LDS, and wave s of its
+// 8 waves sums the contributions to corner s over the list — lanes stride it, add in list order, fold in a fixed order.  The 8 x 3
+// partial sums of a cell go to part[compact cell index]; a node's value is the sum over its 8 cells, taken in a fixed order by the
+// kernel that consumes it (k_mpm_cg_pq, k_mpm_apply_combine).  (A first gather form had one wave per (node, cell): every particle was
+// then read 8 times from L2 — 59 us per application on the 219 k particle cone against 27 us for the whole per-particle kernel.)
+constexpr int CELL_CHUNK = 256;   // particles staged per pass (45 KB of LDS)
+__global__ void __launch_bounds__(512) k_mpm_apply_cells(MGrid G, Part P, const int* __restrict__ cell_start, const int* __restrict__ cell_count,
+                                                         const int* __restrict__ clist, const MpmState* st, int in_solve, double* __restrict__ part)
+{
+    __shared__ double sp[22][CELL_CHUNK];   // 0-8 A_p F_p^T, 9 scale, 10-15 s2 (x0 x1 y0 y1 z0 z1), 16-21 grad
+    if (in_solve && st->cg_done) return;
+    const int nc = st->num_cells;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ca = wv >> 2, cb = (wv >> 1) & 1, cc = wv & 1;   // this wave's corner: node = cell - 1 + (ca, cb, cc)
+    for (int b = blockIdx.x; b < nc; b += gridDim.x) {
+        const long c = clist[b];
+        const int fz = (int)(c % G.N) - G.B, fy = (int)((c / G.N) % G.N) - G.B, fx = (int)(c / ((long)G.N * G.N)) - G.B;
+        const bool node_ok = G.in(fx - 1 + ca, fy - 1 + cb, fz - 1 + cc);
+        const int cnt = cell_count[c];
+        const long j0 = cell_start[c];
+        double acc[3] = {0, 0, 0};
+        for (int base = 0; base < cnt; base += CELL_CHUNK) {
+            const int m = cnt - base < CELL_CHUNK ? cnt - base : CELL_CHUNK;
+            __syncthreads();   // the previous pass has been consumed
+            if ((int)threadIdx.x < m) {   // thread i stages particle i: 22 loads in flight together, each coalesced across the threads
+                const long j = j0 + base + threadIdx.x;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) sp[k][threadIdx.x] = ld(P.node9, P.cap, k, j);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) sp[10 + k][threadIdx.x] = ld(P.wfac, P.cap, k, j);
+            }
+            __syncthreads();
+            if (node_ok) {
+                for (int i = lane; i < m; i += 64) {
+                    const double s2x = sp[10 + ca][i], s2y = sp[12 + cb][i], s2z = sp[14 + cc][i];
+                    const double gx = sp[16 + ca][i], gy = sp[18 + cb][i], gz = sp[20 + cc][i];
+                    const double g[3] = {-1 * gx * s2y * s2z, -1 * s2x * gy * s2z, -1 * s2x * s2y * gz};   // getGradW, deformHeader.h:99-103
+                    const double sc = sp[9][i];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) acc[r] += sc * (sp[3 * r][i] * g[0] + sp[3 * r + 1][i] * g[1] + sp[3 * r + 2][i] * g[2]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double v = acc[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            acc[r] = v;
+        }
+        if (lane < 3) part[(long)b * 24 + 3 * wv + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
+    }
+}
+// value of unknown q, component r: v + (mass factor) x the partial sums of the 8 cells around the node, cells in a fixed order
+__device__ __forceinline__ double apply_combine_one(const MGrid& G, const int* __restrict__ active_cell, const int* __restrict__ cidx,
+                                                    const double* __restrict__ part, const double* __restrict__ invm, int transposed,
+                                                    const double* __restrict__ v, long t)
+{
+    const long q = t / 3;
+    const int r = (int)(t - 3 * q);
+    const long k = active_cell[q];
+    const int nz = (int)(k % G.N) - G.B, ny = (int)((k / G.N) % G.N) - G.B, nx = (int)(k / ((long)G.N * G.N)) - G.B;
+    double sum = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int fx = nx + (d >> 2), fy = ny + ((d >> 1) & 1), fz = nz + (d & 1);
+        if (!G.in(fx, fy, fz)) continue;
+        const int b = cidx[G.at(fx, fy, fz)];
+        if (b < 0) continue;
+        sum += part[(long)b * 24 + 3 * (7 - d) + r];   // the node is corner (1,1,1) - d of that cell
+    }
+    return v[t] + (transposed ? sum : sum * invm[q]);
+}
+__global__ void k_mpm_apply_combine(MGrid G, const MpmState* st, const int* __restrict__ active_cell, const int* __restrict__ cidx,
+                                    const double* __restrict__ part, const double* __restrict__ invm, int transposed, const double* __restrict__ v,
+                                    double* __restrict__ y)
+{
+    const long n3 = 3L * st->num_active;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n3; t += (long)gridDim.x * blockDim.x)
+        y[t] = apply_combine_one(G, active_cell, cidx, part, invm, transposed, v, t);
+}
+// non-empty cells (their compact numbering indexes the operator's partial sums) and the fullest cell
+__global__ void k_mpm_cell_flags(long C, const int* __restrict__ cell_count, int* __restrict__ flag)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < C) flag[k] = cell_count[k] > 0;
+}
+
+// nodes the transfer and the force sums must visit: not solid (mpm.cc:233,620) and within one cell of a particle
+__global__ void k_mpm_touched(MGrid G, const uint8_t* __restrict__ solid, const int* __restrict__ cell_count, int* __restrict__ flag)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= G.cells()) return;
+    const int z = (int)(k % G.N) - G.B, y = (int)((k / G.N) % G.N) - G.B, x = (int)(k / ((long)G.N * G.N)) - G.B;
+    int any = 0;
+    if (!solid[k]) {
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -1; b <= 1; ++b)
+                for (int c = -1; c <= 1; ++c)
+                    if (G.in(x + a, y + b, z + c)) any |= cell_count[G.at(x + a, y + b, z + c)];
+    }
+    flag[k] = any ? 1 : 0;
 }
 
 // per cell: container = float(mass); vels /= w or 0 (mpm.cc:1000-1015); active flag (mpm.cc:1346-1364); output grid
@@ -503,8 +658,8 @@ __global__ void __launch_bounds__(SCAN_T) k_mpm_scan_final(long C, const int* __
 
 // ---- particles in base-cell order (counting sort, every step) ----
 // The scatter kernels run over `order`: lanes of a wave then share their base cell, so the wave-level aggregation above
-// turns thousands of same-address atomics into one per wave and node.  Order inside a cell is whatever the rank atomics
-// give (sums differ in the last bits from run to run, as with any atomic accumulation).
+// turns thousands of same-address atomics into one per wave and node.  (That was the first version; the sums are node
+// gathers over the cell lists now, see k_mpm_gather.)
 __global__ void k_mpm_sort_count(MGrid G, long n, Part P, int* __restrict__ cell_count, int* __restrict__ key, int* __restrict__ rank)
 {
     // The arrays are nearly sorted already (last step's order, particles move a fraction of a cell per step): the lanes of a
@@ -564,11 +719,16 @@ __global__ void __launch_bounds__(SCAN_T) k_mpm_scan_excl(long C, const int* __r
         }
 }
 __global__ void k_mpm_sort_place(long n, const int* __restrict__ key, const int* __restrict__ rank, const int* __restrict__ cell_start,
-                                 int* __restrict__ order)
+                                 const int* __restrict__ pid, int* __restrict__ order, int* __restrict__ spid)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[cell_start[key[i]] + rank[i]] = (int)i;
+    if (i >= n) return;
+    const int d = cell_start[key[i]] + rank[i];
+    order[d] = (int)i;
+    spid[d] = pid[i];   // the upload indices in (unordered) cell order, contiguous per cell: the rank pass streams them
 }
+// (inside a cell the lists are then re-ranked by ascending upload index, fl::launch_bin_rank, so that the node gathers add in an order
+// that is a function of the input alone)
 
 // The particle arrays themselves are put into that order (double-buffered), so that every per-particle kernel of the step —
 // the operator application runs once per CG iteration — reads them coalesced; `pid` keeps the upload index of each slot.
@@ -615,57 +775,38 @@ __global__ void __launch_bounds__(128) k_mpm_volume(MGrid G, long n, Part P, con
 }
 
 // ---- populateGridForces, first loop (mpm.cc:596-644) + the per-particle part of getdPsydx2 (deformHeader.h:253-263) ----
-__global__ void __launch_bounds__(128) k_mpm_forces(MGrid G, long n, Part P, const int* __restrict__ order, const uint8_t* __restrict__ solid, double mu0, double lambda0, double eps,
-                             double* __restrict__ forces)
+// per particle: polar factors, stress, the operator's cache; the node sums follow in k_mpm_gather<1>
+__global__ void __launch_bounds__(128) k_mpm_forces(MGrid G, long n, Part P, double mu0, double lambda0, double eps)
 {
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i0 < n;
-    const long i = order ? order[valid ? i0 : 0] : (valid ? i0 : 0);   // idle lanes of the last wave recompute a particle and store nothing
-    const long C = G.cells();
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     double F[9], FP[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) F[k] = ld(P.FE, P.cap, k, i), FP[k] = ld(P.FP, P.cap, k, i);
     Setup su;
     particle_setup(F, FP, mu0, lambda0, eps, su);
-    const double* sigma = su.sigma;
-    // cache for the operator
-    if (valid) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            stv(P.R, P.cap, k, i, su.R[k]);
-            stv(P.Minv, P.cap, k, i, su.Minv[k]);
-            stv(P.cof, P.cap, k, i, su.cof[k]);
-        }
-        stv(P.coef, P.cap, 0, i, su.mu), stv(P.coef, P.cap, 1, i, su.lambda), stv(P.coef, P.cap, 2, i, su.J);
+    for (int k = 0; k < 9; ++k) {
+        stv(P.R, P.cap, k, i, su.R[k]);
+        stv(P.Minv, P.cap, k, i, su.Minv[k]);
+        stv(P.cof, P.cap, k, i, su.cof[k]);
+        stv(P.node9, P.cap, k, i, su.sigma[k]);
     }
-
-    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
-    const double vol = P.volume[i];
-    Nbh nb;
-    neighbourhood(G, p, nb, true);
-    const Seg sg = seg_setup(base_key(G, p, valid));
+    stv(P.coef, P.cap, 0, i, su.mu), stv(P.coef, P.cap, 1, i, su.lambda), stv(P.coef, P.cap, 2, i, su.J);
+    stv(P.node9, P.cap, 9, i, P.volume[i]);
+    // the gradient-weight factors of the two nodes per axis that carry any (base - 1, base): position only, so once per step — the
+    // operator's cell sums read them instead of evaluating six splines per (particle, node) pair
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a) {
+        const double pa = ld(P.pos, P.cap, a, i);
+        const int f = (int)round(pa);
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int x = nb.lo[0] + a, y = nb.lo[1] + b, z = nb.lo[2] + c;
-                const bool in = valid && x <= nb.hi[0] && y <= nb.hi[1] && z <= nb.hi[2];
-                const long k = in ? G.at(x, y, z) : 0;
-                const bool ok = in && !solid[k];
-                double g[3];
-                grad_w(nb, a, b, c, g);
-                double f[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    f[r] = seg_sum(ok ? -1 * vol * (sigma[3 * r] * g[0] + sigma[3 * r + 1] * g[1] + sigma[3 * r + 2] * g[2]) : 0.0, sg);
-                if (sg.tail && ok) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        if (f[r] != 0) unsafeAtomicAdd(&forces[r * C + k], f[r]);
-                }
-            }
+        for (int k = 0; k < 2; ++k) {
+            const int c = f - 1 + k;
+            stv(P.wfac, P.cap, 2 * a + k, i, mspline2(0.5 + c - pa));
+            stv(P.wfac, P.cap, 6 + 2 * a + k, i, mspline_grad(pa - c - 0.5));
+        }
+    }
 }
 
 // ---- right-hand side and the "Max Force" line, mpm.cc:383-417 ----
@@ -730,52 +871,47 @@ __global__ void k_mpm_maxforce_final(MGrid G, MpmState* st, const float* __restr
     }
 }
 
-// ---- the operator: y = v + beta dt^2 D^-1 K v, one thread per particle (mpm.cc:646-701 + 418-441, matrix-free) ----
-// v, y: 3 * num_active doubles in unknown order; y must hold v on entry (the identity part).
-__global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, const int* __restrict__ order, const int* __restrict__ indices, const double* __restrict__ invm,
-                            const MpmState* st, double beta, int transposed, int in_solve, const double* __restrict__ v, double* __restrict__ y)
+// ---- the operator: y = v + beta dt^2 D^-1 K v (mpm.cc:646-701 + 418-441, matrix-free) ----
+// Two launches per application: per PARTICLE the gather of G = sum_j v_j (x) grad w_j from the unknown vector, one application of
+// the energy Hessian and A_p F_p^T (k_mpm_apply_particles, below); per unknown NODE the sum over the particles around it
+// (k_mpm_gather<2>).  v, y: 3 * num_active doubles in unknown order.
+__global__ void __launch_bounds__(128) k_mpm_apply_particles(MGrid G, long n, Part P, const int* __restrict__ indices, const double* __restrict__ invm,
+                                                             const MpmState* st, double beta, int transposed, int in_solve, const double* __restrict__ v)
 {
     if (in_solve && st->cg_done) return;   // speculative launches past convergence do nothing
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i0 < n;
-    const long i = order ? order[valid ? i0 : 0] : (valid ? i0 : 0);
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
     Nbh nb;
     neighbourhood(G, p, nb, true);
-    // The kernel is a chain of dependent loads (node -> unknown number -> value).  The 27 unknown numbers are fetched first, all
-    // in flight together, and serve the gather and the scatter; everything else a node needs is indexed by that number
-    // (invm = 1 / node mass per unknown).  One array per x-plane so that the rolled plane loops below pick by select.
-    int k0[9], k1[9], k2[9];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int cx = nb.lo[0] + a, cy = nb.lo[1] + b, cz = nb.lo[2] + c;
-                const bool in = valid && cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
-                const int k = in ? indices[G.at(cx, cy, cz)] : -1;
-                if (a == 0) k0[3 * b + c] = k;
-                else if (a == 1) k1[3 * b + c] = k;
-                else k2[3 * b + c] = k;
-            }
-    // G = sum_j v_j (x) grad w_j over the unknown nodes, one x-plane of 9 nodes at a time (its value loads in flight together);
-    // the x factors are picked by selects so that the plane loop stays rolled without indexing registers dynamically
+    // G = sum_j v_j (x) grad w_j over the unknown nodes, one x-plane of 9 nodes at a time (node -> unknown number -> value: the 9
+    // numbers of a plane are fetched together, then their values); the x factors are picked by selects so that the plane loop
+    // stays rolled without indexing registers dynamically
     double Gm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
     for (int a = 0; a < 3; ++a) {
         const double s2x = a == 0 ? nb.s2[0][0] : (a == 1 ? nb.s2[0][1] : nb.s2[0][2]);
         const double gx = a == 0 ? nb.g[0][0] : (a == 1 ? nb.g[0][1] : nb.g[0][2]);
+        const int cx = nb.lo[0] + a;
+        int kk[9];
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int k = a == 0 ? k0[3 * b + c] : (a == 1 ? k1[3 * b + c] : k2[3 * b + c]);
-                const long kk = k >= 0 ? k : 0;
+                const int cy = nb.lo[1] + b, cz = nb.lo[2] + c;
+                const bool in = cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
+                kk[3 * b + c] = in ? indices[G.at(cx, cy, cz)] : -1;
+            }
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int k = kk[3 * b + c];
+                const long kq = k >= 0 ? k : 0;
                 const double g[3] = {-1 * gx * nb.s2[1][b] * nb.s2[2][c], -1 * s2x * nb.g[1][b] * nb.s2[2][c], -1 * s2x * nb.s2[1][b] * nb.g[2][c]};
                 // transposed system (what the reference's Eigen solves, see mpm_hip.h): K D^-1 v — the mass divides the input
-                const double wj = k < 0 ? 0.0 : (transposed ? invm[kk] : 1.0);
-                const double vx = wj * v[3 * kk], vy = wj * v[3 * kk + 1], vz = wj * v[3 * kk + 2];
+                const double wj = k < 0 ? 0.0 : (transposed ? invm[kq] : 1.0);
+                const double vx = wj * v[3 * kq], vy = wj * v[3 * kq + 1], vz = wj * v[3 * kq + 2];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) Gm[d] += vx * g[d], Gm[3 + d] += vy * g[d], Gm[6 + d] += vz * g[d];
             }
@@ -790,31 +926,10 @@ __global__ void __launch_bounds__(128) k_mpm_apply(MGrid G, long n, Part P, cons
     hessian_apply(F, R, Mi, cf, mu, lambda, J, dF, Ap);
     double ApFt[9];
     mat_mul_bt(Ap, F, ApFt);                    // A_p F^T
+#pragma unroll
+    for (int k = 0; k < 9; ++k) stv(P.node9, P.cap, k, i, ApFt[k]);
     const double dt = st->dt;
-    const double sc = beta * dt * dt * P.volume[i];
-    const Seg sg = seg_setup(base_key(G, p, valid));
-#pragma unroll 1
-    for (int a = 0; a < 3; ++a) {
-        const double s2x = a == 0 ? nb.s2[0][0] : (a == 1 ? nb.s2[0][1] : nb.s2[0][2]);
-        const double gx = a == 0 ? nb.g[0][0] : (a == 1 ? nb.g[0][1] : nb.g[0][2]);
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int k = a == 0 ? k0[3 * b + c] : (a == 1 ? k1[3 * b + c] : k2[3 * b + c]);
-                const bool ok = k >= 0;
-                const double g[3] = {-1 * gx * nb.s2[1][b] * nb.s2[2][c], -1 * s2x * nb.g[1][b] * nb.s2[2][c], -1 * s2x * nb.s2[1][b] * nb.g[2][c]};
-                const double f = !ok ? 0.0 : (transposed ? sc : sc * invm[k]);
-                double o[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) o[r] = seg_sum(f * (ApFt[3 * r] * g[0] + ApFt[3 * r + 1] * g[1] + ApFt[3 * r + 2] * g[2]), sg);
-                if (sg.tail && ok) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        if (o[r] != 0) unsafeAtomicAdd(&y[3 * (long)k + r], o[r]);
-                }
-            }
-    }
+    stv(P.node9, P.cap, 9, i, beta * dt * dt * P.volume[i]);
 }
 
 // ---- CG vector kernels (3 * num_active doubles, weighted dots) ----
@@ -873,13 +988,18 @@ __global__ void k_mpm_cg_init(const int* __restrict__ active_cell, const MpmStat
 // of the consumer re-sums the producer's 256 partials from L2 (same order everywhere, so every block takes the same
 // decisions), block 0 records them in the state.  `par` = iteration parity: <r,r>_w lives in two slots so that the kernel that
 // writes the next one never races with readers of the current one.
-__global__ void k_mpm_cg_pq(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
-                            const double* __restrict__ p, const double* __restrict__ q, double* pa, double* pb)
+// (inside a solve it also forms q = A p from the operator's partial sums per cell: k_mpm_apply_combine folded in, one launch less per iteration)
+__global__ void k_mpm_cg_pq(MGrid G, const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
+                            const double* __restrict__ p, double* __restrict__ q, double* pa, double* pb, const int* __restrict__ cidx,
+                            const double* __restrict__ apart, const double* __restrict__ invm)
 {
     const long n3 = st->cg_done ? 0 : 3L * st->num_active;
     double d = 0;
-    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x)
-        d += dot_weight(container[active_cell[k / 3]], transposed) * p[k] * q[k];
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
+        const double qk = apply_combine_one(G, active_cell, cidx, apart, invm, transposed, p, k);
+        q[k] = qk;
+        d += dot_weight(container[active_cell[k / 3]], transposed) * p[k] * qk;
+    }
     block_sum2(0.0, d, pa, pb);
 }
 // alpha = <r,r>_w / <p,Ap>_w; x += alpha p; r -= alpha q; partials |r|^2, <r,r>_w
@@ -1110,6 +1230,7 @@ __global__ void k_mpm_interleave(long C, const double* __restrict__ soa, double*
 }
 
 inline unsigned blocks_for(long n, int t) { return (unsigned)((n + t - 1) / t); }
+constexpr int GATHER_BLOCKS = 2048;   // workgroups of a node gather (each strides the node list: its length stays on the device)
 inline double bits_to_double(unsigned long long b)
 {
     double d;
@@ -1130,9 +1251,14 @@ struct mpm_sim {
     float *container = nullptr, *output = nullptr;
     double *massd = nullptr, *vel = nullptr, *velb = nullptr, *forces = nullptr;
     int *flag = nullptr, *indices = nullptr, *active_cell = nullptr, *sums = nullptr;
-    int *cell_count = nullptr, *cell_start = nullptr, *key = nullptr, *rank = nullptr, *order = nullptr;   // counting sort by base cell
+    int *cell_count = nullptr, *cell_start = nullptr, *key = nullptr, *rank = nullptr, *order = nullptr, *order2 = nullptr, *rank2 = nullptr;   // counting sort by base cell
+    int *tflag = nullptr, *tidx = nullptr, *tlist = nullptr;   // nodes within one cell of a particle: flags, scratch numbering, list
     double *b = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *part = nullptr;
     double* invm = nullptr;       // 1 / node mass per unknown
+    double* apart = nullptr;      // the operator's partial node sums (32 x 3 per unknown), grown with the unknown count
+    size_t apart_cap = 0;
+    int *cflag = nullptr, *cidx = nullptr, *clist = nullptr;   // non-empty cells: flags, compact index per cell (-1: empty), list
+    int num_cells = 0;
     double* stage = nullptr;
     size_t stage_bytes = 0;
     MpmState* state = nullptr;
@@ -1165,12 +1291,12 @@ int ensure_stage(mpm_sim* s, size_t bytes)
 }
 void free_particles(mpm_sim* s)
 {
-    int** ia[] = {&s->key, &s->rank, &s->order, &s->pid, &s->pid2};
+    int** ia[] = {&s->key, &s->rank, &s->rank2, &s->order, &s->order2, &s->pid, &s->pid2};
     for (auto p : ia) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.cof, &s->P.coef,
+    double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.cof, &s->P.coef, &s->P.node9, &s->P.wfac,
                     &s->P2.pos, &s->P2.vel, &s->P2.FE, &s->P2.FP, &s->P2.volume};
     for (auto p : a) {
         if (*p) (void)hipFree(*p);
@@ -1184,7 +1310,8 @@ int alloc_particles(mpm_sim* s, long cap)
     s->P.cap = s->P2.cap = cap;
     if (dalloc(&s->P.pos, 3 * cap) || dalloc(&s->P.vel, 3 * cap) || dalloc(&s->P.FE, 9 * cap) || dalloc(&s->P.FP, 9 * cap) ||
         dalloc(&s->P.gradV, 9 * cap) || dalloc(&s->P.volume, cap) || dalloc(&s->P.R, 9 * cap) || dalloc(&s->P.Minv, 9 * cap) ||
-        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap) || dalloc(&s->key, cap) || dalloc(&s->rank, cap) || dalloc(&s->order, cap) ||
+        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap) || dalloc(&s->P.node9, 10 * cap) || dalloc(&s->P.wfac, 12 * cap) || dalloc(&s->key, cap) || dalloc(&s->rank, cap) ||
+        dalloc(&s->order, cap) || dalloc(&s->order2, cap) || dalloc(&s->rank2, cap) ||
         dalloc(&s->pid, cap) || dalloc(&s->pid2, cap) || dalloc(&s->P2.pos, 3 * cap) || dalloc(&s->P2.vel, 3 * cap) || dalloc(&s->P2.FE, 9 * cap) ||
         dalloc(&s->P2.FP, 9 * cap) || dalloc(&s->P2.volume, cap))
         return FLUID_ERR_HIP;
@@ -1195,8 +1322,15 @@ int alloc_particles(mpm_sim* s, long cap)
 // y = A v on the device (v in s->p, result in s->q)
 int apply_operator(mpm_sim* s, int in_solve)
 {
-    // q holds p already (the identity part)
-    if (s->n) k_mpm_apply<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, nullptr, s->indices, s->invm, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p, s->q);
+    if (s->n) {
+        k_mpm_apply_particles<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, s->indices, s->invm, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p);
+        k_mpm_apply_cells<<<(unsigned)std::min<long>(std::max<long>(s->num_cells, 1), 4096), 512, 0, s->st>>>(s->G, s->P, s->cell_start, s->cell_count, s->clist, s->state,
+                                                                                                           in_solve, s->apart);
+        // inside a solve the next kernel (k_mpm_cg_pq) forms q from the partial sums itself
+        if (!in_solve)
+            k_mpm_apply_combine<<<blocks_for(3L * std::max(s->num_active, 1), 256), 256, 0, s->st>>>(s->G, s->state, s->active_cell, s->cidx, s->apart, s->invm,
+                                                                                                 s->prm.transpose_system, s->p, s->q);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1245,7 +1379,7 @@ int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
     if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) rc = FLUID_ERR_HIP;
     rc = rc || dalloc(&s->solid, C) || dalloc(&s->container, C) || dalloc(&s->output, C) || dalloc(&s->massd, C) || dalloc(&s->vel, 3 * C) ||
          dalloc(&s->velb, 3 * C) || dalloc(&s->forces, 3 * C) || dalloc(&s->flag, C) || dalloc(&s->indices, C) || dalloc(&s->active_cell, C) ||
-         dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C) || dalloc(&s->part, 4 * RED_BLOCKS) || dalloc(&s->state, 1);
+         dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C + 1) || dalloc(&s->tflag, C) || dalloc(&s->tidx, C) || dalloc(&s->tlist, C) || dalloc(&s->cflag, C) || dalloc(&s->cidx, C) || dalloc(&s->clist, C) || dalloc(&s->part, 4 * RED_BLOCKS) || dalloc(&s->state, 1);
     // unknowns live inside the walls only: (2W+1)^3 at most
     const long maxu = (long)(2 * prm->W + 1) * (2 * prm->W + 1) * (2 * prm->W + 1);
     rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu) || dalloc(&s->invm, maxu);
@@ -1273,7 +1407,7 @@ int mpm_destroy(mpm_sim_t* s)
     if (!s) return 0;
     free_particles(s);
     void* a[] = {s->solid, s->container, s->output, s->massd, s->vel, s->velb, s->forces, s->flag, s->indices, s->active_cell, s->sums,
-                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage, s->cell_count, s->cell_start, s->invm};
+                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage, s->cell_count, s->cell_start, s->invm, s->tflag, s->tidx, s->tlist, s->apart, s->cflag, s->cidx, s->clist};
     for (void* p : a)
         if (p) (void)hipFree(p);
     if (s->h_state) (void)hipHostFree(s->h_state);
@@ -1329,6 +1463,7 @@ int64_t mpm_num_particles(const mpm_sim_t* s) { return s ? s->n : -1; }
 int mpm_set_state(mpm_sim_t* s, const double* FE, const double* FP, const double* volume, int32_t step_no)
 {
     if (!s || step_no < 0) return fluid_fail(FLUID_ERR_ARG, "mpm_set_state: bad argument");
+    if (s->mid_step) return fluid_fail(FLUID_ERR_STATE, "mpm_set_state: between mpm_step_solve and mpm_step_advance");
     const long m = s->n;
     const double* src[3] = {FE, FP, volume};
     double* dst[3] = {s->P.FE, s->P.FP, s->P.volume};
@@ -1380,12 +1515,26 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
         k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->cell_count, s->sums);
         k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, nullptr);
         k_mpm_scan_excl<<<nb, SCAN_T, 0, st>>>(C, s->cell_count, s->sums, s->cell_start);
-        k_mpm_sort_place<<<blocks_for(n, 256), 256, 0, st>>>(n, s->key, s->rank, s->cell_start, s->order);
-        k_mpm_permute<<<blocks_for(n, 256), 256, 0, st>>>(n, s->P.cap, s->order, s->P, s->P2, s->pid, s->pid2);
+        k_mpm_sort_place<<<blocks_for(n, 256), 256, 0, st>>>(n, s->key, s->rank, s->cell_start, s->pid, s->order, s->rank2);
+        // inside a cell: ascending upload index (the fluid path's rank pass: ids staged through LDS — a thread per particle walking its
+        // cell's 400 ids took 85-134 us on the reference's scene)
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(s->cell_start + C), (int)n, 1, st));
+        fl::launch_bin_rank(st, n, 0, s->key, s->cell_start, s->order, (const uint32_t*)s->rank2, s->order2);
+        k_mpm_permute<<<blocks_for(n, 256), 256, 0, st>>>(n, s->P.cap, s->order2, s->P, s->P2, s->pid, s->pid2);
         std::swap(s->P.pos, s->P2.pos), std::swap(s->P.vel, s->P2.vel), std::swap(s->P.FE, s->P2.FE), std::swap(s->P.FP, s->P2.FP);
         std::swap(s->P.volume, s->P2.volume), std::swap(s->pid, s->pid2);
     }
-    if (n) k_mpm_p2g<<<pb, 128, 0, st>>>(G, n, s->P, nullptr, s->solid, s->massd, s->vel);
+    if (n) {
+        k_mpm_touched<<<cb, 256, 0, st>>>(G, s->solid, s->cell_count, s->tflag);
+        k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->tflag, s->sums);
+        k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, &s->state->num_touched);
+        k_mpm_scan_final<<<nb, SCAN_T, 0, st>>>(C, s->tflag, s->sums, s->tidx, s->tlist);
+        k_mpm_cell_flags<<<cb, 256, 0, st>>>(C, s->cell_count, s->cflag);
+        k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->cflag, s->sums);
+        k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, &s->state->num_cells);
+        k_mpm_scan_final<<<nb, SCAN_T, 0, st>>>(C, s->cflag, s->sums, s->cidx, s->clist);
+        k_mpm_gather<0><<<GATHER_BLOCKS, 256, 0, st>>>(G, s->P, s->cell_start, s->cell_count, s->tlist, &s->state->num_touched, s->state, 0, 0, nullptr, nullptr, s->massd, s->vel);
+    }
     k_mpm_cells<<<cb, 256, 0, st>>>(G, s->solid, s->massd, s->container, s->output, s->vel, s->velb, s->flag);
     k_mpm_scan_sums<<<nb, SCAN_T, 0, st>>>(C, s->flag, s->sums);
     k_mpm_scan_blocks<<<1, 1024, 0, st>>>(nb, s->sums, &s->state->num_active);
@@ -1395,7 +1544,10 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     // populateGridForces (mpm.cc:1395): mu = E / (2 (1 + nu)), lambda = E nu / ((1 + nu) (1 - 2 nu))
     const double mu0 = pr.youngs_modulus / (2 * (1 + pr.poisson_ratio));
     const double lambda0 = pr.youngs_modulus * pr.poisson_ratio / ((1 + pr.poisson_ratio) * (1 - 2 * pr.poisson_ratio));
-    if (n) k_mpm_forces<<<pb, 128, 0, st>>>(G, n, s->P, nullptr, s->solid, mu0, lambda0, pr.hardening, s->forces);
+    if (n) {
+        k_mpm_forces<<<pb, 128, 0, st>>>(G, n, s->P, mu0, lambda0, pr.hardening);
+        k_mpm_gather<1><<<GATHER_BLOCKS, 256, 0, st>>>(G, s->P, s->cell_start, s->cell_count, s->tlist, &s->state->num_touched, s->state, 0, 0, nullptr, nullptr, s->forces, nullptr);
+    }
     HIPCHK(hipEventRecord(s->ev[2], st));
     // populateMatrices' right-hand side (mpm.cc:383-416) and cg.solve (mpm.cc:1401-1403)
     k_mpm_rhs<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->vel, s->forces, pr.gravity[0], pr.gravity[1], pr.gravity[2],
@@ -1407,6 +1559,15 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     HIPCHK(hipGetLastError());
     if (read_state(s)) return FLUID_ERR_HIP;
     s->num_active = s->h_state->num_active;
+    s->num_cells = s->h_state->num_cells;
+    {
+        const size_t need = (size_t)24 * (size_t)std::max(s->num_cells, 1);
+        if (need > s->apart_cap) {
+            if (s->apart) { HIPCHK(hipStreamSynchronize(s->st)); HIPCHK(hipFree(s->apart)); s->apart = nullptr; s->apart_cap = 0; }
+            HIPCHK(hipMalloc((void**)&s->apart, (need + need / 4) * sizeof(double)));
+            s->apart_cap = need + need / 4;
+        }
+    }
     const long max_iters = pr.cg_max_iters > 0 ? pr.cg_max_iters : (2L * 3 * s->num_active > 0 ? 2L * 3 * s->num_active : 1);
     // Iterations are launched in batches without waiting for the convergence test: every kernel of an iteration returns
     // at once when the device-side flag is set, and the host reads the 100-byte state once per batch.
@@ -1422,7 +1583,7 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
             if (apply_operator(s, 1)) return FLUID_ERR_HIP;
             if (timed) HIPCHK(hipEventRecord(s->ev[7], st));
             double *pa = s->part, *pb = s->part + RED_BLOCKS, *pc = s->part + 2 * RED_BLOCKS, *pd = s->part + 3 * RED_BLOCKS;
-            k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, pa, pb);
+            k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, pa, pb, s->cidx, s->apart, s->invm);
             k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, (int)(launched & 1), pb, s->x, s->r, s->p,
                                                     s->q, pc, pd);
             k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, (int)(launched & 1), pr.cg_tol, max_iters, pc, pd, s->r, s->p, s->q);

@@ -97,7 +97,9 @@ class MpmSim:
     def _run(self, fn):
         st = MpmStepStats()
         check(fn(self._h, C.byref(st)))
-        return st.as_dict()
+        d = st.as_dict()
+        self._num_active = d["num_active"]   # sizes the buffers of system(): the handle's own count, not a caller's
+        return d
 
     def step(self):
         return self._run(lib.mpm_step)
@@ -125,7 +127,13 @@ class MpmSim:
         check(lib.mpm_download_field(self._h, fid, _ptr(out)))
         return out
 
-    def system(self, num_active):
+    def system(self, num_active=None):
+        """Right-hand side and solution of the last solve (3 doubles per unknown).  The buffers are sized by the handle's own
+        unknown count; an explicit `num_active` must agree with it (mpm_download_system copies 3 * its count doubles)."""
+        mine = getattr(self, "_num_active", 0)
+        if num_active is not None and num_active != mine:
+            raise ValueError(f"system(): the last solve had {mine} unknowns, not {num_active}")
+        num_active = mine
         b = np.empty(3 * num_active, np.float64)
         x = np.empty(3 * num_active, np.float64)
         check(lib.mpm_download_system(self._h, _ptr(b), _ptr(x)))

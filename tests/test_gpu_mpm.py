@@ -341,3 +341,26 @@ def test_large_upload_round_trip_and_scaled_scene(fs):
     p = sim.particles(fs.MPM_P.POS)
     assert np.abs(p - pos).max() < 1.0                   # 5 steps at |v| = 50 and dt = 1e-3: a quarter of a cell
     sim.close()
+
+
+def test_two_runs_give_the_same_bits(fs):
+    """The particle -> node sums (transfer, forces, operator) are gathers over cell lists sorted by cell and upload index: no
+    atomics, so two runs of the same input agree bit for bit — every array, every step, and the iteration counts (the first
+    version summed with fp64 atomics and differed in the last bits from run to run).  The upload order must not matter either
+    for the node fields... it does for nothing but the order of the sums, which follows the upload index: same order, same bits."""
+    F, P = fs.MPM_F, fs.MPM_P
+    pos = fs.snow_cone(B=31, W=29, layers=10, points_per_voxel=48.0, seed=3)
+    runs = []
+    for _ in range(2):
+        sim = fs.MpmSim(B=31, W=29)
+        sim.upload_particles(pos)
+        st = [sim.step() for _ in range(6)]
+        runs.append(([s["cg_iters"] for s in st], [s["num_active"] for s in st],
+                     [sim.field(f) for f in (F.CONTAINER, F.VEL, F.FORCES, F.VEL_BEFORE)],
+                     [sim.particles(w) for w in (P.POS, P.VEL, P.FE, P.FP, P.GRADV, P.VOLUME)], sim.system()))
+        sim.close()
+    a, b = runs
+    assert a[0] == b[0] and a[1] == b[1] and max(a[0]) > 3
+    for x, y in zip(a[2] + a[3], b[2] + b[3]):
+        assert np.array_equal(x, y)
+    assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
