@@ -19,6 +19,7 @@
 // halo) and all levels of <= 4 k cells run inside one block (k_mg_tail); it computes in float inside the
 // double PCG (fluid_api.hip, mg_vcycle_t).
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace fl {
@@ -231,17 +232,22 @@ struct UpTile {
                          oC = (oE + nE * (int)sizeof(T) + 15) / 16 * 16, bytes = (oC + nA + 15) / 16 * 16;
 };
 
-// One tile of the down leg by 256 threads (`col` = thread within the tile's group).  sd / si: coefficient tables in LDS; with
-// `cf` the body fills them itself (after issuing its loads), else the caller has, behind a barrier.  `live` = false: a
-// group without a tile of its own walks a valid one for the barriers' sake and stores nothing.
-template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, typename IO>
+// One tile of the down leg by NG groups of 256 threads (`col` = thread within its group, `grp` = the group).  The x planes of
+// every stage are split among the groups — a coarse level of a few hundred tiles leaves most CUs with ONE tile, whose 256 threads
+// walk 14 planes per stage one after the other: four groups walk 3-4 each (NG = 4, levels >= 1 with few tiles) and the leg's
+// dependent chain shrinks accordingly; a level with many tiles per CU is bound by LDS throughput, not by the chain: NG = 1.
+// sd / si: coefficient tables in LDS; with `cf` the body fills them itself (after issuing its loads), else the caller has, behind
+// a barrier.  `live` = false: a group without a tile of its own walks a valid one for the barriers' sake and stores nothing.
+template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, typename IO, int NG = 1>
 __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
                                              T* __restrict__ r, const MLevel& mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
-                                             const MgCoef<T>* cf, T off, int tile, int gx, int gy, bool live, int col, char* lds, T* sd, T* si)
+                                             const MgCoef<T>* cf, T off, int tile, int gx, int gy, bool live, int col, char* lds, T* sd, T* si,
+                                             int grp = 0)
 {
     typedef DownTile<T, TX, TY, TZ, RESTRICT> D;
     constexpr int H = D::H, AX = D::AX, AY = D::AY, AZ = D::AZ, BX = D::BX, BY = D::BY, BZ = D::BZ, CX = D::CX, CY = D::CY, CZ = D::CZ;
-    constexpr int NHC = 256 / (CY * CZ), XC = (CX + NHC - 1) / NHC;   // the r columns are few: NHC threads share one, XC planes each
+    constexpr int PA = (AX + NG - 1) / NG, PB = (BX + NG - 1) / NG;   // planes of regions A / B per group
+    constexpr int NHC = NG * (256 / (CY * CZ)), XC = (CX + NHC - 1) / NHC;   // the r columns are few: NHC threads (over all groups) share one, XC planes each
     static_assert(AY * AZ <= 256 && NHC >= 1 && TX % 2 == 0 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
     T* sA = (T*)(lds + D::oA);
     T* sB = (T*)(lds + D::oB);
@@ -256,25 +262,27 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
     const bool actA = col < AY * AZ;
     const bool okA = actA && (unsigned)(j0 - H + ya) < (unsigned)m.dy && (unsigned)(k0 - H + za) < (unsigned)m.dz;
     const size_t qa = m.at(0, clampi(j0 - H + ya, m.dy - 1), clampi(k0 - H + za, m.dz - 1));
-    int ca[AX];
-    T fa[AX];
+    const int xa0 = grp * PA;
+    int ca[PA];
+    T fa[PA];
 #pragma unroll
-    for (int x = 0; x < AX; ++x) {
-        const int i = i0 - H + x;
+    for (int p = 0; p < PA; ++p) {
+        const int x = xa0 + p, i = i0 - H + x;
         const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
         const int c = cnt[q];
-        fa[x] = (T)IO::ld(f + q);  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
-        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
+        fa[p] = (T)IO::ld(f + q);  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
+        ca[p] = (okA && x < AX && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
     const int yb = col / BZ, zb = col - yb * BZ;
     const bool actB = col < BY * BZ;
     const size_t qb = m.at(0, clampi(j0 - H + 1 + yb, m.dy - 1), clampi(k0 - H + 1 + zb, m.dz - 1));
-    T fb[BX];
+    const int xb0 = grp * PB;
+    T fb[PB];
 #pragma unroll
-    for (int x = 0; x < BX; ++x) fb[x] = (T)IO::ld(f + qb + (size_t)((long)clampi(i0 - H + 1 + x, m.dx - 1) * sx));
-    const int hc = col / (CY * CZ), cc = col - hc * (CY * CZ);
+    for (int p = 0; p < PB; ++p) fb[p] = (T)IO::ld(f + qb + (size_t)((long)clampi(i0 - H + 1 + xb0 + p, m.dx - 1) * sx));
+    const int hc = grp * (256 / (CY * CZ)) + col / (CY * CZ), cc = col % (CY * CZ);
     const int yc = cc / CZ, zc = cc - yc * CZ;
-    const bool actC = hc < NHC;
+    const bool actC = col / (CY * CZ) < 256 / (CY * CZ);
     const int xc0 = hc * XC;
     const size_t qc = m.at(0, clampi(j0 - H + 2 + yc, m.dy - 1), clampi(k0 - H + 2 + zc, m.dz - 1));
     T fr[XC];
@@ -284,33 +292,39 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
     // ---- u1 = W1 D^-1 f on region A ----
     if (actA) {
 #pragma unroll
-        for (int x = 0; x < AX; ++x) {
-            sC[x * AY * AZ + col] = (uint8_t)ca[x];
-            sA[x * AY * AZ + col] = w1 * si[ca[x]] * fa[x];  // si[0] = 0
+        for (int p = 0; p < PA; ++p) {
+            const int x = xa0 + p;
+            if (x < AX) {
+                sC[x * AY * AZ + col] = (uint8_t)ca[p];
+                sA[x * AY * AZ + col] = w1 * si[ca[p]] * fa[p];  // si[0] = 0
+            }
         }
     }
     __syncthreads();
     // ---- u2 on region B (branch-free: a non-unknown has n = 0, si[0] = sd[0] = 0 and u1 = 0, so 0 falls out) ----
-    if (actB) {
-        const int a0 = (yb + 1) * AZ + zb + 1;
+    if (actB && xb0 < BX) {
+        const int a0 = (yb + 1) * AZ + zb + 1 + xb0 * AY * AZ;
         T cm = sA[a0], c0 = sA[a0 + AY * AZ];
         const bool in_yz = live && (unsigned)(yb - (H - 1)) < (unsigned)TY && (unsigned)(zb - (H - 1)) < (unsigned)TZ;
 #pragma unroll
-        for (int x = 0; x < BX; ++x) {
-            const int a = a0 + (x + 1) * AY * AZ;
-            const T cp = sA[a + AY * AZ];
-            const int n = sC[a];
-            const T nb = cm + cp + sA[a - AZ] + sA[a + AZ] + sA[a - 1] + sA[a + 1];
-            const T v = c0 + w2 * si[n] * (fb[x] - (sd[n] * c0 + off * nb));
-            sB[(x * BY + yb) * BZ + zb] = v;
-            if (n && in_yz && x >= H - 1 && x < H - 1 + TX) IO::st(u + qb + (size_t)((long)(i0 - H + 1 + x) * sx), v);  // n != 0: in the level, no clamp
-            cm = c0;
-            c0 = cp;
+        for (int p = 0; p < PB; ++p) {
+            const int x = xb0 + p;
+            if (x < BX) {
+                const int a = a0 + (p + 1) * AY * AZ;
+                const T cp = sA[a + AY * AZ];
+                const int n = sC[a];
+                const T nb = cm + cp + sA[a - AZ] + sA[a + AZ] + sA[a - 1] + sA[a + 1];
+                const T v = c0 + w2 * si[n] * (fb[p] - (sd[n] * c0 + off * nb));
+                sB[(x * BY + yb) * BZ + zb] = v;
+                if (n && in_yz && x >= H - 1 && x < H - 1 + TX) IO::st(u + qb + (size_t)((long)(i0 - H + 1 + x) * sx), v);  // n != 0: in the level, no clamp
+                cm = c0;
+                c0 = cp;
+            }
         }
     }
     __syncthreads();
     // ---- r = f - A u2 on region C ----
-    if (actC) {
+    if (actC && xc0 < CX) {
         const int b0 = ((xc0 + 1) * BY + yc + 1) * BZ + zc + 1;
         T cm = sB[b0 - BY * BZ], c0 = sB[b0];
 #pragma unroll
@@ -331,7 +345,7 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
     if (RESTRICT) {
         __syncthreads();
         constexpr int QX = TX / 2, QY = TY / 2, QZ = TZ / 2;
-        for (int t = col; t < QX * QY * QZ; t += 256) {
+        for (int t = grp * 256 + col; t < QX * QY * QZ; t += 256 * NG) {
             int X, Y, Z;
             region_cell<QY, QZ>(t, X, Y, Z);
             const int I = i0 / 2 + X, J = j0 / 2 + Y, K = k0 / 2 + Z;
@@ -354,10 +368,10 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
     }
 }
 
-template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT>
-__global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
-                                                 T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
-                                                 MgCoef<T> cf, const PcgState* ps, int gx, int gy, const int* __restrict__ tlist)
+template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, int NG = 1>
+__global__ __launch_bounds__(256 * NG) void k_mg_down(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
+                                                      T* __restrict__ r, MLevel mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
+                                                      MgCoef<T> cf, const PcgState* ps, int gx, int gy, const int* __restrict__ tlist)
 {
     __shared__ __attribute__((aligned(16))) char lds[DownTile<T, TX, TY, TZ, RESTRICT>::bytes];
     __shared__ T sd[8], si[8];
@@ -365,23 +379,25 @@ __global__ __launch_bounds__(256) void k_mg_down(MLevel m, const uint8_t* __rest
     // 1-D launch: virtual tile ids are dealt so that each XCD (own L2) gets a contiguous run of tiles, z fastest;
     // tlist (mostly-air box): only the tiles that hold an unknown are launched, in ascending order (k_mg_tile_flags)
     const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);
-    mg_down_body<T, F, TX, TY, TZ, RESTRICT, IoPlain>(m, cnt, f, u, r, mc, cnt_c, fc, &cf, cf.off, tile, gx, gy, true, threadIdx.x, lds, sd, si);
+    mg_down_body<T, F, TX, TY, TZ, RESTRICT, IoPlain, NG>(m, cnt, f, u, r, mc, cnt_c, fc, &cf, cf.off, tile, gx, gy, true, NG > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x,
+                                                          lds, sd, si, NG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0);
 }
 
-// One tile of the up leg by 256 threads; see mg_down_body for col / lds / sd / si / cf / live.  red: 4 doubles (part_dot only).
-template <typename T, typename F, typename O, int TX, int TY, int TZ, typename IO>
+// One tile of the up leg; see mg_down_body for col / grp / lds / sd / si / cf / live.  red: 4 doubles (part_dot only, NG = 1).
+template <typename T, typename F, typename O, int TX, int TY, int TZ, typename IO, int NG = 1>
 __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
                                            O* __restrict__ out, const MLevel& mc, const T* __restrict__ ec, const MgCoef<T>* cf, T off,
                                            double* __restrict__ part_dot, int tile, int gx, int gy, T wc, const uint8_t* __restrict__ own, bool live,
-                                           int col, char* lds, T* sd, T* si, double* red)
+                                           int col, char* lds, T* sd, T* si, double* red, int grp = 0)
 {
     // own (decomposed run, level 0): the PCG's count bytes — the partial f.out counts the rank's owned unknowns only
     // (non-zero byte without bit 7); the result itself is written on every unknown of the local box
     typedef UpTile<T, TX, TY, TZ> D;
     constexpr int AX = D::AX, AY = D::AY, AZ = D::AZ, BX = D::BX, BY = D::BY, BZ = D::BZ, EX = D::EX, EY = D::EY, EZ = D::EZ;
-    constexpr int NE = (EX * EY * EZ + 255) / 256;
-    constexpr int NHT = 256 / (TY * TZ), XT = TX / NHT;               // NHT threads share a tile column, XT planes each
-    static_assert(AY * AZ <= 256 && 256 % (TY * TZ) == 0 && TX % NHT == 0 && TX % 2 == 0 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
+    constexpr int NE = (EX * EY * EZ + 256 * NG - 1) / (256 * NG);
+    constexpr int PA = (AX + NG - 1) / NG, PB = (BX + NG - 1) / NG;
+    constexpr int NHT = NG * (256 / (TY * TZ)), XT = (TX + NHT - 1) / NHT;   // NHT threads (over all groups) share a tile column, XT planes each
+    static_assert(AY * AZ <= 256 && 256 % (TY * TZ) == 0 && TX % 2 == 0 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
     T* sA = (T*)(lds + D::oA);
     T* sB = (T*)(lds + D::oB);
     T* sE = (T*)(lds + D::oE);
@@ -390,12 +406,13 @@ __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __res
     const int i0 = tbz * TX, j0 = tby * TY, k0 = tbx * TZ;
     const int I0 = i0 / 2 - 2, J0 = j0 / 2 - 2, K0 = k0 / 2 - 2;
     const long sx = m.sx;
+    const int tid = grp * 256 + col;
     // ---- every global load of the block ----
     T ee[NE];
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
         int x, y, z;
-        region_cell<EY, EZ>(col + 256 * it, x, y, z);
+        region_cell<EY, EZ>(tid + 256 * NG * it, x, y, z);
         const int I = I0 + x, J = J0 + y, K = K0 + z;
         // the coarse arrays carry a ring of zeros (indices -1 and d*), nothing beyond it
         const bool ok = I >= -1 && I <= mc.dx && J >= -1 && J <= mc.dy && K >= -1 && K <= mc.dz;
@@ -406,23 +423,26 @@ __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __res
     const bool actA = col < AY * AZ;
     const bool okA = actA && (unsigned)(j0 - 2 + ya) < (unsigned)m.dy && (unsigned)(k0 - 2 + za) < (unsigned)m.dz;
     const size_t qa = m.at(0, clampi(j0 - 2 + ya, m.dy - 1), clampi(k0 - 2 + za, m.dz - 1));
-    int ca[AX];
-    T ua[AX];
+    const int xa0 = grp * PA;
+    int ca[PA];
+    T ua[PA];
 #pragma unroll
-    for (int x = 0; x < AX; ++x) {
-        const int i = i0 - 2 + x;
+    for (int p = 0; p < PA; ++p) {
+        const int x = xa0 + p, i = i0 - 2 + x;
         const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
         const int c = cnt[q];
-        ua[x] = IO::ld(u + q);
-        ca[x] = (okA && (unsigned)i < (unsigned)m.dx) ? c : 0;
+        ua[p] = IO::ld(u + q);
+        ca[p] = (okA && (NG == 1 || x < AX) && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
     const int yb = col / BZ, zb = col - yb * BZ;
     const bool actB = col < BY * BZ;
     const size_t qb = m.at(0, clampi(j0 - 1 + yb, m.dy - 1), clampi(k0 - 1 + zb, m.dz - 1));
-    T fb[BX];
+    const int xb0 = grp * PB;
+    T fb[PB];
 #pragma unroll
-    for (int x = 0; x < BX; ++x) fb[x] = (T)IO::ld(f + qb + (size_t)((long)clampi(i0 - 1 + x, m.dx - 1) * sx));
-    const int ht = col / (TY * TZ), ct = col - ht * (TY * TZ);
+    for (int p = 0; p < PB; ++p) fb[p] = (T)IO::ld(f + qb + (size_t)((long)clampi(i0 - 1 + xb0 + p, m.dx - 1) * sx));
+    const int hl = col / (TY * TZ), ct = col - hl * (TY * TZ);
+    const int ht = NG == 1 ? hl : grp * (256 / (TY * TZ)) + hl;
     const int yt = ct / TZ, zt = ct - yt * TZ;
     const int xt0 = ht * XT;
     const size_t qt = m.at(0, clampi(j0 + yt, m.dy - 1), clampi(k0 + zt, m.dz - 1));
@@ -432,7 +452,7 @@ __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __res
     if (cf) mg_load_coef(sd, si, *cf);
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
-        const int t = col + 256 * it;
+        const int t = tid + 256 * NG * it;
         if (t < EX * EY * EZ) sE[t] = ee[it];
     }
     __syncthreads();
@@ -449,70 +469,86 @@ __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __res
             pl[I] = a * a * p[0] + a * b * (p[sy] + p[sz]) + b * b * p[sy + sz];
         }
 #pragma unroll
-        for (int x = 0; x < AX; ++x) {
-            const int I = (x >> 1) + 1, In = (x & 1) ? I + 1 : I - 1;
-            const T pe = a * pl[I] + b * pl[In];
-            sC[x * AY * AZ + col] = (uint8_t)ca[x];
-            sA[x * AY * AZ + col] = ca[x] ? ua[x] + wc * pe : (T)0;
+        for (int p = 0; p < PA; ++p) {
+            const int x = xa0 + p;
+            if (NG == 1 || x < AX) {
+                const int I = (x >> 1) + 1, In = (x & 1) ? I + 1 : I - 1;
+                // (NG > 1: x is not a compile-time constant; the planes are picked by a short select chain over the EX registers)
+                T pI = pl[0], pN = pl[0];
+                if constexpr (NG == 1) {
+                    pI = pl[(p >> 1) + 1], pN = pl[(p & 1) ? (p >> 1) + 2 : (p >> 1)];   // x = p: compile-time planes
+                } else {
+#pragma unroll
+                    for (int e = 1; e < EX; ++e) { pI = e == I ? pl[e] : pI; pN = e == In ? pl[e] : pN; }
+                }
+                const T pe = a * pI + b * pN;
+                sC[x * AY * AZ + col] = (uint8_t)ca[p];
+                sA[x * AY * AZ + col] = ca[p] ? ua[p] + wc * pe : (T)0;
+            }
         }
     }
     __syncthreads();
     // ---- first post-sweep on region B (branch-free: n = 0 has v0 = 0 and si[0] = 0) ----
-    if (actB) {
-        const int a0 = (yb + 1) * AZ + zb + 1;
+    if (actB && (NG == 1 || xb0 < BX)) {
+        const int a0 = (yb + 1) * AZ + zb + 1 + xb0 * AY * AZ;
         T cm = sA[a0], c0 = sA[a0 + AY * AZ];
 #pragma unroll
-        for (int x = 0; x < BX; ++x) {
-            const int a = a0 + (x + 1) * AY * AZ;
-            const T cp = sA[a + AY * AZ];
-            const int n = sC[a];
-            const T nb = cm + cp + sA[a - AZ] + sA[a + AZ] + sA[a - 1] + sA[a + 1];
-            sB[(x * BY + yb) * BZ + zb] = c0 + (T)MG_W2 * si[n] * (fb[x] - (sd[n] * c0 + off * nb));
-            cm = c0;
-            c0 = cp;
+        for (int p = 0; p < PB; ++p) {
+            const int x = xb0 + p;
+            if (NG == 1 || x < BX) {
+                const int a = a0 + (p + 1) * AY * AZ;
+                const T cp = sA[a + AY * AZ];
+                const int n = sC[a];
+                const T nb = cm + cp + sA[a - AZ] + sA[a + AZ] + sA[a - 1] + sA[a + 1];
+                sB[(x * BY + yb) * BZ + zb] = c0 + (T)MG_W2 * si[n] * (fb[p] - (sd[n] * c0 + off * nb));
+                cm = c0;
+                c0 = cp;
+            }
         }
     }
     __syncthreads();
     // ---- second post-sweep on the tile, result + partial of f.out ----
     double acc = 0;
-    {
+    if (NG == 1 || xt0 < TX) {
         const int b0 = ((xt0 + 1) * BY + yt + 1) * BZ + zt + 1;
         T cm = sB[b0 - BY * BZ], c0 = sB[b0];
 #pragma unroll
         for (int x = 0; x < XT; ++x) {
-            const int b = b0 + x * BY * BZ;
-            const T cp = sB[b + BY * BZ];
-            const int n = sC[((xt0 + x + 2) * AY + yt + 2) * AZ + zt + 2];
-            const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
-            const T o = c0 + (T)MG_W1 * si[n] * ((T)ft[x] - (sd[n] * c0 + off * nb));
-            if (n && live) {
-                const size_t qo = qt + (size_t)((long)(i0 + xt0 + x) * sx);
-                IO::st(out + qo, (O)o);  // n != 0: in the level, no clamp
-                if (!own || (own[qo] && !(own[qo] & 0x80))) acc += (double)ft[x] * (double)o;
+            if (NG == 1 || xt0 + x < TX) {
+                const int b = b0 + x * BY * BZ;
+                const T cp = sB[b + BY * BZ];
+                const int n = sC[((xt0 + x + 2) * AY + yt + 2) * AZ + zt + 2];
+                const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
+                const T o = c0 + (T)MG_W1 * si[n] * ((T)ft[x] - (sd[n] * c0 + off * nb));
+                if (n && live) {
+                    const size_t qo = qt + (size_t)((long)(i0 + xt0 + x) * sx);
+                    IO::st(out + qo, (O)o);  // n != 0: in the level, no clamp
+                    if (!own || (own[qo] && !(own[qo] & 0x80))) acc += (double)ft[x] * (double)o;
+                }
+                cm = c0;
+                c0 = cp;
             }
-            cm = c0;
-            c0 = cp;
         }
     }
-    if (part_dot) {
+    if (NG == 1 && part_dot) {
         acc = block_sum<double, 4>(acc, red);
         if (threadIdx.x == 0) part_dot[blockIdx.x] = acc;
     }
 }
 
-template <typename T, typename F, typename O, int TX, int TY, int TZ>
-__global__ __launch_bounds__(256, 5) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
-                                               O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
-                                               double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
-                                               const int* __restrict__ tlist, const uint8_t* __restrict__ own)
+template <typename T, typename F, typename O, int TX, int TY, int TZ, int NG = 1>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
+                                                                      O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
+                                                                      double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
+                                                                      const int* __restrict__ tlist, const uint8_t* __restrict__ own)
 {
     __shared__ __attribute__((aligned(16))) char lds[UpTile<T, TX, TY, TZ>::bytes];
     __shared__ T sd[8], si[8];
     __shared__ double red[4];
     if (ps && ps->done) return;
     const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);  // see k_mg_down
-    mg_up_body<T, F, O, TX, TY, TZ, IoPlain>(m, cnt, f, u, out, mc, ec, &cf, cf.off, part_dot, tile, gx, gy, wc, own, true, threadIdx.x, lds, sd, si,
-                                             red);
+    mg_up_body<T, F, O, TX, TY, TZ, IoPlain, NG>(m, cnt, f, u, out, mc, ec, &cf, cf.off, part_dot, tile, gx, gy, wc, own, true, NG > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x,
+                                                 lds, sd, si, red, NG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0);
 }
 
 // ---- restriction of the level-0 residual (its down kernel has no room for a halo of 3) -----------------
@@ -797,6 +833,7 @@ void launch_mg_restrict(hipStream_t st, MLevel mf, const T* rf, MLevel mc, const
 // tile shapes of the LDS-tiled legs
 constexpr int MG_TX = 8, MG_TY = 8, MG_TZ = 16;   // down (no restriction) and up
 constexpr int MG_RX = 8, MG_RY = 8, MG_RZ = 8;    // down with the restriction folded in (halo 3)
+constexpr unsigned MG_FEW_TILES = 384;            // up to this many tiles a leg takes four thread groups per tile (FLUID_MG_NG4=0: never)
 // flags[t] = tile t of the level-0 legs (MG_TX x MG_TY x MG_TZ cells, numbered as k_mg_down / k_mg_up decode them) holds an unknown
 template <int TX, int TY, int TZ>
 __global__ __launch_bounds__(256) void k_mg_tile_flags(MLevel m, const uint8_t* __restrict__ cnt, int gx, int gy, uint8_t* __restrict__ flags)
@@ -814,6 +851,11 @@ __global__ __launch_bounds__(256) void k_mg_tile_flags(MLevel m, const uint8_t* 
     if (threadIdx.x == 0) flags[tile] = any != 0;
 }
 
+static inline bool mg_ng4()   // FLUID_MG_NG4=0: every leg one thread group per tile (developer switch for A/B runs)
+{
+    static const int on = [] { const char* e = getenv("FLUID_MG_NG4"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
 static inline dim3 mg_tiles(const MLevel& m, int tx, int ty, int tz)
 {
     return dim3((unsigned)((m.dz + tz - 1) / tz), (unsigned)((m.dy + ty - 1) / ty), (unsigned)((m.dx + tx - 1) / tx));
@@ -833,8 +875,13 @@ void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T*
     if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return;   // an empty local level (decomposed run)
     if (fc) {
         const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
-        hipLaunchKernelGGL((k_mg_down<T, F, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
-                           ps, (int)g.x, (int)g.y, (const int*)nullptr);
+        // few tiles (about one per CU or fewer): the leg is bound by one tile's chain of dependent stages — four groups of 256 threads share it
+        if (sizeof(F) == sizeof(T) && g.x * g.y * g.z <= MG_FEW_TILES && mg_ng4())
+            hipLaunchKernelGGL((k_mg_down<T, F, MG_RX, MG_RY, MG_RZ, true, 4>), dim3(g.x * g.y * g.z), dim3(1024), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
+                               ps, (int)g.x, (int)g.y, (const int*)nullptr);
+        else
+            hipLaunchKernelGGL((k_mg_down<T, F, MG_RX, MG_RY, MG_RZ, true>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, r, mc, cnt_c, fc, cf,
+                               ps, (int)g.x, (int)g.y, (const int*)nullptr);
     } else {
         const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
         hipLaunchKernelGGL((k_mg_down<T, F, MG_TX, MG_TY, MG_TZ, false>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u,
@@ -848,6 +895,13 @@ void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, cons
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
     if (!tlist && g.x * g.y * g.z == 0) return;   // an empty local level (decomposed run: a block outside the active box)
+    // (measured at 256^3: the four-group form takes the down legs of levels 1-2 from 6.33 to 5.72 us and the up legs from 5.93 to 6.13 —
+    // a leg is ~3 us of launch and drain + ~2 us of load latency, the arithmetic was never the long part — so only the down leg uses it)
+    if (false && !tlist && !part_dot && !own && sizeof(F) == sizeof(T) && sizeof(O) == sizeof(T) && g.x * g.y * g.z <= MG_FEW_TILES && mg_ng4()) {
+        hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ, 4>), dim3(g.x * g.y * g.z), dim3(1024), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot, ps,
+                           (int)g.x, (int)g.y, (T)wc, tlist, own);
+        return;
+    }
     hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc,
                        ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist, own);
 }
