@@ -103,6 +103,7 @@ struct StepState {
     int max_cell;             // most particles in one cell (P2G picks its kernel by it)
     int pad_;
     int n_tl_mg, n_tl_sq;     // active tiles of the level-0 V-cycle legs / of SQ and XR (mostly-air boxes)
+    int n_rows, pad2_;        // z rows of 32 cells that hold an unknown (XR's list)
     unsigned long long max_speed_bits;  // max |v_p| as non-negative double bits
     double dt;                // fluid.cc:1367 / 992-999
     double err_num;           // |b-b2|^2
@@ -300,6 +301,13 @@ void launch_pcg_sq_list(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, 
 template <typename T>
 void launch_pcg_xr_list(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                         int n_rz, const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* tlist, int nlist);
+// ... and XR over the z rows of 32 cells that hold an unknown (finer than the tiles: the spray leaves most of a touched tile empty)
+int pcg_row_count(const LBox& L);
+int pcg_rows_blocks(int nrows);
+void launch_row_list(hipStream_t st, LBox L, const uint8_t* cnt, int* flags, int* pos, int* list, int* block_sums, int* count);
+template <typename T>
+void launch_pcg_xr_rows(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
+                        int n_rz, const double* part_pq, int n_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* rlist, int nrows);
 template <typename T>
 void launch_pcg_sq_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf, const double* g_rr,
                         const double* g_rz_new, const double* g_rz_old, double* part_pq, PcgState* ps, int first, double tol, int zmode);

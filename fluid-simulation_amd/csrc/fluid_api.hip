@@ -184,7 +184,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -239,6 +239,7 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     if (const char* e = getenv("FLUID_TILE_LISTS")) s->lists_force = atoi(e) != 0;
     if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
+    if (const char* e = getenv("FLUID_XR_ROWS")) s->rows_on = atoi(e) != 0;
     if (const char* e = getenv("FLUID_MG_COARSE")) s->mgc_mode = atoi(e);
     if (const char* e = getenv("FLUID_MG_COARSE_BLOCKS")) s->mgc_max_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("FLUID_MG_COARSE_CELLS")) s->mgc_max_cells = atol(e);
@@ -781,7 +782,9 @@ static int solve_mg(fluid_sim* s)
     const double cells = (double)s->Rb.cells();
     const int sparse = (double)s->stats.num_active < 0.4 * (double)L.cells();  // mostly-air box: SQ / XR test the counts before loading
     const bool lists = s->lists_on;          // ... or, with the active-tile lists of this step, sweep those tiles only
-    const int n_init = pcg_xr_blocks(L), n_list = pcg_list_blocks(s->n_tl_sq);  // partials of the init kernel / of a list-mode launch
+    const bool rows = lists && s->rows_on && s->n_rows > 0;   // XR over the non-empty z rows instead of the SQ tiles
+    // partials of the init kernel / of a list-mode XR launch (what the next SQ launch re-sums)
+    const int n_init = pcg_xr_blocks(L), n_list = rows ? pcg_rows_blocks(s->n_rows) : pcg_list_blocks(s->n_tl_sq);
     // r.z partials come from the level-0 up leg, one per block; every block of the PCG kernels re-sums them from L2.
     // Above 1024 values one extra 1-block launch folds them into a single value first.
     const int n_rz_raw = mg_rz_blocks(s);
@@ -822,7 +825,10 @@ static int solve_mg(fluid_sim* s)
                                  s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            if (lists)
+            if (rows)
+                launch_pcg_xr_rows<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], n_rz, s->part_pq, pcg_list_blocks(s->n_tl_sq), s->part_rr,
+                                      s->part_err, s->ps, s->row_list, s->n_rows);
+            else if (lists)
                 launch_pcg_xr_list<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], n_rz, s->part_pq, s->part_rr, s->part_err, s->ps,
                                       s->tl_sq, s->n_tl_sq);
             else
@@ -913,6 +919,20 @@ int fl::phase_flags(fluid_sim* s)
             launch_compact_flags(s->st, s->tl_flags, n_mg, s->tl_mg, &s->ss->n_tl_mg);
             launch_sq_tile_flags(s->st, s->L, s->cntL, s->tl_flags + n_mg);
             launch_compact_flags(s->st, s->tl_flags + n_mg, n_sq, s->tl_sq, &s->ss->n_tl_sq);
+            if (s->rows_on) {
+                const size_t nr = (size_t)pcg_row_count(s->L);
+                if (nr > s->row_cap) {
+                    HIPCHK(hipStreamSynchronize(s->st));
+                    hipFree(s->row_flags); hipFree(s->row_pos); hipFree(s->row_list);
+                    s->row_flags = s->row_pos = s->row_list = nullptr;
+                    const size_t cap = nr + nr / 4 + 1024;
+                    HIPCHK(hipMalloc((void**)&s->row_flags, cap * sizeof(int)));
+                    HIPCHK(hipMalloc((void**)&s->row_pos, cap * sizeof(int)));
+                    HIPCHK(hipMalloc((void**)&s->row_list, cap * sizeof(int)));
+                    s->row_cap = cap;
+                }
+                launch_row_list(s->st, s->L, s->cntL, s->row_flags, s->row_pos, s->row_list, s->scan_sums, &s->ss->n_rows);
+            }
             built = true;
         }
         HIPCHK(hipGetLastError());
@@ -927,7 +947,7 @@ int fl::phase_flags(fluid_sim* s)
         // mostly air and big enough for the sweep over empty tiles to matter (a dense box keeps the XCD-ordered dense launches)
         const bool airy = (double)s->stats.num_active < 0.45 * (double)s->L.cells() && s->L.cells() > (size_t)1500000;
         s->lists_hint = airy;
-        s->n_tl_mg = s->h_ss->n_tl_mg; s->n_tl_sq = s->h_ss->n_tl_sq;
+        s->n_tl_mg = s->h_ss->n_tl_mg; s->n_tl_sq = s->h_ss->n_tl_sq; s->n_rows = s->h_ss->n_rows;
         s->lists_on = built && s->n_tl_mg > 0 && s->n_tl_sq > 0 && (s->lists_force == 1 || airy);
         if (s->lists_on) s->stats.paths |= FLUID_PATH_TILE_LISTS;
         const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows

@@ -513,6 +513,96 @@ __global__ __launch_bounds__(256) void k_pcg_xr_t(LBox L, const uint8_t* __restr
     if (threadIdx.x == 0) { part_rr[blockIdx.x] = arr; part_rz_next[blockIdx.x] = arz; }
 }
 
+// XR over a list of z ROWS of 32 cells (mostly-air box).  The tile lists above skip the tiles without an unknown, but the spray
+// touches two thirds of the tiles with a droplet or two each: 4 700 tiles x 1 024 cells swept for 1.44 M unknowns.  A row =
+// 32 consecutive z cells of one (x, y) line (one quarter-wave, 256 bytes per vector); rows without an unknown hold zeros in
+// every solver vector and need neither reading nor writing.  Row r of the list -> (ix, iy, tz) by division; a wave takes two
+// rows, a block 8, block b strides the list.  Same update, same partial-sum scheme as k_pcg_xr_t.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_xr_rows(LBox L, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r,
+                                                     const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
+                                                     const double* __restrict__ part_rz_cur, int n_xr, const double* __restrict__ part_pq,
+                                                     int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps,
+                                                     const int* __restrict__ rlist, int nrows)
+{
+    __shared__ double red[16];
+    __shared__ int s_done;
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    if (threadIdx.x == 0) s_done = ps->done;
+    const int ntz = (L.nz + 31) / 32;
+    const int sub = threadIdx.x >> 5, kz = threadIdx.x & 31;
+    auto cell_of = [&](int ri) {
+        const int row = rlist[ri];
+        const int tz = row % ntz, iy = (row / ntz) % L.ny, ix = row / (ntz * L.ny);
+        return ((long)(1 + ix) * L.Ly + (1 + iy)) * L.Lz + LBOX_K0 + tz * 32 + kz;
+    };
+    constexpr int U = 2;   // rows in flight per thread
+    long c[U];
+    uint8_t cv[U];
+    T xv[U], rv[U], sv[U], qv[U];
+    const int stride = gridDim.x * 8;
+    int ri = xcd_remap(blockIdx.x, gridDim.x) * 8 + sub;
+    auto issue = [&](int u, int rr) {
+        cv[u] = 0;
+        c[u] = 0;
+        if (rr < nrows) {
+            c[u] = cell_of(rr);
+            cv[u] = cnt[c[u]];
+            xv[u] = x[c[u]]; rv[u] = r[c[u]]; sv[u] = s[c[u]]; qv[u] = q[c[u]];
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) issue(u, ri + u * stride);
+    __syncthreads();
+    if (s_done) return;
+    double rz, pq, d3;
+    block_sum3(part_rz_cur, n_xr, part_pq, n_sq, part_pq, 0, red, rz, pq, d3);
+    if (!(pq > 0) || !(rz == rz)) {  // not SPD / NaN: stop instead of spreading NaNs
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ps->breakdown = 1; ps->done = 1; }
+        return;
+    }
+    const T alpha = (T)(rz / pq);
+    double arr = 0, arz = 0;
+    for (; ri < nrows; ri += U * stride) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long cc = c[u];
+            const uint8_t cw = cv[u];
+            const T xo = xv[u] + alpha * sv[u], ro = rv[u] - alpha * qv[u];
+            issue(u, ri + (U + u) * stride);   // the row after next: its loads fly while this one is written
+            if (cw) {
+                const T z = ro * sinv[cw];
+                arr += (double)ro * (double)ro;
+                arz += (double)ro * (double)z;
+                x[cc] = xo;
+                r[cc] = ro;
+            }
+        }
+    }
+    arr = block_sum<double, 4>(arr, red);
+    arz = block_sum<double, 4>(arz, red);
+    if (threadIdx.x == 0) { part_rr[blockIdx.x] = arr; part_rz_next[blockIdx.x] = arz; }
+}
+// flags[row] = 1 if the 32-cell z row holds an unknown (rows numbered (ix * ny + iy) * ntz + tz over the box interior)
+__global__ __launch_bounds__(256) void k_row_flags(LBox L, const uint8_t* __restrict__ cnt, int nrows_all, int* __restrict__ flags)
+{
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), kz = threadIdx.x & 31;
+    const int ntz = (L.nz + 31) / 32;
+    int any = 0;
+    if (row < nrows_all) {
+        const int tz = row % ntz, iy = (row / ntz) % L.ny, ix = row / (ntz * L.ny);
+        any = cnt[((long)(1 + ix) * L.Ly + (1 + iy)) * L.Lz + LBOX_K0 + tz * 32 + kz];   // (beyond nz the padding holds 0)
+    }
+    const unsigned long long m = __ballot(any != 0);
+    if (kz == 0 && row < nrows_all) flags[row] = ((m >> (threadIdx.x & 32)) & 0xFFFFFFFFull) != 0;
+}
+__global__ __launch_bounds__(256) void k_row_scatter(int n, const int* __restrict__ flags, const int* __restrict__ pos, int* __restrict__ list)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && flags[i]) list[pos[i]] = i;
+}
+
 // flags[t] = SQ tile t (numbered as k_pcg_sq_l decodes it) holds an unknown
 __global__ __launch_bounds__(256) void k_sq_tile_flags(LBox L, const uint8_t* __restrict__ cnt, uint8_t* __restrict__ flags)
 {
@@ -655,6 +745,23 @@ void launch_pcg_xr_list(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, 
     const int nb = pcg_list_blocks(nlist);
     hipLaunchKernelGGL((k_pcg_xr_t<T>), dim3(nb), dim3(256), 0, st, L, cnt, x, r, s, q, cf, part_rz_cur, n_rz, part_pq, nb, part_rr,
                        part_rz_next, ps, tlist, nlist);
+}
+int pcg_row_count(const LBox& L) { return L.nx * L.ny * ((L.nz + 31) / 32); }
+int pcg_rows_blocks(int nrows) { const int b = (nrows + 7) / 8; return b < 1 ? 1 : (b < SQ_MAX_BLOCKS ? b : SQ_MAX_BLOCKS); }
+// list[0 .. *count) = the z rows of 32 cells that hold an unknown, ascending; flags / pos: pcg_row_count(L) ints each
+void launch_row_list(hipStream_t st, LBox L, const uint8_t* cnt, int* flags, int* pos, int* list, int* block_sums, int* count)
+{
+    const int n = pcg_row_count(L);
+    hipLaunchKernelGGL(k_row_flags, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, L, cnt, n, flags);
+    launch_exclusive_scan(st, flags, pos, (long)n, block_sums, count);
+    hipLaunchKernelGGL(k_row_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const int*)flags, (const int*)pos, list);
+}
+template <typename T>
+void launch_pcg_xr_rows(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
+                        int n_rz, const double* part_pq, int n_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* rlist, int nrows)
+{
+    hipLaunchKernelGGL((k_pcg_xr_rows<T>), dim3(pcg_rows_blocks(nrows)), dim3(256), 0, st, L, cnt, x, r, s, q, cf, part_rz_cur, n_rz, part_pq, n_pq,
+                       part_rr, part_rz_next, ps, rlist, nrows);
 }
 template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure, double* keep, const PcgState* ps)
@@ -1480,6 +1587,8 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
                                         const double*, const double*, double*, PcgState*, int, double, int, int, const int*, int);      \
     template void launch_pcg_xr_list<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, int,      \
                                         const double*, double*, double*, PcgState*, const int*, int);                                    \
+    template void launch_pcg_xr_rows<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, int,      \
+                                        const double*, int, double*, double*, PcgState*, const int*, int);                               \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
     template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*, double*, const PcgState*);      \

@@ -1549,7 +1549,7 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
         k_mpm_gather<1><<<GATHER_BLOCKS, 256, 0, st>>>(G, s->P, s->cell_start, s->cell_count, s->tlist, &s->state->num_touched, s->state, 0, 0, nullptr, nullptr, s->forces, nullptr);
     }
     HIPCHK(hipEventRecord(s->ev[2], st));
-    // populateMatrices' right-hand side (mpm.cc:383-416) and cg.solve (mpm.cc:1401-1403)
+    // populateMatrices' right-hand side (mpm.cc:383-416) and cg.compute / cg.solve (mpm.cc:1404-1405)
     k_mpm_rhs<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->vel, s->forces, pr.gravity[0], pr.gravity[1], pr.gravity[2],
                                           s->b, s->invm, s->part, &s->state->max_coeff_bits);
     k_mpm_maxforce_cell<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->forces);

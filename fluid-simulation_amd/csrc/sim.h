@@ -94,6 +94,10 @@ struct fluid_sim {
     int *tl_mg = nullptr, *tl_sq = nullptr;
     size_t tl_cap = 0;
     int n_tl_mg = 0, n_tl_sq = 0;
+    int *row_flags = nullptr, *row_pos = nullptr, *row_list = nullptr;   // XR's list of non-empty z rows (32 cells), built with the tile lists
+    size_t row_cap = 0;
+    int n_rows = 0;
+    bool rows_on = true;          // FLUID_XR_ROWS=0: XR over the SQ tile list as before
     bool lists_hint = false;      // the previous step's box was mostly air: build the lists before this step's flags sync
     bool lists_on = false;        // this step's solves use them
     int lists_force = -1;         // FLUID_TILE_LISTS=0|1

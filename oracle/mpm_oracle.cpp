@@ -12,7 +12,7 @@
 // Boost, Half are absent).  What pins this file: (1) deformHeader.h's Eigen-only functions (getR, getS, spline2,
 // getSplineGradient, getDelFE, getDelR, getdJF, doubleDot42, doubleDot22, getJFmt, dPsydFdF, getSigma) and mpm.cc's
 // spline(), compiled from the reference's own lines at build time into oracle/_ref/ and compared value for value;
-// (2) the solve against the reference's solver object (Eigen CG + IncompleteCholesky, mpm.cc:1271) on the assembled
+// (2) the solve against the reference's solver object (Eigen CG + IncompleteCholesky, mpm.cc:1283) on the assembled
 // triplets; (3) analytic properties (the assembled matrix is the finite-difference derivative of the grid forces).
 // The loop structure around those functions is a restatement by reading: "parity partially pinned".
 #include <cmath>
@@ -543,7 +543,7 @@ void populateMatrices(Mpm& s, const Params& p, double dt, int numActive, Stats& 
             }
     }
 }
-// cg.compute(A); cg.solve(b), mpm.cc:1401-1403.  The solver object (mpm.cc:1271) is ConjugateGradient<SparseMatrix<double>,
+// cg.compute(A); cg.solve(b), mpm.cc:1404-1405.  The solver object (mpm.cc:1283) is ConjugateGradient<SparseMatrix<double>,
 // Lower|Upper, IncompleteCholesky>: with Lower|Upper and a column-major real matrix Eigen multiplies by the TRANSPOSE of the
 // matrix (ConjugateGradient.h:202-212, `TransposeInput`) — the same thing for the symmetric matrices the class is meant for,
 // but this A = I + beta dt^2 D^-1 K is not symmetric, so what the program computes is the solution of A^T x = b.  Restated

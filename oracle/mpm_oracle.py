@@ -135,7 +135,7 @@ def reference_functions():
 
 
 def eigen_solver_pointer():
-    """Address of eigen_ref_icpcg (the reference's solver object, mpm.cc:1271), or None."""
+    """Address of eigen_ref_icpcg (the reference's solver object, mpm.cc:1283), or None."""
     if not os.path.exists(_EIGEN_SO):
         return None
     lib = C.CDLL(_EIGEN_SO)

@@ -4,11 +4,14 @@ oracle/_ref/libmpm_ref.so and libeigen_ref.so can be built from /root/reference)
 
 mpm_functions.npz      inputs and outputs of the REFERENCE's own constitutive functions (deformHeader.h:22-36, 38-88, 107-249,
                        273-313 and mpm.cc:25-41, compiled as they are against the vendored Eigen): splines on a sweep, getR / getS,
-                       getSigma, dPsydFdF for i = 0..2, and the singular-value clamp of mpm.cc:543-555 through the same
-                       Eigen::JacobiSVD.  Pure reference output: nothing in it comes from the restatement.
+                       getSigma, dPsydFdF for i = 0..2: reference output, nothing in it comes from the restatement.  The
+                       singular-value clamp (clampFE / clampFP) is NOT the reference's code: mpm.cc:543-555 sits inside
+                       updateDeformationGradient, which takes OpenVDB grids and cannot be built here, so oracle/mpm_ref.cpp
+                       (mpm_ref_clamp) is a builder-written wrapper of the same lines around the vendored Eigen::JacobiSVD —
+                       those two arrays pin Eigen's SVD under that wrapper, not the program.
 mpm_solve_ref_scene.npz  the linear system of step 1 of the reference's scene as the restatement assembles it (triplets, b) and
                        the solution returned by the REFERENCE's solver object (ConjugateGradient<SparseMatrix<double>,
-                       Lower|Upper, IncompleteCholesky<double>>, mpm.cc:1271) — the evidence that the program solves A^T x = b.
+                       Lower|Upper, IncompleteCholesky<double>>, mpm.cc:1283) — the evidence that the program solves A^T x = b.
 """
 import os
 import sys

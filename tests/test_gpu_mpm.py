@@ -55,7 +55,7 @@ def test_reference_scene_step_by_step(fs, mo):
     sim, orc = make_pair(fs, mo, scene(fs))
     assert sim.num_particles == orc.num_particles == 6205
     # where oracle/_ref travelled, the oracle's solves go through the reference's own solver object (Eigen CG + IncompleteCholesky,
-    # mpm.cc:1271): the HIP path is then compared with what that object returns for the assembled matrix
+    # mpm.cc:1283): the HIP path is then compared with what that object returns for the assembled matrix
     with_eigen = orc.use_reference_solver()
     print("oracle solves by the reference's Eigen object:", with_eigen)
     for i in range(4):
@@ -103,10 +103,17 @@ def test_solution_solves_the_programs_system(fs, mo):
 
 @pytest.mark.parametrize("ppv,keep", [(8.0, None), (40.0, None), (400.0, 900)])
 def test_sparser_scenes(fs, mo, ppv, keep):
-    """Fewer particles per node: lighter nodes, a stiffer system (more CG iterations), thresholds (mass > 0.1) in play."""
+    """Fewer particles per node: lighter nodes, a stiffer system (more CG iterations), thresholds (mass > 0.1) in play.
+
+    CONVERGENCE, NOT PARITY, wherever the checker's own CG gives up: on these thinned scenes |A - A^T| ~ 1 and the reference's Eigen
+    IC-CG stalls at its 2n-iteration cap with a ~1e-8 residual; the restatement's loop can hit the cap too and then takes the DIRECT
+    solution of the system (oracle/mpm_oracle.cpp: cg_iters < 0).  A step checked against that states "the kernel's CG converged to
+    the exact solution", not "the kernel returns what the reference program would" — printed per step below."""
     sim, orc = make_pair(fs, mo, scene(fs, ppv=ppv, keep=keep, seed=3))
     for i in range(3):
         sg, so = sim.step(), orc.step()
+        print(f"ppv {ppv} keep {keep} step {i}: checker {'direct solve (convergence check)' if so['cg_iters'] < 0 else 'CG loop (parity)'}, "
+              f"gpu iters {sg['cg_iters']}, checker iters {so['cg_iters']}")
         assert sg["num_active"] == so["num_active"]
         assert sg["cg_error"] < 2.3e-16
         compare_step(fs, sim, orc, so, tol_mass=1e-6, tol=1e-8)

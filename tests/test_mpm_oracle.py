@@ -3,7 +3,7 @@
 * function for function against the reference's OWN code: oracle/_ref/libmpm_ref.so is compiled at build time from
   mpm.cc:24-41 and the Eigen-only parts of deformHeader.h where they lie under /root/reference, against the vendored Eigen
   (JacobiSVD, colPivHouseholderQr); skipped where that library was not built (the GPU box);
-* the solve against the reference's solver object (ConjugateGradient + IncompleteCholesky, mpm.cc:1271) on the triplets
+* the solve against the reference's solver object (ConjugateGradient + IncompleteCholesky, mpm.cc:1283) on the triplets
   the restatement assembles;
 * properties the assembled system must have whoever restates it: M is the derivative of the grid forces with respect to
   node displacements (finite differences), D M is symmetric.

@@ -21,6 +21,26 @@ rm -f $O/splash/*/*_kernel_trace.csv
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/settled -- python3 tools/long_run.py 256 450 > $O/settled.log 2>&1
 python tools/step_breakdown.py "$(ls -t $O/settled/*/*_kernel_trace.csv | head -n 1)" 445 > $O/step_breakdown_settled.txt
 timeout -k 10 300 python tools/long_run.py 256 500 > $O/long_run.txt 2>&1
+# the snow-MPM step: kernel statistics of both scenes, and the fabric-side bytes of the operator's kernels on the scaled cone
+bash tools/mpm_prof.sh > $O/mpm_prof.log 2>&1
+cp gpurun_out/mpm_prof/kernel_stats_ref.csv $O/mpm_kernel_stats_ref_scene.csv; cp gpurun_out/mpm_prof/kernel_stats_scaled.csv $O/mpm_kernel_stats_scaled.csv
+cat gpurun_out/mpm_prof/phases_ref.txt gpurun_out/mpm_prof/phases_scaled.txt > $O/mpm_phases.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/mpmc
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/mpmc -- python3 tools/mpm_run.py 63 24 64 6 > $O/mpmc_$c.log 2>&1
+  python3 - "$(ls -t $O/mpmc/*/*_counter_collection.csv | head -n 1)" $c >> $O/mpm_pmc.txt <<'PY'
+import csv, sys, collections
+rows = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if r["Counter_Name"] == sys.argv[2] and "k_mpm_" in r["Kernel_Name"]:
+        rows[r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
+scale = 2.0 if sys.argv[2] == "FETCH_SIZE" else 1.0
+for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+    print(f"{k:28s} {sys.argv[2]:10s} {scale * 1024 * sum(v) / len(v) / 1e6:9.3f} MB per launch ({len(v)} launches; FETCH_SIZE doubled: gfx950 correction)")
+PY
+  rm -rf $O/mpmc
+done
+bash tools/pmc_stencil.sh > $O/pmc_stencil.log 2>&1; cp gpurun_out/pmc_stencil.txt $O/pmc_stencil.txt
 # the raw traces are large: only the summaries travel back
 rm -f $O/trace/*/*_kernel_trace.csv $O/splash/*/*_kernel_trace.csv $O/settled/*/*_kernel_trace.csv $O/fetch/*/*_counter_collection.csv $O/write/*/*_counter_collection.csv
 ls -la $O

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the extrapolated start of the third and later pressure passes of a step (FLUID_EXTRAPOLATE): python tools/extrapolate_ab.py [n] [steps]"""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as entry
 fs = entry.load_package()

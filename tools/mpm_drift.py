@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Free-running drift of the HIP snow-MPM step against its CPU checker: python tools/mpm_drift.py [points_per_voxel] [steps] [print every]
 (test infrastructure: uses oracle/)"""
-import sys
-sys.path.insert(0, '/root/repo')
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as entry
 from oracle import mpm_oracle as mo

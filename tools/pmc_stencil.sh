@@ -7,7 +7,8 @@ export TMPDIR=/tmp
 O=gpurun_out/pmst
 mkdir -p $O
 : > gpurun_out/pmc_stencil.txt
-for cfg in "fp64 20002 32" "fp64 804 32" "fp64 30201 16" "fp32 20002 32" "fp32 10402 16" "fp32 30202 16"; do
+mkdir -p gpurun_out
+for cfg in "fp64 20002 32" "fp64 0 0" "fp64 804 32" "fp32 20002 32" "fp32 0 0" "fp32 10402 16"; do
   set -- $cfg
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/run
