@@ -1435,6 +1435,81 @@ static void lean_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags,
     hipLaunchKernelGGL((k_stencil_lean<T, MY, MD, MODE, AXIS>), dim3(nty * ntz * ncx), dim3((MY + 2) * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
 }
 
+// ---- dense sweep with a linear front ("front") -------------------------------------------------------------------------
+// No march: a wave computes ONE z row of ONE plane and loads the five rows it needs itself — centre, y-1, y+1 (its sibling
+// waves' centres: L1), x-1, x+1 (the rows the same position of the neighbouring planes: L2 / Infinity Cache, fetched a moment ago
+// or a moment later by the blocks of those planes).  Blocks are numbered in MEMORY order and NOT regrouped per XCD, so the chip
+// works on a front of a few consecutive planes and HBM sees one linear read stream and one linear write stream — what the
+// copy has and every march lacks (thousands of 4-16 KB pieces advancing at once).  Price: ~3x the L2 read traffic.
+template <typename T, int MY>
+__global__ __launch_bounds__(MY * 64) void k_stencil_front(Grid g, int nty, int ntz, const uint8_t* __restrict__ flags, const T* __restrict__ s,
+                                                            T* __restrict__ q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    typedef typename VecT<T, V>::type vec;
+    typedef typename FlagT<V>::type fvec;
+    __shared__ T sdiag[8], sinv[8];
+    load_coef(sdiag, sinv, cf);
+    const int N = g.N;
+    const long sx = (long)N * N;
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int tz = b % ntz, ty = (b / ntz) % nty, x = b / (ntz * nty);
+    const int y = ty * MY + wy, z0 = tz * MZV + lane * V;
+    const bool cv = y < N && z0 < N;
+    const long c0 = (long)x * sx + (long)min(y, N - 1) * N + min(z0, N - V);
+    auto active_bits = [](unsigned w) { return (w >> 1) & ((((w >> 2) & 0x07070707u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u; };
+    auto row = [&](long c, bool ok, vec& v, unsigned& a) {   // masked values of one row (ok is wave-uniform)
+        if (ok) {
+            const unsigned w = (unsigned)*reinterpret_cast<const fvec*>(flags + c);
+            const vec t = *reinterpret_cast<const vec*>(s + c);
+            a = cv ? active_bits(w) : 0u;
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = and_mask<T>(t[k], __builtin_amdgcn_sbfe((int)a, 8 * k, 1));
+        } else {
+            a = 0;
+            v = (vec)(T)0;
+        }
+    };
+    vec s0, xm, xp, ym, yp;
+    unsigned a0, au;
+    unsigned w0 = cv ? (unsigned)*reinterpret_cast<const fvec*>(flags + c0) : 0u;
+    row(c0, true, s0, a0);
+    row(c0 - sx, x > 0, xm, au);
+    row(c0 + sx, x < N - 1, xp, au);
+    row(c0 - N, y > 0 && y < N, ym, au);
+    row(c0 + N, y < N - 1, yp, au);
+    T left = dpp_wave_shr1<T>(s0[V - 1]), right = dpp_wave_shl1<T>(s0[0]);
+    if (ntz > 1) {   // a row wider than one wave: lanes 0 / 63 fetch the cell before / after the wave's range
+        const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
+        T rim = 0;
+        if ((lane == 0 || lane == 63) && cv && rz >= 0 && rz < N) {
+            const long c = (long)x * sx + (long)y * N + rz;
+            const uint8_t f = flags[c];
+            rim = ((f & F_FLUID) && (f >> F_CNT_SHIFT)) ? s[c] : (T)0;
+        }
+        left = lane == 0 ? rim : left;
+        right = lane == 63 ? rim : right;
+    }
+    __syncthreads();   // coef table
+    vec out;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const T zl = k ? s0[k > 0 ? k - 1 : 0] : left, zr = k < V - 1 ? s0[k < V - 1 ? k + 1 : 0] : right;
+        const T nb = xm[k] + xp[k] + ym[k] + yp[k] + zl + zr;
+        const T r = sdiag[__builtin_amdgcn_ubfe(w0, 8 * k + F_CNT_SHIFT, 3)] * s0[k] + cf.off * nb;
+        out[k] = and_mask<T>(r, __builtin_amdgcn_sbfe((int)a0, 8 * k, 1));
+    }
+    if (cv) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[c0]));
+}
+template <typename T, int MY>
+static void front_launch(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
+{
+    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
+    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZV - 1) / MZV;
+    hipLaunchKernelGGL((k_stencil_front<T, MY>), dim3((unsigned)((long)nty * ntz * g.N)), dim3(MY * 64), 0, st, g, nty, ntz, flags, s, q, cf);
+}
+
 // ---- streaming probes (developer: FLUID_MARCH_VARIANT=20001 / 20002): what a plain copy of the same arrays reaches ----
 // 20001: q = s, 16 bytes per lane, non-temporal stores; 20002: q = active(flag) ? s : 0 (adds the 1-byte-per-cell flag stream).
 // They bound what the stencil sweep can reach from HBM on this part (tools/sweep.py ... hbm).
@@ -1471,6 +1546,15 @@ void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T*
 {
     constexpr int V = 16 / (int)sizeof(T);
     const bool can_vec = g.N % V == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)q & 15) == 0;
+    if (variant >= 80000 && can_vec) {   // 80000 + MY: the linear-front sweep, MY rows (waves) per block
+        switch (variant - 80000) {
+        case 2: front_launch<T, 2>(st, g, flags, s, q, cf); break;
+        case 4: front_launch<T, 4>(st, g, flags, s, q, cf); break;
+        case 8: front_launch<T, 8>(st, g, flags, s, q, cf); break;
+        default: front_launch<T, 16>(st, g, flags, s, q, cf); break;
+        }
+        return;
+    }
     if (variant >= 60000 && can_vec) {   // 60000 + MY*100 + MD: the lean march along y (every wave one contiguous stream); 70000 + ...: as a copy (probe)
         if (cxlen <= 0) cxlen = 32;
         switch (variant - 60000) {

@@ -381,7 +381,7 @@ def test_marching_stencil_forms_agree(fs, n, monkeypatch):
         want = sim.field(F.Q)
         assert np.abs(want).max() > 0
         for variant, cx in (("10000", "16"), ("10404", "8"), ("11604", "32"), ("10202", "5"), ("1604", "32"), ("804", "7"),
-                            ("30102", "32"), ("30103", "7"), ("30202", "16"), ("30401", "9"), ("40402", "16"), ("40804", "32"), ("41402", "5"), ("40603", "9"), ("60402", "32"), ("60804", "7"), ("61402", "256"),
+                            ("30102", "32"), ("30103", "7"), ("30202", "16"), ("30401", "9"), ("40402", "16"), ("40804", "32"), ("41402", "5"), ("40603", "9"), ("60402", "32"), ("60804", "7"), ("61402", "256"), ("80004", "1"), ("80016", "1"),
                             ("0", "0")):   # 3xxxx: independent waves, R rows each
             monkeypatch.setenv("FLUID_MARCH_VARIANT", variant)
             monkeypatch.setenv("FLUID_MARCH_CX", cx)
