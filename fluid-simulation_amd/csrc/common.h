@@ -272,6 +272,10 @@ void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box);
 void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float* container, double* u, double* v, double* w, double* ub, double* vb,
                        double* wb);
 
+void launch_extrap_init(hipStream_t st, Grid g, const uint8_t* solid, const float* container, int* layer);
+void launch_extrap_layer(hipStream_t st, Grid g, int pass, int* layer, double* u, double* v, double* w, int* n_new);
+void launch_resample(hipStream_t st, Grid g, long n, Particles p, const int* cell_start, int per_cell, int xlim, double far_, int* n_parked);
+
 void launch_spline_eval(hipStream_t st, int which, long n, const double* x, double* w);
 void launch_dot(hipStream_t st, long n, const double* a, const double* b, double* part, int nb, double* out);
 

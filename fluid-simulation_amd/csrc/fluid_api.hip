@@ -1141,6 +1141,60 @@ int fluid_vel_update(fluid_sim_t* s) { PHASE_GUARD(s); return phase_vel_update(s
 int fluid_pressure_pass(fluid_sim_t* s, double* error) { PHASE_GUARD(s); return phase_pressure_pass(s, error); }
 int fluid_flip_advect(fluid_sim_t* s) { PHASE_GUARD(s); return phase_flip_advect(s); }
 
+/* fluid.cc:705-802 where the reference would call it (end of P2Gtransfer, fluid.cc:1147, commented out there): every cell inside W
+ * that P2G left without a velocity gets the average of its defined neighbours, layer by layer, until the grid is full. */
+int fluid_extrapolate(fluid_sim_t* s, int32_t* n_layers)
+{
+    PHASE_GUARD(s);
+    if (!s->have_p2g) return fail(FLUID_ERR_STATE, "extrapolate before p2g");
+    HIPCHK(hipSetDevice(s->prm.device));
+    const Grid g = s->g;
+    int* layer = s->indices;            // free between P2G and the flags pass, which rewrites it
+    int* n_new = s->d_small;
+    launch_extrap_init(s->st, g, s->solid, s->container, layer);
+    int pass = 0;
+    for (bool more = true; more;) {
+        HIPCHK(hipMemsetAsync(n_new, 0, sizeof(int), s->st));
+        for (int k = 0; k < 8; ++k) launch_extrap_layer(s->st, g, ++pass, layer, s->u, s->v, s->w, n_new);   // (a pass that finds nothing is a no-op)
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->h_small, n_new, sizeof(int), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        more = s->h_small[0] != 0 && pass < 3 * g.N + 8;
+    }
+    // velBeforeUpdate is a copy of the grid taken after P2Gtransfer (fluid.cc:1455): it sees the extrapolated values
+    const size_t bytes = s->ncell * sizeof(double);
+    HIPCHK(hipMemcpyAsync(s->ub, s->u, bytes, hipMemcpyDeviceToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(s->vb, s->v, bytes, hipMemcpyDeviceToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(s->wb, s->w, bytes, hipMemcpyDeviceToDevice, s->st));
+    // (s->indices held the layer numbers: the flags pass of this step must sweep the whole grid again)
+    s->flags_valid = false;
+    s->have_flags = false;
+    s->dirty = Box{0, 0, 0, g.nx - 1, g.ny - 1, g.nz - 1};   // velocities everywhere now: the next step zeroes the whole grid
+    HIPCHK(hipStreamSynchronize(s->st));
+    if (n_layers) *n_layers = pass;
+    return FLUID_OK;
+}
+
+/* fluid.cc:1053-1080: at most `per_cell` particles per base cell (index order); the others are parked outside the grid. */
+int fluid_resample(fluid_sim_t* s, int32_t per_cell, int64_t* n_parked)
+{
+    PHASE_GUARD(s);
+    if (per_cell < 0) return fail(FLUID_ERR_ARG, "per_cell must be >= 0");
+    if (s->np == 0) { if (n_parked) *n_parked = 0; return FLUID_OK; }
+    HIPCHK(hipSetDevice(s->prm.device));
+    int rc = phase_sort(s);             // cells contiguous, every cell's particles in ascending original index
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(s->d_small, 0, sizeof(int), s->st));
+    launch_resample(s->st, s->g, s->np - s->n_out, s->pa, s->cell_start, per_cell, s->g.hi - 10, (double)(s->g.hi + 40), s->d_small);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->h_small, s->d_small, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    if (n_parked) *n_parked = s->h_small[0];
+    s->sorted = s->have_p2g = s->have_flags = false;   // positions changed
+    s->sort_hint = false;
+    return FLUID_OK;
+}
+
 int fluid_get_stats(fluid_sim_t* s, fluid_step_stats_t* st)
 {
     if (!s || !st) return fail(FLUID_ERR_ARG, "null argument");

@@ -442,4 +442,82 @@ void launch_dot(hipStream_t st, long n, const double* a, const double* b, double
     hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, st, n, a, b, part);
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, st, (const double*)part, nb, out);
 }
+// ---- extrapolate (fluid.cc:705-802; SURVEY 8(f) row f3: dead code in the reference, an optional entry point here) --------------
+// Breadth-first layers in gather form.  layer[c]: -2 = defined from the start but not a source (outside W, solid), 0 = the sources
+// (weights > 0: P2G only ever writes non-solid cells inside W), k > 0 = defined by pass k, -1 = not yet.  Pass k: every cell still at
+// -1 adds, on top of what it holds, the velocities of its neighbours of layer k-1 (26-neighbourhood clamped to the grid, scanned
+// x, y, z ascending: the order the reference's first sweep accumulates in) and divides by their number.  A pass writes only cells
+// nobody reads in that pass (readers look at layer k-1), so it works in place.
+__global__ __launch_bounds__(256) void k_extrap_init(Grid g, const uint8_t* __restrict__ solid, const float* __restrict__ container, int* __restrict__ layer)
+{
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= (long)g.cells()) return;
+    const int iz = (int)(c % g.nz), iy = (int)((c / g.nz) % g.ny), ix = (int)(c / ((long)g.nz * g.ny));
+    const int N = g.N;
+    const bool outsideW = ix < 2 || ix > N - 3 || iy < 2 || iy > N - 3 || iz < 2 || iz > N - 3;
+    layer[c] = (outsideW || solid[c]) ? -2 : (container[c] > 0 ? 0 : -1);
+}
+__global__ __launch_bounds__(256) void k_extrap_layer(Grid g, int pass, int* __restrict__ layer, double* __restrict__ u, double* __restrict__ v,
+                                                      double* __restrict__ w, int* __restrict__ n_new)
+{
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    int made = 0;
+    if (c < (long)g.cells() && layer[c] == -1) {
+        const int iz = (int)(c % g.nz), iy = (int)((c / g.nz) % g.ny), ix = (int)(c / ((long)g.nz * g.ny));
+        double su = u[c], sv = v[c], sw = w[c];
+        int cnt = 0;
+        for (int i = ix > 0 ? ix - 1 : ix; i <= (ix < g.nx - 1 ? ix + 1 : ix); ++i)
+            for (int j = iy > 0 ? iy - 1 : iy; j <= (iy < g.ny - 1 ? iy + 1 : iy); ++j)
+                for (int k = iz > 0 ? iz - 1 : iz; k <= (iz < g.nz - 1 ? iz + 1 : iz); ++k) {
+                    const size_t q = g.idx(i, j, k);
+                    if (layer[q] == pass - 1) {
+                        su = u[q] + su; sv = v[q] + sv; sw = w[q] + sw;   // fluid.cc:746
+                        ++cnt;
+                    }
+                }
+        if (cnt) {
+            u[c] = su / cnt; v[c] = sv / cnt; w[c] = sw / cnt;          // fluid.cc:757 (Vec3d / int)
+            layer[c] = pass;
+            made = 1;
+        }
+    }
+    if (__syncthreads_or(made) && threadIdx.x == 0) atomicAdd(n_new, 1);
+}
+void launch_extrap_init(hipStream_t st, Grid g, const uint8_t* solid, const float* container, int* layer)
+{
+    hipLaunchKernelGGL(k_extrap_init, dim3((unsigned)((g.cells() + 255) / 256)), dim3(256), 0, st, g, solid, container, layer);
+}
+void launch_extrap_layer(hipStream_t st, Grid g, int pass, int* layer, double* u, double* v, double* w, int* n_new)
+{
+    hipLaunchKernelGGL(k_extrap_layer, dim3((unsigned)((g.cells() + 255) / 256)), dim3(256), 0, st, g, pass, layer, u, v, w, n_new);
+}
+
+// ---- resample (fluid.cc:1053-1080; row f3) ---------------------------------------------------------------------------------
+// After the counting sort a cell's particles are contiguous and in ascending original-index order (k_bin_rank): the particle at
+// sorted position j of cell c is the (j - cell_start[c])-th of its cell in the reference's index order.  Those beyond `per_cell`
+// are parked at (far, far, far) (the reference's (100, 100, 100) = boundary + 40); only cells with x coordinate < xlim are looked at.
+__global__ __launch_bounds__(256) void k_resample(Grid g, long n, Particles p, const int* __restrict__ cell_start, int per_cell, int xlim, double far_,
+                                                  int* __restrict__ n_parked)
+{
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    int parked = 0;
+    if (j < n) {
+        const int rx = (int)round(p.px[j]), ry = (int)round(p.py[j]), rz = (int)round(p.pz[j]);
+        const int bx = rx - g.cx0(), by = ry - g.cy0(), bz = rz - g.cz0();
+        if (rx < xlim && bx >= 0 && bx < g.nx && by >= 0 && by < g.ny && bz >= 0 && bz < g.nz) {
+            const long c = (long)g.idx(bx, by, bz);
+            if (j - cell_start[c] >= per_cell) {
+                p.px[j] = far_; p.py[j] = far_; p.pz[j] = far_;
+                parked = 1;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(parked);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_parked, __popcll(m));
+}
+void launch_resample(hipStream_t st, Grid g, long n, Particles p, const int* cell_start, int per_cell, int xlim, double far_, int* n_parked)
+{
+    if (n > 0) hipLaunchKernelGGL(k_resample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, n, p, cell_start, per_cell, xlim, far_, n_parked);
+}
+
 }  // namespace fl

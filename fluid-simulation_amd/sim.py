@@ -215,6 +215,18 @@ class FluidSim:
         a = np.ascontiguousarray(arr, dtype=dt)
         check(lib.fluid_upload_field(self._h, fid, a.ctypes.data_as(C.c_void_p), a.nbytes))
 
+    def extrapolate(self):
+        """fluid.cc:705-802 after p2g(): velocities for every cell inside W (dead code in the reference; optional here).  Returns the passes run."""
+        n = C.c_int32()
+        check(lib.fluid_extrapolate(self._h, C.byref(n)))
+        return n.value
+
+    def resample(self, per_cell):
+        """fluid.cc:1053-1080: at most per_cell particles per base cell (upload order); returns how many were parked outside the grid."""
+        n = C.c_int64()
+        check(lib.fluid_resample(self._h, int(per_cell), C.byref(n)))
+        return n.value
+
     def stencil_apply(self, reps=1, box=0):
         ms = C.c_float()
         check(lib.fluid_stencil_apply(self._h, reps, box, C.byref(ms)))

@@ -183,6 +183,17 @@ int fluid_download_field(fluid_sim_t* s, int field, void* dst, size_t bytes);
 /* Upload CONTAINER (then call fluid_flags_index), VEL, VEL_BEFORE, DIVER, PRESSURE, SEARCH. */
 int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes);
 
+/* ---- the reference's unused grid / particle utilities --------------------------------------------
+ * `extrapolate` (fluid.cc:705-802) and `PointList::resample` (fluid.cc:1053-1080) are dead code in the reference — the one
+ * call of extrapolate, at the end of P2Gtransfer (fluid.cc:1147), is commented out and resample is never called — so fluid_step
+ * does not run them; they are here for a caller that wants the reference's code path with them switched on.  Single GPU.
+ * fluid_extrapolate: call after fluid_p2g; fills FLUID_FIELD_VEL (and VEL_BEFORE) of every cell inside W that P2G left without
+ * a velocity with the average of its defined 26-neighbours, layer by layer; n_layers (may be NULL) = passes run.
+ * fluid_resample: at most per_cell particles per base cell, in upload-index order; the others are parked at
+ * (hi + 40, hi + 40, hi + 40) (the reference's (100, 100, 100)); only cells with x < hi - 10 (its `rx < 50`). */
+int fluid_extrapolate(fluid_sim_t* s, int32_t* n_layers);
+int fluid_resample(fluid_sim_t* s, int32_t per_cell, int64_t* n_parked);
+
 /* ---- stencil operator alone (micro-benchmark + parity of the 7-point apply) ------------ */
 /* q = A s with the matrix of fluid.cc:304-412 for the current flags and dt; `reps` launches
  * timed with HIP events on the handle's stream; avg_ms = mean duration of one launch.

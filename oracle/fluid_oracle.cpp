@@ -590,6 +590,79 @@ void flip_advect(Oracle& o)
 }
 
 // fluid.cc:1378-1490
+// fluid.cc:705-802 `extrapolate` — dead code in the reference (its only call, at the end of P2Gtransfer, is commented out:
+// fluid.cc:1147), restated for SURVEY 8(f) row f3 as it would run THERE: `defined` is P2Gtransfer's grid (fluid.cc:1109-1146: true
+// outside W, on solid cells and wherever weights > 0), bound = boundary (60 -> [lo,hi]), the literal scan range -60..60 -> [lo,hi],
+// isWithinBounds(c, 58) -> withinW.  Breadth-first: every undefined cell next to the current layer (26-neighbourhood clamped to
+// +-bound) receives the sum of that layer's adjacent velocities on top of what it holds, then the sum is divided by the count.
+void extrapolate(Oracle& o)
+{
+    const int bound_lo = o.lo, bound_hi = o.hi;
+    std::vector<int> nd(o.ncell, 0);                       // numTimesDefined, :707-710
+    std::vector<uint8_t> defined(o.ncell, 0);
+    for (int x = o.lo; x <= o.hi; ++x)                    // P2Gtransfer's defined grid, :1109-1125 and :1138-1143
+        for (int y = o.lo; y <= o.hi; ++y)
+            for (int z = o.lo; z <= o.hi; ++z) {
+                const size_t k = o.idx(x, y, z);
+                defined[k] = (!o.withinW(x, y, z) || o.isSolid(x, y, z) || (double)o.weights[k] > 0) ? 1 : 0;
+            }
+    struct C3 { int x, y, z; };
+    std::vector<C3> definedCoord;
+    auto spread = [&](const C3& c, std::vector<C3>& found) {   // :723-748 / :766-791
+        const int minx = c.x == bound_lo ? c.x : c.x - 1, miny = c.y == bound_lo ? c.y : c.y - 1, minz = c.z == bound_lo ? c.z : c.z - 1;
+        const int maxx = c.x == bound_hi ? c.x : c.x + 1, maxy = c.y == bound_hi ? c.y : c.y + 1, maxz = c.z == bound_hi ? c.z : c.z + 1;
+        const size_t kc = o.idx(c.x, c.y, c.z);
+        for (int i = minx; i <= maxx; ++i)
+            for (int j = miny; j <= maxy; ++j)
+                for (int k = minz; k <= maxz; ++k) {
+                    const size_t kn = o.idx(i, j, k);
+                    if (!defined[kn]) {
+                        if (nd[kn] == 0) found.push_back(C3{i, j, k});
+                        nd[kn] = nd[kn] + 1;
+                        for (int a = 0; a < 3; ++a) o.vel[3 * kn + a] = o.vel[3 * kc + a] + o.vel[3 * kn + a];   // :746
+                    }
+                }
+    };
+    for (int x = o.lo; x <= o.hi; ++x)                    // :714-753
+        for (int y = o.lo; y <= o.hi; ++y)
+            for (int z = o.lo; z <= o.hi; ++z)
+                if (defined[o.idx(x, y, z)] && !o.isSolid(x, y, z) && o.withinW(x, y, z)) spread(C3{x, y, z}, definedCoord);
+    auto settle = [&](const std::vector<C3>& v) {        // :755-759 / :794-798
+        for (const C3& c : v) {
+            const size_t k = o.idx(c.x, c.y, c.z);
+            for (int a = 0; a < 3; ++a) o.vel[3 * k + a] = o.vel[3 * k + a] / nd[k];   // Vec3d / int
+            defined[k] = 1;
+        }
+    };
+    settle(definedCoord);
+    while (definedCoord.size()) {                          // :760-801
+        std::vector<C3> tempCoord;
+        for (const C3& c : definedCoord) spread(c, tempCoord);
+        settle(tempCoord);
+        definedCoord = tempCoord;
+    }
+}
+
+// fluid.cc:1053-1080 `PointList::resample(numParticlesPerCell)` — never called by the reference's main(); restated serially (the
+// tbb::parallel_for in index order: under real TBB WHICH particles of an over-full cell go is schedule-dependent).  A particle whose
+// base cell already holds numParticlesPerCell earlier particles is parked at (100, 100, 100) — generalised: boundary + 40 — and only
+// cells with rx < 50 (boundary - 10) are looked at.
+void resample(Oracle& o, int per_cell)
+{
+    std::vector<int> number(o.ncell, 0);
+    const size_t np = o.ppos.size() / 3;
+    const int xlim = o.hi - 10;
+    const double far_ = (double)(o.hi + 40);
+    for (size_t i = 0; i < np; ++i) {
+        const int rx = (int)round(o.ppos[3 * i]), ry = (int)round(o.ppos[3 * i + 1]), rz = (int)round(o.ppos[3 * i + 2]);
+        if (rx < xlim && o.inRange(rx, ry, rz)) {        // (off the grid the reference indexes its lock cube out of bounds: left alone here)
+            const size_t k = o.idx(rx, ry, rz);
+            if (number[k] + 1 > per_cell) o.ppos[3 * i] = o.ppos[3 * i + 1] = o.ppos[3 * i + 2] = far_;
+            else number[k] = number[k] + 1;
+        }
+    }
+}
+
 void step(Oracle& o, int max_passes)
 {
     o.outer_passes = 0;
@@ -683,6 +756,8 @@ void oracle_vel_update(void* h) { Oracle* o = (Oracle*)h; velUpdate(*o, o->dt * 
 double oracle_pressure_pass(void* h) { return pressure_pass(*(Oracle*)h); }
 void oracle_flip_advect(void* h) { flip_advect(*(Oracle*)h); }
 void oracle_step(void* h, int max_passes) { step(*(Oracle*)h, max_passes); }
+void oracle_extrapolate(void* h) { extrapolate(*(Oracle*)h); }
+void oracle_resample(void* h, int per_cell) { resample(*(Oracle*)h, per_cell); }
 
 // stats: [dt, numActive, outer_passes, cg_iters_total, cg_iters_last, relres_last, error, maxSpeed]
 void oracle_stats(void* h, double* out)

@@ -48,6 +48,8 @@ for _n in ("p2g", "flags_index", "rhs_div", "build_matrix", "solve", "vel_update
 _lib.oracle_pressure_pass.restype = C.c_double
 _lib.oracle_pressure_pass.argtypes = [_P]
 _lib.oracle_step.argtypes = [_P, C.c_int]
+_lib.oracle_extrapolate.argtypes = [_P]
+_lib.oracle_resample.argtypes = [_P, C.c_int]
 _lib.oracle_stats.argtypes = [_P, _P]
 _lib.oracle_get_field.restype = C.c_int
 _lib.oracle_get_field.argtypes = [_P, C.c_int, _P]
@@ -207,6 +209,14 @@ class Oracle:
     def vel_update(self): _lib.oracle_vel_update(self._h)
     def pressure_pass(self): return _lib.oracle_pressure_pass(self._h)
     def flip_advect(self): _lib.oracle_flip_advect(self._h)
+
+    def extrapolate(self):
+        """fluid.cc:705-802 on the velocity grid as P2Gtransfer leaves it (call after p2g())."""
+        _lib.oracle_extrapolate(self._h)
+
+    def resample(self, per_cell):
+        """fluid.cc:1053-1080: park the particles beyond `per_cell` per base cell (index order)."""
+        _lib.oracle_resample(self._h, int(per_cell))
 
     def step(self, max_passes=0):
         _lib.oracle_step(self._h, max_passes)

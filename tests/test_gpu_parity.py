@@ -667,6 +667,48 @@ def test_persistent_coarse_launch_is_bit_identical(fs, mode, tpt, monkeypatch):
         assert np.array_equal(pra, prb) and np.array_equal(pa, pb) and np.array_equal(va, vb)
 
 
+@pytest.mark.parametrize("n,ppc", [(24, 4), (40, 2)])
+def test_extrapolate_and_resample(fs, oracle, n, ppc):
+    """SURVEY 8(f) row f3, the reference's unused utilities as optional entry points: `extrapolate` (fluid.cc:705-802, where the
+    reference would call it: after P2Gtransfer, fluid.cc:1147) and `PointList::resample` (fluid.cc:1053-1080) against their
+    restatements.  Extrapolation: (i) from the SAME P2G result (the oracle's, uploaded) every cell agrees to rounding — the first
+    layer adds in the reference's own order, later layers in another; (ii) end to end after each side's own P2G within the float
+    tolerance; every cell inside W ends up with a velocity, velBeforeUpdate sees them.  Resampling: the same particles are parked,
+    bit for bit (index order)."""
+    sim, orc, pos = make_pair(fs, oracle, n, ppc, vel_scale=1.0)
+    F = fs.FIELD
+    orc.p2g()
+    sim.upload_field(F.CONTAINER, orc.field(1))          # weights (= container in this build: one array serves both)
+    sim.upload_field(F.VEL, orc.field(2))
+    layers = sim.extrapolate()
+    orc.extrapolate()
+    vg, vo = sim.field(F.VEL), orc.field(2)
+    lo2 = slice(2, n - 2)
+    assert layers >= 3 and np.all(np.abs(vo[:, lo2, lo2, lo2]).sum(0) > 0)      # the whole interior is filled, layer by layer
+    assert np.abs(vg - vo).max() <= 1e-12 * np.abs(vo).max(), np.abs(vg - vo).max()
+    assert np.array_equal(sim.field(F.VEL_BEFORE), vg)
+    assert np.all(vg[:, :2] == 0) and np.all(vg[:, :, :, -2:] == 0)             # outside W: defined from the start, never a target
+    # end to end: each side's own P2G first
+    sim2, orc2, _ = make_pair(fs, oracle, n, ppc, vel_scale=1.0)
+    sim2.p2g(); orc2.p2g()
+    sim2.extrapolate(); orc2.extrapolate()
+    assert rel_l2(sim2.field(F.VEL), orc2.field(2)) < 1e-6
+    # the step goes on from there (flags, pressure, FLIP) without complaint
+    sim2.flags_index(); sim2.pressure_pass(); sim2.flip_advect()
+    sim2.close()
+    # resample: a crowded cube, at most 3 per cell
+    rng = np.random.default_rng(5)
+    crowd = np.concatenate([pos, rng.uniform(-2.4, 2.4, size=(4000, 3))])
+    sim.upload_particles(crowd); orc.set_particles(crowd)
+    parked = sim.resample(3)
+    orc.resample(3)
+    pg, _ = sim.download_particles()
+    po, _ = orc.particles()
+    assert np.array_equal(pg, po)
+    assert parked == int((po[:, 0] > n).sum()) and parked > 1000
+    sim.close()
+
+
 def test_edge_no_particles(fs, oracle):
     """Empty PointList: nothing is fluid, b = 0, the do..while ends on NaN after one pass (fluid.cc:1483-1484)."""
     sim = fs.FluidSim(n=24)

@@ -142,3 +142,51 @@ def test_hydrostatic_column(oracle):
         layer = p[2:n - 2, iy, 2:n - 2]
         expect = rho * g * dx * (top - iy + 1)
         assert np.allclose(layer, expect, rtol=1e-6), (iy, layer.min(), layer.max(), expect)
+
+
+def test_extrapolate_and_resample_restatements():
+    """The two unused utilities of the reference, restated in oracle/fluid_oracle.cpp: properties that follow from
+    fluid.cc:705-802 and 1053-1080.  Extrapolation: cells P2G wrote keep their value, every other cell inside W gets one, the first
+    layer is the mean of its defined 26-neighbours, cells outside W stay 0.  Resampling: no base cell keeps more than the cap, the
+    first particles of a cell (index order) stay, the parked ones sit at boundary + 40."""
+    from oracle import oracle
+    n = 20
+    o = oracle.Oracle(n=n)
+    rng = np.random.default_rng(2)
+    pos = rng.uniform(-3, 3, size=(1500, 3))
+    vel = rng.standard_normal((1500, 3))
+    o.set_particles(pos, vel)
+    o.p2g()
+    w, v0 = o.field(1).copy(), o.field(2).copy()
+    o.extrapolate()
+    v1 = o.field(2)
+    src = w > 0
+    assert np.array_equal(v1[:, src], v0[:, src])
+    inner = np.zeros((n, n, n), bool); inner[2:-2, 2:-2, 2:-2] = True
+    assert np.all(np.abs(v1[:, inner]).sum(0) > 0) and np.all(v1[:, ~inner] == 0)
+    # one first-layer cell by hand: mean of the source neighbours, scanned x, y, z ascending
+    ix, iy, iz = [int(a[0]) for a in np.nonzero(inner & ~src & (np.abs(v0).sum(0) == 0) &
+                                                 (np.array([[[src[max(i-1,0):i+2, max(j-1,0):j+2, max(k-1,0):k+2].any() for k in range(n)] for j in range(n)] for i in range(n)])))]
+    nb = [(i, j, k) for i in range(ix - 1, ix + 2) for j in range(iy - 1, iy + 2) for k in range(iz - 1, iz + 2) if src[i, j, k]]
+    acc = np.zeros(3)
+    for q in nb:
+        acc = v0[:, q[0], q[1], q[2]] + acc
+    assert np.array_equal(v1[:, ix, iy, iz], acc / len(nb))
+    o.resample(2)
+    p, _ = o.particles()
+    lo = -(n // 2)
+    cells = np.floor(np.abs(pos) + 0.5) * np.sign(pos)
+    kept = p[:, 0] < n
+    hi = lo + n - 1
+    seen = {}
+    for i in range(len(pos)):
+        c = tuple(cells[i])
+        if c[0] >= hi - 10:                  # the reference's `rx < 50` (boundary - 10): cells beyond are not looked at
+            assert kept[i]
+            continue
+        want = seen.get(c, 0) < 2
+        assert kept[i] == want
+        if want:
+            seen[c] = seen.get(c, 0) + 1
+    assert (~kept).sum() > 100 and np.all(p[~kept] == hi + 40)
+    assert np.array_equal(p[kept], pos[kept])
