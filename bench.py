@@ -325,7 +325,7 @@ def main():
             weak = {"workload": f"water_cube_drop {nw}^3 grid, {ppcw} particles/cell, {len(posw)} particles, decomposed solve", "grid": nw,
                     "cells_vs_256": nw ** 3 / 256.0 ** 3, "value": a.steps / el, "unit": "substeps/s", "ms_per_step": el / a.steps * 1e3,
                     "cg_iters_total": sum(x["cg_iters"] for x in stw), "num_active_last": stw[-1]["num_active"],
-                    "note": "one GPU runs 512^3 / 4 per cell at 72 substeps/s (profiles/r02/bench_512_single_gpu.json)"}
+                    "note": "one GPU runs 512^3 / 4 per cell at 71 substeps/s (profiles/r03/bench_512.json)"}
             simw.close()
         except StopIteration:
             pass
