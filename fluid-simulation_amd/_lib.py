@@ -55,7 +55,7 @@ class MpmStepStats(C.Structure):
     _fields_ = [("dt_in", C.c_double), ("dt_out", C.c_double), ("cg_error", C.c_double), ("max_speed", C.c_double),
                 ("max_grad", C.c_double), ("max_fp", C.c_double), ("max_fe", C.c_double), ("max_force", C.c_double * 3),
                 ("max_mi", C.c_double), ("max_force_coeff2", C.c_double), ("num_active", C.c_int32),
-                ("cg_iters", C.c_int32), ("any_active", C.c_int32), ("pad_", C.c_int32),
+                ("cg_iters", C.c_int32), ("any_active", C.c_int32), ("cg_status", C.c_int32),
                 ("ms_transfer", C.c_double), ("ms_forces", C.c_double), ("ms_solve", C.c_double),
                 ("ms_deform", C.c_double), ("ms_advect", C.c_double), ("ms_apply_avg", C.c_double)]
 
@@ -121,6 +121,7 @@ SYMBOLS = [
     ("mpm_destroy", C.c_int, [_P]),
     ("mpm_upload_particles", C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int64)]),
     ("mpm_num_particles", C.c_int64, [_P]),
+    ("mpm_num_active", C.c_int32, [_P]),
     ("mpm_set_state", C.c_int, [_P, _P, _P, _P, C.c_int32]),
     ("mpm_set_dt", C.c_int, [_P, C.c_double]),
     ("mpm_get_dt", C.c_double, [_P]),

@@ -1459,6 +1459,7 @@ int mpm_upload_particles(mpm_sim_t* s, int64_t n, const double* pos, const doubl
 }
 
 int64_t mpm_num_particles(const mpm_sim_t* s) { return s ? s->n : -1; }
+int32_t mpm_num_active(const mpm_sim_t* s) { return s ? s->num_active : -1; }
 
 int mpm_set_state(mpm_sim_t* s, const double* FE, const double* FP, const double* volume, int32_t step_no)
 {
@@ -1610,12 +1611,14 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     for (int a = 0; a < 3; ++a) o.max_force[a] = h.max_force[a];
     o.max_mi = h.max_mi, o.max_force_coeff2 = bits_to_double(h.max_coeff_bits);
     o.num_active = h.num_active, o.cg_iters = iters, o.any_active = h.any_active;
+    o.cg_status = h.cg_done;
     float ms;
     double* dst[3] = {&o.ms_transfer, &o.ms_forces, &o.ms_solve};
     for (int k = 0; k < 3; ++k)
         if (hipEventElapsedTime(&ms, s->ev[k], s->ev[k + 1]) == hipSuccess) *dst[k] = ms;
     o.ms_apply_avg = n_apply ? ms_apply / n_apply : 0.0;
     if (out) *out = o;
+    if (h.cg_done == 2) return fluid_fail(FLUID_ERR_SOLVER, "mpm_step_solve: CG breakdown (<p, A p> <= 0 or not finite): the operator is not positive for these particles");
     return 0;
 }
 

@@ -130,7 +130,7 @@ class MpmSim:
     def system(self, num_active=None):
         """Right-hand side and solution of the last solve (3 doubles per unknown).  The buffers are sized by the handle's own
         unknown count; an explicit `num_active` must agree with it (mpm_download_system copies 3 * its count doubles)."""
-        mine = getattr(self, "_num_active", 0)
+        mine = int(lib.mpm_num_active(self._h))   # the handle's own count sizes the buffers
         if num_active is not None and num_active != mine:
             raise ValueError(f"system(): the last solve had {mine} unknowns, not {num_active}")
         num_active = mine

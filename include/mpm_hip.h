@@ -60,7 +60,9 @@ typedef struct {
     int32_t num_active;       /* grid nodes with mass > 0.1                mpm.cc:1346-1364 */
     int32_t cg_iters;         /* iterations of this library's solver (NOT the reference's count: other preconditioner) */
     int32_t any_active;       /* the "yes" flag of the Max Force line */
-    int32_t pad_;
+    int32_t cg_status;        /* how the solve ended: 1 converged (or b = 0), 2 breakdown (<p, A p> <= 0 or NaN: mpm_step_solve
+                                 returns FLUID_ERR_SOLVER), 3 stopped at the iteration cap like Eigen does (x is what the last
+                                 iteration left; cg_error says how far it got) */
     double ms_transfer, ms_forces, ms_solve, ms_deform, ms_advect, ms_apply_avg;   /* HIP-event times of the phases */
 } mpm_step_stats_t;
 
@@ -112,6 +114,8 @@ int mpm_step_advance(mpm_sim_t* s, mpm_step_stats_t* stats);
 int mpm_download_particles(mpm_sim_t* s, int32_t what, double* out);
 int mpm_download_field(mpm_sim_t* s, int32_t field, void* out);
 
+/* Unknowns of the last mpm_step_solve: mpm_download_system copies 3 x this many doubles into each buffer. */
+int32_t mpm_num_active(const mpm_sim_t* s);
 /* The linear system of the last step as the reference assembles it (mpm.cc:370-444): right-hand side b and solution x,
  * 3 * num_active doubles each (unknown k holds 3k..3k+2). */
 int mpm_download_system(mpm_sim_t* s, double* b, double* x);
