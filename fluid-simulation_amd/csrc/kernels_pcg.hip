@@ -240,6 +240,9 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
 
     int lidx = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring list entries (tiles) on the same XCD
     int tile = tlist ? (lidx < nlist ? tlist[lidx] : ntiles) : lidx;
+    // the list entry of the round after this one is fetched a round early: an address that hangs on a load issued a moment ago stalls the issue of the whole tile
+    auto entry = [&](int li) { return tlist ? (li < nlist ? tlist[li < nlist ? li : 0] : ntiles) : li; };
+    int nxt = entry(lidx + (int)gridDim.x);
     // ---- issue the first tile's loads -------------------------------------------------------
     uint8_t fc[TX + 2], fy = 0, fz = 0;
     T rv[TX + 2], sv[TX + 2], ry = 0, sy = 0, rz = 0, sz = 0;
@@ -285,7 +288,9 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
 #pragma unroll
             for (int m = 1; m <= TX; ++m) any |= fc[m];
             if (!__syncthreads_or(any)) {  // (also the barrier that frees the LDS tile of the previous round)
-                tile += gridDim.x;
+                tile = nxt;
+                lidx += gridDim.x;
+                nxt = entry(lidx + (int)gridDim.x);
                 continue;
             }
             issue(tile, false, true);
@@ -315,8 +320,9 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
             cen[lx] = val[lx + 1];
             nbv[lx] = val[lx] + val[lx + 2] + sT[o - PZ] + sT[o + PZ] + sT[o - 1] + sT[o + 1];
         }
-        int next = tile + gridDim.x;
-        if (tlist) { lidx += gridDim.x; next = lidx < nlist ? tlist[lidx] : ntiles; }
+        const int next = nxt;
+        lidx += gridDim.x;
+        nxt = entry(lidx + (int)gridDim.x);
         __syncthreads();  // LDS free for the next tile
         if (!sparse && next < ntiles) issue(next, true, true);  // next tile's loads fly while this tile finishes
 #pragma unroll
@@ -356,16 +362,18 @@ __global__ __launch_bounds__(256) void k_sum2(const double* __restrict__ a, int 
 
 // XR: alpha, x += alpha s, r -= alpha q, partial |r|^2 and r.(invdiag r)   (ConjugateGradient.h:70-74,79-81)
 // Flat stream over the local box, two cells (16 bytes) per lane per access, 4 accesses in flight.
-template <typename T>
+template <typename T, bool SPARSE>
 __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r,
                                                   const T* __restrict__ s, const T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rz_cur, int n_xr, const double* __restrict__ part_pq,
                                                   int n_sq, double* __restrict__ part_rr, double* __restrict__ part_rz_next, PcgState* ps,
-                                                  int sparse, int dist)
+                                                  int dist)
 {
     // dist (decomposed run): count bytes with bit 7 are the ring cells of the local box (another rank's unknowns): skipped
-    // sparse (box mostly air): the four vector loads of a pair are issued only if it holds an unknown — one dependent
-    // load more on the critical path, a fraction of the traffic; dense boxes keep the unconditional loads
+    // SPARSE (box mostly air): the four vector loads of a pair are issued only if it holds an unknown — the count words of a
+    // round are loaded together, then the vectors: one dependent load on the critical path per round, a fraction of the traffic.
+    // Dense boxes load everything unconditionally (index clamped into the array, the result masked where it is used): a
+    // load behind a test of another load's result, or inside a branch, makes the compiler drain the queue at every access.
     __shared__ double red[16];
     __shared__ int s_done;
     __shared__ T sdiag[8], sinv[8];
@@ -389,12 +397,16 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
     auto issue = [&](long base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long e = base + u * 256;
-            if (e < e1) {
-                cv[u] = c2[e];
-                if (!sparse || cv[u]) { xv[u] = x2[e]; rv[u] = r2[e]; sv[u] = s2[e]; qv[u] = q2[e]; }
-            } else {
-                cv[u] = 0;
+            const long e = base + u * 256, ec = e < n2 ? e : n2 - 1;
+            cv[u] = c2[ec];
+            if (!SPARSE) { xv[u] = x2[ec]; rv[u] = r2[ec]; sv[u] = s2[ec]; qv[u] = q2[ec]; }
+        }
+        if (SPARSE) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long e = base + u * 256;
+                if (e >= e1) cv[u] = 0;
+                if (cv[u]) { xv[u] = x2[e]; rv[u] = r2[e]; sv[u] = s2[e]; qv[u] = q2[e]; }
             }
         }
     };
@@ -410,32 +422,39 @@ __global__ __launch_bounds__(256) void k_pcg_xr_l(long n2, const uint8_t* __rest
     const T alpha = (T)(rz / pq);
     double arr = 0, arz = 0;
     for (; i < e1; i += U * 256) {
+        V2 xo[U], ro[U];
+        uint16_t cw[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long e = i + u * 256;
-            if (cv[u]) {
-                int ca = cv[u] & 0xff, cb = cv[u] >> 8;
+            cw[u] = i + u * 256 < e1 ? cv[u] : (uint16_t)0;
+            xo[u] = xv[u]; ro[u] = rv[u];
+            if (cw[u]) {
+                int ca = cw[u] & 0xff, cb = cw[u] >> 8;
                 if (dist) { ca = (ca & 0x80) ? 0 : ca; cb = (cb & 0x80) ? 0 : cb; }
-                V2 xo = xv[u], ro = rv[u];
                 if (ca) {
-                    xo.a = xo.a + alpha * sv[u].a;
-                    ro.a = ro.a - alpha * qv[u].a;
-                    const T z = ro.a * sinv[ca];
-                    arr += (double)ro.a * (double)ro.a;
-                    arz += (double)ro.a * (double)z;
+                    xo[u].a = xo[u].a + alpha * sv[u].a;
+                    ro[u].a = ro[u].a - alpha * qv[u].a;
+                    const T z = ro[u].a * sinv[ca];
+                    arr += (double)ro[u].a * (double)ro[u].a;
+                    arz += (double)ro[u].a * (double)z;
                 }
                 if (cb) {
-                    xo.b = xo.b + alpha * sv[u].b;
-                    ro.b = ro.b - alpha * qv[u].b;
-                    const T z = ro.b * sinv[cb];
-                    arr += (double)ro.b * (double)ro.b;
-                    arz += (double)ro.b * (double)z;
+                    xo[u].b = xo[u].b + alpha * sv[u].b;
+                    ro[u].b = ro[u].b - alpha * qv[u].b;
+                    const T z = ro[u].b * sinv[cb];
+                    arr += (double)ro[u].b * (double)ro[u].b;
+                    arz += (double)ro[u].b * (double)z;
                 }
-                ((V2*)x)[e] = xo;
-                ((V2*)r)[e] = ro;
             }
         }
-        if (i + U * 256 < e1) issue(i + U * 256);
+        const long ib = i;
+        if (!SPARSE || i + U * 256 < e1) issue(i + U * 256);   // the next round's loads fly while this one is written
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (cw[u]) {
+                ((V2*)x)[ib + u * 256] = xo[u];
+                ((V2*)r)[ib + u * 256] = ro[u];
+            }
     }
     arr = block_sum<double, 4>(arr, red);
     arz = block_sum<double, 4>(arz, red);
@@ -532,28 +551,33 @@ __global__ __launch_bounds__(256) void k_pcg_xr_rows(LBox L, const uint8_t* __re
     if (threadIdx.x == 0) s_done = ps->done;
     const int ntz = (L.nz + 31) / 32;
     const int sub = threadIdx.x >> 5, kz = threadIdx.x & 31;
-    auto cell_of = [&](int ri) {
-        const int row = rlist[ri];
-        const int tz = row % ntz, iy = (row / ntz) % L.ny, ix = row / (ntz * L.ny);
-        return ((long)(1 + ix) * L.Ly + (1 + iy)) * L.Lz + LBOX_K0 + tz * 32 + kz;
-    };
-    constexpr int U = 2;   // rows in flight per thread
+    // U rows in flight per thread.  Every load is unconditional (a list index past the end is clamped to the last row and the
+    // count byte masked where it is used) and a row's list entry is fetched one round before its vectors: a load inside a
+    // branch, or an address that hangs on a load issued a moment ago, drains the whole queue at every row.
+    constexpr int U = 2;
     long c[U];
     uint8_t cv[U];
     T xv[U], rv[U], sv[U], qv[U];
+    int rown[U];
     const int stride = gridDim.x * 8;
     int ri = xcd_remap(blockIdx.x, gridDim.x) * 8 + sub;
-    auto issue = [&](int u, int rr) {
-        cv[u] = 0;
-        c[u] = 0;
-        if (rr < nrows) {
-            c[u] = cell_of(rr);
-            cv[u] = cnt[c[u]];
-            xv[u] = x[c[u]]; rv[u] = r[c[u]]; sv[u] = s[c[u]]; qv[u] = q[c[u]];
-        }
+    auto row_at = [&](int rr) { return rlist[rr < nrows ? rr : nrows - 1]; };
+    auto cell_row = [&](int row) {
+        const int tz = row % ntz, iy = (row / ntz) % L.ny, ix = row / (ntz * L.ny);
+        return ((long)(1 + ix) * L.Ly + (1 + iy)) * L.Lz + LBOX_K0 + tz * 32 + kz;
+    };
+    auto issue = [&](int u, int row) {
+        c[u] = cell_row(row);
+        cv[u] = cnt[c[u]];
+        xv[u] = x[c[u]]; rv[u] = r[c[u]]; sv[u] = s[c[u]]; qv[u] = q[c[u]];
     };
 #pragma unroll
-    for (int u = 0; u < U; ++u) issue(u, ri + u * stride);
+    for (int u = 0; u < U; ++u) rown[u] = row_at(ri + u * stride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        issue(u, rown[u]);
+        rown[u] = row_at(ri + (U + u) * stride);
+    }
     __syncthreads();
     if (s_done) return;
     double rz, pq, d3;
@@ -568,9 +592,10 @@ __global__ __launch_bounds__(256) void k_pcg_xr_rows(LBox L, const uint8_t* __re
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long cc = c[u];
-            const uint8_t cw = cv[u];
+            const uint8_t cw = ri + u * stride < nrows ? cv[u] : (uint8_t)0;
             const T xo = xv[u] + alpha * sv[u], ro = rv[u] - alpha * qv[u];
-            issue(u, ri + (U + u) * stride);   // the row after next: its loads fly while this one is written
+            issue(u, rown[u]);                              // the row after next: its loads fly while this one is written
+            rown[u] = row_at(ri + (2 * U + u) * stride);    // ... and the list entry of the one after that
             if (cw) {
                 const T z = ro * sinv[cw];
                 arr += (double)ro * (double)ro;
@@ -704,8 +729,8 @@ template <typename T>
 void launch_pcg_xr_dist(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
                         const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps)
 {
-    hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, g_rz_cur, 1,
-                       g_pq, 1, part_rr, part_rz_next, ps, 0, 1);
+    hipLaunchKernelGGL((k_pcg_xr_l<T, false>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, g_rz_cur, 1,
+                       g_pq, 1, part_rr, part_rz_next, ps, 1);
 }
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b)
 {
@@ -715,8 +740,12 @@ template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz, int sparse)
 {
-    hipLaunchKernelGGL((k_pcg_xr_l<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
-                       n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, sparse, 0);
+    if (sparse)
+        hipLaunchKernelGGL((k_pcg_xr_l<T, true>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
+                           n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, 0);
+    else
+        hipLaunchKernelGGL((k_pcg_xr_l<T, false>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, part_rz_cur,
+                           n_rz < 0 ? pcg_xr_blocks(L) : n_rz, part_pq, pcg_sq_blocks(L), part_rr, part_rz_next, ps, 0);
 }
 
 int sq_tile_count(const LBox& L) { return sq_tiles(L); }
@@ -1306,7 +1335,7 @@ __device__ __forceinline__ T and_mask(T v, int m)
 // rows; the waves of a block are MY neighbouring x planes and exchange the x neighbours through the LDS plane, the y neighbours
 // stay in registers).  The sum keeps the order x-, x+, y-, y+, z-, z+ either way.
 // MODE 1 (probe): q = masked s with the same loads, stores and march, no LDS, barrier or arithmetic.
-template <typename T, int MY, int MD, int MODE = 0, int AXIS = 0>
+template <typename T, int MY, int MD, int MODE = 0, int AXIS = 0, bool RIMS = false>
 __global__ __launch_bounds__((MY + 2) * 64) void k_stencil_lean(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
                                                                 const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
 {
@@ -1332,8 +1361,7 @@ __global__ __launch_bounds__((MY + 2) * 64) void k_stencil_lean(Grid g, int cxle
     const unsigned cvm = cv ? 0xFFFFFFFFu : 0u;
     const long col = (long)min(max(y, 0), N - 1) * sr + min(z0, N - V);
     // z rim (only when a row is wider than one wave): lane 0 the cell before the wave's range, lane 63 the cell after it
-    const bool rims = ntz > 1;
-    const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
+    const int rz = lane < 32 ? tz * MZV - 1 : tz * MZV + MZV;
     const bool rv = own && (lane == 0 || lane == 63) && y < N && rz >= 0 && rz < N;
     const long rcol = (long)min(max(y, 0), N - 1) * sr + min(max(rz, 0), N - 1);
     // per-cell masks (all ones / zero) of a packed flag word: unknown = fluid and at least one non-solid neighbour
@@ -1344,25 +1372,24 @@ __global__ __launch_bounds__((MY + 2) * 64) void k_stencil_lean(Grid g, int cxle
         for (int c = 0; c < V; ++c) o[c] = and_mask<T>(v[c], __builtin_amdgcn_sbfe((int)a, 8 * c, 1));
         return o;
     };
+    // Loads are unconditional and their results are masked only where they are consumed: a select right behind a load (or a load
+    // inside a branch) makes the compiler wait for it at once, and the MD planes in flight collapse to one.
     auto ldp = [&](int x, vec& v, unsigned& w) {   // one step of this wave's row: x is wave-uniform
-        if (x >= 0 && x <= xlast) {
-            const long c = (long)x * sm + col;
-            w = (unsigned)*reinterpret_cast<const fvec*>(flags + c) & cvm;
-            v = *reinterpret_cast<const vec*>(s + c);
-        } else {
-            w = 0;
-            v = (vec)(T)0;
-        }
+        const long c = (long)min(max(x, 0), xlast) * sm + col;
+        w = (unsigned)*reinterpret_cast<const fvec*>(flags + c);
+        v = *reinterpret_cast<const vec*>(s + c);
     };
-    auto ldr = [&](int x, T& v, unsigned& f) {     // the rim cell of lanes 0 / 63
+    auto okw = [&](int x, unsigned w) { return x >= 0 && x <= xlast ? w & cvm : 0u; };
+    auto ldr = [&](int x, T& v, unsigned& f) {     // the rim cell of lanes 0 / 63 (every lane loads: no branch)
         v = 0;
         f = 0;
-        if (rims && x >= 0 && x <= xlast) {
-            const long c = (long)x * sm + rcol;
-            f = rv ? flags[c] : 0;
+        if constexpr (RIMS) {
+            const long c = (long)min(max(x, 0), xlast) * sm + rcol;
+            f = flags[c];
             v = s[c];
         }
     };
+    auto okr = [&](int x, unsigned f) { return rv && x >= 0 && x <= xlast ? f : 0u; };
     vec vm1, v0;
     unsigned wm1, w0, rf0;
     T r0;
@@ -1377,54 +1404,61 @@ __global__ __launch_bounds__((MY + 2) * 64) void k_stencil_lean(Grid g, int cxle
         ldp(xa + 1 + d, qv[d], qw[d]);
         ldr(xa + 1 + d, rq[d], rqf[d]);
     }
-    vec sm1 = mkv(vm1, active_bits(wm1)), s0 = mkv(v0, active_bits(w0));
-    T rim = and_mask<T>(r0, __builtin_amdgcn_sbfe((int)active_bits(rf0), 0, 1));
+    w0 = okw(xa, w0);
+    vec sm1 = mkv(vm1, active_bits(okw(xa - 1, wm1))), s0 = mkv(v0, active_bits(w0));
+    T rim = and_mask<T>(r0, __builtin_amdgcn_sbfe((int)active_bits(okr(xa, rf0)), 0, 1));
     const T off = cf.off;
     __syncthreads();  // coef table
-    for (int xb = xa; xb < xe; xb += MD) {
-#pragma unroll
-        for (int d = 0; d < MD; ++d) {
-            const int x = xb + d;
-            if (x < xe) {  // block-uniform
-                const int buf = x & 1;
-                if (MODE == 1) {
-                    if (own && cv) __builtin_nontemporal_store(s0, reinterpret_cast<vec*>(&q[(long)x * sm + col]));
-                    s0 = mkv(qv[d], active_bits(qw[d]));
-                    ldp(x + 1 + MD, qv[d], qw[d]);
-                    continue;
-                }
-                *reinterpret_cast<vec*>(&pl[buf][lrow][lane * V]) = s0;
-                __syncthreads();
-                const unsigned an = active_bits(qw[d]);
-                const vec sp1 = mkv(qv[d], an);
-                if (own) {   // wave-uniform
-                    const vec up = *reinterpret_cast<const vec*>(&pl[buf][lrow - 1][lane * V]);
-                    const vec dn = *reinterpret_cast<const vec*>(&pl[buf][lrow + 1][lane * V]);
-                    T left = dpp_wave_shr1<T>(s0[V - 1]), right = dpp_wave_shl1<T>(s0[0]);
-                    if (rims) {
-                        left = lane == 0 ? rim : left;
-                        right = lane == 63 ? rim : right;
-                    }
-                    const unsigned a0 = active_bits(w0);
-                    vec out;
-#pragma unroll
-                    for (int c = 0; c < V; ++c) {
-                        const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
-                        const T nb = AXIS == 0 ? sm1[c] + sp1[c] + up[c] + dn[c] + zl + zr : up[c] + dn[c] + sm1[c] + sp1[c] + zl + zr;
-                        const T r = sdiag[__builtin_amdgcn_ubfe(w0, 8 * c + F_CNT_SHIFT, 3)] * s0[c] + off * nb;
-                        out[c] = and_mask<T>(r, __builtin_amdgcn_sbfe((int)a0, 8 * c, 1));
-                    }
-                    if (cv) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sm + col]));  // streamed once: keep s, not q, in cache
-                }
-                sm1 = s0;
-                s0 = sp1;
-                w0 = qw[d];
-                rim = and_mask<T>(rq[d], __builtin_amdgcn_sbfe((int)active_bits(rqf[d]), 0, 1));
-                ldp(x + 1 + MD, qv[d], qw[d]);
-                ldr(x + 1 + MD, rq[d], rqf[d]);
-            }
+    // one step of the march; d = the slot of the ring that holds step x+1 and is refilled with step x+1+MD
+    auto step = [&](int x, vec& nv, unsigned& nw, T& nr, unsigned& nrf) {
+        const int buf = x & 1;
+        const unsigned wn = okw(x + 1, nw);
+        if (MODE == 1) {
+            if (own && cv) __builtin_nontemporal_store(s0, reinterpret_cast<vec*>(&q[(long)x * sm + col]));
+            s0 = mkv(nv, active_bits(wn));
+            ldp(x + 1 + MD, nv, nw);
+            return;
         }
+        *reinterpret_cast<vec*>(&pl[buf][lrow][lane * V]) = s0;
+        __syncthreads();
+        const unsigned an = active_bits(wn);
+        const vec sp1 = mkv(nv, an);
+        if (own) {   // wave-uniform
+            const vec up = *reinterpret_cast<const vec*>(&pl[buf][lrow - 1][lane * V]);
+            const vec dn = *reinterpret_cast<const vec*>(&pl[buf][lrow + 1][lane * V]);
+            T left = dpp_wave_shr1<T>(s0[V - 1]), right = dpp_wave_shl1<T>(s0[0]);
+            if (RIMS) {
+                left = lane == 0 ? rim : left;
+                right = lane == 63 ? rim : right;
+            }
+            const unsigned a0 = active_bits(w0);
+            vec out;
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+                const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
+                const T nb = AXIS == 0 ? sm1[c] + sp1[c] + up[c] + dn[c] + zl + zr : up[c] + dn[c] + sm1[c] + sp1[c] + zl + zr;
+                const T r = sdiag[__builtin_amdgcn_ubfe(w0, 8 * c + F_CNT_SHIFT, 3)] * s0[c] + off * nb;
+                out[c] = and_mask<T>(r, __builtin_amdgcn_sbfe((int)a0, 8 * c, 1));
+            }
+            if (cv) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sm + col]));  // streamed once: keep s, not q, in cache
+        }
+        sm1 = s0;
+        s0 = sp1;
+        w0 = wn;
+        rim = and_mask<T>(nr, __builtin_amdgcn_sbfe((int)active_bits(okr(x + 1, nrf)), 0, 1));
+        ldp(x + 1 + MD, nv, nw);
+        ldr(x + 1 + MD, nr, nrf);
+    };
+    // whole rounds of the ring run unguarded: a guard inside the round is a path on which the newest load is the next one
+    // consumed, and the compiler then drains the queue at every step
+    int xb = xa;
+    for (; xb + MD <= xe; xb += MD) {
+#pragma unroll
+        for (int d = 0; d < MD; ++d) step(xb + d, qv[d], qw[d], rq[d], rqf[d]);
     }
+#pragma unroll
+    for (int d = 0; d < MD; ++d)
+        if (xb + d < xe) step(xb + d, qv[d], qw[d], rq[d], rqf[d]);   // block-uniform
 }
 
 template <typename T, int MY, int MD, int MODE = 0, int AXIS = 0>
@@ -1432,7 +1466,10 @@ static void lean_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags,
 {
     constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
     const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZV - 1) / MZV, ncx = (g.N + cxlen - 1) / cxlen;
-    hipLaunchKernelGGL((k_stencil_lean<T, MY, MD, MODE, AXIS>), dim3(nty * ntz * ncx), dim3((MY + 2) * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
+    if (ntz > 1)
+        hipLaunchKernelGGL((k_stencil_lean<T, MY, MD, MODE, AXIS, true>), dim3(nty * ntz * ncx), dim3((MY + 2) * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
+    else
+        hipLaunchKernelGGL((k_stencil_lean<T, MY, MD, MODE, AXIS, false>), dim3(nty * ntz * ncx), dim3((MY + 2) * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
 }
 
 // ---- dense sweep with a linear front ("front") -------------------------------------------------------------------------
@@ -1567,8 +1604,16 @@ void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T*
         case 804: lean_launch<T, 8, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
         case 1402: lean_launch<T, 14, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
         case 1404: lean_launch<T, 14, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 408: lean_launch<T, 4, 8, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 416: lean_launch<T, 4, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 616: lean_launch<T, 6, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 808: lean_launch<T, 8, 8, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 816: lean_launch<T, 8, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 1416: lean_launch<T, 14, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
         case 10402: lean_launch<T, 4, 2, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
         case 10804: lean_launch<T, 8, 4, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 10416: lean_launch<T, 4, 16, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
+        case 10816: lean_launch<T, 8, 16, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
         default: lean_launch<T, 8, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
         }
         return;
@@ -1579,9 +1624,12 @@ void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T*
         case 402: lean_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
         case 403: lean_launch<T, 4, 3>(st, g, cxlen, flags, s, q, cf); break;
         case 404: lean_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
+        case 408: lean_launch<T, 4, 8>(st, g, cxlen, flags, s, q, cf); break;
         case 602: lean_launch<T, 6, 2>(st, g, cxlen, flags, s, q, cf); break;
         case 604: lean_launch<T, 6, 4>(st, g, cxlen, flags, s, q, cf); break;
         case 802: lean_launch<T, 8, 2>(st, g, cxlen, flags, s, q, cf); break;
+        case 808: lean_launch<T, 8, 8>(st, g, cxlen, flags, s, q, cf); break;
+        case 1408: lean_launch<T, 14, 8>(st, g, cxlen, flags, s, q, cf); break;
         case 803: lean_launch<T, 8, 3>(st, g, cxlen, flags, s, q, cf); break;
         case 804: lean_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
         case 806: lean_launch<T, 8, 6>(st, g, cxlen, flags, s, q, cf); break;
@@ -1618,8 +1666,9 @@ void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T*
         return;
     }
     if (variant == 0 && can_vec) {
-        if (sizeof(T) == 4) lean_launch<T, 4, 2>(st, g, 16, flags, s, q, cf);
-        else lean_launch<T, 4, 2>(st, g, 32, flags, s, q, cf);
+        // measured from HBM at 256^3 (tools/stencil_hbm.py): 4 planes in flight, chunks of 32 (fp32) / 64 (fp64) planes
+        const int cx = (sizeof(T) == 4 ? 32 : 64) >> (g.N < 256 ? 1 : 0);
+        lean_launch<T, 4, 4>(st, g, cx, flags, s, q, cf);
         return;
     }
     if (can_vec && variant >= 10000) {
