@@ -104,6 +104,7 @@ SYMBOLS = [
     ("fluid_stencil_apply", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fluid_extrapolate", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("fluid_resample", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64)]),
+    ("fluid_get_droplets", C.c_int, [_P, C.POINTER(C.c_int32), _P, C.c_int32]),
     ("fluid_stencil_apply_hbm", C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     ("fluid_profile_enable", C.c_int, [_P, C.c_int]),
     ("fluid_profile_read", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -1,6 +1,7 @@
 // libfluid_hip.so — C ABI (include/fluid_hip.h) and host orchestration of the step
 // fluid.cc:1378-1490 on one MI355X.  One handle = one HIP stream; all fields live in HBM.
 #include "sim.h"
+#include <algorithm>
 
 using namespace fl;
 
@@ -184,7 +185,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -240,6 +241,8 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
     if (const char* e = getenv("FLUID_XR_ROWS")) s->rows_on = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_DROPLETS")) s->drops_on = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_DROPLETS_MIN")) s->drop_min = atoi(e);
     if (const char* e = getenv("FLUID_MG_COARSE")) s->mgc_mode = atoi(e);
     if (const char* e = getenv("FLUID_MG_COARSE_BLOCKS")) s->mgc_max_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("FLUID_MG_COARSE_CELLS")) s->mgc_max_cells = atol(e);
@@ -861,6 +864,8 @@ static int solve_mg(fluid_sim* s)
     if (!s->h_ps->done) iters = (int)max_it;
     // the new solution goes into the buffer of the older guess, which then becomes the latest
     launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, s->warm ? s->p_guess2 : nullptr, s->ps);
+    launch_drop_solve(s->st, g, L, s->n_drop, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol, s->pressure,
+                      s->warm ? s->p_guess2 : nullptr);
     if (s->warm) s->rotate_guess();
     s->have_guess = s->warm;
     HIPCHK(hipGetLastError());
@@ -895,7 +900,8 @@ int fl::phase_flags(fluid_sim* s)
     s->flag_x1 = none ? -1 : s->Sb.x1;
     s->flags_valid = true;
     HIPCHK(hipGetLastError());
-    bool built = false;
+    bool built = false, drops = false;
+    s->n_drop = 0;
     if (!box_empty(s->Rb)) {
         // box-local solver layout of this step: diag counts (and, in a mostly-air box, the lists of the tiles that hold an
         // unknown: their lengths come back with num_active in the one read below)
@@ -914,6 +920,18 @@ int fl::phase_flags(fluid_sim* s)
                 HIPCHK(hipMalloc((void**)&s->tl_mg, cap * sizeof(int)));
                 HIPCHK(hipMalloc((void**)&s->tl_sq, cap * sizeof(int)));
                 s->tl_cap = cap;
+            }
+            // the airborne droplets leave the system first: tiles, rows and coarse levels are built without them
+            // (a few hundred droplets do not pay for the search: while the last search found fewer than drop_min, look every 8th
+            // step only — the pressure is the same either way)
+            if (s->drops_on && !s->dist && (s->drop_last < 0 || s->drop_last >= s->drop_min || ++s->drop_skipped >= 8)) {
+                s->drop_skipped = 0;
+                if (!s->drop_cells) {
+                    HIPCHK(hipMalloc((void**)&s->drop_n, (size_t)DROP_CAP * sizeof(int)));
+                    HIPCHK(hipMalloc((void**)&s->drop_cells, (size_t)DROP_CAP * 64 * sizeof(int)));
+                }
+                launch_drop_find(s->st, s->L, s->cntL, DROP_CAP, &s->ss->n_drop, s->drop_n, s->drop_cells);
+                drops = true;
             }
             launch_mg_tile_flags(s->st, m0, s->cntL, s->tl_flags);
             launch_compact_flags(s->st, s->tl_flags, n_mg, s->tl_mg, &s->ss->n_tl_mg);
@@ -948,6 +966,9 @@ int fl::phase_flags(fluid_sim* s)
         const bool airy = (double)s->stats.num_active < 0.45 * (double)s->L.cells() && s->L.cells() > (size_t)1500000;
         s->lists_hint = airy;
         s->n_tl_mg = s->h_ss->n_tl_mg; s->n_tl_sq = s->h_ss->n_tl_sq; s->n_rows = s->h_ss->n_rows;
+        s->n_drop = drops ? std::min(s->h_ss->n_drop, DROP_CAP) : 0;
+        if (drops) s->drop_last = s->n_drop;
+        if (s->n_drop > 0) s->stats.paths |= FLUID_PATH_DROPLETS;
         s->lists_on = built && s->n_tl_mg > 0 && s->n_tl_sq > 0 && (s->lists_force == 1 || airy);
         if (s->lists_on) s->stats.paths |= FLUID_PATH_TILE_LISTS;
         const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);  // incl. the spare wrap rows
@@ -1033,6 +1054,7 @@ static int solve_impl(fluid_sim* s)
         iters = (int)max_it;
     }
     launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
+    launch_drop_solve(s->st, g, L, s->n_drop, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol, s->pressure, nullptr);
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
@@ -1176,6 +1198,32 @@ int fluid_extrapolate(fluid_sim_t* s, int32_t* n_layers)
 }
 
 /* fluid.cc:1053-1080: at most `per_cell` particles per base cell (index order); the others are parked outside the grid. */
+int fluid_get_droplets(fluid_sim_t* s, int32_t* n_components, int64_t* cells, int32_t cap_components)
+{
+    if (!s) return fail(FLUID_ERR_ARG, "null handle");
+    if (n_components) *n_components = s->n_drop;
+    if (!cells || s->n_drop <= 0 || cap_components <= 0) return FLUID_OK;
+    HIPCHK(hipSetDevice(s->prm.device));
+    const int n = std::min(s->n_drop, (int)cap_components);
+    std::vector<int> hn(n), hc((size_t)n * 64);
+    HIPCHK(hipStreamSynchronize(s->st));
+    HIPCHK(hipMemcpy(hn.data(), s->drop_n, hn.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hc.data(), s->drop_cells, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const LBox L = s->L;
+    for (int c = 0; c < n; ++c) {
+        int64_t* o = cells + (size_t)c * 64;
+        const int m = std::min(std::max(hn[c], 0), 64);
+        for (int q = 0; q < m; ++q) {
+            const long t = hc[(size_t)c * 64 + q];
+            const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
+            o[q] = (int64_t)s->g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
+        }
+        std::sort(o, o + m);
+        for (int q = m; q < 64; ++q) o[q] = -1;
+    }
+    return FLUID_OK;
+}
+
 int fluid_resample(fluid_sim_t* s, int32_t per_cell, int64_t* n_parked)
 {
     PHASE_GUARD(s);

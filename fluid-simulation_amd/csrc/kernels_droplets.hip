@@ -1,0 +1,256 @@
+// Closed pockets of the pressure system ("droplets"), solved on their own.
+//
+// fluid.cc:304-412 builds one matrix over every fluid cell with a non-zero diagonal and hands it to one CG solve
+// (fluid.cc:624-637).  After the splash that system is block diagonal: the pool is one connected component, and every
+// airborne droplet — a handful of fluid cells with no fluid neighbour outside the droplet — is a block of its own (at 256^3,
+// step 445: 11 575 components, 11 415 of them with at most 64 cells, together 10 % of the unknowns but 32 % of the solver's
+// tiles and 26 % of its rows; tools/spray_stats.py).  A block that shares no entry with the rest has the same solution
+// whether it is solved with the rest or alone, so the small ones are taken out of the global solve:
+//   k_drop_find   once per step (the flags are fixed for all passes of the step): every 8^3 block of the solver box whose core
+//                 holds a possible first cell of a component (an unknown with no unknown before it on any axis) floods the
+//                 unknowns of its 16^3 window from those cells (min-label propagation in LDS) and claims the components that
+//                 (a) lie wholly inside the window with a free layer around them (closed: every neighbour is seen),
+//                 (b) have their first cell (lowest index) in the block's own 8^3 core (one owner), (c) have <= 64 cells;
+//   k_drop_clear  their count bytes are zeroed, so tile lists, row lists, the multigrid hierarchy and every PCG kernel of
+//                 the step work on the system without them;
+//   k_drop_solve  once per pass: one wave per droplet runs Jacobi-preconditioned CG on its <= 64 unknowns in registers (the
+//                 same matrix entries, right-hand side and tolerance as the global solve) and writes the pressure cells.
+// Everything is a fixed function of the flags: the cells of a droplet are sorted by index before the solve, so the sums do
+// not depend on the order in which blocks or atomics happened to run.
+#include "common.h"
+
+namespace fl {
+
+constexpr int DW = 16, DA = 4, DC = 8;            // window, apron, core
+constexpr int DCELLS = DW * DW * DW;
+constexpr int DROP_MAXSWEEPS = 14;   // cells a pocket may reach from its first cell (path length)
+
+__device__ __forceinline__ double wsum_d(double v)   // every lane gets the total; fixed order
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(512) void k_drop_find(LBox L, const uint8_t* __restrict__ cnt, int ncx, int ncy, int ncz, int cap,
+                                                   int* __restrict__ n_comp, int* __restrict__ comp_n, int* __restrict__ comp_cells)
+{
+    constexpr unsigned AIR = 0xFFFFu, NEW = 0xFFFEu;   // not an unknown / an unknown the search has not reached
+    __shared__ uint16_t lab[DCELLS], lab2[DCELLS];
+    // per label = per seed = per cell of the core (index core_of(label))
+    __shared__ uint8_t bad[DC * DC * DC];
+    __shared__ int meta[DC * DC * DC];    // number of cells, then (claimed) ~slot
+    __shared__ int fill[DC * DC * DC];    // cells emitted so far
+    auto core_of = [](unsigned w) { return (int)((((w >> 8) - DA) * DC + (((w >> 4) & 15) - DA)) * DC + ((w & 15) - DA)); };
+    const int tid = threadIdx.x;
+    const int bz = blockIdx.x % ncz, by = (blockIdx.x / ncz) % ncy, bx = blockIdx.x / (ncz * ncy);
+    const int i0 = 1 + bx * DC - DA, j0 = 1 + by * DC - DA, k0 = LBOX_K0 + bz * DC - DA;   // window origin (local box coordinates)
+    const long sx = (long)L.Ly * L.Lz, sy = L.Lz;
+    // The first cell of a component (lowest index) has no unknown before it on any axis.  A block whose core holds no such cell
+    // owns nothing — that is every block inside the pool and nearly every block on its surface (the cell below is water).
+    const int ci = tid >> 6, cj = (tid >> 3) & 7, ck = tid & 7;
+    bool seed = false;
+    {
+        const int i = i0 + DA + ci, j = j0 + DA + cj, k = k0 + DA + ck;   // >= 1 on every axis: the cells before it exist
+        if (i < L.Lx && j < L.Ly && k < L.Lz) {
+            const long t = i * sx + j * sy + k;
+            seed = cnt[t] != 0 && cnt[t - sx] == 0 && cnt[t - sy] == 0 && cnt[t - 1] == 0;
+        }
+        if (!__syncthreads_or(seed)) return;
+    }
+    for (int w = tid; w < DCELLS; w += 512) {
+        const int wi = w >> 8, wj = (w >> 4) & 15, wk = w & 15;
+        const int i = i0 + wi, j = j0 + wj, k = k0 + wk;
+        const bool in = i >= 0 && i < L.Lx && j >= 0 && j < L.Ly && k >= 0 && k < L.Lz;
+        lab[w] = in && cnt[i * sx + j * sy + k] != 0 ? (uint16_t)NEW : (uint16_t)AIR;
+    }
+    bad[tid] = 0;
+    meta[tid] = 0;
+    fill[tid] = 0;
+    __syncthreads();
+    if (seed) {
+        const int w = ((DA + ci) * DW + DA + cj) * DW + DA + ck;
+        lab[w] = (uint16_t)w;
+    }
+    __syncthreads();
+    // The search spreads from the seeds one cell per sweep (every sweep reads the labels of the sweep before: which cells a
+    // sweep reaches does not depend on the order the threads run in): a reached cell takes the lowest label among itself and
+    // its reached neighbours.  A droplet is done in a few sweeps and the loop ends; a seed that hangs on the pool, or a pocket
+    // that winds further than DROP_MAXSWEEPS cells from its first cell, is found out below and stays in the global solve.
+    uint16_t* cur = lab;
+    uint16_t* nxt = lab2;
+    for (int sweep = 0; sweep < DROP_MAXSWEEPS; ++sweep) {
+        int changed = 0;
+        for (int w = tid; w < DCELLS; w += 512) {
+            const unsigned l = cur[w];
+            unsigned m = l;   // NEW is larger than every label: min() ignores unreached neighbours and reaches an unreached cell
+            if (l != AIR) {
+                const int wi = w >> 8, wj = (w >> 4) & 15, wk = w & 15;
+                if (wk > 0) m = min(m, (unsigned)cur[w - 1]);
+                if (wk < DW - 1) m = min(m, (unsigned)cur[w + 1]);
+                if (wj > 0) m = min(m, (unsigned)cur[w - DW]);
+                if (wj < DW - 1) m = min(m, (unsigned)cur[w + DW]);
+                if (wi > 0) m = min(m, (unsigned)cur[w - DW * DW]);
+                if (wi < DW - 1) m = min(m, (unsigned)cur[w + DW * DW]);
+                changed |= m < l;
+            }
+            nxt[w] = (uint16_t)m;
+        }
+        uint16_t* t = cur; cur = nxt; nxt = t;
+        if (!__syncthreads_or(changed)) break;
+    }
+    if (cur != lab) {   // (block-uniform) the labels of the last sweep go back into lab
+        for (int w = tid; w < DCELLS; w += 512) lab[w] = cur[w];
+        __syncthreads();
+    }
+    // A label is bad if one of its cells (a) lies on the window's outer layer (the component may go on outside), (b) touches an
+    // unknown with another label or none (the search has not finished there: every label region of an unfinished component
+    // has such a border), or (c) comes before the label's own cell (the component's first cell is not a seed of this core:
+    // another block owns it).  A label without a bad cell is a whole component whose first cell lies in this core.
+    for (int w = tid; w < DCELLS; w += 512) {
+        const unsigned l = lab[w];
+        if (l >= NEW) continue;
+        const int wi = w >> 8, wj = (w >> 4) & 15, wk = w & 15;
+        bool b = wi == 0 || wi == DW - 1 || wj == 0 || wj == DW - 1 || wk == 0 || wk == DW - 1 || (unsigned)w < l;
+        if (!b) {
+            const unsigned n0 = lab[w - 1], n1 = lab[w + 1], n2 = lab[w - DW], n3 = lab[w + DW], n4 = lab[w - DW * DW], n5 = lab[w + DW * DW];
+            b = (n0 != AIR && n0 != l) || (n1 != AIR && n1 != l) || (n2 != AIR && n2 != l) || (n3 != AIR && n3 != l) ||
+                (n4 != AIR && n4 != l) || (n5 != AIR && n5 != l);
+        }
+        if (b) bad[core_of(l)] = 1;
+        atomicAdd(&meta[core_of(l)], 1);
+    }
+    __syncthreads();
+    for (int w = tid; w < DCELLS; w += 512) {
+        if (lab[w] != (unsigned)w) continue;   // roots only (seeds of this core that kept their own label)
+        const int r = core_of((unsigned)w);
+        const int n = meta[r];
+        int claim = 0;
+        if (!bad[r] && n <= 64) {
+            const int slot = atomicAdd(n_comp, 1);
+            if (slot < cap) {
+                comp_n[slot] = n;
+                claim = ~slot;
+            }
+        }
+        meta[r] = claim;
+    }
+    __syncthreads();
+    for (int w = tid; w < DCELLS; w += 512) {
+        const unsigned l = lab[w];
+        if (l >= NEW || meta[core_of(l)] >= 0) continue;
+        const int slot = ~meta[core_of(l)];
+        const int pos = atomicAdd(&fill[core_of(l)], 1);
+        const int wi = w >> 8, wj = (w >> 4) & 15, wk = w & 15;
+        comp_cells[(size_t)slot * 64 + pos] = (int)((i0 + wi) * sx + (j0 + wj) * sy + (k0 + wk));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_drop_clear(const int* __restrict__ n_comp, int cap, const int* __restrict__ comp_n,
+                                                    const int* __restrict__ comp_cells, uint8_t* __restrict__ cnt)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, slot = t >> 6, pos = t & 63;
+    const int n = *n_comp < cap ? *n_comp : cap;
+    if (slot >= n || pos >= comp_n[slot]) return;
+    cnt[comp_cells[t]] = 0;
+}
+
+// one wave per droplet
+__global__ __launch_bounds__(256) void k_drop_solve(Grid g, LBox L, int n_comp, const int* __restrict__ comp_n, const int* __restrict__ comp_cells,
+                                                    const uint8_t* __restrict__ flags, const float* __restrict__ b, Coef<double> cf, double tol,
+                                                    double* __restrict__ pressure, double* __restrict__ keep)
+{
+    __shared__ int skey[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + wv;
+    if (slot >= n_comp) return;
+    const int n = comp_n[slot];
+    int key = lane < n ? comp_cells[(size_t)slot * 64 + lane] : 0x7fffffff;
+    // bitonic sort of the 64 keys across the wave (ascending): the order of the unknowns is the order of their cells
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int other = __shfl_xor(key, j, 64);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            key = (lower == up) ? min(key, other) : max(key, other);
+        }
+    skey[wv][lane] = key;
+    __builtin_amdgcn_wave_barrier();
+    const bool live = lane < n;
+    const long sx = (long)L.Ly * L.Lz, sy = L.Lz;
+    auto find = [&](long t) {   // lane that holds cell t, or -1
+        int lo = 0, hi = n - 1, r = -1;
+#pragma unroll 1
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1, v = skey[wv][mid];
+            if (v == t) { r = mid; break; }
+            if (v < t) lo = mid + 1; else hi = mid - 1;
+        }
+        return r;
+    };
+    int nb[6] = {-1, -1, -1, -1, -1, -1};
+    double diag = 1, inv = 1, bv = 0;
+    size_t c = 0;
+    if (live) {
+        const long t = key;
+        nb[0] = find(t - sx); nb[1] = find(t + sx); nb[2] = find(t - sy); nb[3] = find(t + sy); nb[4] = find(t - 1); nb[5] = find(t + 1);
+        const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / sx);
+        c = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
+        const int cntv = flags[c] >> F_CNT_SHIFT;
+        diag = cf.diag[cntv];
+        inv = cf.inv[cntv];
+        bv = (double)b[c];
+    }
+    const double off = cf.off;
+    // ConjugateGradient.h:28-90 with the diagonal preconditioner, x0 = 0
+    double x = 0, r = bv, z = r * inv, s = z;
+    const double bb = wsum_d(bv * bv);
+    double rz = wsum_d(r * z), rr = bb;
+    const double thr = tol * tol * bb;
+    if (bb > 0) {
+#pragma unroll 1
+        for (int it = 0; it < n + 8 && rr > thr; ++it) {
+            double q = diag * s;
+            double acc = 0;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const double sn = __shfl(s, nb[d] < 0 ? lane : nb[d], 64);
+                acc += nb[d] < 0 ? 0.0 : sn;
+            }
+            q = live ? q + off * acc : 0.0;
+            const double pq = wsum_d(s * q);
+            if (!(pq > 0)) break;
+            const double alpha = rz / pq;
+            x += alpha * s;
+            r -= alpha * q;
+            z = r * inv;
+            rr = wsum_d(r * r);
+            const double rzn = wsum_d(r * z);
+            if (!(rzn > 0)) break;
+            s = z + (rzn / rz) * s;
+            rz = rzn;
+        }
+    }
+    if (live) {
+        pressure[c] = x;
+        if (keep) keep[c] = x;
+    }
+}
+
+// cells: 64 ints per component; blocks of 8^3 over the interior of the local box
+void launch_drop_find(hipStream_t st, LBox L, uint8_t* cnt, int cap, int* n_comp, int* comp_n, int* comp_cells)
+{
+    const int ncx = (L.nx + DC - 1) / DC, ncy = (L.ny + DC - 1) / DC, ncz = (L.nz + DC - 1) / DC;
+    hipMemsetAsync(n_comp, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_drop_find, dim3((unsigned)(ncx * ncy * ncz)), dim3(512), 0, st, L, cnt, ncx, ncy, ncz, cap, n_comp, comp_n, comp_cells);
+    hipLaunchKernelGGL(k_drop_clear, dim3((unsigned)(((size_t)cap * 64 + 255) / 256)), dim3(256), 0, st, n_comp, cap, comp_n, comp_cells, cnt);
+}
+void launch_drop_solve(hipStream_t st, Grid g, LBox L, int n_comp, const int* comp_n, const int* comp_cells, const uint8_t* flags, const float* b,
+                       Coef<double> cf, double tol, double* pressure, double* keep)
+{
+    if (n_comp <= 0) return;
+    hipLaunchKernelGGL(k_drop_solve, dim3((unsigned)((n_comp + 3) / 4)), dim3(256), 0, st, g, L, n_comp, comp_n, comp_cells, flags, b, cf, tol, pressure, keep);
+}
+
+}  // namespace fl

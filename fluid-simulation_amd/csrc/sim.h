@@ -98,6 +98,14 @@ struct fluid_sim {
     size_t row_cap = 0;
     int n_rows = 0;
     bool rows_on = true;          // FLUID_XR_ROWS=0: XR over the SQ tile list as before
+    // closed pockets (airborne droplets) of the pressure system, solved on their own (kernels_droplets.hip; FLUID_DROPLETS=0: off)
+    bool drops_on = true;
+    int* drop_n = nullptr;        // cells per component
+    int* drop_cells = nullptr;    // 64 local-box cell indices per component
+    int n_drop = 0;               // components taken out of this step's global solve
+    int drop_last = -1;           // ... found by the last search (-1: none yet); below drop_min the search runs every 8th step only
+    int drop_min = 4000;          // FLUID_DROPLETS_MIN (measured at 256^3: the search pays from ~4 000 droplets on)
+    int drop_skipped = 0;
     bool lists_hint = false;      // the previous step's box was mostly air: build the lists before this step's flags sync
     bool lists_on = false;        // this step's solves use them
     int lists_force = -1;         // FLUID_TILE_LISTS=0|1

@@ -221,6 +221,16 @@ class FluidSim:
         check(lib.fluid_extrapolate(self._h, C.byref(n)))
         return n.value
 
+    def droplets(self):
+        """The closed pockets of the last step's pressure system that were solved apart (include/fluid_hip.h, fluid_get_droplets):
+        an (n, 64) int64 array of cell indices per component, ascending, padded with -1."""
+        n = C.c_int32(0)
+        check(lib.fluid_get_droplets(self._h, C.byref(n), None, 0))
+        cells = np.full((max(n.value, 0), 64), -1, dtype=np.int64)
+        if n.value > 0:
+            check(lib.fluid_get_droplets(self._h, C.byref(n), cells.ctypes.data_as(C.c_void_p), n.value))
+        return cells
+
     def resample(self, per_cell):
         """fluid.cc:1053-1080: at most per_cell particles per base cell (upload order); returns how many were parked outside the grid."""
         n = C.c_int64()

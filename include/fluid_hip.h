@@ -120,6 +120,7 @@ typedef struct fluid_step_stats {
 #define FLUID_PATH_DIST_REPLICATED 8  /* multi-GPU: particles sharded, pressure block replicated on every rank              */
 #define FLUID_PATH_DIST_REBALANCED 32 /* multi-GPU: the cut planes were moved at the end of this step (the window changed)      */
 #define FLUID_PATH_MG_COARSE 16       /* the V-cycle's coarse levels ran as one persistent launch (FLUID_MG_COARSE=1|2; off by default) */
+#define FLUID_PATH_DROPLETS 64        /* closed pockets of <= 64 unknowns (airborne droplets) were solved apart from the global system   */
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 /* Reference defaults (N=121, g=(0,-10,0), dx=1, rho=1, max_dt=0.1, outer_tol=0.1,
@@ -193,6 +194,11 @@ int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
  * (hi + 40, hi + 40, hi + 40) (the reference's (100, 100, 100)); only cells with x < hi - 10 (its `rx < 50`). */
 int fluid_extrapolate(fluid_sim_t* s, int32_t* n_layers);
 int fluid_resample(fluid_sim_t* s, int32_t per_cell, int64_t* n_parked);
+
+/* The closed pockets of the last step's pressure system that were solved apart from the global solve (FLUID_PATH_DROPLETS;
+ * kernels_droplets.hip): n_components of them; cells (may be NULL) receives 64 entries per component — the window-array cell
+ * indices (ix * ny + iy) * nz + iz of its unknowns, ascending, padded with -1 — for at most cap_components components. */
+int fluid_get_droplets(fluid_sim_t* s, int32_t* n_components, int64_t* cells, int32_t cap_components);
 
 /* ---- stencil operator alone (micro-benchmark + parity of the 7-point apply) ------------ */
 /* q = A s with the matrix of fluid.cc:304-412 for the current flags and dt; `reps` launches

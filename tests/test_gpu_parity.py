@@ -641,6 +641,69 @@ def test_forms_switch_by_themselves(fs, monkeypatch):
     assert rel_l2(pra, prb) < 1e-6 and rel_l2(pa, pb) < 1e-9 and rel_l2(va, vb) < 1e-6
 
 
+def _pool_and_spray(fs, n, rng, depth=8, ndrops=300):
+    """A shallow pool over the whole floor and `ndrops` airborne clusters of a dozen particles within one cell's reach:
+    each cluster marks a pocket of 8-27 fluid cells with nothing but air around it."""
+    lo, hi = fs.grid_bounds(n)
+    m = (n - 6) * (n - 6) * depth * 2
+    pool = np.stack([rng.uniform(lo + 3, hi - 3, m), rng.uniform(lo + 2, lo + 2 + depth, m), rng.uniform(lo + 3, hi - 3, m)], axis=1)
+    c = np.stack([rng.uniform(lo + 6, hi - 6, ndrops), rng.uniform(lo + depth + 10, hi - 8, ndrops), rng.uniform(lo + 6, hi - 6, ndrops)], axis=1)
+    drops = (c[:, None, :] + rng.uniform(-0.6, 0.6, size=(ndrops, 12, 3))).reshape(-1, 3)
+    pos = np.concatenate([pool, drops])
+    return pos, rng.standard_normal(pos.shape) * 0.3
+
+
+def test_droplets_are_solved_apart_and_change_nothing(fs, monkeypatch):
+    """kernels_droplets.hip: the closed pockets of the pressure system (airborne droplets: components of <= 64 unknowns with air
+    all around) leave the global solve and are solved one wave each.  The matrix is block diagonal, so the pressure is the same
+    with the feature off (FLUID_DROPLETS=0) — in the pool and inside every droplet — and so is the run."""
+    n = 160
+    pos, vel = _pool_and_spray(fs, n, np.random.default_rng(5))
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim = fs.FluidSim(n=n); sim.upload_particles(pos, vel)
+        st = [sim.step() for _ in range(4)]
+        p, v = sim.download_particles()
+        pr = sim.field(fs.FIELD.PRESSURE); idx = sim.field(fs.FIELD.INDICES)
+        sim.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return st, p, v, pr, idx
+
+    sa, pa, va, pra, ia = run({"FLUID_DROPLETS_MIN": "0"})   # (by default a search that finds under 4 000 is repeated every 8th step only)
+    sb, pb, vb, prb, ib = run({"FLUID_DROPLETS": "0"})
+    assert all(s["paths"] & 64 for s in sa[1:]) and all(s["paths"] & 64 == 0 for s in sb)   # (the lists, and the droplets with them, start at step 2)
+    assert [s["num_active"] for s in sa] == [s["num_active"] for s in sb]                  # the unknown count still counts them
+    assert [s["outer_passes"] for s in sa] == [s["outer_passes"] for s in sb]
+    assert np.array_equal(ia, ib)
+    assert rel_l2(pra, prb) < 1e-9 and rel_l2(pa, pb) < 1e-10 and rel_l2(va, vb) < 1e-8
+    # inside the droplets (cells well above the pool): the same pressures, cell by cell
+    lo, hi = fs.grid_bounds(n)
+    up = np.zeros((n, n, n), bool); up[:, 24:, :] = True
+    dm = (ia.reshape(n, n, n) >= 0) & up
+    assert dm.sum() > 2000
+    a, b = pra.reshape(n, n, n)[dm], prb.reshape(n, n, n)[dm]
+    assert np.abs(a).max() > 0 and np.abs(a - b).max() <= 1e-7 * np.abs(b).max()
+
+
+def test_droplets_against_the_oracle(fs, oracle, monkeypatch):
+    """The same scene small enough for the CPU restatement (which solves the one big system, fluid.cc:624-637), the tile lists —
+    and with them the droplet pass — forced on: unknown numbering, pressure, particles after two steps."""
+    n = 56
+    monkeypatch.setenv("FLUID_TILE_LISTS", "1")
+    monkeypatch.setenv("FLUID_DROPLETS_MIN", "0")
+    pos, vel = _pool_and_spray(fs, n, np.random.default_rng(6), depth=5, ndrops=60)
+    sim, orc = _compare_step(fs, oracle, n, pos, vel, steps=2)
+    assert sim.stats()["paths"] & 64
+    assert rel_l2(sim.field(fs.FIELD.PRESSURE), orc.field(7)) < TOL_F
+    pr, po = sim.field(fs.FIELD.PRESSURE).reshape(n, n, n), orc.field(7).reshape(n, n, n)
+    up = np.zeros((n, n, n), bool); up[:, 18:, :] = True
+    dm = (sim.field(fs.FIELD.INDICES).reshape(n, n, n) >= 0) & up
+    assert dm.sum() > 300 and np.abs(pr[dm] - po[dm]).max() <= 1e-6 * np.abs(po).max()
+
+
 @pytest.mark.parametrize("mode,tpt", [("1", "1"), ("2", "1"), ("2", "4")])
 def test_persistent_coarse_launch_is_bit_identical(fs, mode, tpt, monkeypatch):
     """The V-cycle's coarse levels as ONE persistent launch (k_mg_coarse: phases handed from workgroup to workgroup through

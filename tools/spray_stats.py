@@ -43,3 +43,9 @@ for E in (3, 5, 9, 13):
     rest = keep[lab]
     print(f"  extent <= {E:2d}: {ok.sum():6d} components, {sizes[ok].sum():7d} unknowns; without them: tiles {tiles(rest, np.max).sum()} (of {any_unk.sum()}), "
           f"z rows of 32: {rest.reshape(n, n, n // 32, 32).max(3).sum()} (of {rows_all}), 8x8x16 tiles {rest.reshape(n//8,8,n//8,8,n//16,16).max(5).max(3).max(1).sum()} (of {unk.reshape(n//8,8,n//8,8,n//16,16).max(5).max(3).max(1).sum()})")
+# tile shapes (x, y, z) and the cells they sweep for the unknowns of this state (y is up)
+def swept(a, tx, ty, tz):
+    t = a.reshape(n // tx, tx, n // ty, ty, n // tz, tz).max(5).max(3).max(1)
+    return int(t.sum()) * tx * ty * tz
+for shape in ((4, 8, 32), (8, 4, 32), (4, 4, 32), (8, 8, 16), (8, 4, 16), (16, 4, 16), (8, 2, 32), (16, 2, 32), (4, 8, 64), (8, 4, 64)):
+    print(f"  tiles {shape}: cells swept {swept(unk, *shape):9d} for {int(unk.sum())} unknowns; without the small components {swept(rest, *shape):9d}")
