@@ -311,9 +311,10 @@ int pcg_rows_blocks(int nrows);
 void launch_row_list(hipStream_t st, LBox L, const uint8_t* cnt, int* flags, int* pos, int* list, int* block_sums, int* count);
 // closed pockets of the pressure system (kernels_droplets.hip): found and taken out of cnt once per step, solved once per pass
 constexpr int DROP_CAP = 65536;   // components the buffers hold (64 cells each); the ones beyond stay in the global solve
-void launch_drop_find(hipStream_t st, LBox L, uint8_t* cnt, int cap, int* n_comp, int* comp_n, int* comp_cells);
-void launch_drop_solve(hipStream_t st, Grid g, LBox L, int n_comp, const int* comp_n, const int* comp_cells, const uint8_t* flags, const float* b,
-                       Coef<double> cf, double tol, double* pressure, double* keep);
+constexpr int DROP_NCTR = 64;     // ... in as many ranges, each with a counter of its own
+void launch_drop_find(hipStream_t st, LBox L, uint8_t* cnt, int* ctr, int* pre, int* total, int* comp_n, int* comp_cells);
+void launch_drop_solve(hipStream_t st, Grid g, LBox L, int n_comp, const int* pre, const int* comp_n, const int* comp_cells, const uint8_t* flags,
+                       const float* b, Coef<double> cf, double tol, double* pressure, double* keep);
 template <typename T>
 void launch_pcg_xr_rows(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                         int n_rz, const double* part_pq, int n_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* rlist, int nrows);

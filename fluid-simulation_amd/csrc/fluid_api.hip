@@ -185,7 +185,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -864,8 +864,8 @@ static int solve_mg(fluid_sim* s)
     if (!s->h_ps->done) iters = (int)max_it;
     // the new solution goes into the buffer of the older guess, which then becomes the latest
     launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, s->warm ? s->p_guess2 : nullptr, s->ps);
-    launch_drop_solve(s->st, g, L, s->n_drop, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol, s->pressure,
-                      s->warm ? s->p_guess2 : nullptr);
+    launch_drop_solve(s->st, g, L, s->n_drop, s->drop_ctr + 64 * DROP_NCTR, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol,
+                      s->pressure, s->warm ? s->p_guess2 : nullptr);
     if (s->warm) s->rotate_guess();
     s->have_guess = s->warm;
     HIPCHK(hipGetLastError());
@@ -927,10 +927,11 @@ int fl::phase_flags(fluid_sim* s)
             if (s->drops_on && !s->dist && (s->drop_last < 0 || s->drop_last >= s->drop_min || ++s->drop_skipped >= 8)) {
                 s->drop_skipped = 0;
                 if (!s->drop_cells) {
+                    HIPCHK(hipMalloc((void**)&s->drop_ctr, (size_t)(64 * DROP_NCTR + DROP_NCTR + 1) * sizeof(int)));
                     HIPCHK(hipMalloc((void**)&s->drop_n, (size_t)DROP_CAP * sizeof(int)));
                     HIPCHK(hipMalloc((void**)&s->drop_cells, (size_t)DROP_CAP * 64 * sizeof(int)));
                 }
-                launch_drop_find(s->st, s->L, s->cntL, DROP_CAP, &s->ss->n_drop, s->drop_n, s->drop_cells);
+                launch_drop_find(s->st, s->L, s->cntL, s->drop_ctr, s->drop_ctr + 64 * DROP_NCTR, &s->ss->n_drop, s->drop_n, s->drop_cells);
                 drops = true;
             }
             launch_mg_tile_flags(s->st, m0, s->cntL, s->tl_flags);
@@ -1054,7 +1055,8 @@ static int solve_impl(fluid_sim* s)
         iters = (int)max_it;
     }
     launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
-    launch_drop_solve(s->st, g, L, s->n_drop, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol, s->pressure, nullptr);
+    launch_drop_solve(s->st, g, L, s->n_drop, s->drop_ctr + 64 * DROP_NCTR, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol,
+                      s->pressure, nullptr);
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
@@ -1205,10 +1207,17 @@ int fluid_get_droplets(fluid_sim_t* s, int32_t* n_components, int64_t* cells, in
     if (!cells || s->n_drop <= 0 || cap_components <= 0) return FLUID_OK;
     HIPCHK(hipSetDevice(s->prm.device));
     const int n = std::min(s->n_drop, (int)cap_components);
-    std::vector<int> hn(n), hc((size_t)n * 64);
+    std::vector<int> pre(DROP_NCTR + 1), an(DROP_CAP), ac((size_t)DROP_CAP * 64), hn(n), hc((size_t)n * 64);
     HIPCHK(hipStreamSynchronize(s->st));
-    HIPCHK(hipMemcpy(hn.data(), s->drop_n, hn.size() * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hc.data(), s->drop_cells, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pre.data(), s->drop_ctr + 64 * DROP_NCTR, pre.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(an.data(), s->drop_n, an.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ac.data(), s->drop_cells, ac.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int d = 0, c = 0; d < n; ++d) {   // dense index -> slot, as k_drop_solve does
+        while (c + 1 < DROP_NCTR && pre[c + 1] <= d) ++c;
+        const size_t slot = (size_t)c * (DROP_CAP / DROP_NCTR) + (size_t)(d - pre[c]);
+        hn[d] = an[slot];
+        std::copy(ac.begin() + slot * 64, ac.begin() + slot * 64 + 64, hc.begin() + (size_t)d * 64);
+    }
     const LBox L = s->L;
     for (int c = 0; c < n; ++c) {
         int64_t* o = cells + (size_t)c * 64;

@@ -100,6 +100,7 @@ struct fluid_sim {
     bool rows_on = true;          // FLUID_XR_ROWS=0: XR over the SQ tile list as before
     // closed pockets (airborne droplets) of the pressure system, solved on their own (kernels_droplets.hip; FLUID_DROPLETS=0: off)
     bool drops_on = true;
+    int* drop_ctr = nullptr;      // 64 x DROP_NCTR ints: the slot counters, then DROP_NCTR + 1 range starts of the dense numbering
     int* drop_n = nullptr;        // cells per component
     int* drop_cells = nullptr;    // 64 local-box cell indices per component
     int n_drop = 0;               // components taken out of this step's global solve
