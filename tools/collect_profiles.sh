@@ -41,6 +41,10 @@ PY
   rm -rf $O/mpmc
 done
 bash tools/pmc_stencil.sh > $O/pmc_stencil.log 2>&1; cp gpurun_out/pmc_stencil.txt $O/pmc_stencil.txt
+# the droplets: on / off from the same late states, and every claimed set against scipy's labelling
+timeout -k 10 300 python tools/droplet_ab.py 256 200 300 400 445 490 > $O/droplet_ab.txt 2>&1
+timeout -k 10 300 python tools/droplet_check.py 256 460 115 > $O/droplet_check.txt 2>&1
+timeout -k 10 300 python tools/spray_stats.py 256 445 > $O/spray_stats_445.txt 2>&1
 # the raw traces are large: only the summaries travel back
 rm -f $O/trace/*/*_kernel_trace.csv $O/splash/*/*_kernel_trace.csv $O/settled/*/*_kernel_trace.csv $O/fetch/*/*_counter_collection.csv $O/write/*/*_counter_collection.csv
 ls -la $O
