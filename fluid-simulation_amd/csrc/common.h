@@ -291,7 +291,7 @@ void launch_pcg_init(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const f
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol, int n_rz = -1, int zmode = 0, int sparse = 0);
+                   double tol, int n_rz = -1, int zmode = 0, int sparse = 0, int n_prev = -1);   // n_prev: partials in part_rr (default: an XR launch's)
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1, int sparse = 0);
@@ -349,6 +349,11 @@ constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel c
 constexpr size_t MG_TAIL_LDS = 144 * 1024;  // dynamic LDS the tail kernel may use (160 KB per CU on gfx950): levels whose u, v, f + counts fit go into the tail
 size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem);
 int mg_up_blocks(const MLevel& m);
+// XR of a PCG iteration + the level-0 down leg of the next V-cycle in one launch (kernels_mg.hip, k_mg_down_xr): mg_up_blocks(m) blocks
+// and |r|^2 partials; r_out != r_in
+template <typename T>
+void launch_mg_down_xr(hipStream_t st, MLevel m, const uint8_t* cnt, const double* r_in, double* r_out, const double* q, double* x, const double* s_vec,
+                       T* u, T* r0, MgCoef<T> cf, PcgState* ps, const double* part_rz_cur, int n_rz, const double* part_pq, int n_pq, double* part_rr);
 // T = the V-cycle's arithmetic/storage type, F / O = element types of a level's rhs / result (double at level 0)
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,

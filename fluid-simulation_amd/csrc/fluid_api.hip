@@ -185,7 +185,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->R2};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -241,6 +241,7 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
     if (const char* e = getenv("FLUID_XR_ROWS")) s->rows_on = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_XR_FUSE")) s->xr_fuse = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DROPLETS")) s->drops_on = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DROPLETS_MIN")) s->drop_min = atoi(e);
     if (const char* e = getenv("FLUID_MG_COARSE")) s->mgc_mode = atoi(e);
@@ -716,7 +717,7 @@ static int mg_coarse_prepare(fluid_sim* s)
 }
 
 template <typename V>
-static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, bool down0_done = false)
 {
     const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
@@ -734,7 +735,8 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         V* fc = fold ? F(l + 1) : nullptr;
         const uint8_t* cc = fold ? s->mg_cnt[l + 1] : nullptr;
         const bool lst = s->lists_on && !fold;
-        if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
+        if (l == 0 && down0_done) { /* the fused XR of the iteration before has run this leg (k_mg_down_xr) */ }
+        else if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
         else launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps);
         if (!fold && !(pc && s->mgc_restrict0)) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
     }
@@ -761,9 +763,9 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
-static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, bool down0_done = false)
 {
-    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz) : mg_vcycle_t<double>(s, rhs0, z0, part_rz);
+    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz, down0_done) : mg_vcycle_t<double>(s, rhs0, z0, part_rz, down0_done);
 }
 
 // PCG loop of ConjugateGradient.h:28-90 with z = V-cycle(r); same start, stopping rule and cap as solve_impl.
@@ -773,7 +775,7 @@ static int solve_mg(fluid_sim* s)
     const Grid g = s->g;
     const LBox L = s->L;
     T* X = (T*)s->X;
-    T* R = (T*)s->R;
+    T* R = (T*)s->R;   // (the fused form below alternates between R and a second array)
     T* Q = (T*)s->Q;
     T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
     T* Z = (T*)s->Zmg;  // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
@@ -794,8 +796,19 @@ static int solve_mg(fluid_sim* s)
     const bool fold = n_rz_raw > 1024;
     const int n_rz = fold ? 1 : n_rz_raw;
     int rc;
+    // XR and the level-0 down leg of the next V-cycle as one launch (k_mg_down_xr): dense level 0 with its own restriction launch
+    // (not the small boxes whose down leg restricts itself), one |r|^2 partial per tile (at most 1024 of them)
+    const MLevel& m0 = s->mgl[0];
+    const int n_tiles0 = mg_up_blocks(m0);
+    const bool fuse = s->xr_fuse && !lists && !s->mgc_on && (long)m0.dx * m0.dy * m0.dz > 200000 && n_tiles0 <= 1024 && s->mg_nl >= 2;
+    if (fuse && !s->R2) HIPCHK(hipMalloc((void**)&s->R2, s->lmax * sizeof(double)));
+    T* Rb[2] = {R, fuse ? (T*)s->R2 : R};
+    int rp = 0;                 // Rb[rp] holds the current residual
+    bool down0_done = false;    // the level-0 down leg of the next V-cycle has already run (inside the fused launch)
+    const int n_xr = fuse ? n_tiles0 : n_list;   // |r|^2 partials of an XR launch after the first iteration (dense unfused: launch_pcg_sq's default)
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     if ((rc = mg_coarse_prepare(s))) return rc;
+    if (fuse) HIPCHK(hipMemsetAsync(s->R2, 0, (s->L.cells() + 2 * (size_t)s->L.Lz) * sizeof(double), s->st));   // zeros off the unknowns, like R
     // Start: x = 0 like the reference's cg.solve(b) — or, by default, the previous solve's pressure (Eigen's solveWithGuess
     // form of the same loop: r0 = b - A x0, same threshold tol^2 |b|^2).  The converged p does not depend on the start
     // beyond the tolerance; a settled pool needs far fewer iterations.  r0.r0 partials travel in part_rz[1] (unused by body 0).
@@ -816,7 +829,7 @@ static int solve_mg(fluid_sim* s)
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur]))) return rc;
+            if ((rc = mg_vcycle(s, Rb[rp], Z, fold ? s->mg_part : s->part_rz[cur], down0_done))) return rc;
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
             if (lists)
@@ -825,10 +838,19 @@ static int solve_mg(fluid_sim* s)
                                       s->n_tl_sq);
             else
                 launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
-                                 s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse);
+                                 s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse, fuse && it > 0 ? n_xr : -1);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            if (rows)
+            if (fuse) {
+                if (s->mg_fp32)
+                    launch_mg_down_xr<float>(s->st, m0, cnt, Rb[rp], Rb[rp ^ 1], Q, X, Sx[cur], (float*)s->mg_u[0], (float*)s->mg_r[0], mg_coef_as<float>(s, 0),
+                                             s->ps, s->part_rz[cur], n_rz, s->part_pq, pcg_sq_blocks(L), s->part_rr);
+                else
+                    launch_mg_down_xr<double>(s->st, m0, cnt, Rb[rp], Rb[rp ^ 1], Q, X, Sx[cur], (double*)s->mg_u[0], (double*)s->mg_r[0],
+                                              mg_coef_as<double>(s, 0), s->ps, s->part_rz[cur], n_rz, s->part_pq, pcg_sq_blocks(L), s->part_rr);
+                rp ^= 1;
+                down0_done = true;
+            } else if (rows)
                 launch_pcg_xr_rows<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], n_rz, s->part_pq, pcg_list_blocks(s->n_tl_sq), s->part_rr,
                                       s->part_err, s->ps, s->row_list, s->n_rows);
             else if (lists)
@@ -847,7 +869,8 @@ static int solve_mg(fluid_sim* s)
                 launch_pcg_sq_list<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, n_list, s->part_rz[prv], s->part_rz[prv], s->part_pq,
                                       s->ps, 0, tol, n_rz, 1, s->tl_sq, s->n_tl_sq);
             else
-                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1);
+                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1, 0,
+                                 fuse ? n_xr : -1);
         }
         HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
         HIPCHK(hipStreamSynchronize(s->st));

@@ -238,11 +238,13 @@ struct UpTile {
 // dependent chain shrinks accordingly; a level with many tiles per CU is bound by LDS throughput, not by the chain: NG = 1.
 // sd / si: coefficient tables in LDS; with `cf` the body fills them itself (after issuing its loads), else the caller has, behind
 // a barrier.  `live` = false: a group without a tile of its own walks a valid one for the barriers' sake and stores nothing.
-template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, typename IO, int NG = 1>
-__device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
-                                             T* __restrict__ r, const MLevel& mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
-                                             const MgCoef<T>* cf, T off, int tile, int gx, int gy, bool live, int col, char* lds, T* sd, T* si,
-                                             int grp = 0)
+// rhs(q): the right-hand side at array index q (the plain form loads f[q]; the fused XR + down leg of level 0 forms r - alpha q there);
+// core(q): called once for every unknown of the tile itself, by the thread that forms its residual (the fused leg updates x and r there).
+template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, typename IO, int NG, typename RhsFn, typename CoreFn>
+__device__ __forceinline__ void mg_down_body_fn(const MLevel& m, const uint8_t* __restrict__ cnt, T* __restrict__ u,
+                                                T* __restrict__ r, const MLevel& mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
+                                                const MgCoef<T>* cf, T off, int tile, int gx, int gy, bool live, int col, char* lds, T* sd, T* si,
+                                                int grp, RhsFn rhs, CoreFn core)
 {
     typedef DownTile<T, TX, TY, TZ, RESTRICT> D;
     constexpr int H = D::H, AX = D::AX, AY = D::AY, AZ = D::AZ, BX = D::BX, BY = D::BY, BZ = D::BZ, CX = D::CX, CY = D::CY, CZ = D::CZ;
@@ -270,7 +272,7 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
         const int x = xa0 + p, i = i0 - H + x;
         const size_t q = qa + (size_t)((long)clampi(i, m.dx - 1) * sx);
         const int c = cnt[q];
-        fa[p] = (T)IO::ld(f + q);  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
+        fa[p] = (T)rhs(q);  // (same loop as the count load: split into two loops, the selects below stall the f loads behind the counts)
         ca[p] = (okA && x < AX && (unsigned)i < (unsigned)m.dx) ? c : 0;
     }
     const int yb = col / BZ, zb = col - yb * BZ;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
     const int xb0 = grp * PB;
     T fb[PB];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) fb[p] = (T)IO::ld(f + qb + (size_t)((long)clampi(i0 - H + 1 + xb0 + p, m.dx - 1) * sx));
+    for (int p = 0; p < PB; ++p) fb[p] = (T)rhs(qb + (size_t)((long)clampi(i0 - H + 1 + xb0 + p, m.dx - 1) * sx));
     const int hc = grp * (256 / (CY * CZ)) + col / (CY * CZ), cc = col % (CY * CZ);
     const int yc = cc / CZ, zc = cc - yc * CZ;
     const bool actC = col / (CY * CZ) < 256 / (CY * CZ);
@@ -287,7 +289,7 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
     const size_t qc = m.at(0, clampi(j0 - H + 2 + yc, m.dy - 1), clampi(k0 - H + 2 + zc, m.dz - 1));
     T fr[XC];
 #pragma unroll
-    for (int x = 0; x < XC; ++x) fr[x] = (T)IO::ld(f + qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx));
+    for (int x = 0; x < XC; ++x) fr[x] = (T)rhs(qc + (size_t)((long)clampi(i0 - H + 2 + xc0 + x, m.dx - 1) * sx));
     if (cf) mg_load_coef(sd, si, *cf);
     // ---- u1 = W1 D^-1 f on region A ----
     if (actA) {
@@ -336,7 +338,10 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
                 const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
                 const T v = n ? fr[x] - (sd[n] * c0 + off * nb) : (T)0;
                 if (RESTRICT) sR[((xc0 + x) * CY + yc) * CZ + zc] = v;
-                else if (n && live) IO::st(r + qc + (size_t)((long)(i0 + xc0 + x) * sx), v);
+                else if (n && live) {
+                    IO::st(r + qc + (size_t)((long)(i0 + xc0 + x) * sx), v);
+                    core(qc + (size_t)((long)(i0 + xc0 + x) * sx));
+                }
                 cm = c0;
                 c0 = cp;
             }
@@ -366,6 +371,16 @@ __device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __r
             IO::st(fc + C, acc * (T)0.125);
         }
     }
+}
+
+template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, typename IO, int NG = 1>
+__device__ __forceinline__ void mg_down_body(const MLevel& m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, T* __restrict__ u,
+                                             T* __restrict__ r, const MLevel& mc, const uint8_t* __restrict__ cnt_c, T* __restrict__ fc,
+                                             const MgCoef<T>* cf, T off, int tile, int gx, int gy, bool live, int col, char* lds, T* sd, T* si,
+                                             int grp = 0)
+{
+    mg_down_body_fn<T, F, TX, TY, TZ, RESTRICT, IO, NG>(m, cnt, u, r, mc, cnt_c, fc, cf, off, tile, gx, gy, live, col, lds, sd, si, grp,
+                                                        [&](size_t q) { return IO::ld(f + q); }, [](size_t) {});
 }
 
 template <typename T, typename F, int TX, int TY, int TZ, bool RESTRICT, int NG = 1>
@@ -851,6 +866,49 @@ __global__ __launch_bounds__(256) void k_mg_tile_flags(MLevel m, const uint8_t* 
     if (threadIdx.x == 0) flags[tile] = any != 0;
 }
 
+// XR of one PCG iteration and the level-0 down leg of the NEXT V-cycle as one launch (dense level 0 of at most 1024 tiles; the
+// tile lists, the row list and the decomposed solve keep the two launches).  XR is a stream over x, r, s, q that ends in a grid-wide
+// dependency (the next kernel reads r with a halo), the down leg a tile kernel that begins by loading r with a halo: fused, the leg
+// forms r' = r - alpha q wherever it would have loaded r — on its halo too, recomputed like everything else there — and the thread that
+// forms a tile cell's residual also stores r' and x' = x + alpha s for it and adds r'^2 to the tile's partial.  r' goes into a SECOND
+// array (neighbouring tiles still read r on their halos); the solve swaps the two after every iteration.  One launch less per
+// iteration and r read once; the values are those of the two launches, the |r|^2 partials are per tile instead of per XR block.
+template <typename T>
+__global__ __launch_bounds__(256) void k_mg_down_xr(MLevel m, const uint8_t* __restrict__ cnt, const double* __restrict__ r_in, double* __restrict__ r_out,
+                                                    const double* __restrict__ qv, double* __restrict__ x, const double* __restrict__ sv,
+                                                    T* __restrict__ u, T* __restrict__ r0, MgCoef<T> cf, PcgState* ps, int gx, int gy,
+                                                    const double* __restrict__ part_rz_cur, int n_rz, const double* __restrict__ part_pq, int n_pq,
+                                                    double* __restrict__ part_rr)
+{
+    __shared__ __attribute__((aligned(16))) char lds[DownTile<T, MG_TX, MG_TY, MG_TZ, false>::bytes];
+    __shared__ T sd[8], si[8];
+    __shared__ double red[16];
+    __shared__ int s_done;
+    if (threadIdx.x == 0) s_done = ps->done;   // one read per block, broadcast: block 0 of this launch may set it while we start
+    __syncthreads();
+    if (s_done) return;
+    double rz, pq, d3;
+    block_sum3(part_rz_cur, n_rz, part_pq, n_pq, part_pq, 0, red, rz, pq, d3);
+    if (!(pq > 0) || !(rz == rz)) {  // not SPD / NaN: stop instead of spreading NaNs (as k_pcg_xr_l)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ps->breakdown = 1; ps->done = 1; }
+        return;
+    }
+    const double alpha = rz / pq;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const MLevel none{};
+    double arr = 0;
+    auto rnew = [&](size_t q) { return r_in[q] - alpha * qv[q]; };   // (-ffp-contract=off: the same two operations as k_pcg_xr_l)
+    mg_down_body_fn<T, double, MG_TX, MG_TY, MG_TZ, false, IoPlain, 1>(
+        m, cnt, u, r0, none, nullptr, nullptr, &cf, cf.off, tile, gx, gy, true, (int)threadIdx.x, lds, sd, si, 0, rnew, [&](size_t q) {
+            const double rn = rnew(q);
+            r_out[q] = rn;
+            x[q] = x[q] + alpha * sv[q];
+            arr += rn * rn;
+        });
+    arr = block_sum<double, 4>(arr, red);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = arr;
+}
+
 static inline bool mg_ng4()   // FLUID_MG_NG4=0: every leg one thread group per tile (developer switch for A/B runs)
 {
     static const int on = [] { const char* e = getenv("FLUID_MG_NG4"); return e ? atoi(e) : 1; }();
@@ -888,6 +946,19 @@ void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T*
                            r, mc, cnt_c, fc, cf, ps, (int)g.x, (int)g.y, tlist);
     }
 }
+// XR + the level-0 down leg (k_mg_down_xr): mg_up_blocks(m) blocks, as many |r|^2 partials
+template <typename T>
+void launch_mg_down_xr(hipStream_t st, MLevel m, const uint8_t* cnt, const double* r_in, double* r_out, const double* q, double* x, const double* s_vec,
+                       T* u, T* r0, MgCoef<T> cf, PcgState* ps, const double* part_rz_cur, int n_rz, const double* part_pq, int n_pq, double* part_rr)
+{
+    const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
+    hipLaunchKernelGGL((k_mg_down_xr<T>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, r_in, r_out, q, x, s_vec, u, r0, cf, ps, (int)g.x, (int)g.y,
+                       part_rz_cur, n_rz, part_pq, n_pq, part_rr);
+}
+template void launch_mg_down_xr<float>(hipStream_t, MLevel, const uint8_t*, const double*, double*, const double*, double*, const double*, float*, float*,
+                                       MgCoef<float>, PcgState*, const double*, int, const double*, int, double*);
+template void launch_mg_down_xr<double>(hipStream_t, MLevel, const uint8_t*, const double*, double*, const double*, double*, const double*, double*, double*,
+                                        MgCoef<double>, PcgState*, const double*, int, const double*, int, double*);
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,

@@ -710,11 +710,11 @@ void launch_pcg_init_guess(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, c
 template <typename T>
 void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const T* s_in, T* s_out, T* q, Coef<T> cf,
                    const double* part_rr, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
-                   double tol, int n_rz, int zmode, int sparse)
+                   double tol, int n_rz, int zmode, int sparse, int n_prev)
 {
     const int nx = pcg_xr_blocks(L);
     hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
-                       part_rz_new, part_rz_old, part_pq, nx, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode, sparse, (const int*)nullptr, 0);
+                       part_rz_new, part_rz_old, part_pq, n_prev < 0 ? nx : n_prev, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode, sparse, (const int*)nullptr, 0);
 }
 // decomposed run: g_* = single all-reduced scalars; cnt carries the ring bit (k_cnt_pcg); writes pcg_sq_blocks(L) partials of s'.q
 template <typename T>
@@ -1713,7 +1713,7 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_pcg_init<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, T*, T*, Coef<T>, double*, double*,          \
                                      PcgState*);                                                                                       \
     template void launch_pcg_sq<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
-                                   const double*, double*, PcgState*, int, double, int, int, int);                                     \
+                                   const double*, double*, PcgState*, int, double, int, int, int, int);                                \
     template void launch_pcg_xr<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, const double*, \
                                    double*, double*, PcgState*, int, int);                                                                \
     template void launch_pcg_sq_list<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, int,      \

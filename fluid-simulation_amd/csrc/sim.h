@@ -98,6 +98,9 @@ struct fluid_sim {
     size_t row_cap = 0;
     int n_rows = 0;
     bool rows_on = true;          // FLUID_XR_ROWS=0: XR over the SQ tile list as before
+    bool xr_fuse = false;         // FLUID_XR_FUSE=1: XR and the level-0 down leg of the next V-cycle as ONE launch (k_mg_down_xr; dense level 0 only).
+                                  // Measured at 256^3: 2.947 ms/step against 2.895 for the two launches (the leg reads r AND q with its halo) - off
+    double* R2 = nullptr;         // the second residual array of the fused form (lmax doubles, allocated when first needed)
     // closed pockets (airborne droplets) of the pressure system, solved on their own (kernels_droplets.hip; FLUID_DROPLETS=0: off)
     bool drops_on = true;
     int* drop_ctr = nullptr;      // 64 x DROP_NCTR ints: the slot counters, then DROP_NCTR + 1 range starts of the dense numbering

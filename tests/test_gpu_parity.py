@@ -641,6 +641,29 @@ def test_forms_switch_by_themselves(fs, monkeypatch):
     assert rel_l2(pra, prb) < 1e-6 and rel_l2(pa, pb) < 1e-9 and rel_l2(va, vb) < 1e-6
 
 
+def test_fused_xr_and_down_leg_give_the_same_solve(fs, monkeypatch):
+    """k_mg_down_xr (kernels_mg.hip): XR of an iteration and the level-0 down leg of the next V-cycle in one launch (a dense level 0
+    with more than 200 k cells: the 64^3 box of the 176^3 drop).  x and r get the values of the two launches; only the |r|^2
+    partials are summed per tile instead of per XR block, so the iteration counts may differ by one now and then.  (Off by default:
+    it measured 2 % slower than the two launches at 256^3)"""
+    n = 176
+    outs = []
+    for env in ({"FLUID_XR_FUSE": "0"}, {"FLUID_XR_FUSE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim = fs.FluidSim(n=n); sim.upload_particles(fs.water_cube_drop(n, 4, seed=3))
+        st = [sim.step() for _ in range(3)]
+        p, v = sim.download_particles()
+        outs.append((st, p, v, sim.field(fs.FIELD.PRESSURE)))
+        sim.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    (sa, pa, va, pra), (sb, pb, vb, prb) = outs
+    assert [s["outer_passes"] for s in sa] == [s["outer_passes"] for s in sb]
+    assert all(abs(a["cg_iters"] - b["cg_iters"]) <= a["outer_passes"] for a, b in zip(sa, sb))
+    assert rel_l2(pra, prb) < 1e-12 and rel_l2(pa, pb) < 1e-13 and rel_l2(va, vb) < 1e-11
+
+
 def _pool_and_spray(fs, n, rng, depth=8, ndrops=300):
     """A shallow pool over the whole floor and `ndrops` airborne clusters of a dozen particles within one cell's reach:
     each cluster marks a pocket of 8-27 fluid cells with nothing but air around it."""
