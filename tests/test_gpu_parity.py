@@ -727,6 +727,58 @@ def test_droplets_against_the_oracle(fs, oracle, monkeypatch):
     assert dm.sum() > 300 and np.abs(pr[dm] - po[dm]).max() <= 1e-6 * np.abs(po).max()
 
 
+def test_droplets_on_solids_and_walls(fs, oracle, monkeypatch):
+    """Droplets whose cells have solid neighbours (a shelf inside W, the domain wall): their matrix rows carry smaller diagonal counts
+    and Neumann faces (fluid.cc:326-407) — the wave solve reads them from the same flag bytes as the global one.  Against the oracle's
+    one big system, and two runs of the device path bit for bit (the order the search emits cells in must not reach the sums)."""
+    n = 48
+    monkeypatch.setenv("FLUID_TILE_LISTS", "1")
+    monkeypatch.setenv("FLUID_DROPLETS_MIN", "0")
+    lo, hi = fs.grid_bounds(n)
+    rng = np.random.default_rng(21)
+    sim = fs.FluidSim(n=n); orc = oracle.Oracle(n=n)
+    solid = sim.field(fs.FIELD.SOLID).copy()
+    solid[10:38, 20:22, 10:38] = 1                      # a shelf two cells thick in mid air
+    sim.set_solid(solid); orc.set_solid(solid)
+    pool = np.stack([rng.uniform(lo + 3, hi - 3, 30000), rng.uniform(lo + 2, lo + 6, 30000), rng.uniform(lo + 3, hi - 3, 30000)], axis=1)
+    on_shelf = np.stack([rng.uniform(lo + 11, lo + 37, 40), np.full(40, lo + 22.3), rng.uniform(lo + 11, lo + 37, 40)], axis=1)   # resting on the shelf
+    at_wall = np.stack([np.full(20, lo + 1.2), rng.uniform(lo + 26, hi - 6, 20), rng.uniform(lo + 6, hi - 6, 20)], axis=1)          # against the x wall
+    free = np.stack([rng.uniform(lo + 6, hi - 6, 40), rng.uniform(lo + 28, hi - 6, 40), rng.uniform(lo + 6, hi - 6, 40)], axis=1)
+    c = np.concatenate([on_shelf, at_wall, free])
+    drops = (c[:, None, :] + rng.uniform(-0.55, 0.55, size=(len(c), 10, 3))).reshape(-1, 3)
+    pos = np.concatenate([pool, drops]); vel = rng.standard_normal(pos.shape) * 0.2
+    sim.upload_particles(pos, vel); orc.set_particles(pos, vel)
+    for i in range(2):
+        sg = sim.step(); so = orc.step()
+        assert sg["num_active"] == so["num_active"] and sg["outer_passes"] == so["outer_passes"], (i, sg, so)
+        assert sg["paths"] & 64
+    cells = sim.droplets()
+    assert len(cells) >= 30
+    sol = solid.reshape(-1) != 0
+    touching = 0
+    for d in cells:
+        d = d[d >= 0]
+        x, y, z = np.unravel_index(d, (n, n, n))
+        for dx, dy, dz in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+            q = (np.clip(x + dx, 0, n - 1) * n + np.clip(y + dy, 0, n - 1)) * n + np.clip(z + dz, 0, n - 1)
+            if sol[q].any():
+                touching += 1
+                break
+    assert touching >= 8                                 # droplets with Neumann faces took part
+    pr, po = sim.field(fs.FIELD.PRESSURE).reshape(-1), orc.field(7).reshape(-1)
+    assert rel_l2(pr, po) < TOL_F
+    dc = cells[cells >= 0]
+    assert np.abs(pr[dc] - po[dc]).max() <= 1e-6 * np.abs(po).max()
+    p, v = sim.download_particles(); pp, vv = orc.particles()
+    assert np.allclose(p, pp, rtol=0, atol=1e-7) and np.allclose(v, vv, rtol=0, atol=1e-6)
+    sim2 = fs.FluidSim(n=n); sim2.set_solid(solid); sim2.upload_particles(pos, vel)
+    for i in range(2):
+        sim2.step()
+    assert np.array_equal(sim2.field(fs.FIELD.PRESSURE), sim.field(fs.FIELD.PRESSURE))
+    p2, v2 = sim2.download_particles()
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+
+
 @pytest.mark.parametrize("mode,tpt", [("1", "1"), ("2", "1"), ("2", "4")])
 def test_persistent_coarse_launch_is_bit_identical(fs, mode, tpt, monkeypatch):
     """The V-cycle's coarse levels as ONE persistent launch (k_mg_coarse: phases handed from workgroup to workgroup through
