@@ -460,11 +460,13 @@ def main():
             siml = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
             siml.upload_particles(pos0)
             ts, its, passes, boxes, its_by_step = [], 0, 0, [], []
+            forms = {"p2g_tile_form": 0, "tile_lists": 0, "droplets_solved_apart": 0}   # steps that took each form (stats.paths bits 1, 2, 64)
             for _ in range(a.long_steps):
                 c0 = time.perf_counter()
                 st = siml.step()
                 ts.append((time.perf_counter() - c0) * 1e3)
                 its += st["cg_iters"]; passes += st["outer_passes"]
+                forms["p2g_tile_form"] += bool(st["paths"] & 1); forms["tile_lists"] += bool(st["paths"] & 2); forms["droplets_solved_apart"] += bool(st["paths"] & 64)
                 boxes.append((tuple(st["box_lo"]), tuple(st["box_hi"]))); its_by_step.append((st["cg_iters"], st["outer_passes"]))
             ts = np.array(ts)
             # phases of the run by the active box: free fall (the cube has not reached the floor: the box is still the cube's), splash (the box
@@ -474,7 +476,7 @@ def main():
                                "total_s": float(ts.sum() / 1e3), "substeps_per_s": float(a.long_steps / (ts.sum() / 1e3)),
                                "mean_ms_by_100": [float(ts[i:i + 100].mean()) for i in range(0, a.long_steps, 100)],
                                "cg_iters_total": its, "outer_passes_total": passes, "box_last": [st["box_lo"], st["box_hi"]],
-                               "num_active_last": st["num_active"]}
+                               "num_active_last": st["num_active"], "steps_by_form": forms, "droplets_last": int(len(siml.droplets()))}
             siml.close()
 
         if not a.no_mpm and world == 1:
