@@ -49,3 +49,14 @@ def swept(a, tx, ty, tz):
     return int(t.sum()) * tx * ty * tz
 for shape in ((4, 8, 32), (8, 4, 32), (4, 4, 32), (8, 8, 16), (8, 4, 16), (16, 4, 16), (8, 2, 32), (16, 2, 32), (4, 8, 64), (8, 4, 64)):
     print(f"  tiles {shape}: cells swept {swept(unk, *shape):9d} for {int(unk.sum())} unknowns; without the small components {swept(rest, *shape):9d}")
+# how much lower would the solver box be without the droplets?  (y is up; box of all unknowns against the box of what stays in the global solve)
+ys = np.nonzero(unk.any(axis=(0, 2)))[0]
+for E in (5,):
+    ok = (sizes <= 64) & (ext.max(1) <= E)
+    keep = np.ones(ncomp + 1, bool); keep[1:] = ~ok; keep[0] = False
+    rest = keep[lab]
+    yr = np.nonzero(rest.any(axis=(0, 2)))[0]
+    ym = np.nonzero(main.any(axis=(0, 2)))[0]
+    cnt_by_y = rest.sum(axis=(0, 2))
+    print(f"  y range of all unknowns {ys.min()}..{ys.max()}, without the droplets {yr.min()}..{yr.max()}, of the largest component {ym.min()}..{ym.max()}; "
+          f"unknowns above y = 40 that stay: {int(cnt_by_y[41:].sum())}, above 60: {int(cnt_by_y[61:].sum())}")
