@@ -132,7 +132,7 @@ variants = {
     "v33": dict(wts=(0.52, 0.8, 1.7)),
     "wc14": dict(wc=(1.4, 1.2, 1.0)),
 }
-if __name__ == "__main__" and not os.environ.get("MG_GALERKIN"):
+if __name__ == "__main__" and not os.environ.get("MG_GALERKIN") and not os.environ.get("MG_MOD"):
     names = sys.argv[2:] or ["base"]
     rule = os.environ.get("MG_RULE", "any_air")
     levels = build(rule)
@@ -210,3 +210,34 @@ if __name__ == "__main__" and os.environ.get("MG_GALERKIN"):
         t = time.time()
         x, it, rel = pcg(gl[0], b0, lambda r: g_vcycle(gl, 0, r, dict(wc=wc)))
         print(f"galerkin aggregation wc {wc}: iterations {it} (rel {rel:.1e}) in {time.time()-t:.0f} s", flush=True)
+
+
+# ---- variant: rediscretised coarse operators (uniform off-diagonals, trilinear transfers — the product's legs as they are) on NON-eroded coarse
+# domains (a coarse cell is an unknown if any child is fluid), the free surface inside a partly filled coarse cell accounted for by a larger
+# diagonal: diag = scale (non-solid neighbours + extra(air children))
+class MLevel(Level):
+    def __init__(self, typ, scale, nair, formula, beta):
+        Level.__init__(self, typ, scale)
+        k = nair.astype(np.float64)
+        extra = beta * k if formula == "lin" else beta * k / np.maximum(8.0 - k, 1.0)
+        self.diag = np.where(self.f, self.diag + extra * scale, 1.0)
+        self.inv = np.where(self.f, 1.0 / self.diag, 0.0)
+
+def coarsen_mod(t):
+    s = [(dd + 1) // 2 * 2 for dd in t.shape]
+    tp = np.zeros(s, dtype=np.int8); tp[:t.shape[0], :t.shape[1], :t.shape[2]] = t
+    c = tp.reshape(s[0]//2, 2, s[1]//2, 2, s[2]//2, 2)
+    nfl = (c == 2).sum(axis=(1, 3, 5)); nair = (c == 1).sum(axis=(1, 3, 5)); all_solid = (c == 0).all(axis=(1, 3, 5))
+    return np.where(all_solid, 0, np.where(nfl > 0, 2, 1)).astype(np.int8), nair
+
+if __name__ == "__main__" and os.environ.get("MG_MOD"):
+    formula, betas = os.environ["MG_MOD"].split(":")
+    for beta in [float(a) for a in betas.split(",")]:
+        levels = [Level(t0, float(d["dt"]))]
+        nair_acc = None
+        while max(levels[-1].typ.shape) > 8:
+            tc, nair = coarsen_mod(levels[-1].typ)
+            levels.append(MLevel(tc, levels[-1].scale / 4, nair, formula, beta))
+        t = time.time()
+        x, it, rel = pcg(levels[0], b0, lambda r: vcycle(levels, 0, r, dict(wc=tuple(float(a) for a in os.environ.get("MG_WC", "1.25,1.1,1.0").split(",")))))
+        print(f"non-eroded + diag extra {formula} beta {beta}: unknowns per level {[int(l.f.sum()) for l in levels]} iterations {it} (rel {rel:.1e}) in {time.time()-t:.0f} s", flush=True)
