@@ -103,7 +103,8 @@ struct StepState {
     int max_cell;             // most particles in one cell (P2G picks its kernel by it)
     int n_drop;               // closed pockets of the pressure system found this step (kernels_droplets.hip); may exceed the buffer's capacity
     int n_tl_mg, n_tl_sq;     // active tiles of the level-0 V-cycle legs / of SQ and XR (mostly-air boxes)
-    int n_rows, pad2_;        // z rows of 32 cells that hold an unknown (XR's list)
+    int n_rows, n_l1_old;     // z rows of 32 cells that hold an unknown (XR's list); unknowns of level 1 as the re-discretised cycle types it ...
+    int n_l1_gal, pad3_;      // ... and as aggregation does (any child): their ratio says how much of the pool the coarse levels lose (kernels_gal.hip)
     unsigned long long max_speed_bits;  // max |v_p| as non-negative double bits
     double dt;                // fluid.cc:1367 / 992-999
     double err_num;           // |b-b2|^2
@@ -360,7 +361,22 @@ void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T*
                     const PcgState* ps, const int* tlist = nullptr, int nlist = 0);
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0, const uint8_t* own = nullptr);
+                  double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0, const uint8_t* own = nullptr,
+                  int pconst = 0);   // pconst: piecewise-constant prolongation (the Galerkin coarse levels of kernels_gal.hip)
+// Galerkin coarse levels by 2 x 2 x 2 aggregation (kernels_gal.hip; mostly-air boxes): per-cell coefficients gd (diagonal) and gx, gy, gz (+face weights)
+bool gal_fits_coarsest(const MLevel& m);
+void launch_gal_level1(hipStream_t st, MLevel m0, const uint8_t* cnt0, MgCoef<float> cf0, MLevel m1, float* gd, float* gx, float* gy, float* gz, uint8_t* cnt1);
+void launch_gal_coarsen(hipStream_t st, MLevel mf, const float* fd, const float* fx, const float* fy, const float* fz, const uint8_t* cntf, MLevel mc,
+                        float* gd, float* gx, float* gy, float* gz, uint8_t* cntc);
+// counts[0] += unknowns of level 1 by the count bytes of the re-discretised cycle, counts[1] += by aggregation's flags
+void launch_gal_erosion(hipStream_t st, MLevel m1, const uint8_t* cnt_old, const uint8_t* cnt_gal, int* counts);
+void launch_gal_restrict0(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, const uint8_t* cnt1, float* f1, const PcgState* ps);
+void launch_gal_down(hipStream_t st, MLevel m, const uint8_t* cnt, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, float* u,
+                     MLevel mc, float* fc, const PcgState* ps);
+void launch_gal_up(hipStream_t st, MLevel m, const uint8_t* cnt, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, const float* u,
+                   float* out, MLevel mc, const float* ec, float wc, const PcgState* ps);
+void launch_gal_coarsest(hipStream_t st, MLevel m, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, float* u, int sweeps,
+                         const PcgState* ps);
 // Active-tile lists of a mostly-air box (level 0 only): flags per tile of the V-cycle legs / of the SQ kernel, and their
 // compaction in ascending tile order (list[0..*count)); the legs, SQ and XR are then launched over the listed tiles only.
 void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags);

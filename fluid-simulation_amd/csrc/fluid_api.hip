@@ -185,7 +185,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->R2};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->R2, s->gal_slab};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -242,6 +242,10 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
     if (const char* e = getenv("FLUID_XR_ROWS")) s->rows_on = atoi(e) != 0;
     if (const char* e = getenv("FLUID_XR_FUSE")) s->xr_fuse = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_MG_GALERKIN")) s->gal_mode = atoi(e);
+    if (const char* e = getenv("FLUID_MG_GALERKIN_THR")) s->gal_thr = atof(e);
+    if (const char* e = getenv("FLUID_MG_GALERKIN_WC")) s->gal_wc = atof(e);
+    if (const char* e = getenv("FLUID_MG_GALERKIN_SWEEPS")) s->gal_sweeps = atoi(e);
     if (const char* e = getenv("FLUID_DROPLETS")) s->drops_on = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DROPLETS_MIN")) s->drop_min = atoi(e);
     if (const char* e = getenv("FLUID_MG_COARSE")) s->mgc_mode = atoi(e);
@@ -595,6 +599,7 @@ hipError_t fl::zero_search(fluid_sim* s, size_t lb)
 // (multi-GPU: the same V-cycle applied per slab, neighbour-slab unknowns treated as p = 0: block preconditioner, no halo traffic)
 
 // Level hierarchy of this step: level 0 = the box-local solver layout, coarsened until <= 8^3.
+static int gal_build(fluid_sim* s);
 static int mg_setup(fluid_sim* s)
 {
     s->mgl[0] = mg_level0(s->L);
@@ -657,6 +662,7 @@ static int mg_setup(fluid_sim* s)
     }
     launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
     for (int l = 1; l < nl; ++l) launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
+    { int rcg = gal_build(s); if (rcg) return rcg; }
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
@@ -693,6 +699,55 @@ static MgCoef<V> mg_coef_as(const fluid_sim* s, int level)
     c.off = (V)d.off;
     return c;
 }
+// (re)build the Galerkin coefficients of this step's levels (they carry dt: rebuilt by the solve if dt has changed since)
+static int gal_build(fluid_sim* s)
+{
+    // Mostly-air box: the coarse levels of the cycle as Galerkin operators by aggregation (kernels_gal.hip) — the free surface stays where
+    // it is on every level.  Level 0 with its own restriction launch only (big boxes), float cycle, one GPU.
+    s->gal = false;
+    s->gal_probe = false;
+    const int nl = s->mg_nl;
+    if (s->gal_mode && s->lists_on && s->mg_fp32 && !s->dist && !s->mgc_on && (long)s->mgl[0].dx * s->mgl[0].dy * s->mgl[0].dz > 200000) {
+        int lc = 1;
+        while (lc < nl - 1 && !gal_fits_coarsest(s->mgl[lc])) ++lc;
+        if (gal_fits_coarsest(s->mgl[lc]) && lc >= 2) {
+            size_t total = 0, off[fluid_sim::MG_MAXL][5];
+            for (int l = 1; l <= lc; ++l)
+                for (int q = 0; q < 5; ++q) {
+                    off[l][q] = total;
+                    total += ((q < 4 ? sizeof(float) : 1) * (s->mgl[l].cells + 64) + 255) / 256 * 256;
+                }
+            if (total > s->gal_slab_cap) {
+                if (s->gal_slab) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->gal_slab); s->gal_slab = nullptr; }
+                HIPCHK(hipMalloc((void**)&s->gal_slab, total + total / 4));
+                s->gal_slab_cap = total + total / 4;
+            }
+            HIPCHK(hipMemsetAsync(s->gal_slab, 0, total, s->st));
+            for (int l = 1; l <= lc; ++l) {
+                for (int q = 0; q < 4; ++q) s->gal_c[l][q] = (float*)(s->gal_slab + off[l][q]);
+                s->gal_cnt[l] = (uint8_t*)(s->gal_slab + off[l][4]);
+            }
+            launch_gal_level1(s->st, s->mgl[0], s->cntL, mg_coef_as<float>(s, 0), s->mgl[1], s->gal_c[1][0], s->gal_c[1][1], s->gal_c[1][2], s->gal_c[1][3],
+                              s->gal_cnt[1]);
+            // Which cycle?  Aggregation wins where the re-discretised levels lose much of the pool (rough, filmy water: 23 iterations against 30 at
+            // step 445 of the 256^3 drop, ratio 0.53) and loses on dense or flat water (30 against 21 in free fall, ratio 0.97): the unknowns of
+            // level 1 under both rules are counted here and read with the next copy of the step state — the decision lags by a pass or a step.
+            HIPCHK(hipMemsetAsync(&s->ss->n_l1_old, 0, 2 * sizeof(int), s->st));
+            launch_gal_erosion(s->st, s->mgl[1], s->mg_cnt[1], s->gal_cnt[1], &s->ss->n_l1_old);
+            s->gal_probe = true;
+            if (s->gal_mode >= 2 || (s->gal_ratio >= 0 && s->gal_ratio < s->gal_thr)) {
+                for (int l = 2; l <= lc; ++l)
+                    launch_gal_coarsen(s->st, s->mgl[l - 1], s->gal_c[l - 1][0], s->gal_c[l - 1][1], s->gal_c[l - 1][2], s->gal_c[l - 1][3], s->gal_cnt[l - 1],
+                                       s->mgl[l], s->gal_c[l][0], s->gal_c[l][1], s->gal_c[l][2], s->gal_c[l][3], s->gal_cnt[l]);
+                s->gal = true;
+                s->gal_lc = lc;
+            }
+        }
+    }
+    s->gal_dt = s->dt;
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
 // descriptor of the persistent coarse-level launch for this solve (stream-ordered; the coefficients follow dt)
 static int mg_coarse_prepare(fluid_sim* s)
 {
@@ -712,6 +767,33 @@ static int mg_coarse_prepare(fluid_sim* s)
     a.wc_tail = s->mg_wc[3];
     a.sweeps = s->mg_csweeps;
     launch_mg_coarse_store<V>(s->st, a, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->mgc_max_blocks, s->mgc_tpt, &s->mgc_blocks, &s->mgc_lds);
+    HIPCHK(hipGetLastError());
+    return FLUID_OK;
+}
+
+// The cycle with Galerkin coarse levels (kernels_gal.hip): level 0 by the kernels of kernels_mg.hip (its own coefficients; the up leg
+// takes the parent's value as the correction), levels 1 .. gal_lc - 1 by k_gal_down / k_gal_up, the coarsest by one block.
+static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+{
+    typedef float V;
+    const PcgState* ps = s->ps;
+    const int lc = s->gal_lc;
+    auto U = [&](int l) { return (V*)s->mg_u[l]; };
+    auto W = [&](int l) { return (V*)s->mg_v[l]; };
+    auto F = [&](int l) { return (V*)s->mg_f[l]; };
+    auto C = [&](int l, int q) { return (const float*)s->gal_c[l][q]; };
+    const MLevel& m0 = s->mgl[0];
+    launch_mg_down<V, double>(s->st, m0, s->cntL, rhs0, U(0), (V*)s->mg_r[0], s->mgl[1], nullptr, nullptr, mg_coef_as<V>(s, 0), ps, s->tl_mg, s->n_tl_mg);
+    launch_gal_restrict0(s->st, m0, s->cntL, (const V*)s->mg_r[0], s->mgl[1], s->gal_cnt[1], F(1), ps);
+    for (int l = 1; l < lc; ++l) launch_gal_down(s->st, s->mgl[l], s->gal_cnt[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), s->mgl[l + 1], F(l + 1), ps);
+    launch_gal_coarsest(s->st, s->mgl[lc], C(lc, 0), C(lc, 1), C(lc, 2), C(lc, 3), F(lc), U(lc), s->gal_sweeps, ps);
+    for (int l = lc - 1; l >= 1; --l)
+        launch_gal_up(s->st, s->mgl[l], s->gal_cnt[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), W(l), s->mgl[l + 1], l + 1 == lc ? U(l + 1) : W(l + 1),
+                      (float)s->gal_wc, ps);
+    const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)s->Rb.cells());
+    launch_mg_up<V, double, double>(s->st, m0, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], W(1), mg_coef_as<V>(s, 0), part_rz, ps, s->gal_wc, s->tl_mg, s->n_tl_mg,
+                                    nullptr, 1);
+    prof_end(s, FLUID_PROF_MG_UP0, tok);
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
@@ -765,6 +847,7 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
 }
 static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, bool down0_done = false)
 {
+    if (s->gal && s->lists_on) return mg_vcycle_gal(s, rhs0, z0, part_rz);
     return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz, down0_done) : mg_vcycle_t<double>(s, rhs0, z0, part_rz, down0_done);
 }
 
@@ -808,6 +891,8 @@ static int solve_mg(fluid_sim* s)
     const int n_xr = fuse ? n_tiles0 : n_list;   // |r|^2 partials of an XR launch after the first iteration (dense unfused: launch_pcg_sq's default)
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     if ((rc = mg_coarse_prepare(s))) return rc;
+    if (s->gal && s->gal_dt != s->dt && (rc = gal_build(s))) return rc;
+    if (s->gal) s->stats.paths |= FLUID_PATH_MG_GALERKIN;
     if (fuse) HIPCHK(hipMemsetAsync(s->R2, 0, (s->L.cells() + 2 * (size_t)s->L.Lz) * sizeof(double), s->st));   // zeros off the unknowns, like R
     // Start: x = 0 like the reference's cg.solve(b) — or, by default, the previous solve's pressure (Eigen's solveWithGuess
     // form of the same loop: r0 = b - A x0, same threshold tol^2 |b|^2).  The converged p does not depend on the start
@@ -1122,6 +1207,7 @@ int fl::phase_pressure_pass(fluid_sim* s, double* error)
         HIPCHK(hipGetLastError());
         if ((rc = read_ss(s))) return rc;
         err = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);  // fluid.cc:1483
+        if (s->gal_probe && s->h_ss->n_l1_gal > 0) s->gal_ratio = (double)s->h_ss->n_l1_old / (double)s->h_ss->n_l1_gal;
     }
     s->stats.error = err;
     s->stats.outer_passes++;

@@ -403,8 +403,9 @@ template <typename T, typename F, typename O, int TX, int TY, int TZ, typename I
 __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
                                            O* __restrict__ out, const MLevel& mc, const T* __restrict__ ec, const MgCoef<T>* cf, T off,
                                            double* __restrict__ part_dot, int tile, int gx, int gy, T wc, const uint8_t* __restrict__ own, bool live,
-                                           int col, char* lds, T* sd, T* si, double* red, int grp = 0)
+                                           int col, char* lds, T* sd, T* si, double* red, int grp = 0, bool pconst = false)
 {
+    // pconst: the correction of a fine cell is its PARENT's value (piecewise-constant prolongation: the Galerkin coarse levels of kernels_gal.hip)
     // own (decomposed run, level 0): the PCG's count bytes — the partial f.out counts the rank's owned unknowns only
     // (non-zero byte without bit 7); the result itself is written on every unknown of the local box
     typedef UpTile<T, TX, TY, TZ> D;
@@ -481,7 +482,7 @@ __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __res
 #pragma unroll
         for (int I = 0; I < EX; ++I) {
             const T* p = sE + I * EY * EZ + eb;
-            pl[I] = a * a * p[0] + a * b * (p[sy] + p[sz]) + b * b * p[sy + sz];
+            pl[I] = pconst ? p[0] : a * a * p[0] + a * b * (p[sy] + p[sz]) + b * b * p[sy + sz];
         }
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
@@ -496,7 +497,7 @@ __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __res
 #pragma unroll
                     for (int e = 1; e < EX; ++e) { pI = e == I ? pl[e] : pI; pN = e == In ? pl[e] : pN; }
                 }
-                const T pe = a * pI + b * pN;
+                const T pe = pconst ? pI : a * pI + b * pN;
                 sC[x * AY * AZ + col] = (uint8_t)ca[p];
                 sA[x * AY * AZ + col] = ca[p] ? ua[p] + wc * pe : (T)0;
             }
@@ -555,7 +556,7 @@ template <typename T, typename F, typename O, int TX, int TY, int TZ, int NG = 1
 __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
                                                                       O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
                                                                       double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
-                                                                      const int* __restrict__ tlist, const uint8_t* __restrict__ own)
+                                                                      const int* __restrict__ tlist, const uint8_t* __restrict__ own, int pconst)
 {
     __shared__ __attribute__((aligned(16))) char lds[UpTile<T, TX, TY, TZ>::bytes];
     __shared__ T sd[8], si[8];
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void k_mg_up(MLevel m, c
     if (ps && ps->done) return;
     const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);  // see k_mg_down
     mg_up_body<T, F, O, TX, TY, TZ, IoPlain, NG>(m, cnt, f, u, out, mc, ec, &cf, cf.off, part_dot, tile, gx, gy, wc, own, true, NG > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x,
-                                                 lds, sd, si, red, NG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0);
+                                                 lds, sd, si, red, NG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0, pconst != 0);
 }
 
 // ---- restriction of the level-0 residual (its down kernel has no room for a halo of 3) -----------------
@@ -962,7 +963,7 @@ template void launch_mg_down_xr<double>(hipStream_t, MLevel, const uint8_t*, con
 // prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
-                  double* part_dot, const PcgState* ps, double wc, const int* tlist, int nlist, const uint8_t* own)
+                  double* part_dot, const PcgState* ps, double wc, const int* tlist, int nlist, const uint8_t* own, int pconst)
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
     if (!tlist && g.x * g.y * g.z == 0) return;   // an empty local level (decomposed run: a block outside the active box)
@@ -970,11 +971,11 @@ void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, cons
     // a leg is ~3 us of launch and drain + ~2 us of load latency, the arithmetic was never the long part — so only the down leg uses it)
     if (false && !tlist && !part_dot && !own && sizeof(F) == sizeof(T) && sizeof(O) == sizeof(T) && g.x * g.y * g.z <= MG_FEW_TILES && mg_ng4()) {
         hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ, 4>), dim3(g.x * g.y * g.z), dim3(1024), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot, ps,
-                           (int)g.x, (int)g.y, (T)wc, tlist, own);
+                           (int)g.x, (int)g.y, (T)wc, tlist, own, pconst);
         return;
     }
     hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc,
-                       ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist, own);
+                       ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist, own, pconst);
 }
 // flags of the level-0 leg tiles (mg_up_blocks(m) of them), see k_mg_tile_flags
 void launch_mg_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags)
@@ -1262,7 +1263,7 @@ template void launch_mg_coarse<float>(hipStream_t, const void*, int, size_t, int
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*, \
                                        const int*, int); \
     template void launch_mg_up<T, T, T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*,  \
-                                        const PcgState*, double, const int*, int, const uint8_t*);                                                                               \
+                                        const PcgState*, double, const int*, int, const uint8_t*, int);                                                                          \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                     \
     template void launch_mg_tail<T>(hipStream_t, int, const T*, const MLevel*, uint8_t* const*, T*, const T*, int, const PcgState*, double);
 INSTMG(double)
@@ -1271,6 +1272,6 @@ INSTMG(float)
 template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
                                             MgCoef<float>, const PcgState*, const int*, int);
 template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
-                                                  MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*);
+                                                  MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*, int);
 
 }  // namespace fl

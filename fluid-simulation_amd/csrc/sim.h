@@ -138,6 +138,20 @@ struct fluid_sim {
     int mg_csweeps = 3;           // red-black sweeps (each direction) on the coarsest level (12 -> 2 changes the PCG count by 1 in 520)
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
+    // Galerkin coarse levels by aggregation (kernels_gal.hip): mostly-air boxes, float cycle, one GPU.  FLUID_MG_GALERKIN=0|1
+    int gal_mode = 1;             // FLUID_MG_GALERKIN: 0 never, 1 when the re-discretised level 1 keeps under gal_thr of the cells aggregation keeps, 2 always (in a mostly-air box)
+    double gal_thr = 0.7;
+    double gal_ratio = -1;        // that ratio as last read back (one step or pass behind); < 0: not known yet
+    bool gal_probe = false;       // this step's counts are on their way (read with the next step-state copy)
+    bool gal = false;             // ... and in use this step (set by mg_setup)
+    int gal_lc = 0;               // the coarsest level of the Galerkin cycle (one block)
+    double gal_dt = 0;            // dt the coefficients were built with
+    double gal_wc = 1.8;          // over-correction of the piecewise-constant prolongation (FLUID_MG_GALERKIN_WC)
+    int gal_sweeps = 3;           // red-black sweeps, each direction, on the coarsest level (2 ... 16: the same iteration counts)
+    char* gal_slab = nullptr;     // per level 1..gal_lc: gd, gx, gy, gz (float) and the unknown flags
+    size_t gal_slab_cap = 0;
+    float* gal_c[MG_MAXL][4] = {};
+    uint8_t* gal_cnt[MG_MAXL] = {};
     char *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual (float or double)
     double mg_wc[4] = {1.25, 1.1, 1.0, 1.0};   // weight of the coarse correction at level 0 / level 1 / deeper kernel levels / inside the tail (FLUID_MG_WC=a,b,c,d)
     bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (FLUID_MG_FP64=1: double)

@@ -727,6 +727,45 @@ def test_droplets_against_the_oracle(fs, oracle, monkeypatch):
     assert dm.sum() > 300 and np.abs(pr[dm] - po[dm]).max() <= 1e-6 * np.abs(po).max()
 
 
+def test_galerkin_coarse_levels_give_the_same_solve(fs, oracle, monkeypatch):
+    """kernels_gal.hip: in a mostly-air box the V-cycle's coarse levels can be Galerkin operators by 2 x 2 x 2 aggregation (a coarse cell
+    is an unknown if any child is: the free surface stays where it is on every level) instead of re-discretised ones.  Only the
+    preconditioner changes: the converged pressure and the run are the same with the cycle forced on (FLUID_MG_GALERKIN=2) and off (0), and
+    the oracle's plain CG agrees.  On its own (1, the default) the step takes it where the re-discretised level 1 keeps under 70 % of the
+    cells aggregation keeps — not for this flat slab, where it would cost iterations (the settled pool of the 256^3 drop: 31 -> 22)."""
+    n = 160
+    pos, vel = _pool_and_spray(fs, n, np.random.default_rng(9), depth=10, ndrops=100)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim = fs.FluidSim(n=n); sim.upload_particles(pos, vel)
+        st = [sim.step() for _ in range(4)]
+        p, v = sim.download_particles()
+        pr = sim.field(fs.FIELD.PRESSURE)
+        sim.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return st, p, v, pr
+
+    sa, pa, va, pra = run({"FLUID_MG_GALERKIN": "2"})
+    sb, pb, vb, prb = run({"FLUID_MG_GALERKIN": "0"})
+    sc, pc, vc, prc = run({})
+    assert all(s["paths"] & 128 for s in sa[1:]) and all(s["paths"] & 128 == 0 for s in sb)   # with the lists, from the second step on
+    assert all(s["paths"] & 128 == 0 for s in sc)                                           # a flat slab keeps the re-discretised levels
+    assert [s["outer_passes"] for s in sa] == [s["outer_passes"] for s in sb]
+    assert rel_l2(pra, prb) < 1e-9 and rel_l2(pa, pb) < 1e-10 and rel_l2(va, vb) < 1e-8
+    assert np.array_equal(prb, prc)
+    # a smaller copy of the scene against the oracle (lists and cycle forced on from the first step)
+    n2 = 64
+    monkeypatch.setenv("FLUID_TILE_LISTS", "1")
+    monkeypatch.setenv("FLUID_MG_GALERKIN", "2")
+    pos2, vel2 = _pool_and_spray(fs, n2, np.random.default_rng(10), depth=6, ndrops=30)
+    sim, orc = _compare_step(fs, oracle, n2, pos2, vel2, steps=2)
+    assert sim.stats()["paths"] & 128
+    assert rel_l2(sim.field(fs.FIELD.PRESSURE), orc.field(7)) < TOL_F
+
+
 def test_droplets_on_solids_and_walls(fs, oracle, monkeypatch):
     """Droplets whose cells have solid neighbours (a shelf inside W, the domain wall): their matrix rows carry smaller diagonal counts
     and Neumann faces (fluid.cc:326-407) — the wave solve reads them from the same flag bytes as the global one.  Against the oracle's
