@@ -460,13 +460,13 @@ def main():
             siml = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
             siml.upload_particles(pos0)
             ts, its, passes, boxes, its_by_step = [], 0, 0, [], []
-            forms = {"p2g_tile_form": 0, "tile_lists": 0, "droplets_solved_apart": 0}   # steps that took each form (stats.paths bits 1, 2, 64)
+            forms = {"p2g_tile_form": 0, "tile_lists": 0, "droplets_solved_apart": 0, "galerkin_coarse_levels": 0}   # steps that took each form (stats.paths bits 1, 2, 64, 128)
             for _ in range(a.long_steps):
                 c0 = time.perf_counter()
                 st = siml.step()
                 ts.append((time.perf_counter() - c0) * 1e3)
                 its += st["cg_iters"]; passes += st["outer_passes"]
-                forms["p2g_tile_form"] += bool(st["paths"] & 1); forms["tile_lists"] += bool(st["paths"] & 2); forms["droplets_solved_apart"] += bool(st["paths"] & 64)
+                forms["p2g_tile_form"] += bool(st["paths"] & 1); forms["tile_lists"] += bool(st["paths"] & 2); forms["droplets_solved_apart"] += bool(st["paths"] & 64); forms["galerkin_coarse_levels"] += bool(st["paths"] & 128)
                 boxes.append((tuple(st["box_lo"]), tuple(st["box_hi"]))); its_by_step.append((st["cg_iters"], st["outer_passes"]))
             ts = np.array(ts)
             # phases of the run by the active box: free fall (the cube has not reached the floor: the box is still the cube's), splash (the box

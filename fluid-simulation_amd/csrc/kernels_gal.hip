@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_gal_restrict0(MLevel m0, const uint8_t*
 
 constexpr int GT = 8, GA = GT + 4, GB = GT + 2;              // tile, region A (halo 2), region B (halo 1)
 constexpr int GNA = GA * GA * GA, GNB = GB * GB * GB, GNT = GT * GT * GT;
+constexpr int GNTH = 512;   // threads of a leg block (a tile's three stages are 4 + 2 + 1 rounds of them)
 struct GalLds {
     float f[GNA], d[GNA], wx[GNA], wy[GNA], wz[GNA], a[GNA], b[GNB], r[GNT];
 };
@@ -152,7 +153,7 @@ __device__ __forceinline__ float gal_apply_b(const GalLds& s, const float* u, in
 __device__ __forceinline__ bool gal_tile_empty(const MLevel& m, const uint8_t* __restrict__ cnt, int i0, int j0, int k0)
 {
     int any = 0;
-    for (int t = threadIdx.x; t < GNT; t += 256) {
+    for (int t = threadIdx.x; t < GNT; t += GNTH) {
         const int i = i0 + t / (GT * GT), j = j0 + (t / GT) % GT, k = k0 + t % GT;
         if (gal_in(m, i, j, k)) any |= cnt[m.at(i, j, k)];
     }
@@ -165,12 +166,12 @@ __device__ __forceinline__ void gal_load(GalLds& s, const MLevel& m, const float
                                          const float* __restrict__ gz, const float* __restrict__ f, int i0, int j0, int k0, const float* __restrict__ u,
                                          const MLevel& mc, const float* __restrict__ ec, float wc)
 {
-    constexpr int NIT = (GNA + 255) / 256;
+    constexpr int NIT = (GNA + GNTH - 1) / GNTH;
     float d[NIT], wx[NIT], wy[NIT], wz[NIT], ff[NIT], uu[NIT], ee[NIT];
     bool in[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int t = min((int)threadIdx.x + 256 * it, GNA - 1);
+        const int t = min((int)threadIdx.x + GNTH * it, GNA - 1);
         const int x = t / (GA * GA), y = (t / GA) % GA, z = t % GA;
         const int i = i0 - 2 + x, j = j0 - 2 + y, k = k0 - 2 + z;
         in[it] = gal_in(m, i, j, k);
@@ -182,7 +183,7 @@ __device__ __forceinline__ void gal_load(GalLds& s, const MLevel& m, const float
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int t = (int)threadIdx.x + 256 * it;
+        const int t = (int)threadIdx.x + GNTH * it;
         if (t < GNA) {
             const float dd = in[it] ? d[it] : 0.0f;
             s.d[t] = dd;
@@ -194,7 +195,7 @@ __device__ __forceinline__ void gal_load(GalLds& s, const MLevel& m, const float
 }
 
 // down leg of a level >= 1: both pre-sweeps from u = 0, residual, restriction (sum of the children) into fc
-__global__ __launch_bounds__(256) void k_gal_down(MLevel m, const uint8_t* __restrict__ cnt, const float* __restrict__ gd, const float* __restrict__ gx,
+__global__ __launch_bounds__(GNTH) void k_gal_down(MLevel m, const uint8_t* __restrict__ cnt, const float* __restrict__ gd, const float* __restrict__ gx,
                                                   const float* __restrict__ gy, const float* __restrict__ gz, const float* __restrict__ f, float* __restrict__ u,
                                                   MLevel mc, float* __restrict__ fc, const PcgState* ps, int ntx, int nty)
 {
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_gal_down(MLevel m, const uint8_t* __res
     if (gal_tile_empty(m, cnt, i0, j0, k0)) return;
     gal_load<false>(s, m, gd, gx, gy, gz, f, i0, j0, k0, nullptr, mc, nullptr, 0.0f);
     __syncthreads();
-    for (int t = threadIdx.x; t < GNB; t += 256) {
+    for (int t = threadIdx.x; t < GNB; t += GNTH) {
         const int x = t / (GB * GB), y = (t / GB) % GB, z = t % GB;
         const int q = ((x + 1) * GA + y + 1) * GA + z + 1;
         const float dd = s.d[q];
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void k_gal_down(MLevel m, const uint8_t* __res
         if (x >= 1 && x <= GT && y >= 1 && y <= GT && z >= 1 && z <= GT && dd > 0) u[m.at(i0 + x - 1, j0 + y - 1, k0 + z - 1)] = v;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < GNT; t += 256) {
+    for (int t = threadIdx.x; t < GNT; t += GNTH) {
         const int x = t / (GT * GT), y = (t / GT) % GT, z = t % GT;
         const int q = ((x + 2) * GA + y + 2) * GA + z + 2, p = ((x + 1) * GB + y + 1) * GB + z + 1;
         s.r[t] = s.d[q] > 0 ? s.f[q] - gal_apply_b(s, s.b, p, q) : 0.0f;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_gal_down(MLevel m, const uint8_t* __res
     }
 }
 // up leg of a level >= 1: u + wc * (the parent's correction), both post-sweeps
-__global__ __launch_bounds__(256) void k_gal_up(MLevel m, const uint8_t* __restrict__ cnt, const float* __restrict__ gd, const float* __restrict__ gx,
+__global__ __launch_bounds__(GNTH) void k_gal_up(MLevel m, const uint8_t* __restrict__ cnt, const float* __restrict__ gd, const float* __restrict__ gx,
                                                 const float* __restrict__ gy, const float* __restrict__ gz, const float* __restrict__ f,
                                                 const float* __restrict__ u, float* __restrict__ out, MLevel mc, const float* __restrict__ ec, float wc,
                                                 const PcgState* ps, int ntx, int nty)
@@ -246,13 +247,13 @@ __global__ __launch_bounds__(256) void k_gal_up(MLevel m, const uint8_t* __restr
     if (gal_tile_empty(m, cnt, i0, j0, k0)) return;
     gal_load<true>(s, m, gd, gx, gy, gz, f, i0, j0, k0, u, mc, ec, wc);
     __syncthreads();
-    for (int t = threadIdx.x; t < GNB; t += 256) {
+    for (int t = threadIdx.x; t < GNB; t += GNTH) {
         const int x = t / (GB * GB), y = (t / GB) % GB, z = t % GB;
         const int q = ((x + 1) * GA + y + 1) * GA + z + 1;
         s.b[t] = s.a[q] + GAL_W2 * gal_inv(s.d[q]) * (s.f[q] - gal_apply_a(s, s.a, q));
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < GNT; t += 256) {
+    for (int t = threadIdx.x; t < GNT; t += GNTH) {
         const int x = t / (GT * GT), y = (t / GT) % GT, z = t % GT;
         const int q = ((x + 2) * GA + y + 2) * GA + z + 2, p = ((x + 1) * GB + y + 1) * GB + z + 1;
         if (s.d[q] > 0) out[m.at(i0 + x, j0 + y, k0 + z)] = s.b[p] + GAL_W1 * gal_inv(s.d[q]) * (s.f[q] - gal_apply_b(s, s.b, p, q));
@@ -339,14 +340,14 @@ void launch_gal_down(hipStream_t st, MLevel m, const uint8_t* cnt, const float* 
 {
     int ntx, nty; unsigned n;
     gal_tiles(m, ntx, nty, n);
-    hipLaunchKernelGGL(k_gal_down, dim3(n), dim3(256), 0, st, m, cnt, gd, gx, gy, gz, f, u, mc, fc, ps, ntx, nty);
+    hipLaunchKernelGGL(k_gal_down, dim3(n), dim3(GNTH), 0, st, m, cnt, gd, gx, gy, gz, f, u, mc, fc, ps, ntx, nty);
 }
 void launch_gal_up(hipStream_t st, MLevel m, const uint8_t* cnt, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, const float* u,
                    float* out, MLevel mc, const float* ec, float wc, const PcgState* ps)
 {
     int ntx, nty; unsigned n;
     gal_tiles(m, ntx, nty, n);
-    hipLaunchKernelGGL(k_gal_up, dim3(n), dim3(256), 0, st, m, cnt, gd, gx, gy, gz, f, u, out, mc, ec, wc, ps, ntx, nty);
+    hipLaunchKernelGGL(k_gal_up, dim3(n), dim3(GNTH), 0, st, m, cnt, gd, gx, gy, gz, f, u, out, mc, ec, wc, ps, ntx, nty);
 }
 void launch_gal_coarsest(hipStream_t st, MLevel m, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, float* u, int sweeps,
                          const PcgState* ps)
