@@ -243,7 +243,6 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     if (const char* e = getenv("FLUID_XR_ROWS")) s->rows_on = atoi(e) != 0;
     if (const char* e = getenv("FLUID_XR_FUSE")) s->xr_fuse = atoi(e) != 0;
     if (const char* e = getenv("FLUID_MG_GALERKIN")) s->gal_mode = atoi(e);
-    if (const char* e = getenv("FLUID_MG_GALERKIN_THR")) s->gal_thr = atof(e);
     if (const char* e = getenv("FLUID_MG_GALERKIN_WC")) s->gal_wc = atof(e);
     if (const char* e = getenv("FLUID_MG_GALERKIN_SWEEPS")) s->gal_sweeps = atoi(e);
     if (const char* e = getenv("FLUID_DROPLETS")) s->drops_on = atoi(e) != 0;
@@ -705,45 +704,53 @@ static int gal_build(fluid_sim* s)
     // Mostly-air box: the coarse levels of the cycle as Galerkin operators by aggregation (kernels_gal.hip) — the free surface stays where
     // it is on every level.  Level 0 with its own restriction launch only (big boxes), float cycle, one GPU.
     s->gal = false;
-    s->gal_probe = false;
+    s->gal_eligible = false;
     const int nl = s->mg_nl;
-    if (s->gal_mode && s->lists_on && s->mg_fp32 && !s->dist && !s->mgc_on && (long)s->mgl[0].dx * s->mgl[0].dy * s->mgl[0].dz > 200000) {
-        int lc = 1;
-        while (lc < nl - 1 && !gal_fits_coarsest(s->mgl[lc])) ++lc;
-        if (gal_fits_coarsest(s->mgl[lc]) && lc >= 2) {
-            size_t total = 0, off[fluid_sim::MG_MAXL][5];
-            for (int l = 1; l <= lc; ++l)
-                for (int q = 0; q < 5; ++q) {
-                    off[l][q] = total;
-                    total += ((q < 4 ? sizeof(float) : 1) * (s->mgl[l].cells + 64) + 255) / 256 * 256;
-                }
-            if (total > s->gal_slab_cap) {
-                if (s->gal_slab) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->gal_slab); s->gal_slab = nullptr; }
-                HIPCHK(hipMalloc((void**)&s->gal_slab, total + total / 4));
-                s->gal_slab_cap = total + total / 4;
-            }
-            HIPCHK(hipMemsetAsync(s->gal_slab, 0, total, s->st));
-            for (int l = 1; l <= lc; ++l) {
-                for (int q = 0; q < 4; ++q) s->gal_c[l][q] = (float*)(s->gal_slab + off[l][q]);
-                s->gal_cnt[l] = (uint8_t*)(s->gal_slab + off[l][4]);
-            }
-            launch_gal_level1(s->st, s->mgl[0], s->cntL, mg_coef_as<float>(s, 0), s->mgl[1], s->gal_c[1][0], s->gal_c[1][1], s->gal_c[1][2], s->gal_c[1][3],
-                              s->gal_cnt[1]);
-            // Which cycle?  Aggregation wins where the re-discretised levels lose much of the pool (rough, filmy water: 23 iterations against 30 at
-            // step 445 of the 256^3 drop, ratio 0.53) and loses on dense or flat water (30 against 21 in free fall, ratio 0.97): the unknowns of
-            // level 1 under both rules are counted here and read with the next copy of the step state — the decision lags by a pass or a step.
-            HIPCHK(hipMemsetAsync(&s->ss->n_l1_old, 0, 2 * sizeof(int), s->st));
-            launch_gal_erosion(s->st, s->mgl[1], s->mg_cnt[1], s->gal_cnt[1], &s->ss->n_l1_old);
-            s->gal_probe = true;
-            if (s->gal_mode >= 2 || (s->gal_ratio >= 0 && s->gal_ratio < s->gal_thr)) {
-                for (int l = 2; l <= lc; ++l)
-                    launch_gal_coarsen(s->st, s->mgl[l - 1], s->gal_c[l - 1][0], s->gal_c[l - 1][1], s->gal_c[l - 1][2], s->gal_c[l - 1][3], s->gal_cnt[l - 1],
-                                       s->mgl[l], s->gal_c[l][0], s->gal_c[l][1], s->gal_c[l][2], s->gal_c[l][3], s->gal_cnt[l]);
-                s->gal = true;
-                s->gal_lc = lc;
-            }
+    int lc = 1;
+    while (lc < nl - 1 && !gal_fits_coarsest(s->mgl[lc])) ++lc;
+    if (!(s->gal_mode && s->lists_on && s->mg_fp32 && !s->dist && !s->mgc_on && (long)s->mgl[0].dx * s->mgl[0].dy * s->mgl[0].dz > 200000 &&
+          gal_fits_coarsest(s->mgl[lc]) && lc >= 2)) {
+        s->gal_it[0] = s->gal_it[1] = -1;   // (measured again when the box is mostly air again)
+        return FLUID_OK;
+    }
+    // Which cycle?  Aggregation wins where the re-discretised levels lose much of the water — rough, filmy pools and splashes: 22 iterations
+    // against 31 at step 445 of the 256^3 drop, 61 against 72 (three passes) at step 210 — and loses on dense or flat water (30 against 21
+    // in free fall, +8 % on a flat slab); the share of level-1 cells the re-discretised rule keeps does not separate the splash (0.80) from the
+    // slab (0.8).  Both cycles give the same pressure, so the step simply measures: the first-pass iteration count of each is kept, the
+    // better one is used, and the other is looked at again every 32nd step.
+    s->gal_eligible = true;
+    bool use = s->gal_mode >= 2;
+    if (s->gal_mode == 1) {
+        if (s->gal_it[0] < 0) use = false;
+        else if (s->gal_it[1] < 0) use = true;
+        else {
+            use = s->gal_it[1] < s->gal_it[0];
+            if (++s->gal_since_probe >= 32) { use = !use; s->gal_since_probe = 0; }
         }
     }
+    if (!use) return FLUID_OK;
+    size_t total = 0, off[fluid_sim::MG_MAXL][5];
+    for (int l = 1; l <= lc; ++l)
+        for (int q = 0; q < 5; ++q) {
+            off[l][q] = total;
+            total += ((q < 4 ? sizeof(float) : 1) * (s->mgl[l].cells + 64) + 255) / 256 * 256;
+        }
+    if (total > s->gal_slab_cap) {
+        if (s->gal_slab) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->gal_slab); s->gal_slab = nullptr; }
+        HIPCHK(hipMalloc((void**)&s->gal_slab, total + total / 4));
+        s->gal_slab_cap = total + total / 4;
+    }
+    HIPCHK(hipMemsetAsync(s->gal_slab, 0, total, s->st));
+    for (int l = 1; l <= lc; ++l) {
+        for (int q = 0; q < 4; ++q) s->gal_c[l][q] = (float*)(s->gal_slab + off[l][q]);
+        s->gal_cnt[l] = (uint8_t*)(s->gal_slab + off[l][4]);
+    }
+    launch_gal_level1(s->st, s->mgl[0], s->cntL, mg_coef_as<float>(s, 0), s->mgl[1], s->gal_c[1][0], s->gal_c[1][1], s->gal_c[1][2], s->gal_c[1][3], s->gal_cnt[1]);
+    for (int l = 2; l <= lc; ++l)
+        launch_gal_coarsen(s->st, s->mgl[l - 1], s->gal_c[l - 1][0], s->gal_c[l - 1][1], s->gal_c[l - 1][2], s->gal_c[l - 1][3], s->gal_cnt[l - 1], s->mgl[l],
+                           s->gal_c[l][0], s->gal_c[l][1], s->gal_c[l][2], s->gal_c[l][3], s->gal_cnt[l]);
+    s->gal = true;
+    s->gal_lc = lc;
     s->gal_dt = s->dt;
     HIPCHK(hipGetLastError());
     return FLUID_OK;
@@ -891,7 +898,10 @@ static int solve_mg(fluid_sim* s)
     const int n_xr = fuse ? n_tiles0 : n_list;   // |r|^2 partials of an XR launch after the first iteration (dense unfused: launch_pcg_sq's default)
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
     if ((rc = mg_coarse_prepare(s))) return rc;
-    if (s->gal && s->gal_dt != s->dt && (rc = gal_build(s))) return rc;
+    if (s->gal && s->gal_dt != s->dt) {   // dt changed since the coefficients were built (phase API): same decision, new coefficients
+        const int keep = s->gal_mode; s->gal_mode = 2; rc = gal_build(s); s->gal_mode = keep;
+        if (rc) return rc;
+    }
     if (s->gal) s->stats.paths |= FLUID_PATH_MG_GALERKIN;
     if (fuse) HIPCHK(hipMemsetAsync(s->R2, 0, (s->L.cells() + 2 * (size_t)s->L.Lz) * sizeof(double), s->st));   // zeros off the unknowns, like R
     // Start: x = 0 like the reference's cg.solve(b) — or, by default, the previous solve's pressure (Eigen's solveWithGuess
@@ -981,6 +991,7 @@ static int solve_mg(fluid_sim* s)
     s->stats.cg_iters_last = iters;
     s->stats.cg_iters += iters;
     s->mg_last_iters_k[pclass] = iters;
+    if (s->gal_eligible && s->stats.outer_passes == 0) s->gal_it[s->gal ? 1 : 0] = iters;   // the first pass of the step: what the two cycles are compared by
     s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
     if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
     return FLUID_OK;
@@ -1207,7 +1218,6 @@ int fl::phase_pressure_pass(fluid_sim* s, double* error)
         HIPCHK(hipGetLastError());
         if ((rc = read_ss(s))) return rc;
         err = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);  // fluid.cc:1483
-        if (s->gal_probe && s->h_ss->n_l1_gal > 0) s->gal_ratio = (double)s->h_ss->n_l1_old / (double)s->h_ss->n_l1_gal;
     }
     s->stats.error = err;
     s->stats.outer_passes++;

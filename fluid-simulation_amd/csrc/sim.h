@@ -139,10 +139,10 @@ struct fluid_sim {
     MLevel mgl[MG_MAXL];
     uint8_t *mg_typ[MG_MAXL] = {}, *mg_cnt[MG_MAXL] = {};
     // Galerkin coarse levels by aggregation (kernels_gal.hip): mostly-air boxes, float cycle, one GPU.  FLUID_MG_GALERKIN=0|1
-    int gal_mode = 1;             // FLUID_MG_GALERKIN: 0 never, 1 when the re-discretised level 1 keeps under gal_thr of the cells aggregation keeps, 2 always (in a mostly-air box)
-    double gal_thr = 0.7;
-    double gal_ratio = -1;        // that ratio as last read back (one step or pass behind); < 0: not known yet
-    bool gal_probe = false;       // this step's counts are on their way (read with the next step-state copy)
+    int gal_mode = 1;             // FLUID_MG_GALERKIN: 0 never, 1 whichever cycle needed fewer iterations when last measured (mostly-air boxes), 2 always there
+    int gal_it[2] = {-1, -1};     // first-pass iterations of the last step that used the re-discretised / the Galerkin cycle (-1: not measured)
+    int gal_since_probe = 0;      // steps since the worse cycle was last looked at
+    bool gal_eligible = false;    // this step could have taken the Galerkin cycle
     bool gal = false;             // ... and in use this step (set by mg_setup)
     int gal_lc = 0;               // the coarsest level of the Galerkin cycle (one block)
     double gal_dt = 0;            // dt the coefficients were built with
