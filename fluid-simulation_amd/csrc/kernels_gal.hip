@@ -119,6 +119,27 @@ __global__ __launch_bounds__(256) void k_gal_restrict0(MLevel m0, const uint8_t*
     int I, J, K;
     if (!gal_cell(m1, (long)blockIdx.x * 256 + threadIdx.x, I, J, K)) return;
     if (!cnt1[m1.at(I, J, K)]) return;   // no unknown child: f1 stays the zero the step's clearing left
+    // (the level-0 residual is written on unknowns only and zero elsewhere: no test of the children's count bytes, eight independent loads)
+    float v[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int i = 2 * I + (a & 1), j = 2 * J + ((a >> 1) & 1), k = 2 * K + (a >> 2);
+        const float x = r0[m0.at(min(i, m0.dx - 1), min(j, m0.dy - 1), min(k, m0.dz - 1))];
+        v[a] = gal_in(m0, i, j, k) ? x : 0.0f;
+    }
+    f1[m1.at(I, J, K)] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
+// ... over the list of level-0 leg tiles that hold an unknown (8 x 8 x 16 fine cells = 4 x 4 x 8 coarse ones per block)
+__global__ __launch_bounds__(128) void k_gal_restrict0_tiles(MLevel m0, const uint8_t* __restrict__ cnt0, const float* __restrict__ r0, MLevel m1,
+                                                             float* __restrict__ f1, const PcgState* ps, const int* __restrict__ tlist, int gx, int gy)
+{
+    if (ps && ps->done) return;
+    const int tile = tlist[blockIdx.x];
+    const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
+    const int X = threadIdx.x >> 5, Y = (threadIdx.x >> 3) & 3, Z = threadIdx.x & 7;
+    const int I = tbz * 4 + X, J = tby * 4 + Y, K = tbx * 8 + Z;
+    if (!gal_in(m1, I, J, K)) return;
     float acc = 0;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
@@ -329,6 +350,13 @@ void launch_gal_erosion(hipStream_t st, MLevel m1, const uint8_t* cnt_old, const
 void launch_gal_restrict0(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, const uint8_t* cnt1, float* f1, const PcgState* ps)
 {
     hipLaunchKernelGGL(k_gal_restrict0, dim3(gal_blocks(m1)), dim3(256), 0, st, m0, cnt0, r0, m1, cnt1, f1, ps);
+}
+void launch_gal_restrict0_tiles(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, float* f1, const PcgState* ps, const int* tlist,
+                                int nlist)
+{
+    if (nlist <= 0) return;
+    const int gx = (m0.dz + 15) / 16, gy = (m0.dy + 7) / 8;   // the level-0 leg tiles of kernels_mg.hip: 8 x 8 x 16, z fastest
+    hipLaunchKernelGGL(k_gal_restrict0_tiles, dim3((unsigned)nlist), dim3(128), 0, st, m0, cnt0, r0, m1, f1, ps, tlist, gx, gy);
 }
 static inline void gal_tiles(const MLevel& m, int& ntx, int& nty, unsigned& n)
 {
