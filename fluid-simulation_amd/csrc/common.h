@@ -358,7 +358,7 @@ void launch_mg_down_xr(hipStream_t st, MLevel m, const uint8_t* cnt, const doubl
 // T = the V-cycle's arithmetic/storage type, F / O = element types of a level's rhs / result (double at level 0)
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
-                    const PcgState* ps, const int* tlist = nullptr, int nlist = 0);
+                    const PcgState* ps, const int* tlist = nullptr, int nlist = 0, bool pcr = false);   // pcr: fc = sum of the residual over each coarse cell's children (kernels_gal.hip)
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
                   double* part_dot, const PcgState* ps, double wc, const int* tlist = nullptr, int nlist = 0, const uint8_t* own = nullptr,

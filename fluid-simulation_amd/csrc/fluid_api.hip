@@ -790,8 +790,8 @@ static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, double* z0, double* p
     auto F = [&](int l) { return (V*)s->mg_f[l]; };
     auto C = [&](int l, int q) { return (const float*)s->gal_c[l][q]; };
     const MLevel& m0 = s->mgl[0];
-    launch_mg_down<V, double>(s->st, m0, s->cntL, rhs0, U(0), (V*)s->mg_r[0], s->mgl[1], nullptr, nullptr, mg_coef_as<V>(s, 0), ps, s->tl_mg, s->n_tl_mg);
-    launch_gal_restrict0(s->st, m0, s->cntL, (const V*)s->mg_r[0], s->mgl[1], s->gal_cnt[1], F(1), ps);
+    // (the level-0 down leg forms the coarse right-hand side itself: the sum of the residual over each coarse cell's children, all inside its tile)
+    launch_mg_down<V, double>(s->st, m0, s->cntL, rhs0, U(0), (V*)s->mg_r[0], s->mgl[1], nullptr, F(1), mg_coef_as<V>(s, 0), ps, s->tl_mg, s->n_tl_mg, true);
     for (int l = 1; l < lc; ++l) launch_gal_down(s->st, s->mgl[l], s->gal_cnt[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), s->mgl[l + 1], F(l + 1), ps);
     launch_gal_coarsest(s->st, s->mgl[lc], C(lc, 0), C(lc, 1), C(lc, 2), C(lc, 3), F(lc), U(lc), s->gal_sweeps, ps);
     for (int l = lc - 1; l >= 1; --l)

@@ -326,6 +326,9 @@ __device__ __forceinline__ void mg_down_body_fn(const MLevel& m, const uint8_t* 
     }
     __syncthreads();
     // ---- r = f - A u2 on region C ----
+    T rk[XC];   // (kept for the piecewise-constant restriction below)
+#pragma unroll
+    for (int x = 0; x < XC; ++x) rk[x] = 0;
     if (actC && xc0 < CX) {
         const int b0 = ((xc0 + 1) * BY + yc + 1) * BZ + zc + 1;
         T cm = sB[b0 - BY * BZ], c0 = sB[b0];
@@ -337,6 +340,7 @@ __device__ __forceinline__ void mg_down_body_fn(const MLevel& m, const uint8_t* 
                 const int n = sC[((xc0 + x + 2) * AY + yc + 2) * AZ + zc + 2];
                 const T nb = cm + cp + sB[b - BZ] + sB[b + BZ] + sB[b - 1] + sB[b + 1];
                 const T v = n ? fr[x] - (sd[n] * c0 + off * nb) : (T)0;
+                rk[x] = v;
                 if (RESTRICT) sR[((xc0 + x) * CY + yc) * CZ + zc] = v;
                 else if (n && live) {
                     IO::st(r + qc + (size_t)((long)(i0 + xc0 + x) * sx), v);
@@ -344,6 +348,29 @@ __device__ __forceinline__ void mg_down_body_fn(const MLevel& m, const uint8_t* 
                 }
                 cm = c0;
                 c0 = cp;
+            }
+        }
+    }
+    if constexpr (!RESTRICT) {
+        // fc given without the trilinear restriction: the Galerkin levels' restriction (kernels_gal.hip) — the coarse right-hand side is the SUM
+        // of the residual over a coarse cell's 8 children, all of them cells of this tile: through the LDS region u2 no longer needs
+        if (fc) {   // (block-uniform)
+            __syncthreads();
+            if (actC && xc0 < CX) {
+#pragma unroll
+                for (int x = 0; x < XC; ++x)
+                    if (xc0 + x < CX) sB[((xc0 + x) * CY + yc) * CZ + zc] = rk[x];
+            }
+            __syncthreads();
+            constexpr int QX = TX / 2, QY = TY / 2, QZ = TZ / 2;
+            for (int t = grp * 256 + col; t < QX * QY * QZ; t += 256 * NG) {
+                int X, Y, Z;
+                region_cell<QY, QZ>(t, X, Y, Z);
+                const int I = i0 / 2 + X, J = j0 / 2 + Y, K = k0 / 2 + Z;
+                if (!live || !in_level(mc, I, J, K)) continue;
+                const T* p = sB + ((2 * X) * CY + 2 * Y) * CZ + 2 * Z;
+                const T acc = ((p[0] + p[1]) + (p[CZ] + p[CZ + 1])) + ((p[CY * CZ] + p[CY * CZ + 1]) + (p[CY * CZ + CZ] + p[CY * CZ + CZ + 1]));
+                IO::st(fc + mc.at(I, J, K), acc);
             }
         }
     }
@@ -929,10 +956,11 @@ int mg_up_blocks(const MLevel& m)
 // both pre-sweeps + residual; with a coarse level (fc != nullptr) the restricted residual goes straight to fc and r is not written
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
-                    const PcgState* ps, const int* tlist, int nlist)
+                    const PcgState* ps, const int* tlist, int nlist, bool pcr)
 {
+    // pcr: fc is the coarse right-hand side of the Galerkin levels (sum of the children): the leg WITHOUT the trilinear restriction forms it
     if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return;   // an empty local level (decomposed run)
-    if (fc) {
+    if (fc && !pcr) {
         const dim3 g = mg_tiles(m, MG_RX, MG_RY, MG_RZ);
         // few tiles (about one per CU or fewer): the leg is bound by one tile's chain of dependent stages — four groups of 256 threads share it
         if (sizeof(F) == sizeof(T) && g.x * g.y * g.z <= MG_FEW_TILES && mg_ng4())
@@ -1261,7 +1289,7 @@ template void launch_mg_coarse<float>(hipStream_t, const void*, int, size_t, int
 
 #define INSTMG(T)                                                                                                                        \
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*, \
-                                       const int*, int); \
+                                       const int*, int, bool); \
     template void launch_mg_up<T, T, T>(hipStream_t, MLevel, const uint8_t*, const T*, const T*, T*, MLevel, const T*, MgCoef<T>, double*,  \
                                         const PcgState*, double, const int*, int, const uint8_t*, int);                                                                          \
     template void launch_mg_restrict<T>(hipStream_t, MLevel, const T*, MLevel, const uint8_t*, T*, const PcgState*);                     \
@@ -1270,7 +1298,7 @@ INSTMG(double)
 INSTMG(float)
 // level 0 of a single-precision V-cycle inside the double-precision PCG
 template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
-                                            MgCoef<float>, const PcgState*, const int*, int);
+                                            MgCoef<float>, const PcgState*, const int*, int, bool);
 template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
                                                   MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*, int);
 
