@@ -373,6 +373,9 @@ void launch_gal_erosion(hipStream_t st, MLevel m1, const uint8_t* cnt_old, const
 void launch_gal_restrict0_tiles(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, float* f1, const PcgState* ps, const int* tlist,
                                 int nlist);   // ... over the listed level-0 leg tiles (8 x 8 x 16) only
 void launch_gal_restrict0(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, const uint8_t* cnt1, float* f1, const PcgState* ps);
+int gal_tile_count(const MLevel& m);   // leg tiles (8^3) of a level
+void launch_gal_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags);   // flags[tile] = the tile holds an unknown
+// (cnt of the two legs: the tile flags)
 void launch_gal_down(hipStream_t st, MLevel m, const uint8_t* cnt, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, float* u,
                      MLevel mc, float* fc, const PcgState* ps);
 void launch_gal_up(hipStream_t st, MLevel m, const uint8_t* cnt, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, const float* u,

@@ -729,11 +729,11 @@ static int gal_build(fluid_sim* s)
         }
     }
     if (!use) return FLUID_OK;
-    size_t total = 0, off[fluid_sim::MG_MAXL][5];
+    size_t total = 0, off[fluid_sim::MG_MAXL][6];
     for (int l = 1; l <= lc; ++l)
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < 6; ++q) {
             off[l][q] = total;
-            total += ((q < 4 ? sizeof(float) : 1) * (s->mgl[l].cells + 64) + 255) / 256 * 256;
+            total += (q < 5 ? ((q < 4 ? sizeof(float) : 1) * (s->mgl[l].cells + 64) + 255) / 256 * 256 : ((size_t)gal_tile_count(s->mgl[l]) + 255) / 256 * 256);
         }
     if (total > s->gal_slab_cap) {
         if (s->gal_slab) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->gal_slab); s->gal_slab = nullptr; }
@@ -744,11 +744,13 @@ static int gal_build(fluid_sim* s)
     for (int l = 1; l <= lc; ++l) {
         for (int q = 0; q < 4; ++q) s->gal_c[l][q] = (float*)(s->gal_slab + off[l][q]);
         s->gal_cnt[l] = (uint8_t*)(s->gal_slab + off[l][4]);
+        s->gal_tfl[l] = (uint8_t*)(s->gal_slab + off[l][5]);
     }
     launch_gal_level1(s->st, s->mgl[0], s->cntL, mg_coef_as<float>(s, 0), s->mgl[1], s->gal_c[1][0], s->gal_c[1][1], s->gal_c[1][2], s->gal_c[1][3], s->gal_cnt[1]);
     for (int l = 2; l <= lc; ++l)
         launch_gal_coarsen(s->st, s->mgl[l - 1], s->gal_c[l - 1][0], s->gal_c[l - 1][1], s->gal_c[l - 1][2], s->gal_c[l - 1][3], s->gal_cnt[l - 1], s->mgl[l],
                            s->gal_c[l][0], s->gal_c[l][1], s->gal_c[l][2], s->gal_c[l][3], s->gal_cnt[l]);
+    for (int l = 1; l < lc; ++l) launch_gal_tile_flags(s->st, s->mgl[l], s->gal_cnt[l], s->gal_tfl[l]);
     s->gal = true;
     s->gal_lc = lc;
     s->gal_dt = s->dt;
@@ -792,10 +794,10 @@ static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, double* z0, double* p
     const MLevel& m0 = s->mgl[0];
     // (the level-0 down leg forms the coarse right-hand side itself: the sum of the residual over each coarse cell's children, all inside its tile)
     launch_mg_down<V, double>(s->st, m0, s->cntL, rhs0, U(0), (V*)s->mg_r[0], s->mgl[1], nullptr, F(1), mg_coef_as<V>(s, 0), ps, s->tl_mg, s->n_tl_mg, true);
-    for (int l = 1; l < lc; ++l) launch_gal_down(s->st, s->mgl[l], s->gal_cnt[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), s->mgl[l + 1], F(l + 1), ps);
+    for (int l = 1; l < lc; ++l) launch_gal_down(s->st, s->mgl[l], s->gal_tfl[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), s->mgl[l + 1], F(l + 1), ps);
     launch_gal_coarsest(s->st, s->mgl[lc], C(lc, 0), C(lc, 1), C(lc, 2), C(lc, 3), F(lc), U(lc), s->gal_sweeps, ps);
     for (int l = lc - 1; l >= 1; --l)
-        launch_gal_up(s->st, s->mgl[l], s->gal_cnt[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), W(l), s->mgl[l + 1], l + 1 == lc ? U(l + 1) : W(l + 1),
+        launch_gal_up(s->st, s->mgl[l], s->gal_tfl[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), W(l), s->mgl[l + 1], l + 1 == lc ? U(l + 1) : W(l + 1),
                       (float)s->gal_wc, ps);
     const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)s->Rb.cells());
     launch_mg_up<V, double, double>(s->st, m0, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], W(1), mg_coef_as<V>(s, 0), part_rz, ps, s->gal_wc, s->tl_mg, s->n_tl_mg,

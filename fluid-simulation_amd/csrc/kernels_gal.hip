@@ -170,15 +170,20 @@ __device__ __forceinline__ float gal_apply_b(const GalLds& s, const float* u, in
     return s.d[q] * u[p] - (s.wx[q] * u[p + GB * GB] + s.wx[q - GA * GA] * u[p - GB * GB] + s.wy[q] * u[p + GB] + s.wy[q - GA] * u[p - GB] +
                             s.wz[q] * u[p + 1] + s.wz[q - 1] * u[p - 1]);
 }
-// a tile whose own cells hold no unknown has nothing to do (its outputs stay the zeros the step's clearing left)
-__device__ __forceinline__ bool gal_tile_empty(const MLevel& m, const uint8_t* __restrict__ cnt, int i0, int j0, int k0)
+// flags[tile] = the tile's own cells hold an unknown (once per step; a leg tile without one has nothing to do: its outputs stay the zeros
+// the step's clearing left)
+__global__ __launch_bounds__(256) void k_gal_tile_flags(MLevel m, const uint8_t* __restrict__ cnt, int ntx, int nty, uint8_t* __restrict__ flags)
 {
+    const int tile = blockIdx.x;
+    const int tz = tile % ntx, ty = (tile / ntx) % nty, tx = tile / (ntx * nty);
+    const int i0 = tx * GT, j0 = ty * GT, k0 = tz * GT;
     int any = 0;
-    for (int t = threadIdx.x; t < GNT; t += GNTH) {
+    for (int t = threadIdx.x; t < GNT; t += 256) {
         const int i = i0 + t / (GT * GT), j = j0 + (t / GT) % GT, k = k0 + t % GT;
         if (gal_in(m, i, j, k)) any |= cnt[m.at(i, j, k)];
     }
-    return !__syncthreads_or(any);
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) flags[tile] = any != 0;
 }
 // region A of a tile: coefficients, rhs and (UP) u + wc * the parent's correction, every load issued before the first is used
 // (addresses clamped into the level, values masked afterwards)
@@ -216,7 +221,7 @@ __device__ __forceinline__ void gal_load(GalLds& s, const MLevel& m, const float
 }
 
 // down leg of a level >= 1: both pre-sweeps from u = 0, residual, restriction (sum of the children) into fc
-__global__ __launch_bounds__(GNTH) void k_gal_down(MLevel m, const uint8_t* __restrict__ cnt, const float* __restrict__ gd, const float* __restrict__ gx,
+__global__ __launch_bounds__(GNTH) void k_gal_down(MLevel m, const uint8_t* __restrict__ tflags, const float* __restrict__ gd, const float* __restrict__ gx,
                                                   const float* __restrict__ gy, const float* __restrict__ gz, const float* __restrict__ f, float* __restrict__ u,
                                                   MLevel mc, float* __restrict__ fc, const PcgState* ps, int ntx, int nty)
 {
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(GNTH) void k_gal_down(MLevel m, const uint8_t* __re
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tz = tile % ntx, ty = (tile / ntx) % nty, tx = tile / (ntx * nty);
     const int i0 = tx * GT, j0 = ty * GT, k0 = tz * GT;
-    if (gal_tile_empty(m, cnt, i0, j0, k0)) return;
+    if (!tflags[tile]) return;   // (block-uniform)
     gal_load<false>(s, m, gd, gx, gy, gz, f, i0, j0, k0, nullptr, mc, nullptr, 0.0f);
     __syncthreads();
     for (int t = threadIdx.x; t < GNB; t += GNTH) {
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(GNTH) void k_gal_down(MLevel m, const uint8_t* __re
     }
 }
 // up leg of a level >= 1: u + wc * (the parent's correction), both post-sweeps
-__global__ __launch_bounds__(GNTH) void k_gal_up(MLevel m, const uint8_t* __restrict__ cnt, const float* __restrict__ gd, const float* __restrict__ gx,
+__global__ __launch_bounds__(GNTH) void k_gal_up(MLevel m, const uint8_t* __restrict__ tflags, const float* __restrict__ gd, const float* __restrict__ gx,
                                                 const float* __restrict__ gy, const float* __restrict__ gz, const float* __restrict__ f,
                                                 const float* __restrict__ u, float* __restrict__ out, MLevel mc, const float* __restrict__ ec, float wc,
                                                 const PcgState* ps, int ntx, int nty)
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(GNTH) void k_gal_up(MLevel m, const uint8_t* __rest
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tz = tile % ntx, ty = (tile / ntx) % nty, tx = tile / (ntx * nty);
     const int i0 = tx * GT, j0 = ty * GT, k0 = tz * GT;
-    if (gal_tile_empty(m, cnt, i0, j0, k0)) return;
+    if (!tflags[tile]) return;   // (block-uniform)
     gal_load<true>(s, m, gd, gx, gy, gz, f, i0, j0, k0, u, mc, ec, wc);
     __syncthreads();
     for (int t = threadIdx.x; t < GNB; t += GNTH) {
@@ -362,6 +367,18 @@ static inline void gal_tiles(const MLevel& m, int& ntx, int& nty, unsigned& n)
 {
     ntx = (m.dz + GT - 1) / GT; nty = (m.dy + GT - 1) / GT;
     n = (unsigned)(ntx * nty * ((m.dx + GT - 1) / GT));
+}
+int gal_tile_count(const MLevel& m)
+{
+    int ntx, nty; unsigned n;
+    gal_tiles(m, ntx, nty, n);
+    return (int)n;
+}
+void launch_gal_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags)
+{
+    int ntx, nty; unsigned n;
+    gal_tiles(m, ntx, nty, n);
+    hipLaunchKernelGGL(k_gal_tile_flags, dim3(n), dim3(256), 0, st, m, cnt, ntx, nty, flags);
 }
 void launch_gal_down(hipStream_t st, MLevel m, const uint8_t* cnt, const float* gd, const float* gx, const float* gy, const float* gz, const float* f, float* u,
                      MLevel mc, float* fc, const PcgState* ps)

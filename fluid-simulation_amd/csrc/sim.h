@@ -152,6 +152,7 @@ struct fluid_sim {
     size_t gal_slab_cap = 0;
     float* gal_c[MG_MAXL][4] = {};
     uint8_t* gal_cnt[MG_MAXL] = {};
+    uint8_t* gal_tfl[MG_MAXL] = {};   // per leg tile: holds an unknown
     char *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual (float or double)
     double mg_wc[4] = {1.25, 1.1, 1.0, 1.0};   // weight of the coarse correction at level 0 / level 1 / deeper kernel levels / inside the tail (FLUID_MG_WC=a,b,c,d)
     bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (FLUID_MG_FP64=1: double)
