@@ -368,11 +368,6 @@ bool gal_fits_coarsest(const MLevel& m);
 void launch_gal_level1(hipStream_t st, MLevel m0, const uint8_t* cnt0, MgCoef<float> cf0, MLevel m1, float* gd, float* gx, float* gy, float* gz, uint8_t* cnt1);
 void launch_gal_coarsen(hipStream_t st, MLevel mf, const float* fd, const float* fx, const float* fy, const float* fz, const uint8_t* cntf, MLevel mc,
                         float* gd, float* gx, float* gy, float* gz, uint8_t* cntc);
-// counts[0] += unknowns of level 1 by the count bytes of the re-discretised cycle, counts[1] += by aggregation's flags
-void launch_gal_erosion(hipStream_t st, MLevel m1, const uint8_t* cnt_old, const uint8_t* cnt_gal, int* counts);
-void launch_gal_restrict0_tiles(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, float* f1, const PcgState* ps, const int* tlist,
-                                int nlist);   // ... over the listed level-0 leg tiles (8 x 8 x 16) only
-void launch_gal_restrict0(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, const uint8_t* cnt1, float* f1, const PcgState* ps);
 int gal_tile_count(const MLevel& m);   // leg tiles (8^3) of a level
 void launch_gal_tile_flags(hipStream_t st, MLevel m, const uint8_t* cnt, uint8_t* flags);   // flags[tile] = the tile holds an unknown
 // (cnt of the two legs: the tile flags)

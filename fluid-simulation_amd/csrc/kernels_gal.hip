@@ -11,10 +11,10 @@
 // is the sum of the 8 children, the prolongation the parent's value times an over-correction (piecewise-constant P under-
 // estimates smooth corrections; 1.8 measured best).  Same damped-Jacobi sweeps (MG_W1, MG_W2 before, reversed after) — M stays SPD.
 //
-// Level 0 keeps the reference's own coefficients and the kernels of kernels_mg.hip (the down leg without restriction, the up leg
-// with PCONST prolongation); this file holds the coefficient set-up, the restriction of the level-0 residual, the legs of the
-// levels >= 1 (8^3 tiles + halo 2 staged in LDS as plain 3-D arrays: these levels are small and latency-bound, the code is
-// kept simple) and the coarsest level's symmetric red-black Gauss-Seidel in one block.
+// Level 0 keeps the reference's own coefficients and the kernels of kernels_mg.hip (its down leg also forms the coarse right-hand side: the sum
+// of its residual over each coarse cell's children, x pairs first, then y, then z; its up leg takes the parent's value: `pconst`); this file
+// holds the coefficient set-up, the legs of the levels >= 1 (8^3 tiles + halo 2 staged in LDS as plain 3-D arrays: these levels are small
+// and latency-bound, the code is kept simple) and the coarsest level's symmetric red-black Gauss-Seidel in one block.
 #include "common.h"
 
 namespace fl {
@@ -93,62 +93,6 @@ __global__ __launch_bounds__(256) void k_gal_coarsen(MLevel mf, const float* __r
     gd[C] = any ? dsum - 2.0f * inner : 0.0f;
     gx[C] = ox; gy[C] = oy; gz[C] = oz;
     cntc[C] = (uint8_t)any;
-}
-
-// how many level-1 cells each typing rule keeps (the host switches cycles by the ratio)
-__global__ __launch_bounds__(256) void k_gal_erosion(MLevel m1, const uint8_t* __restrict__ cnt_old, const uint8_t* __restrict__ cnt_gal, int* __restrict__ counts)
-{
-    __shared__ int sn[2];
-    if (threadIdx.x < 2) sn[threadIdx.x] = 0;
-    __syncthreads();
-    int I, J, K;
-    if (gal_cell(m1, (long)blockIdx.x * 256 + threadIdx.x, I, J, K)) {
-        const size_t C = m1.at(I, J, K);
-        const unsigned long long a = __ballot(cnt_old[C] != 0), b = __ballot(cnt_gal[C] != 0);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&sn[0], __popcll(a)); atomicAdd(&sn[1], __popcll(b)); }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 && sn[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sn[threadIdx.x]);
-}
-
-// f1 = sum of the level-0 residual over the unknown children
-__global__ __launch_bounds__(256) void k_gal_restrict0(MLevel m0, const uint8_t* __restrict__ cnt0, const float* __restrict__ r0, MLevel m1,
-                                                       const uint8_t* __restrict__ cnt1, float* __restrict__ f1, const PcgState* ps)
-{
-    if (ps && ps->done) return;
-    int I, J, K;
-    if (!gal_cell(m1, (long)blockIdx.x * 256 + threadIdx.x, I, J, K)) return;
-    if (!cnt1[m1.at(I, J, K)]) return;   // no unknown child: f1 stays the zero the step's clearing left
-    // (the level-0 residual is written on unknowns only and zero elsewhere: no test of the children's count bytes, eight independent loads)
-    float v[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int i = 2 * I + (a & 1), j = 2 * J + ((a >> 1) & 1), k = 2 * K + (a >> 2);
-        const float x = r0[m0.at(min(i, m0.dx - 1), min(j, m0.dy - 1), min(k, m0.dz - 1))];
-        v[a] = gal_in(m0, i, j, k) ? x : 0.0f;
-    }
-    f1[m1.at(I, J, K)] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-}
-
-// ... over the list of level-0 leg tiles that hold an unknown (8 x 8 x 16 fine cells = 4 x 4 x 8 coarse ones per block)
-__global__ __launch_bounds__(128) void k_gal_restrict0_tiles(MLevel m0, const uint8_t* __restrict__ cnt0, const float* __restrict__ r0, MLevel m1,
-                                                             float* __restrict__ f1, const PcgState* ps, const int* __restrict__ tlist, int gx, int gy)
-{
-    if (ps && ps->done) return;
-    const int tile = tlist[blockIdx.x];
-    const int tbx = tile % gx, tby = (tile / gx) % gy, tbz = tile / (gx * gy);
-    const int X = threadIdx.x >> 5, Y = (threadIdx.x >> 3) & 3, Z = threadIdx.x & 7;
-    const int I = tbz * 4 + X, J = tby * 4 + Y, K = tbx * 8 + Z;
-    if (!gal_in(m1, I, J, K)) return;
-    float acc = 0;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int i = 2 * I + (a & 1), j = 2 * J + ((a >> 1) & 1), k = 2 * K + (a >> 2);
-        if (!gal_in(m0, i, j, k)) continue;
-        const size_t q = m0.at(i, j, k);
-        if (cnt0[q]) acc += r0[q];
-    }
-    f1[m1.at(I, J, K)] = acc;
 }
 
 constexpr int GT = 8, GA = GT + 4, GB = GT + 2;              // tile, region A (halo 2), region B (halo 1)
@@ -347,21 +291,6 @@ void launch_gal_coarsen(hipStream_t st, MLevel mf, const float* fd, const float*
                         float* gd, float* gx, float* gy, float* gz, uint8_t* cntc)
 {
     hipLaunchKernelGGL(k_gal_coarsen, dim3(gal_blocks(mc)), dim3(256), 0, st, mf, fd, fx, fy, fz, cntf, mc, gd, gx, gy, gz, cntc);
-}
-void launch_gal_erosion(hipStream_t st, MLevel m1, const uint8_t* cnt_old, const uint8_t* cnt_gal, int* counts)
-{
-    hipLaunchKernelGGL(k_gal_erosion, dim3(gal_blocks(m1)), dim3(256), 0, st, m1, cnt_old, cnt_gal, counts);
-}
-void launch_gal_restrict0(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, const uint8_t* cnt1, float* f1, const PcgState* ps)
-{
-    hipLaunchKernelGGL(k_gal_restrict0, dim3(gal_blocks(m1)), dim3(256), 0, st, m0, cnt0, r0, m1, cnt1, f1, ps);
-}
-void launch_gal_restrict0_tiles(hipStream_t st, MLevel m0, const uint8_t* cnt0, const float* r0, MLevel m1, float* f1, const PcgState* ps, const int* tlist,
-                                int nlist)
-{
-    if (nlist <= 0) return;
-    const int gx = (m0.dz + 15) / 16, gy = (m0.dy + 7) / 8;   // the level-0 leg tiles of kernels_mg.hip: 8 x 8 x 16, z fastest
-    hipLaunchKernelGGL(k_gal_restrict0_tiles, dim3((unsigned)nlist), dim3(128), 0, st, m0, cnt0, r0, m1, f1, ps, tlist, gx, gy);
 }
 static inline void gal_tiles(const MLevel& m, int& ntx, int& nty, unsigned& n)
 {

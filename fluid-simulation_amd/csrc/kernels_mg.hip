@@ -369,7 +369,7 @@ __device__ __forceinline__ void mg_down_body_fn(const MLevel& m, const uint8_t* 
                 const int I = i0 / 2 + X, J = j0 / 2 + Y, K = k0 / 2 + Z;
                 if (!live || !in_level(mc, I, J, K)) continue;
                 const T* p = sB + ((2 * X) * CY + 2 * Y) * CZ + 2 * Z;
-                // (the order of k_gal_restrict0: x pairs, then y, then z)
+                // (x pairs first, then y, then z)
                 const T acc = ((p[0] + p[CY * CZ]) + (p[CZ] + p[CY * CZ + CZ])) + ((p[1] + p[CY * CZ + 1]) + (p[CZ + 1] + p[CY * CZ + CZ + 1]));
                 IO::st(fc + mc.at(I, J, K), acc);
             }
