@@ -19,7 +19,7 @@
 
 namespace fl {
 
-constexpr float GAL_W1 = 0.5617f, GAL_W2 = 1.3895f;   // = MG_W1, MG_W2 of kernels_mg.hip
+constexpr float GAL_W1 = 0.5617f, GAL_W2 = 1.6f;   // MG_W1 of kernels_mg.hip; the second sweep heavier than its 1.3895 (step 445: 1.39 -> 22 iterations, 1.6 ... 2.0 -> 21; step 210: 59 -> 56)
 
 __device__ __forceinline__ bool gal_in(const MLevel& m, int i, int j, int k)
 {
