@@ -143,25 +143,36 @@ __global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const 
     const long n = (long)L.cells();
     const long sx = (long)L.Ly * L.Lz, sy = L.Lz;
     double abb = 0, arr = 0;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
-        const uint8_t c = cnt[t];
-        T rv = 0, xv = 0;
-        if (c && !(c & 0x80)) {  // unknowns are interior cells: all six neighbours exist in both layouts (bit 7: ring cell of a decomposed run, another rank's unknown — it counts as a neighbour below, not here)
-            const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
-            const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
-            const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;
-            const T bv = (T)b[gc];
-            auto G = [&](size_t q) { return guess2 ? (T)(ca * guess[q] + cb * guess2[q]) : (T)guess[q]; };
-            xv = G(gc);
-            const T nb = (cnt[t - sx] ? G(gc - gx) : (T)0) + (cnt[t + sx] ? G(gc + gx) : (T)0) +
-                         (cnt[t - sy] ? G(gc - gy) : (T)0) + (cnt[t + sy] ? G(gc + gy) : (T)0) +
-                         (cnt[t - 1] ? G(gc - 1) : (T)0) + (cnt[t + 1] ? G(gc + 1) : (T)0);
-            rv = bv - (sdiag[c] * xv + cf.off * nb);
-            abb += (double)bv * (double)bv;
-            arr += (double)rv * (double)rv;
+    // A mostly-air box is 30 rounds of one count byte and two stores per thread: four rounds' bytes are asked for together (the cells of a
+    // thread, and the order it adds them in, stay what they were).
+    const long stride = (long)gridDim.x * 256;
+    for (long t0 = (long)blockIdx.x * 256 + threadIdx.x; t0 < n; t0 += 4 * stride) {
+        uint8_t c4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long t = t0 + q * stride; c4[q] = cnt[t < n ? t : n - 1]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long t = t0 + q * stride;
+            if (t >= n) break;
+            const uint8_t c = c4[q];
+            T rv = 0, xv = 0;
+            if (c && !(c & 0x80)) {  // unknowns are interior cells: all six neighbours exist in both layouts (bit 7: ring cell of a decomposed run, another rank's unknown — it counts as a neighbour below, not here)
+                const int k = (int)(t % L.Lz), j = (int)((t / L.Lz) % L.Ly), i = (int)(t / ((long)L.Lz * L.Ly));
+                const size_t gc = g.idx(L.x0 + i - 1, L.y0 + j - 1, L.z0 + k - LBOX_K0);
+                const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;
+                const T bv = (T)b[gc];
+                auto G = [&](size_t q2) { return guess2 ? (T)(ca * guess[q2] + cb * guess2[q2]) : (T)guess[q2]; };
+                xv = G(gc);
+                const T nb = (cnt[t - sx] ? G(gc - gx) : (T)0) + (cnt[t + sx] ? G(gc + gx) : (T)0) +
+                             (cnt[t - sy] ? G(gc - gy) : (T)0) + (cnt[t + sy] ? G(gc + gy) : (T)0) +
+                             (cnt[t - 1] ? G(gc - 1) : (T)0) + (cnt[t + 1] ? G(gc + 1) : (T)0);
+                rv = bv - (sdiag[c] * xv + cf.off * nb);
+                abb += (double)bv * (double)bv;
+                arr += (double)rv * (double)rv;
+            }
+            x[t] = xv;
+            r[t] = rv;
         }
-        x[t] = xv;
-        r[t] = rv;
     }
     abb = block_sum<double, 4>(abb, red);
     arr = block_sum<double, 4>(arr, red);
