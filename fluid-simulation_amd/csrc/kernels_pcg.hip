@@ -162,10 +162,11 @@ __global__ __launch_bounds__(256) void k_pcg_init_guess_l(Grid g, LBox L, const 
                 const size_t gx = (size_t)g.sx(), gy = (size_t)g.nz;
                 const T bv = (T)b[gc];
                 auto G = [&](size_t q2) { return guess2 ? (T)(ca * guess[q2] + cb * guess2[q2]) : (T)guess[q2]; };
+                // (the six neighbours' counts and guesses are all asked for, then chosen: a load behind a branch on another load is a round trip each)
+                const uint8_t n0 = cnt[t - sx], n1 = cnt[t + sx], n2 = cnt[t - sy], n3 = cnt[t + sy], n4 = cnt[t - 1], n5 = cnt[t + 1];
+                const T g0 = G(gc - gx), g1 = G(gc + gx), g2 = G(gc - gy), g3 = G(gc + gy), g4 = G(gc - 1), g5 = G(gc + 1);
                 xv = G(gc);
-                const T nb = (cnt[t - sx] ? G(gc - gx) : (T)0) + (cnt[t + sx] ? G(gc + gx) : (T)0) +
-                             (cnt[t - sy] ? G(gc - gy) : (T)0) + (cnt[t + sy] ? G(gc + gy) : (T)0) +
-                             (cnt[t - 1] ? G(gc - 1) : (T)0) + (cnt[t + 1] ? G(gc + 1) : (T)0);
+                const T nb = (n0 ? g0 : (T)0) + (n1 ? g1 : (T)0) + (n2 ? g2 : (T)0) + (n3 ? g3 : (T)0) + (n4 ? g4 : (T)0) + (n5 ? g5 : (T)0);
                 rv = bv - (sdiag[c] * xv + cf.off * nb);
                 abb += (double)bv * (double)bv;
                 arr += (double)rv * (double)rv;
