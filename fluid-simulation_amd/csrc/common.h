@@ -261,7 +261,7 @@ void launch_index_scan(hipStream_t st, Grid g, const uint8_t* flags, int* indice
 void launch_flags(hipStream_t st, Grid g, const uint8_t* solid, const float* container, uint8_t* flags, int x0, int x1);
 void launch_index_scan_range(hipStream_t st, Grid g, const uint8_t* flags, int* indices, int* block_sums, int* total, int x0, int x1);
 void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w,
-                    float* rhs, float* diver, double dx, double gdt0, double gdt1, double gdt2);
+                    float* rhs, float* diver, double dx, double gdt0, double gdt1, double gdt2, bool rows = false);
 void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w,
                        double k, double g0, double g1, double g2);
 void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w,

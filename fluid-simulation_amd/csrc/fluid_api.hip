@@ -1111,7 +1111,7 @@ static int phase_rhs_div(fluid_sim* s, int which)
     if (box_empty(s->Rb)) return FLUID_OK;
     const double dt = s->dt;
     launch_rhs_div(s->st, s->g, s->Rb, s->flags, s->u, s->v, s->w, s->rhs, which ? s->diver2 : s->diver, s->prm.dx,
-                   s->prm.gravity[0] * dt, s->prm.gravity[1] * dt, s->prm.gravity[2] * dt);  // gravity*dt, fluid.cc:420
+                   s->prm.gravity[0] * dt, s->prm.gravity[1] * dt, s->prm.gravity[2] * dt, !s->dist);  // gravity*dt, fluid.cc:420
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }

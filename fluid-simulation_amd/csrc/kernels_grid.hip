@@ -223,6 +223,38 @@ __device__ __forceinline__ CellIt box_cell(const Grid& g, const Box& box)
 // ---- setRHS + setDiver -------------------------------------------------------------------------
 // fluid.cc:414-479 then 566-610, per fluid cell, with the reference's float32 grid
 // narrowing after every accumulation and its term order (-x,+x,-y,+y,-z,+z).
+// one fluid cell of setRHS + setDiver from its loaded values (both kernels below): s?? = that neighbour exists and is solid
+__device__ __forceinline__ void rhs_div_vals(double uc, double vc, double wc, double ui, double vj, double wk, bool sxm, bool sxp, bool sym,
+                                             bool syp, bool szm, bool szp, double dx, double g0, double g1, double g2, float& r, float& d)
+{
+    const double scale = 1.0 / dx;
+    r = 0.0f;
+    if (sxm) r = (float)((double)r - (scale * (uc + g0)));
+    if (sxp) r = (float)((double)r + (scale * (ui + g0)));
+    if (sym) r = (float)((double)r - (scale * (vc + g1)));
+    if (syp) r = (float)((double)r + (scale * (vj + g1)));
+    if (szm) r = (float)((double)r - (scale * (wc + g2)));
+    if (szp) r = (float)((double)r + (scale * (wk + g2)));
+    double du = 0, dv = 0, dw = 0;
+    if (!sxp) du = (ui - uc) / dx;
+    if (!syp) dv = (vj - vc) / dx;
+    if (!szp) dw = (wk - wc) / dx;
+    d = (float)(((double)r) - du - dv - dw);
+}
+__device__ __forceinline__ void rhs_div_cell(const Grid& g, const uint8_t* __restrict__ flags, const double* __restrict__ u,
+                                             const double* __restrict__ v, const double* __restrict__ w, size_t c, int ix, int iy, int iz,
+                                             double dx, double g0, double g1, double g2, float& r, float& d)
+{
+    const long sx = g.sx(), sy = g.nz;
+    const bool hxm = ix > 0, hxp = ix < g.nx - 1, hym = iy > 0, hyp = iy < g.ny - 1, hzm = iz > 0, hzp = iz < g.nz - 1;
+    const double uc = u[c], vc = v[c], wc = w[c];
+    const double ui = hxp ? u[c + sx] : 0.0, vj = hyp ? v[c + sy] : 0.0, wk = hzp ? w[c + 1] : 0.0;
+    const bool sxm = hxm && (flags[c - sx] & F_SOLID), sxp = hxp && (flags[c + sx] & F_SOLID);
+    const bool sym = hym && (flags[c - sy] & F_SOLID), syp = hyp && (flags[c + sy] & F_SOLID);
+    const bool szm = hzm && (flags[c - 1] & F_SOLID), szp = hzp && (flags[c + 1] & F_SOLID);
+    rhs_div_vals(uc, vc, wc, ui, vj, wk, sxm, sxp, sym, syp, szm, szp, dx, g0, g1, g2, r, d);
+}
+
 __global__ __launch_bounds__(256) void k_rhs_div(Grid g, Box box, const uint8_t* __restrict__ flags, const double* __restrict__ u,
                                                  const double* __restrict__ v, const double* __restrict__ w, float* __restrict__ rhs,
                                                  float* __restrict__ diver, double dx, double g0, double g1, double g2)
@@ -230,36 +262,62 @@ __global__ __launch_bounds__(256) void k_rhs_div(Grid g, Box box, const uint8_t*
     CellIt it = box_cell(g, box);
     if (!it.ok) return;
     const size_t c = it.c;
-    const uint8_t f = flags[c];
     float r = 0.0f, d = 0.0f;
-    if (f & F_FLUID) {
-        const double scale = 1.0 / dx;
-        const long sx = g.sx(), sy = g.nz;
-        const bool hxm = it.ix > 0, hxp = it.ix < g.nx - 1, hym = it.iy > 0, hyp = it.iy < g.ny - 1, hzm = it.iz > 0, hzp = it.iz < g.nz - 1;
-        const double uc = u[c], vc = v[c], wc = w[c];
-        const double ui = hxp ? u[c + sx] : 0.0, vj = hyp ? v[c + sy] : 0.0, wk = hzp ? w[c + 1] : 0.0;
-        const bool sxm = hxm && (flags[c - sx] & F_SOLID), sxp = hxp && (flags[c + sx] & F_SOLID);
-        const bool sym = hym && (flags[c - sy] & F_SOLID), syp = hyp && (flags[c + sy] & F_SOLID);
-        const bool szm = hzm && (flags[c - 1] & F_SOLID), szp = hzp && (flags[c + 1] & F_SOLID);
-        if (sxm) r = (float)((double)r - (scale * (uc + g0)));
-        if (sxp) r = (float)((double)r + (scale * (ui + g0)));
-        if (sym) r = (float)((double)r - (scale * (vc + g1)));
-        if (syp) r = (float)((double)r + (scale * (vj + g1)));
-        if (szm) r = (float)((double)r - (scale * (wc + g2)));
-        if (szp) r = (float)((double)r + (scale * (wk + g2)));
-        double du = 0, dv = 0, dw = 0;
-        if (!sxp) du = (ui - uc) / dx;
-        if (!syp) dv = (vj - vc) / dx;
-        if (!szp) dw = (wk - wc) / dx;
-        d = (float)(((double)r) - du - dv - dw);
-    }
+    if (flags[c] & F_FLUID) rhs_div_cell(g, flags, u, v, w, c, it.ix, it.iy, it.iz, dx, g0, g1, g2, r, d);
     rhs[c] = r;
     diver[c] = d;
 }
 
-void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w, float* rhs,
-                    float* diver, double dx, double gdt0, double gdt1, double gdt2)
+// The same over whole z rows of the box's x-y range, four cells per thread (nz a multiple of 4; the box spans most of z: the late
+// phases, where 4/5 of the box is air): one word of flags decides, a row of air is two float4 stores.  The cells of those rows outside the
+// box get the zeros they hold already (one GPU only: `rows`; a rank of a decomposed run does not own them).
+__global__ __launch_bounds__(256) void k_rhs_div4(Grid g, Box box, const uint8_t* __restrict__ flags, const double* __restrict__ u,
+                                                  const double* __restrict__ v, const double* __restrict__ w, float* __restrict__ rhs,
+                                                  float* __restrict__ diver, double dx, double g0, double g1, double g2)
 {
+    const int nzq = g.nz >> 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)box.nx() * box.ny() * nzq) return;
+    const int iz = (int)(t % nzq) * 4, iy = (int)((t / nzq) % box.ny()) + box.y0, ix = (int)(t / ((long)nzq * box.ny())) + box.x0;
+    const size_t c = g.idx(ix, iy, iz);
+    const uint32_t f4 = *(const uint32_t*)(flags + c);
+    float r[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (f4 & (0x01010101u * F_FLUID)) {
+        // everything the four cells can want, asked for at once (one body per cell behind its own flag is four round trips in a row)
+        const long sx = g.sx(), sy = g.nz;
+        const bool hxm = ix > 0, hxp = ix < g.nx - 1, hym = iy > 0, hyp = iy < g.ny - 1;
+        const size_t cxp = hxp ? c + sx : c, cyp = hyp ? c + sy : c, cxm = hxm ? c - sx : c, cym = hym ? c - sy : c;
+        const double2 ua = *(const double2*)(u + c), ub = *(const double2*)(u + c + 2), va = *(const double2*)(v + c), vb = *(const double2*)(v + c + 2);
+        const double2 wa = *(const double2*)(w + c), wb = *(const double2*)(w + c + 2);
+        const double2 xa = *(const double2*)(u + cxp), xb = *(const double2*)(u + cxp + 2), ya = *(const double2*)(v + cyp), yb = *(const double2*)(v + cyp + 2);
+        const double w4 = w[iz + 4 < g.nz ? c + 4 : c];
+        const uint32_t fxm = *(const uint32_t*)(flags + cxm), fxp = *(const uint32_t*)(flags + cxp), fym = *(const uint32_t*)(flags + cym),
+                       fyp = *(const uint32_t*)(flags + cyp);
+        const uint32_t fzm = iz > 0 ? flags[c - 1] : 0u, fzp = iz + 4 < g.nz ? flags[c + 4] : 0u;
+        const double uc[4] = {ua.x, ua.y, ub.x, ub.y}, vc[4] = {va.x, va.y, vb.x, vb.y}, wc[5] = {wa.x, wa.y, wb.x, wb.y, w4};
+        const double ui[4] = {xa.x, xa.y, xb.x, xb.y}, vj[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!(((f4 >> (8 * q)) & F_FLUID) && iz + q >= box.z0 && iz + q <= box.z1)) continue;
+            const bool hzp = iz + q < g.nz - 1;
+            const uint32_t zm = q == 0 ? fzm : (f4 >> (8 * (q - 1))) & 0xffu, zp = q == 3 ? fzp : (f4 >> (8 * (q + 1))) & 0xffu;
+            rhs_div_vals(uc[q], vc[q], wc[q], hxp ? ui[q] : 0.0, hyp ? vj[q] : 0.0, hzp ? wc[q + 1] : 0.0,
+                         hxm && ((fxm >> (8 * q)) & F_SOLID), hxp && ((fxp >> (8 * q)) & F_SOLID), hym && ((fym >> (8 * q)) & F_SOLID),
+                         hyp && ((fyp >> (8 * q)) & F_SOLID), (zm & F_SOLID) != 0, hzp && (zp & F_SOLID), dx, g0, g1, g2, r[q], d[q]);
+        }
+    }
+    *(float4*)(rhs + c) = make_float4(r[0], r[1], r[2], r[3]);
+    *(float4*)(diver + c) = make_float4(d[0], d[1], d[2], d[3]);
+}
+
+void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w, float* rhs,
+                    float* diver, double dx, double gdt0, double gdt1, double gdt2, bool rows)
+{
+    if (rows && g.nz % 4 == 0 && 4 * box.nz() >= 3 * g.nz) {
+        const long n = (long)box.nx() * box.ny() * (g.nz >> 2);
+        hipLaunchKernelGGL(k_rhs_div4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, box, flags, u, v, w, rhs, diver, dx, gdt0, gdt1, gdt2);
+        return;
+    }
     hipLaunchKernelGGL(k_rhs_div, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, flags, u, v, w, rhs, diver, dx,
                        gdt0, gdt1, gdt2);
 }
