@@ -263,13 +263,13 @@ void launch_index_scan_range(hipStream_t st, Grid g, const uint8_t* flags, int* 
 void launch_rhs_div(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* u, const double* v, const double* w,
                     float* rhs, float* diver, double dx, double gdt0, double gdt1, double gdt2, bool rows = false);
 void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w,
-                       double k, double g0, double g1, double g2);
+                       double k, double g0, double g1, double g2, bool rows = false);
 void launch_flip_delta(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w,
                        const double* ub, const double* vb, const double* wb, double* dcx, double* dcy, double* dcz, double* pcx, double* pcy, double* pcz);
 void launch_err_norm(hipStream_t st, Grid g, Box box, const uint8_t* flags, const float* b, const float* b2, double* part, StepState* ss);
 void launch_zero_step_state(hipStream_t st, StepState* ss, int N);
 struct ZeroList { float* f4[4]; double* f8[7]; };
-void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box);
+void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box, bool rows = false);
 void launch_unpack_box(hipStream_t st, Grid g, Box box, const double* buf, float* container, double* u, double* v, double* w, double* ub, double* vb,
                        double* wb);
 

@@ -438,7 +438,7 @@ int fl::clear_dirty(fluid_sim* s)
 {
     if (box_empty(s->dirty)) return FLUID_OK;
     const ZeroList z = {{s->container, s->rhs, s->diver, s->diver2}, {s->u, s->v, s->w, s->ub, s->vb, s->wb, s->pressure}};
-    launch_zero_fields(s->st, z, s->g, s->dirty);
+    launch_zero_fields(s->st, z, s->g, s->dirty, !s->dist);
     HIPCHK(hipGetLastError());
     s->dirty = Box{0, 0, 0, -1, -1, -1};
     return FLUID_OK;
@@ -1202,7 +1202,7 @@ static int phase_vel_update(fluid_sim* s)
     const double dtp = s->dt * s->prm.update_frac;      // dt/10, fluid.cc:1475
     const double k = dtp / (s->prm.rho * s->prm.dx);    // :614
     launch_vel_update(s->st, s->g, s->Sb, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,
-                      s->prm.gravity[2] * dtp);         // gravity*dt, :638
+                      s->prm.gravity[2] * dtp, !s->dist);         // gravity*dt, :638
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }

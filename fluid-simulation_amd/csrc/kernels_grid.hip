@@ -355,9 +355,64 @@ __global__ __launch_bounds__(256) void k_vel_update(Grid g, Box box, const uint8
     u[c] = uc; v[c] = vc; w[c] = wc;
 }
 
-void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w, double k,
-                       double g0, double g1, double g2)
+// The same over whole z rows of the box's x-y range, four cells per thread (see k_rhs_div4; one GPU only).  A cell changes only if it or
+// one of its three lower neighbours is fluid or solid: the flag words decide before any of the 48 bytes per cell are touched, and 4/5 of a
+// late-phase box is air next to air.
+__global__ __launch_bounds__(256) void k_vel_update4(Grid g, Box box, const uint8_t* __restrict__ flags, const double* __restrict__ p,
+                                                     double* __restrict__ u, double* __restrict__ v, double* __restrict__ w, double k,
+                                                     double g0, double g1, double g2)
 {
+    const int nzq = g.nz >> 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)box.nx() * box.ny() * nzq) return;
+    const int iz = (int)(t % nzq) * 4, iy = (int)((t / nzq) % box.ny()) + box.y0, ix = (int)(t / ((long)nzq * box.ny())) + box.x0;
+    const size_t c = g.idx(ix, iy, iz);
+    const long sx = g.sx(), sy = g.nz;
+    const size_t cxm = ix > 0 ? c - sx : c, cym = iy > 0 ? c - sy : c;
+    const uint32_t f4 = *(const uint32_t*)(flags + c);
+    const uint32_t fx4 = ix > 0 ? *(const uint32_t*)(flags + cxm) : 0u, fy4 = iy > 0 ? *(const uint32_t*)(flags + cym) : 0u;
+    const uint32_t fz0 = iz > 0 ? flags[c - 1] : 0u;
+    const uint32_t fz4 = (f4 << 8) | fz0;   // byte q = flags of the cell below cell q in z
+    if (!((f4 | fx4 | fy4 | fz4) & (0x01010101u * (F_FLUID | F_SOLID)))) return;
+    const double2 ua = *(const double2*)(u + c), ub = *(const double2*)(u + c + 2), va = *(const double2*)(v + c), vb = *(const double2*)(v + c + 2);
+    const double2 wa = *(const double2*)(w + c), wb = *(const double2*)(w + c + 2);
+    const double2 pa = *(const double2*)(p + c), pb = *(const double2*)(p + c + 2);
+    const double2 xa = *(const double2*)(p + cxm), xb = *(const double2*)(p + cxm + 2), ya = *(const double2*)(p + cym), yb = *(const double2*)(p + cym + 2);
+    const double pz0 = p[iz > 0 ? c - 1 : c];
+    double uc[4] = {ua.x, ua.y, ub.x, ub.y}, vc[4] = {va.x, va.y, vb.x, vb.y}, wc[4] = {wa.x, wa.y, wb.x, wb.y};
+    const double pc[4] = {pa.x, pa.y, pb.x, pb.y}, px[4] = {xa.x, xa.y, xb.x, xb.y}, py[4] = {ya.x, ya.y, yb.x, yb.y};
+    const double pz[4] = {pz0, pa.x, pa.y, pb.x};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (iz + q < box.z0 || iz + q > box.z1) continue;
+        const uint32_t f = (f4 >> (8 * q)) & 0xffu, fxm = (fx4 >> (8 * q)) & 0xffu, fym = (fy4 >> (8 * q)) & 0xffu, fzm = (fz4 >> (8 * q)) & 0xffu;
+        if (fxm & F_FLUID) uc[q] = uc[q] + k * px[q];   // :646
+        if (fym & F_FLUID) vc[q] = vc[q] + k * py[q];   // :653
+        if (fzm & F_FLUID) wc[q] = wc[q] + k * pz[q];   // :660
+        if (f & F_FLUID) {
+            const double pre = pc[q];
+            uc[q] = uc[q] - k * pre + g0;               // :639
+            vc[q] = vc[q] - k * pre + g1;               // :640
+            wc[q] = wc[q] - k * pre + g2;               // :641
+        }
+        if (f & F_SOLID) { uc[q] = 0; vc[q] = 0; wc[q] = 0; }  // :682
+        if (fxm & F_SOLID) uc[q] = 0;                   // :686
+        if (fym & F_SOLID) vc[q] = 0;                   // :691
+        if (fzm & F_SOLID) wc[q] = 0;                   // :696
+    }
+    *(double2*)(u + c) = make_double2(uc[0], uc[1]); *(double2*)(u + c + 2) = make_double2(uc[2], uc[3]);
+    *(double2*)(v + c) = make_double2(vc[0], vc[1]); *(double2*)(v + c + 2) = make_double2(vc[2], vc[3]);
+    *(double2*)(w + c) = make_double2(wc[0], wc[1]); *(double2*)(w + c + 2) = make_double2(wc[2], wc[3]);
+}
+
+void launch_vel_update(hipStream_t st, Grid g, Box box, const uint8_t* flags, const double* p, double* u, double* v, double* w, double k,
+                       double g0, double g1, double g2, bool rows)
+{
+    if (rows && g.nz % 4 == 0 && 4 * box.nz() >= 3 * g.nz) {
+        const long n = (long)box.nx() * box.ny() * (g.nz >> 2);
+        hipLaunchKernelGGL(k_vel_update4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, box, flags, p, u, v, w, k, g0, g1, g2);
+        return;
+    }
     hipLaunchKernelGGL(k_vel_update, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, flags, p, u, v, w, k, g0, g1,
                        g2);
 }
@@ -496,9 +551,33 @@ __global__ __launch_bounds__(256) void k_zero_fields(ZeroList z, Grid g, Box box
     if (a < 4) pf[it.c] = 0.0f;
     else pd[it.c] = 0.0;
 }
-void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box)
+// whole z rows of the box's x-y range, 16-byte stores (a box that spans most of z; one GPU: the cells of those rows outside the box hold
+// zeros already)
+__global__ __launch_bounds__(256) void k_zero_fields4(ZeroList z, Grid g, Box box)
+{
+    const int a = blockIdx.y;
+    float* pf = z.f4[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) pf = (a == q) ? z.f4[q] : pf;
+    double* pd = z.f8[0];
+#pragma unroll
+    for (int q = 1; q < 7; ++q) pd = (a - 4 == q) ? z.f8[q] : pd;
+    const int nzq = g.nz >> 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)box.nx() * box.ny() * nzq) return;
+    const int iz = (int)(t % nzq) * 4, iy = (int)((t / nzq) % box.ny()) + box.y0, ix = (int)(t / ((long)nzq * box.ny())) + box.x0;
+    const size_t c = g.idx(ix, iy, iz);
+    if (a < 4) *(float4*)(pf + c) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    else { *(double2*)(pd + c) = make_double2(0.0, 0.0); *(double2*)(pd + c + 2) = make_double2(0.0, 0.0); }
+}
+void launch_zero_fields(hipStream_t st, const ZeroList& z, Grid g, Box box, bool rows)
 {
     if (box.cells() <= 0) return;
+    if (rows && g.nz % 4 == 0 && 4 * box.nz() >= 3 * g.nz) {
+        const long n = (long)box.nx() * box.ny() * (g.nz >> 2);
+        hipLaunchKernelGGL(k_zero_fields4, dim3((unsigned)((n + 255) / 256), 11), dim3(256), 0, st, z, g, box);
+        return;
+    }
     hipLaunchKernelGGL(k_zero_fields, dim3((unsigned)((box.cells() + 255) / 256), 11), dim3(256), 0, st, z, g, box);
 }
 
