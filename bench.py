@@ -95,7 +95,16 @@ def pmc_traffic(kernel, n, ppc):
     tj = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r03", "r02")) if os.path.exists(q)), None)
     if n != 256 or ppc != 8 or tj is None:
         return None
-    return json.load(open(tj)).get("kernels_final", {}).get(kernel, {}).get("bytes_per_launch")
+    table = json.load(open(tj))
+    table = table.get("kernels_final", table)   # (round 2 wrapped the per-kernel table; tools/pmc_summary.py writes it bare)
+    if kernel not in table:
+        # template arguments added since the key was written (k_pcg_xr_l<double> -> k_pcg_xr_l<double, false>): same base name, same leading arguments
+        base, args = kernel.split("<")[0], kernel.partition("<")[2].rstrip(">")
+        cand = [k for k in table if k.split("<")[0].split(" ")[0] == base and k.partition("<")[2].startswith(args)]
+        if len(cand) != 1:
+            return None
+        kernel = cand[0]
+    return table[kernel].get("bytes_per_launch")
 
 
 def stencil_microbench(fs, n, device):
@@ -365,7 +374,7 @@ def main():
         ach = algo / (avg_ms * 1e-3) / 1e9
         e = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": pmc_traffic(key, n, ppc) if transport is None else None,
-             "traffic_source": "profiles/r0N/pmc_traffic.json (kernels_final; newest round present): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload", "algorithmic_bytes_per_launch": algo,
+             "traffic_source": "profiles/r0N/pmc_traffic.json (newest round present): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE doubled (gfx950)", "algorithmic_bytes_per_launch": algo,
              "cells_per_launch": cells, "avg_launch_us": avg_ms * 1e3, "launches": prof["launches"], "sampled": prof["sampled"],
              "total_ms_in_timed_region": avg_ms * prof["launches"]}
         if note:
