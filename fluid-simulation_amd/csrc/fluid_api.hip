@@ -246,6 +246,7 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     if (const char* e = getenv("FLUID_MG_GALERKIN_WC")) s->gal_wc = atof(e);
     if (const char* e = getenv("FLUID_MG_GALERKIN_SWEEPS")) s->gal_sweeps = atoi(e);
     if (const char* e = getenv("FLUID_DROPLETS")) s->drops_on = atoi(e) != 0;
+    if (const char* e = getenv("FLUID_ROW_SWEEPS")) s->row_sweeps = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DROPLETS_MIN")) s->drop_min = atoi(e);
     if (const char* e = getenv("FLUID_MG_COARSE")) s->mgc_mode = atoi(e);
     if (const char* e = getenv("FLUID_MG_COARSE_BLOCKS")) s->mgc_max_blocks = std::max(1, atoi(e));
@@ -438,7 +439,7 @@ int fl::clear_dirty(fluid_sim* s)
 {
     if (box_empty(s->dirty)) return FLUID_OK;
     const ZeroList z = {{s->container, s->rhs, s->diver, s->diver2}, {s->u, s->v, s->w, s->ub, s->vb, s->wb, s->pressure}};
-    launch_zero_fields(s->st, z, s->g, s->dirty, !s->dist);
+    launch_zero_fields(s->st, z, s->g, s->dirty, !s->dist && s->row_sweeps);
     HIPCHK(hipGetLastError());
     s->dirty = Box{0, 0, 0, -1, -1, -1};
     return FLUID_OK;
@@ -1111,7 +1112,7 @@ static int phase_rhs_div(fluid_sim* s, int which)
     if (box_empty(s->Rb)) return FLUID_OK;
     const double dt = s->dt;
     launch_rhs_div(s->st, s->g, s->Rb, s->flags, s->u, s->v, s->w, s->rhs, which ? s->diver2 : s->diver, s->prm.dx,
-                   s->prm.gravity[0] * dt, s->prm.gravity[1] * dt, s->prm.gravity[2] * dt, !s->dist);  // gravity*dt, fluid.cc:420
+                   s->prm.gravity[0] * dt, s->prm.gravity[1] * dt, s->prm.gravity[2] * dt, !s->dist && s->row_sweeps);  // gravity*dt, fluid.cc:420
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
@@ -1202,7 +1203,7 @@ static int phase_vel_update(fluid_sim* s)
     const double dtp = s->dt * s->prm.update_frac;      // dt/10, fluid.cc:1475
     const double k = dtp / (s->prm.rho * s->prm.dx);    // :614
     launch_vel_update(s->st, s->g, s->Sb, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,
-                      s->prm.gravity[2] * dtp, !s->dist);         // gravity*dt, :638
+                      s->prm.gravity[2] * dtp, !s->dist && s->row_sweeps);         // gravity*dt, :638
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }

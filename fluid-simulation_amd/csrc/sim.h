@@ -103,6 +103,7 @@ struct fluid_sim {
     double* R2 = nullptr;         // the second residual array of the fused form (lmax doubles, allocated when first needed)
     // closed pockets (airborne droplets) of the pressure system, solved on their own (kernels_droplets.hip; FLUID_DROPLETS=0: off)
     bool drops_on = true;
+    bool row_sweeps = true;       // FLUID_ROW_SWEEPS=0: the per-step box sweeps keep their cell-per-thread forms (kernels_grid.hip, k_*4)
     int* drop_ctr = nullptr;      // 64 x DROP_NCTR ints: the slot counters, then DROP_NCTR + 1 range starts of the dense numbering
     int* drop_n = nullptr;        // cells per component
     int* drop_cells = nullptr;    // 64 local-box cell indices per component

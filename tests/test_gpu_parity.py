@@ -972,3 +972,39 @@ def test_edge_clustered_particles(fs, oracle):
     assert np.array_equal(sim.field(F.VEL), sim2.field(F.VEL))
     p1, v1 = sim.download_particles(); p2, v2 = sim2.download_particles()
     assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+
+
+def test_row_wise_box_sweeps_change_nothing(fs, monkeypatch):
+    """Where the active box spans most of z the per-step sweeps run over whole z rows, four cells per thread (k_rhs_div4, k_vel_update4,
+    k_zero_fields4, kernels_grid.hip): same cells, same arithmetic per cell (fluid.cc:414-479, 566-610, 612-703).  A pool over the whole
+    floor with a shelf in it and water against the walls, stepped with the row forms and with the cell-per-thread forms
+    (FLUID_ROW_SWEEPS=0): every field and every particle bit for bit, and the box is one that takes the row forms."""
+    n = 48
+    lo, hi = fs.grid_bounds(n)
+    rng = np.random.default_rng(33)
+    pool = np.stack([rng.uniform(lo + 1.2, hi - 1.2, 40000), rng.uniform(lo + 1.2, lo + 9, 40000), rng.uniform(lo + 1.2, hi - 1.2, 40000)], axis=1)
+    blob = np.stack([rng.uniform(lo + 18, lo + 28, 6000), rng.uniform(lo + 24, lo + 34, 6000), rng.uniform(lo + 18, lo + 28, 6000)], axis=1)
+    pos = np.concatenate([pool, blob]); vel = rng.standard_normal(pos.shape) * 0.3
+
+    def run(rows):
+        monkeypatch.setenv("FLUID_ROW_SWEEPS", "1" if rows else "0")
+        sim = fs.FluidSim(n=n)
+        solid = sim.field(fs.FIELD.SOLID).copy()
+        solid[12:30, 5:8, 14:40] = 1                    # a shelf standing in the pool
+        sim.set_solid(solid)
+        sim.upload_particles(pos, vel)
+        stats = [sim.step() for _ in range(4)]
+        F = fs.FIELD
+        fields = {f: sim.field(f).copy() for f in (F.PRESSURE, F.VEL, F.VEL_BEFORE, F.RHS, F.DIVER, F.DIVER2, F.CONTAINER, F.FLAGS)}
+        p, v = sim.download_particles()
+        return stats, fields, p, v
+
+    s1, f1, p1, v1 = run(True)
+    s0, f0, p0, v0 = run(False)
+    zlo, zhi = s1[-1]["box_lo"][2], s1[-1]["box_hi"][2]
+    assert 4 * (zhi - zlo + 1) >= 3 * n, (zlo, zhi)      # the box of this scene takes the row forms
+    for a, b in zip(s1, s0):
+        assert a["num_active"] == b["num_active"] and a["cg_iters"] == b["cg_iters"] and a["outer_passes"] == b["outer_passes"], (a, b)
+    for k in f1:
+        assert np.array_equal(f1[k], f0[k]), k
+    assert np.array_equal(p1, p0) and np.array_equal(v1, v0)
