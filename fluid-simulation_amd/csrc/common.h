@@ -330,6 +330,9 @@ template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf);
 template <typename T>
 void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen);
+// the same sweep through an LDS-DMA plane ring (kernels_stencil.hip); false = the form does not apply to this grid (nothing launched)
+template <typename T>
+bool launch_stencil_dma(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxcode);
 template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure, double* keep = nullptr,
                            const PcgState* ps = nullptr);

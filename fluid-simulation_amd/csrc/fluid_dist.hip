@@ -117,6 +117,9 @@ struct DistState {
     int rb_every = 0;
     double rb_ratio = 2.0;
     int n_rebalanced = 0;
+    int n_rebalance_refused = 0;     // re-balances every rank gave up together (some rank had no room for a second window)
+    // test hooks, read once in fluid_create_dist: the rank whose growth (route_round) / second window (dist_rebalance) is refused; -1 = none
+    int fail_grow_rank = -1, fail_rebuild_rank = -1;
     int* rb_buf = nullptr;            // device: 3 N axis histograms + one count per rank
     std::vector<uint8_t> solid_global;   // what fluid_set_solid was given (empty: the default shell): a new window needs it again
     // overlap of the residual's halo exchange with the interior tiles of the level-0 down leg (FLUID_DIST_OVERLAP=0: off)
@@ -340,7 +343,7 @@ int route_round(fluid_sim* s)
             d->mig_s = d->mig_r = nullptr;
             d->mig_cap = 0;
             const long cap = std::max(stot, rtot) * 3 / 2 + 4096;
-            if (getenv("FLUID_DIST_FAIL_GROW") && atoi(getenv("FLUID_DIST_FAIL_GROW")) == d->comm.rank)   // (tests: a rank that cannot grow)
+            if (d->fail_grow_rank == d->comm.rank)   // (tests: a rank that cannot grow)
                 return fail(FLUID_ERR_HIP, "migration buffers: allocation refused (FLUID_DIST_FAIL_GROW)");
             HIPCHK(hipMalloc((void**)&d->mig_s, (size_t)cap * 56));
             HIPCHK(hipMalloc((void**)&d->mig_r, (size_t)cap * 56));
@@ -1117,22 +1120,30 @@ int dist_rebalance(fluid_sim* s)
     DistState* d = s->ds;
     const int N = s->g.N, R = d->comm.size, me = d->comm.rank;
     int rc;
-    const int64_t live = fluid_download_particles_ids(s, nullptr, nullptr, nullptr);
-    if (live < 0) return fail(FLUID_ERR_HIP, "rebalance: counting the live particles failed");
-    std::vector<double> pos(3 * (size_t)live), vel(3 * (size_t)live);
-    std::vector<uint32_t> ids((size_t)live);
-    if (live && fluid_download_particles_ids(s, pos.data(), vel.data(), ids.data()) != live) return fail(FLUID_ERR_HIP, "rebalance: download failed");
-    // 1. histograms of the base cells (fluid.cc:267: round half away from zero) and the per-rank counts, summed over the ranks
+    // Everything that can fail on ONE rank before the first collective is brought to dist_agree first: a rank that returned
+    // from here alone would leave its peers in the all-reduce below for ever.
+    int64_t live = 0;
+    std::vector<double> pos, vel;
+    std::vector<uint32_t> ids;
     std::vector<int> h(3 * (size_t)N + R, 0);
     const int lo = s->g.lo;
-    for (int64_t i = 0; i < live; ++i)
-        for (int a = 0; a < 3; ++a) {
-            long b = std::lround(pos[3 * i + a]) - lo;
-            b = b < 0 ? 0 : (b > N - 1 ? N - 1 : b);
-            h[(size_t)a * N + b]++;
-        }
-    h[3 * (size_t)N + me] = (int)live;
-    HIPCHK(hipMemcpyAsync(d->rb_buf, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+    auto gather_local = [&]() -> int {
+        live = fluid_download_particles_ids(s, nullptr, nullptr, nullptr);
+        if (live < 0) return fail(FLUID_ERR_HIP, "rebalance: counting the live particles failed");
+        pos.resize(3 * (size_t)live); vel.resize(3 * (size_t)live); ids.resize((size_t)live);
+        if (live && fluid_download_particles_ids(s, pos.data(), vel.data(), ids.data()) != live) return fail(FLUID_ERR_HIP, "rebalance: download failed");
+        // 1. histograms of the base cells (fluid.cc:267: round half away from zero) and the per-rank counts, summed over the ranks
+        for (int64_t i = 0; i < live; ++i)
+            for (int a = 0; a < 3; ++a) {
+                long b = std::lround(pos[3 * i + a]) - lo;
+                b = b < 0 ? 0 : (b > N - 1 ? N - 1 : b);
+                h[(size_t)a * N + b]++;
+            }
+        h[3 * (size_t)N + me] = (int)live;
+        HIPCHK(hipMemcpyAsync(d->rb_buf, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+        return FLUID_OK;
+    };
+    if ((rc = dist_agree(s, gather_local()))) return rc;
     if ((rc = comm_allreduce(s, d->rb_buf, (long)h.size(), FLUID_DT_I32, FLUID_OP_SUM))) return rc;
     HIPCHK(hipMemcpyAsync(h.data(), d->rb_buf, h.size() * sizeof(int), hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
@@ -1233,14 +1244,20 @@ int dist_rebalance(fluid_sim* s)
     auto build = [&]() -> int {
         fluid_decomp_t dc;
         for (int a = 0; a < 3; ++a) { dc.dims[a] = d->dims[a]; dc.cuts[a] = nc[a].data(); }
+        if (d->fail_rebuild_rank == me) return fail(FLUID_ERR_HIP, "rebalance: second window refused (FLUID_DIST_FAIL_REBUILD)");
         int r2 = fluid_create_dist(&s->prm, &d->comm, &dc, &t);
         if (r2) return r2;
         if (!d->solid_global.empty() && (r2 = fluid_set_solid(t, d->solid_global.data()))) return r2;
         return fluid_upload_particles_ids(t, mine, npos.data(), nvel.data(), nids.data());
     };
     if ((rc = dist_agree(s, build()))) {
+        // Some rank could not build its second window (normally: no room for it).  The outcome is decided by the AGREED flag alone,
+        // so every rank takes the same way out: drop the new handle, forget the failed allocation (a runtime that keeps the last
+        // error set until it is read would hand it to the next step's first check on this rank only) and go on with the old planes.
         if (t) fluid_destroy(t);
-        return rc == FLUID_ERR_PEER || rc == FLUID_ERR_HIP ? FLUID_OK : rc;   // no room for a second window somewhere: go on with the old planes
+        (void)hipGetLastError();
+        d->n_rebalance_refused++;
+        return FLUID_OK;
     }
     DistState* nd = t->ds;
     nd->rb_every = d->rb_every; nd->rb_ratio = d->rb_ratio; nd->n_rebalanced = d->n_rebalanced + 1; nd->n_routed = d->n_routed;
@@ -1338,6 +1355,8 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
     if (d->split_force < 0 || d->split_force > 2) d->split_force = 0;
     if (const char* e = getenv("FLUID_DIST_OVERLAP")) d->overlap = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DIST_REBALANCE")) d->rb_every = std::max(0, atoi(e));
+    if (const char* e = getenv("FLUID_DIST_FAIL_GROW")) d->fail_grow_rank = atoi(e);         // test hooks (tests/test_gpu_dist.py)
+    if (const char* e = getenv("FLUID_DIST_FAIL_REBUILD")) d->fail_rebuild_rank = atoi(e);
     if (const char* e = getenv("FLUID_DIST_GATHER")) d->split_exchange_force = !strcmp(e, "exchange") ? 1 : (!strcmp(e, "allreduce") ? 0 : -1);
     Grid g;
     g.N = p->n;

@@ -22,6 +22,7 @@
 //
 // Bandwidth/latency-bound fp64 work: no MFMA.
 #include "common.h"
+#include "stencil_vec.h"
 
 namespace fl {
 
@@ -1023,16 +1024,6 @@ static void march_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags
 // write, 2/V LDS reads, 2/V shuffles instead of 1 write + 4 reads — the scalar float kernel was bound by exactly that
 // (54 % of the HBM peak against 75-80 % for double).  Needs N % V == 0 (rows 16-byte aligned); same term order as the scalar
 // kernel (x-, x+, y-, y+, z-, z+), so the results are bit-identical.
-template <typename T, int V>
-struct VecT {
-    typedef T type __attribute__((ext_vector_type(V)));
-};
-template <int V>
-struct FlagT;
-template <>
-struct FlagT<4> { typedef uint32_t type; };
-template <>
-struct FlagT<2> { typedef uint16_t type; };
 
 template <typename T, int MY, int MD>
 __global__ __launch_bounds__(MY * 64) void k_stencil_vec(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
@@ -1334,13 +1325,6 @@ __device__ __forceinline__ T dpp_wave_shl1(T v)   // lane i <- lane i+1, lane 63
         return __builtin_bit_cast(T, ((long long)hi << 32) | lo);
     }
 }
-// v where the mask word is all ones, +0 where it is zero
-template <typename T>
-__device__ __forceinline__ T and_mask(T v, int m)
-{
-    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_bit_cast(int, v) & m);
-    else return __builtin_bit_cast(T, __builtin_bit_cast(long long, v) & (long long)m);   // m sign-extends
-}
 
 // AXIS = the axis of the march: 0 = x (a wave steps from plane to plane: successive loads of a wave lie N^2 elements apart),
 // 1 = y (a wave owns one z row segment of ONE x plane and walks it row by row: its loads are one contiguous stream of N-element
@@ -1595,6 +1579,8 @@ void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T*
 {
     constexpr int V = 16 / (int)sizeof(T);
     const bool can_vec = g.N % V == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)q & 15) == 0;
+    if (variant >= 900000 && launch_stencil_dma<T>(st, g, flags, s, q, cf, variant - 900000, cxlen)) return;   // 900000 + D G NP RY: the LDS-DMA plane ring
+    if (variant >= 900000) { variant = 0; cxlen = 0; }
     if (variant >= 80000 && can_vec) {   // 80000 + MY: the linear-front sweep, MY rows (waves) per block
         switch (variant - 80000) {
         case 2: front_launch<T, 2>(st, g, flags, s, q, cf); break;

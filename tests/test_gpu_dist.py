@@ -241,6 +241,25 @@ def test_cut_planes_follow_the_water(fs, mode):
     compare(d, ref, len(pos), f"rebalance {mode}", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
 
 
+def test_a_rank_that_cannot_build_its_new_window_keeps_every_rank_on_the_old_planes(fs, monkeypatch):
+    """Re-balancing needs a second window per rank for a moment.  When ONE rank cannot build it (FLUID_DIST_FAIL_REBUILD names the
+    rank), every rank must take the same way out — drop the attempt, keep the old planes — and the FOLLOWING steps must run on all of
+    them: no rank fails alone later on a stale error, nobody waits for a peer.  The answer is the one of a run that never re-balanced."""
+    monkeypatch.setenv("FLUID_DIST_FAIL_REBUILD", "3")
+    n, steps = 48, 10
+    pos, vel = scene(fs, n, 4, vel=0.3)
+    pos = pos + np.array([5.0, 7.0, -3.0])
+    ref = single(fs, n, pos, vel, steps)
+    d = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed", uniform=True, rebalance=(3, 1.1))
+    assert d["moved"] == [0] * 8                                  # every attempt was given up, on every rank
+    assert all(c == d["all_cuts"][0] for c in d["all_cuts"])
+    monkeypatch.delenv("FLUID_DIST_FAIL_REBUILD")
+    plain = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed", uniform=True)
+    assert d["cuts"] == plain["cuts"]
+    assert np.array_equal(d["pos"], plain["pos"]) and np.array_equal(d["pressure"], plain["pressure"])   # the refused attempts changed nothing
+    compare(d, ref, len(pos), "refused re-balance", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
+
+
 def test_a_rank_that_cannot_grow_fails_every_rank(fs, monkeypatch):
     """The one allocation a step can still need is room for particles that migrate in.  When ONE rank cannot get it
     (FLUID_DIST_FAIL_GROW names the rank), every rank must leave that step with an error — the one that failed with its own,
