@@ -326,13 +326,18 @@ template <typename T>
 void launch_pcg_xr_dist(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
                         const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps);
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b);
+void launch_sum4(hipStream_t st, const double* a, int na, const double* b, int nb, const double* c, int nc, const double* e, int ne, double* out);
+// Chronopoulos-Gear form of the decomposed PCG (one all-reduce per iteration): w = A z + partials of z.w; the fused update
+template <typename T>
+void launch_pcg_az_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* z, T* w, Coef<T> cf, double* part_zw, PcgState* ps);
+template <typename T>
+void launch_pcg_cgear_upd(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, T* s, T* q, const T* z, const T* w, const double* g, double* cg, int cur,
+                          double* part_rr, PcgState* ps, int first, double tol);
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf);
+// dense sweep q = A s over the whole grid (kernels_stencil.hip): the LDS-DMA plane ring, or the lean march; false = nothing launched
 template <typename T>
-void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen);
-// the same sweep through an LDS-DMA plane ring (kernels_stencil.hip); false = the form does not apply to this grid (nothing launched)
-template <typename T>
-bool launch_stencil_dma(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxcode);
+bool launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxcode);
 template <typename T>
 void launch_store_pressure(hipStream_t st, Grid g, LBox L, const uint8_t* cnt, const T* x, double* pressure, double* keep = nullptr,
                            const PcgState* ps = nullptr);

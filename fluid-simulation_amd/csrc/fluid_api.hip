@@ -1467,7 +1467,7 @@ static int stencil_run(fluid_sim* s, int reps, int box_mode, int nsets, void* co
     const int N = s->g.N;
     const Box box = box_mode == 1 ? s->Rb : Box{0, 0, 0, N - 1, N - 1, N - 1};
     if (box_empty(box)) return fail(FLUID_ERR_STATE, "empty active box");
-    // tuning knobs of the marching kernel (developer use): FLUID_MARCH_VARIANT=MY*100+MD, FLUID_MARCH_CX=planes/chunk
+    // form of the dense sweep (developer use / tests): FLUID_MARCH_VARIANT, FLUID_MARCH_CX — launch_stencil_march (kernels_stencil.hip)
     const char* ev = getenv("FLUID_MARCH_VARIANT");
     const char* ec = getenv("FLUID_MARCH_CX");
     const int mv = ev ? atoi(ev) : 0, mc = ec ? atoi(ec) : 0;
@@ -1479,14 +1479,14 @@ static int stencil_run(fluid_sim* s, int reps, int box_mode, int nsets, void* co
         const void* S = nsets > 1 ? sets[i % nsets][0] : s->S[0];
         void* Q = nsets > 1 ? sets[i % nsets][1] : s->Q;
         const uint8_t* fl = nsets > 1 ? (const uint8_t*)sets[i % nsets][2] : s->flags;
-        // box_mode 0: dense sweep (x-marching kernel; grids under 192^3 cannot fill 256 CUs with 32-plane chunks -> tiled);
+        // box_mode 0: dense sweep (LDS-DMA plane ring / lean march; grids under 192^3 cannot fill 256 CUs with whole-plane chunks -> tiled);
         // 1: active box, tiled kernel; 2: dense sweep, tiled kernel
         if (s->prm.precision == FLUID_PRECISION_FP32) {
-            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<float>(s->st, s->g, fl, (const float*)S, (float*)Q, make_coef<float>(s), mv, mc);
-            else launch_stencil_apply<float>(s->st, s->g, box, fl, (const float*)S, (float*)Q, make_coef<float>(s));
+            if (!(box_mode == 0 && (N >= 192 || mv) && launch_stencil_march<float>(s->st, s->g, fl, (const float*)S, (float*)Q, make_coef<float>(s), mv, mc)))
+                launch_stencil_apply<float>(s->st, s->g, box, fl, (const float*)S, (float*)Q, make_coef<float>(s));
         } else {
-            if (box_mode == 0 && (N >= 192 || mv)) launch_stencil_march<double>(s->st, s->g, fl, (const double*)S, (double*)Q, make_coef<double>(s), mv, mc);
-            else launch_stencil_apply<double>(s->st, s->g, box, fl, (const double*)S, (double*)Q, make_coef<double>(s));
+            if (!(box_mode == 0 && (N >= 192 || mv) && launch_stencil_march<double>(s->st, s->g, fl, (const double*)S, (double*)Q, make_coef<double>(s), mv, mc)))
+                launch_stencil_apply<double>(s->st, s->g, box, fl, (const double*)S, (double*)Q, make_coef<double>(s));
         }
     }
     HIPCHK(hipEventRecord(e1, s->st));

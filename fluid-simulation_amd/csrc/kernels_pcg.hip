@@ -26,19 +26,6 @@
 
 namespace fl {
 
-// static indices only: a runtime index into a by-value kernel argument would go through scratch
-template <typename T>
-__device__ __forceinline__ void load_coef(T* sdiag, T* sinv, const Coef<T>& cf)
-{
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            sdiag[i] = cf.diag[i];
-            sinv[i] = cf.inv[i];
-        }
-    }
-}
-
 // ================================================================================================
 // Box-local PCG
 // ================================================================================================
@@ -225,7 +212,7 @@ __device__ __forceinline__ bool pcg_head(const double* __restrict__ part_rr, con
 // of halo cells next to the owned ones (z and s are valid there, so s' is formed there too and no exchange of s' is
 // needed) and is 0 beyond; q and the partial s'.q are formed on the owned cells only.  The scalars are single
 // all-reduced values (n_prev = n_rz = 1).
-template <typename T, bool DIST>
+template <typename T, bool DIST, bool AZ = false>
 __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
                                                   const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
@@ -291,7 +278,9 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     T beta = 0;
     __syncthreads();  // s_done, coef tables
     if (s_done) return;
-    if (!pcg_head<T>(part_rr, part_rz_new, part_rz_old, n_prev, n_rz, ps, first, tol, red, beta)) return;
+    // AZ (Chronopoulos-Gear form of the decomposed solve): q = A r and the partials of r.q only — no scalars to derive, s_in unread
+    // (the caller passes first = 1), s_out unwritten
+    if (!AZ && !pcg_head<T>(part_rr, part_rz_new, part_rz_old, n_prev, n_rz, ps, first, tol, red, beta)) return;
 
     double acc = 0;
     while (tile < ntiles) {
@@ -346,7 +335,7 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
                 qv = sdiag[fcc[lx]] * cen[lx] + cf.off * nbv[lx];
                 acc += (double)cen[lx] * (double)qv;
             }
-            s_out[c] = cen[lx];
+            if (!AZ) s_out[c] = cen[lx];
             q[c] = qv;
         }
         tile = next;
@@ -371,6 +360,105 @@ __global__ __launch_bounds__(256) void k_sum2(const double* __restrict__ a, int 
         out_a[0] = ra;
         if (out_b) out_b[0] = rb;
     }
+}
+
+// out[0..3] = the sums of four partial arrays (one block; fixed order; an array with n = 0 gives 0)
+__global__ __launch_bounds__(256) void k_sum4(const double* __restrict__ a, int na, const double* __restrict__ b, int nb, const double* __restrict__ c, int nc,
+                                              const double* __restrict__ e, int ne, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    double ra, rb, rc, re, d1, d2;
+    block_sum3(a, na, b, nb, c, nc, red, ra, rb, rc);
+    __syncthreads();
+    block_sum3(e, ne, e, 0, e, 0, red, re, d1, d2);
+    if (threadIdx.x == 0) { out[0] = ra; out[1] = rb; out[2] = rc; out[3] = re; }
+}
+
+// Chronopoulos-Gear form of the preconditioned CG loop (decomposed solve, FLUID_DIST_CG=cgear): with z = M^-1 r and w = A z
+// already formed, ONE all-reduce carries {|r|^2, gamma = r.z, delta = w.z} of the iteration (g[0..2]; g[3] = |r0|^2 of a solve
+// started from a guess), and this kernel does the rest of the body in one stream over the local box:
+//   beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)
+//   s = z + beta s ; q = w + beta q  (= A s by recurrence) ; x += alpha s ; r -= alpha q ; partial |r|^2
+// on the owned unknowns (count byte non-zero, bit 7 clear).  Same start, stopping rule and iteration count as pcg_head
+// (ConjugateGradient.h:28-90); in exact arithmetic the same iterates.  cg = {gamma, alpha} of the last two bodies, by parity.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcg_cgear_upd(long n2, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r, T* __restrict__ s,
+                                                       T* __restrict__ q, const T* __restrict__ z, const T* __restrict__ w, const double* __restrict__ g,
+                                                       double* __restrict__ cg, int cur, double* __restrict__ part_rr, PcgState* ps, int first, double tol)
+{
+    __shared__ double red[16];
+    __shared__ int s_done;
+    if (threadIdx.x == 0) s_done = ps->done;
+    typedef Vec2<T> V2;
+    const uint16_t* c2 = (const uint16_t*)cnt;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const long per = (n2 + gridDim.x - 1) / gridDim.x;
+    const long e0 = (long)vb * per, e1 = e0 + per < n2 ? e0 + per : n2;
+    __syncthreads();
+    if (s_done) return;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const double gamma = g[1], delta = g[2];
+    double beta = 0, alpha;
+    if (first) {
+        const double bb = g[0], rr0 = first == 2 ? g[3] : bb;
+        const bool go = bb > 0 && !(rr0 < tol * tol * bb);
+        if (lead) {
+            ps->bb = bb;
+            ps->thr = tol * tol * bb;
+            ps->rr = rr0;
+            if (!go) ps->done = 1;
+        }
+        if (!go) return;
+        alpha = gamma / delta;
+        if (!(delta > 0) || !(gamma == gamma)) {
+            if (lead) { ps->breakdown = 1; ps->done = 1; }
+            return;
+        }
+    } else {
+        const double rr = g[0];
+        if (rr < ps->thr) {
+            if (lead) { ps->rr = rr; ps->done = 1; }
+            return;
+        }
+        const double go = cg[2 * (cur ^ 1)], ao = cg[2 * (cur ^ 1) + 1];
+        beta = gamma / go;
+        const double den = delta - beta * gamma / ao;      // = s.As of the standard recurrence
+        if (!(den > 0) || !(gamma == gamma)) {
+            if (lead) { ps->breakdown = 1; ps->done = 1; }
+            return;
+        }
+        alpha = gamma / den;
+        if (lead) { ps->rr = rr; ps->iters += 1; }
+    }
+    if (lead) { cg[2 * cur] = gamma; cg[2 * cur + 1] = alpha; }
+    const T be = (T)beta, al = (T)alpha;
+    double arr = 0;
+    for (long i = e0 + threadIdx.x; i < e1; i += 256) {
+        const uint16_t cw = c2[i];
+        int ca = cw & 0xff, cb = cw >> 8;
+        ca = (ca & 0x80) ? 0 : ca;
+        cb = (cb & 0x80) ? 0 : cb;
+        if (!(ca | cb)) continue;
+        const V2 zv = ((const V2*)z)[i], wv = ((const V2*)w)[i];
+        V2 sv = ((V2*)s)[i], qv = ((V2*)q)[i], xv = ((V2*)x)[i], rv = ((V2*)r)[i];
+        if (ca) {
+            sv.a = zv.a + be * sv.a;
+            qv.a = wv.a + be * qv.a;
+            xv.a = xv.a + al * sv.a;
+            rv.a = rv.a - al * qv.a;
+            arr += (double)rv.a * (double)rv.a;
+        }
+        if (cb) {
+            sv.b = zv.b + be * sv.b;
+            qv.b = wv.b + be * qv.b;
+            xv.b = xv.b + al * sv.b;
+            rv.b = rv.b - al * qv.b;
+            arr += (double)rv.b * (double)rv.b;
+        }
+        ((V2*)s)[i] = sv; ((V2*)q)[i] = qv; ((V2*)x)[i] = xv; ((V2*)r)[i] = rv;
+    }
+    arr = block_sum<double, 4>(arr, red);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = arr;
 }
 
 // XR: alpha, x += alpha s, r -= alpha q, partial |r|^2 and r.(invdiag r)   (ConjugateGradient.h:70-74,79-81)
@@ -745,6 +833,24 @@ void launch_pcg_xr_dist(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, 
     hipLaunchKernelGGL((k_pcg_xr_l<T, false>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, cf, g_rz_cur, 1,
                        g_pq, 1, part_rr, part_rz_next, ps, 1);
 }
+void launch_sum4(hipStream_t st, const double* a, int na, const double* b, int nb, const double* c, int nc, const double* e, int ne, double* out)
+{
+    hipLaunchKernelGGL(k_sum4, dim3(1), dim3(256), 0, st, a, na, b, nb, c, nc, e, ne, out);
+}
+// Chronopoulos-Gear form (decomposed solve): w = A z on the owned cells + pcg_sq_blocks(L) partials of z.w ...
+template <typename T>
+void launch_pcg_az_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* z, T* w, Coef<T> cf, double* part_zw, PcgState* ps)
+{
+    hipLaunchKernelGGL((k_pcg_sq_l<T, true, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, z, (const T*)nullptr, (T*)nullptr, w, cf, (const double*)nullptr,
+                       (const double*)nullptr, (const double*)nullptr, part_zw, 1, ps, 1, 0.0, 1, 1, 0, (const int*)nullptr, 0);
+}
+// ... and the rest of the body from the all-reduced scalars g; writes pcg_xr_blocks(L) partials of |r|^2
+template <typename T>
+void launch_pcg_cgear_upd(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, T* s, T* q, const T* z, const T* w, const double* g, double* cg, int cur,
+                          double* part_rr, PcgState* ps, int first, double tol)
+{
+    hipLaunchKernelGGL((k_pcg_cgear_upd<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, z, w, g, cg, cur, part_rr, ps, first, tol);
+}
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b)
 {
     hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, st, a, na, b, nb, out_a, out_b);
@@ -913,790 +1019,6 @@ __global__ __launch_bounds__(256) void k_stencil_g(Grid g, Box box, Tiles tl, co
     }
 }
 
-// ---- dense sweep, x-marching ("2.5D") ------------------------------------------------------------
-// One block = footprint MY x MZ in (y,z), marched through a chunk of x planes.  The x
-// neighbours of a cell stay in the thread's registers (s at x-1, x, x+1), the y/z neighbours
-// come from ONE double-buffered LDS plane, so each s value is fetched once per block (+ the
-// 1-cell y/z rim, served by L2 when neighbouring footprints share an XCD) and there is one
-// barrier per plane.  Loads run D planes ahead of use to keep ~64 KB per CU in flight.
-constexpr int MZ = 64;
-
-template <typename T, int MY, int MD>
-__global__ __launch_bounds__(MY * 64) void k_stencil_march(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
-                                                       const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
-{
-    __shared__ T pl[2][MY + 2][MZ + 2];
-    __shared__ T sdiag[8], sinv[8];
-    const int tid = threadIdx.x, wy = tid >> 6, lz = tid & 63;
-    load_coef(sdiag, sinv, cf);
-    const int N = g.N;
-    const long sx = (long)N * N;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int tz = vb % ntz, ty = (vb / ntz) % nty, cx = vb / (ntz * nty);
-    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
-    const int y = ty * MY + wy, z = tz * MZ + lz;
-    const bool cv = y < N && z < N;
-    const long col = (long)y * N + z;
-    // rim duty: threads 0..127 the two y rows, 128..143 the 2 x MY z cells
-    int hy = -1, hz = -1, hly = 0, hlz = 0;
-    if (tid < 128) {
-        const int r = tid >> 6;
-        hy = r ? ty * MY + MY : ty * MY - 1;
-        hz = tz * MZ + (tid & 63);
-        hly = r ? MY + 1 : 0;
-        hlz = (tid & 63) + 1;
-    } else if (tid < 128 + 2 * MY) {
-        const int k = tid - 128, r = k >> 1, side = k & 1;
-        hy = ty * MY + r;
-        hz = side ? tz * MZ + MZ : tz * MZ - 1;
-        hly = r + 1;
-        hlz = side ? MZ + 1 : 0;
-    }
-    const bool hduty = tid < 128 + 2 * MY;
-    const bool hv = hduty && hy >= 0 && hy < N && hz >= 0 && hz < N;
-    const long hcol = (long)hy * N + hz;
-    auto ld = [&](int x, long colx, bool ok, T& val, uint8_t& f) {
-        if (ok && x >= 0 && x < N && x <= xe) {   // plane xe is the last one this chunk reads (x+ neighbour of its last plane)
-            const long c = (long)x * sx + colx;
-            f = flags[c];
-            val = s[c];
-        } else {
-            f = 0;
-            val = 0;
-        }
-    };
-    auto mk = [](T v, uint8_t f) { return ((f & F_FLUID) && (f >> F_CNT_SHIFT)) ? v : (T)0; };
-    T vm1, v0, hv0;
-    uint8_t fm1, f0, hf0;
-    ld(xa - 1, col, cv, vm1, fm1);
-    ld(xa, col, cv, v0, f0);
-    ld(xa, hcol, hv, hv0, hf0);
-    T qv[MD], hq[MD];
-    uint8_t qf[MD], hqf[MD];
-#pragma unroll
-    for (int d = 0; d < MD; ++d) {
-        ld(xa + 1 + d, col, cv, qv[d], qf[d]);
-        ld(xa + 1 + d, hcol, hv, hq[d], hqf[d]);
-    }
-    T sm1 = mk(vm1, fm1), s0 = mk(v0, f0), h0 = mk(hv0, hf0);
-    __syncthreads();  // coef tables
-    for (int xb = xa; xb < xe; xb += MD) {
-#pragma unroll
-        for (int d = 0; d < MD; ++d) {
-            const int x = xb + d;
-            if (x < xe) {  // block-uniform
-                const int buf = x & 1;
-                pl[buf][wy + 1][lz + 1] = s0;
-                if (hduty) pl[buf][hly][hlz] = h0;
-                __syncthreads();
-                const T sp1 = mk(qv[d], qf[d]);
-                if (cv) {
-                    T out = 0;
-                    if ((f0 & F_FLUID) && (f0 >> F_CNT_SHIFT)) {
-                        const T nb = sm1 + sp1 + pl[buf][wy][lz + 1] + pl[buf][wy + 2][lz + 1] + pl[buf][wy + 1][lz] + pl[buf][wy + 1][lz + 2];
-                        out = sdiag[f0 >> F_CNT_SHIFT] * s0 + cf.off * nb;
-                    }
-                    __builtin_nontemporal_store(out, &q[(long)x * sx + col]);  // streamed once: keep s, not q, in cache
-                }
-                sm1 = s0;
-                s0 = sp1;
-                f0 = qf[d];
-                h0 = mk(hq[d], hqf[d]);
-                ld(x + 1 + MD, col, cv, qv[d], qf[d]);
-                ld(x + 1 + MD, hcol, hv, hq[d], hqf[d]);
-            }
-        }
-    }
-}
-
-template <typename T, int MY, int MD>
-static void march_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
-{
-    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZ - 1) / MZ, ncx = (g.N + cxlen - 1) / cxlen;
-    hipLaunchKernelGGL((k_stencil_march<T, MY, MD>), dim3(nty * ntz * ncx), dim3(MY * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
-}
-
-// ---- dense sweep, x-marching, 16 bytes per lane ----------------------------------------------------------------------
-// The same march with V = 16 / sizeof(T) cells per lane along z (float: 4, double: 2): a wave covers 64 V cells of a z
-// row with ONE 16-byte load per lane and plane (1 KB per wave instead of 256 B for float), the LDS plane is read and
-// written as 16-byte vectors (y neighbours), the z neighbours inside a lane are registers and across lanes two wave
-// shuffles; lanes 0 / 63 take the cell before / after the wave's z range from a scalar rim load.  Per cell: 1/V LDS
-// write, 2/V LDS reads, 2/V shuffles instead of 1 write + 4 reads — the scalar float kernel was bound by exactly that
-// (54 % of the HBM peak against 75-80 % for double).  Needs N % V == 0 (rows 16-byte aligned); same term order as the scalar
-// kernel (x-, x+, y-, y+, z-, z+), so the results are bit-identical.
-
-template <typename T, int MY, int MD>
-__global__ __launch_bounds__(MY * 64) void k_stencil_vec(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
-                                                          const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    typedef typename VecT<T, V>::type vec;
-    typedef typename FlagT<V>::type fvec;
-    __shared__ __attribute__((aligned(16))) T pl[2][MY + 2][MZV];
-    __shared__ T sdiag[8], sinv[8];
-    const int tid = threadIdx.x, wy = tid >> 6, lane = tid & 63;
-    load_coef(sdiag, sinv, cf);
-    const int N = g.N;
-    const long sx = (long)N * N;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int tz = vb % ntz, ty = (vb / ntz) % nty, cx = vb / (ntz * nty);
-    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
-    const int y = ty * MY + wy, z0 = tz * MZV + lane * V;
-    const bool cv = y < N && z0 < N;                      // N % V == 0: a lane's cells are all inside or all outside
-    const long col = (long)y * N + z0;
-    // rim rows: waves 0 and 1 also carry the row below / above the footprint
-    const int hy = wy == 0 ? ty * MY - 1 : ty * MY + MY;
-    const bool hduty = wy < 2;
-    const bool hv = hduty && hy >= 0 && hy < N && z0 < N;
-    const long hcol = (long)hy * N + z0;
-    // z rim: lane 0 the cell before the wave's range, lane 63 the cell after it
-    const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
-    const bool rduty = lane == 0 || lane == 63;
-    const bool rv = rduty && y < N && rz >= 0 && rz < N;
-    const long rcol = (long)y * N + rz;
-    auto act = [](uint8_t f) { return (f & F_FLUID) && (f >> F_CNT_SHIFT); };
-    auto ldv = [&](int x, long colx, bool ok, vec& val, fvec& f) {
-        if (ok && x >= 0 && x < N && x <= xe) {   // plane xe is the last one this chunk reads
-            const long c = (long)x * sx + colx;
-            f = *reinterpret_cast<const fvec*>(flags + c);
-            val = *reinterpret_cast<const vec*>(s + c);
-        } else {
-            f = 0;
-            val = (vec)(T)0;
-        }
-    };
-    auto lds1 = [&](int x, long colx, bool ok, T& val, uint8_t& f) {
-        if (ok && x >= 0 && x < N && x <= xe) {
-            const long c = (long)x * sx + colx;
-            f = flags[c];
-            val = s[c];
-        } else {
-            f = 0;
-            val = 0;
-        }
-    };
-    auto mkv = [&](vec v, fvec f) {
-        vec o;
-#pragma unroll
-        for (int c = 0; c < V; ++c) o[c] = act((uint8_t)(f >> (8 * c))) ? v[c] : (T)0;
-        return o;
-    };
-    vec vm1, v0, hv0;
-    fvec fm1, f0, hf0;
-    T r0;
-    uint8_t rf0;
-    ldv(xa - 1, col, cv, vm1, fm1);
-    ldv(xa, col, cv, v0, f0);
-    ldv(xa, hcol, hv, hv0, hf0);
-    lds1(xa, rcol, rv, r0, rf0);
-    vec qv[MD], hq[MD];
-    fvec qf[MD], hqf[MD];
-    T rq[MD];
-    uint8_t rqf[MD];
-#pragma unroll
-    for (int d = 0; d < MD; ++d) {
-        ldv(xa + 1 + d, col, cv, qv[d], qf[d]);
-        ldv(xa + 1 + d, hcol, hv, hq[d], hqf[d]);
-        lds1(xa + 1 + d, rcol, rv, rq[d], rqf[d]);
-    }
-    vec sm1 = mkv(vm1, fm1), s0 = mkv(v0, f0), h0 = mkv(hv0, hf0);
-    T rim = act(rf0) ? r0 : (T)0;
-    __syncthreads();  // coef tables
-    for (int xb = xa; xb < xe; xb += MD) {
-#pragma unroll
-        for (int d = 0; d < MD; ++d) {
-            const int x = xb + d;
-            if (x < xe) {  // block-uniform
-                const int buf = x & 1;
-                *reinterpret_cast<vec*>(&pl[buf][wy + 1][lane * V]) = s0;
-                if (hduty) *reinterpret_cast<vec*>(&pl[buf][wy == 0 ? 0 : MY + 1][lane * V]) = h0;
-                __syncthreads();
-                const vec sp1 = mkv(qv[d], qf[d]);
-                if (cv) {
-                    const vec up = *reinterpret_cast<const vec*>(&pl[buf][wy][lane * V]);
-                    const vec dn = *reinterpret_cast<const vec*>(&pl[buf][wy + 2][lane * V]);
-                    T left = __shfl_up(s0[V - 1], 1, 64), right = __shfl_down(s0[0], 1, 64);
-                    if (lane == 0) left = rim;
-                    if (lane == 63) right = rim;
-                    vec out;
-#pragma unroll
-                    for (int c = 0; c < V; ++c) {
-                        const uint8_t fc = (uint8_t)(f0 >> (8 * c));
-                        const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
-                        const T nb = sm1[c] + sp1[c] + up[c] + dn[c] + zl + zr;
-                        out[c] = act(fc) ? sdiag[fc >> F_CNT_SHIFT] * s0[c] + cf.off * nb : (T)0;
-                    }
-                    __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sx + col]));  // streamed once: keep s, not q, in cache
-                }
-                sm1 = s0;
-                s0 = sp1;
-                f0 = qf[d];
-                h0 = mkv(hq[d], hqf[d]);
-                rim = act(rqf[d]) ? rq[d] : (T)0;
-                ldv(x + 1 + MD, col, cv, qv[d], qf[d]);
-                ldv(x + 1 + MD, hcol, hv, hq[d], hqf[d]);
-                lds1(x + 1 + MD, rcol, rv, rq[d], rqf[d]);
-            }
-        }
-    }
-}
-
-template <typename T, int MY, int MD>
-static void vec_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZV - 1) / MZV, ncx = (g.N + cxlen - 1) / cxlen;
-    hipLaunchKernelGGL((k_stencil_vec<T, MY, MD>), dim3(nty * ntz * ncx), dim3(MY * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
-}
-
-// ---- dense sweep, x-marching, independent waves ("rows") ---------------------------------------------------------------
-// Measured from HBM (launches rotating over > 1 GiB of operands, fluid_stencil_apply_hbm) the LDS-plane marches above reach
-// 53-59 % of the peak where a plain copy of the same arrays with the flag stream reaches 72-75 %: a block's waves are
-// coupled by one barrier per plane (the slowest load of 16 waves sets the pace, and HBM latency varies far more than the
-// Infinity Cache's), and every block re-reads a rim that its neighbours own.  Here a WAVE is the unit: it owns R
-// consecutive z rows (V = 16 / sizeof(T) cells per lane, 64 V cells per row segment) and marches them through a chunk
-// of x planes; per plane it loads rows y0-1 .. y0+R itself, 16 bytes per lane each — the two outer rows are some other
-// wave's own rows, fetched at about the same time, so they come from L2 — keeps the x neighbours in registers and takes
-// the z neighbours inside a lane from registers, across lanes from two shuffles.  No LDS plane, no barrier in the loop:
-// every wave streams like a copy loop with MD planes in flight.  Same term order as the other forms (bit-identical).
-template <typename T, int R, int MD>
-__global__ __launch_bounds__(256) void k_stencil_rows(Grid g, int cxlen, int nyg, int ntz, const uint8_t* __restrict__ flags,
-                                                      const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    typedef typename VecT<T, V>::type vec;
-    typedef typename FlagT<V>::type fvec;
-    __shared__ T sdiag[8], sinv[8];
-    load_coef(sdiag, sinv, cf);
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int N = g.N;
-    const long sx = (long)N * N;
-    // wave id: blocks dealt XCD-contiguously, the 4 waves of a block are neighbours in (z, y)
-    const int w = xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
-    const int tz = w % ntz, yg = (w / ntz) % nyg, cx = w / (ntz * nyg);
-    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
-    if (xa >= N) return;
-    const int y0 = yg * R, z0 = tz * MZV + lane * V;
-    const bool zin = z0 < N;   // N % V == 0: a lane's cells are all inside or all outside
-    // z rim of the wave's segment: lane 0 the cell before it, lane 63 the cell after it
-    const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
-    const bool rduty = (lane == 0 || lane == 63) && rz >= 0 && rz < N;
-    auto act = [](uint8_t f) { return (f & F_FLUID) && (f >> F_CNT_SHIFT); };
-    auto mkv = [&](vec v, fvec f) {
-        vec o;
-#pragma unroll
-        for (int c = 0; c < V; ++c) o[c] = act((uint8_t)(f >> (8 * c))) ? v[c] : (T)0;
-        return o;
-    };
-    struct Plane {
-        vec v[R + 2];     // rows y0-1 .. y0+R
-        fvec f[R + 2];
-        T rv[R];          // rim cells of the own rows
-        uint8_t rf[R];
-    };
-    auto load = [&](int x, Plane& P) {
-        const bool xok = x >= 0 && x < N && x <= xe;
-#pragma unroll
-        for (int j = 0; j < R + 2; ++j) {
-            const int y = y0 - 1 + j;
-            if (xok && zin && y >= 0 && y < N) {
-                const long c = (long)x * sx + (long)y * N + z0;
-                P.f[j] = *reinterpret_cast<const fvec*>(flags + c);
-                P.v[j] = *reinterpret_cast<const vec*>(s + c);
-            } else {
-                P.f[j] = 0;
-                P.v[j] = (vec)(T)0;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int y = y0 + j;
-            if (xok && rduty && y < N) {
-                const long c = (long)x * sx + (long)y * N + rz;
-                P.rf[j] = flags[c];
-                P.rv[j] = s[c];
-            } else {
-                P.rf[j] = 0;
-                P.rv[j] = 0;
-            }
-        }
-    };
-    Plane A[MD];
-    vec sm1[R], cen[R + 2];
-    fvec f0[R];
-    T rim[R];
-    {
-        Plane P;
-        load(xa - 1, P);
-#pragma unroll
-        for (int j = 0; j < R; ++j) sm1[j] = mkv(P.v[j + 1], P.f[j + 1]);
-        load(xa, P);
-#pragma unroll
-        for (int j = 0; j < R + 2; ++j) cen[j] = mkv(P.v[j], P.f[j]);
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            f0[j] = P.f[j + 1];
-            rim[j] = act(P.rf[j]) ? P.rv[j] : (T)0;
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < MD; ++d) load(xa + 1 + d, A[d]);
-    for (int xb = xa; xb < xe; xb += MD) {
-#pragma unroll
-        for (int d = 0; d < MD; ++d) {
-            const int x = xb + d;
-            if (x < xe) {  // wave-uniform
-                vec nxt[R + 2];
-#pragma unroll
-                for (int j = 0; j < R + 2; ++j) nxt[j] = mkv(A[d].v[j], A[d].f[j]);
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const vec s0 = cen[j + 1], up = cen[j], dn = cen[j + 2], sp1 = nxt[j + 1];
-                    T left = __shfl_up(s0[V - 1], 1, 64), right = __shfl_down(s0[0], 1, 64);
-                    if (lane == 0) left = rim[j];
-                    if (lane == 63) right = rim[j];
-                    vec out;
-#pragma unroll
-                    for (int c = 0; c < V; ++c) {
-                        const uint8_t fc = (uint8_t)(f0[j] >> (8 * c));
-                        const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
-                        const T nb = sm1[j][c] + sp1[c] + up[c] + dn[c] + zl + zr;
-                        out[c] = act(fc) ? sdiag[fc >> F_CNT_SHIFT] * s0[c] + cf.off * nb : (T)0;
-                    }
-                    if (zin && y0 + j < N) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sx + (long)(y0 + j) * N + z0]));
-                    sm1[j] = s0;
-                    f0[j] = A[d].f[j + 1];
-                    rim[j] = act(A[d].rf[j]) ? A[d].rv[j] : (T)0;
-                }
-#pragma unroll
-                for (int j = 0; j < R + 2; ++j) cen[j] = nxt[j];
-                load(x + 1 + MD, A[d]);
-            }
-        }
-    }
-}
-
-template <typename T, int R, int MD>
-static void rows_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    const int nyg = (g.N + R - 1) / R, ntz = (g.N + MZV - 1) / MZV, ncx = (g.N + cxlen - 1) / cxlen;
-    const long waves = (long)nyg * ntz * ncx;
-    hipLaunchKernelGGL((k_stencil_rows<T, R, MD>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, cxlen, nyg, ntz, flags, s, q, cf);
-}
-
-// ---- dense sweep, x-marching, lean ("lean") -----------------------------------------------------------------------------
-// The marches above spend ~70 instructions per cell, half of them scalar branches (every guarded load and every
-// `active ? .. : 0` became a branch): from HBM they stop at 53-59 % of the peak where a copy of the same bytes reaches
-// 72-75 % (tools/sweep.py 256 hbm).  Same data flow as k_stencil_vec — one row of 64 V cells per wave and plane, x
-// neighbours in registers, y neighbours through one double-buffered LDS plane, one barrier per plane — rebuilt for a
-// short instruction stream:
-//   * loads are unconditional, from clamped addresses; what lies outside the grid is masked, planes outside the
-//     chunk's reach are skipped by ONE wave-uniform branch;
-//   * the "unknown" predicate of the V flag bytes of a lane is formed on the packed word (SWAR) and expanded to one
-//     all-ones / zero word per cell (v_bfe_i32); values are masked by AND, results too: no per-cell branch;
-//   * the rim rows (y0 - 1, y0 + MY) belong to two EXTRA waves that only load, mask and publish them, so no wave of the
-//     block carries two rows to the barrier;
-//   * z neighbours across lanes by DPP wave shifts (zero fill at the wave's ends = the grid's edge when a row is one
-//     wave's width; else lanes 0 / 63 load the two rim cells).
-// Same term order as the other forms: bit-identical results.
-template <typename T>
-__device__ __forceinline__ T dpp_wave_shr1(T v)   // lane i <- lane i-1, lane 0 <- 0
-{
-    if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-    } else {
-        const long long b = __builtin_bit_cast(long long, v);
-        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, true);
-        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, true);
-        return __builtin_bit_cast(T, ((long long)hi << 32) | lo);
-    }
-}
-template <typename T>
-__device__ __forceinline__ T dpp_wave_shl1(T v)   // lane i <- lane i+1, lane 63 <- 0
-{
-    if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-    } else {
-        const long long b = __builtin_bit_cast(long long, v);
-        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x130, 0xf, 0xf, true);
-        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x130, 0xf, 0xf, true);
-        return __builtin_bit_cast(T, ((long long)hi << 32) | lo);
-    }
-}
-
-// AXIS = the axis of the march: 0 = x (a wave steps from plane to plane: successive loads of a wave lie N^2 elements apart),
-// 1 = y (a wave owns one z row segment of ONE x plane and walks it row by row: its loads are one contiguous stream of N-element
-// rows; the waves of a block are MY neighbouring x planes and exchange the x neighbours through the LDS plane, the y neighbours
-// stay in registers).  The sum keeps the order x-, x+, y-, y+, z-, z+ either way.
-// MODE 1 (probe): q = masked s with the same loads, stores and march, no LDS, barrier or arithmetic.
-template <typename T, int MY, int MD, int MODE = 0, int AXIS = 0, bool RIMS = false>
-__global__ __launch_bounds__((MY + 2) * 64) void k_stencil_lean(Grid g, int cxlen, int nty, int ntz, const uint8_t* __restrict__ flags,
-                                                                const T* __restrict__ s, T* __restrict__ q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    typedef typename VecT<T, V>::type vec;
-    typedef typename FlagT<V>::type fvec;
-    __shared__ __attribute__((aligned(16))) T pl[2][MY + 2][MZV];
-    __shared__ T sdiag[8], sinv[8];
-    const int tid = threadIdx.x, wy = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    load_coef(sdiag, sinv, cf);
-    const int N = g.N;
-    const long sm = AXIS == 0 ? (long)N * N : (long)N;   // stride of the march axis (index m below)
-    const long sr = AXIS == 0 ? (long)N : (long)N * N;   // stride of the row axis (index r: the waves of a block)
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int tz = vb % ntz, ty = (vb / ntz) % nty, cx = vb / (ntz * nty);
-    const int xa = cx * cxlen, xe = xa + cxlen < N ? xa + cxlen : N;
-    const int xlast = xe < N ? xe : N - 1;          // last march index anybody of this chunk reads
-    const bool own = wy < MY;                       // waves MY, MY+1: the rim rows
-    const int y = own ? ty * MY + wy : (wy == MY ? ty * MY - 1 : ty * MY + MY);
-    const int lrow = own ? wy + 1 : (wy == MY ? 0 : MY + 1);
-    const int z0 = tz * MZV + lane * V;
-    const bool cv = y >= 0 && y < N && z0 < N;      // N % V == 0: a lane's cells are all inside or all outside
-    const unsigned cvm = cv ? 0xFFFFFFFFu : 0u;
-    const long col = (long)min(max(y, 0), N - 1) * sr + min(z0, N - V);
-    // z rim (only when a row is wider than one wave): lane 0 the cell before the wave's range, lane 63 the cell after it
-    const int rz = lane < 32 ? tz * MZV - 1 : tz * MZV + MZV;
-    const bool rv = own && (lane == 0 || lane == 63) && y < N && rz >= 0 && rz < N;
-    const long rcol = (long)min(max(y, 0), N - 1) * sr + min(max(rz, 0), N - 1);
-    // per-cell masks (all ones / zero) of a packed flag word: unknown = fluid and at least one non-solid neighbour
-    auto active_bits = [](unsigned w) { return (w >> 1) & ((((w >> 2) & 0x07070707u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u; };
-    auto mkv = [&](vec v, unsigned a) {
-        vec o;
-#pragma unroll
-        for (int c = 0; c < V; ++c) o[c] = and_mask<T>(v[c], __builtin_amdgcn_sbfe((int)a, 8 * c, 1));
-        return o;
-    };
-    // Loads are unconditional and their results are masked only where they are consumed: a select right behind a load (or a load
-    // inside a branch) makes the compiler wait for it at once, and the MD planes in flight collapse to one.
-    auto ldp = [&](int x, vec& v, unsigned& w) {   // one step of this wave's row: x is wave-uniform
-        const long c = (long)min(max(x, 0), xlast) * sm + col;
-        w = (unsigned)*reinterpret_cast<const fvec*>(flags + c);
-        v = *reinterpret_cast<const vec*>(s + c);
-    };
-    auto okw = [&](int x, unsigned w) { return x >= 0 && x <= xlast ? w & cvm : 0u; };
-    auto ldr = [&](int x, T& v, unsigned& f) {     // the rim cell of lanes 0 / 63 (every lane loads: no branch)
-        v = 0;
-        f = 0;
-        if constexpr (RIMS) {
-            const long c = (long)min(max(x, 0), xlast) * sm + rcol;
-            f = flags[c];
-            v = s[c];
-        }
-    };
-    auto okr = [&](int x, unsigned f) { return rv && x >= 0 && x <= xlast ? f : 0u; };
-    vec vm1, v0;
-    unsigned wm1, w0, rf0;
-    T r0;
-    ldp(xa - 1, vm1, wm1);
-    ldp(xa, v0, w0);
-    ldr(xa, r0, rf0);
-    vec qv[MD];
-    unsigned qw[MD], rqf[MD];
-    T rq[MD];
-#pragma unroll
-    for (int d = 0; d < MD; ++d) {
-        ldp(xa + 1 + d, qv[d], qw[d]);
-        ldr(xa + 1 + d, rq[d], rqf[d]);
-    }
-    w0 = okw(xa, w0);
-    vec sm1 = mkv(vm1, active_bits(okw(xa - 1, wm1))), s0 = mkv(v0, active_bits(w0));
-    T rim = and_mask<T>(r0, __builtin_amdgcn_sbfe((int)active_bits(okr(xa, rf0)), 0, 1));
-    const T off = cf.off;
-    __syncthreads();  // coef table
-    // one step of the march; d = the slot of the ring that holds step x+1 and is refilled with step x+1+MD
-    auto step = [&](int x, vec& nv, unsigned& nw, T& nr, unsigned& nrf) {
-        const int buf = x & 1;
-        const unsigned wn = okw(x + 1, nw);
-        if (MODE == 1) {
-            if (own && cv) __builtin_nontemporal_store(s0, reinterpret_cast<vec*>(&q[(long)x * sm + col]));
-            s0 = mkv(nv, active_bits(wn));
-            ldp(x + 1 + MD, nv, nw);
-            return;
-        }
-        *reinterpret_cast<vec*>(&pl[buf][lrow][lane * V]) = s0;
-        __syncthreads();
-        const unsigned an = active_bits(wn);
-        const vec sp1 = mkv(nv, an);
-        if (own) {   // wave-uniform
-            const vec up = *reinterpret_cast<const vec*>(&pl[buf][lrow - 1][lane * V]);
-            const vec dn = *reinterpret_cast<const vec*>(&pl[buf][lrow + 1][lane * V]);
-            T left = dpp_wave_shr1<T>(s0[V - 1]), right = dpp_wave_shl1<T>(s0[0]);
-            if (RIMS) {
-                left = lane == 0 ? rim : left;
-                right = lane == 63 ? rim : right;
-            }
-            const unsigned a0 = active_bits(w0);
-            vec out;
-#pragma unroll
-            for (int c = 0; c < V; ++c) {
-                const T zl = c ? s0[c > 0 ? c - 1 : 0] : left, zr = c < V - 1 ? s0[c < V - 1 ? c + 1 : 0] : right;
-                const T nb = AXIS == 0 ? sm1[c] + sp1[c] + up[c] + dn[c] + zl + zr : up[c] + dn[c] + sm1[c] + sp1[c] + zl + zr;
-                const T r = sdiag[__builtin_amdgcn_ubfe(w0, 8 * c + F_CNT_SHIFT, 3)] * s0[c] + off * nb;
-                out[c] = and_mask<T>(r, __builtin_amdgcn_sbfe((int)a0, 8 * c, 1));
-            }
-            if (cv) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[(long)x * sm + col]));  // streamed once: keep s, not q, in cache
-        }
-        sm1 = s0;
-        s0 = sp1;
-        w0 = wn;
-        rim = and_mask<T>(nr, __builtin_amdgcn_sbfe((int)active_bits(okr(x + 1, nrf)), 0, 1));
-        ldp(x + 1 + MD, nv, nw);
-        ldr(x + 1 + MD, nr, nrf);
-    };
-    // whole rounds of the ring run unguarded: a guard inside the round is a path on which the newest load is the next one
-    // consumed, and the compiler then drains the queue at every step
-    int xb = xa;
-    for (; xb + MD <= xe; xb += MD) {
-#pragma unroll
-        for (int d = 0; d < MD; ++d) step(xb + d, qv[d], qw[d], rq[d], rqf[d]);
-    }
-#pragma unroll
-    for (int d = 0; d < MD; ++d)
-        if (xb + d < xe) step(xb + d, qv[d], qw[d], rq[d], rqf[d]);   // block-uniform
-}
-
-template <typename T, int MY, int MD, int MODE = 0, int AXIS = 0>
-static void lean_launch(hipStream_t st, Grid g, int cxlen, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZV - 1) / MZV, ncx = (g.N + cxlen - 1) / cxlen;
-    if (ntz > 1)
-        hipLaunchKernelGGL((k_stencil_lean<T, MY, MD, MODE, AXIS, true>), dim3(nty * ntz * ncx), dim3((MY + 2) * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
-    else
-        hipLaunchKernelGGL((k_stencil_lean<T, MY, MD, MODE, AXIS, false>), dim3(nty * ntz * ncx), dim3((MY + 2) * 64), 0, st, g, cxlen, nty, ntz, flags, s, q, cf);
-}
-
-// ---- dense sweep with a linear front ("front") -------------------------------------------------------------------------
-// No march: a wave computes ONE z row of ONE plane and loads the five rows it needs itself — centre, y-1, y+1 (its sibling
-// waves' centres: L1), x-1, x+1 (the rows the same position of the neighbouring planes: L2 / Infinity Cache, fetched a moment ago
-// or a moment later by the blocks of those planes).  Blocks are numbered in MEMORY order and NOT regrouped per XCD, so the chip
-// works on a front of a few consecutive planes and HBM sees one linear read stream and one linear write stream — what the
-// copy has and every march lacks (thousands of 4-16 KB pieces advancing at once).  Price: ~3x the L2 read traffic.
-template <typename T, int MY>
-__global__ __launch_bounds__(MY * 64) void k_stencil_front(Grid g, int nty, int ntz, const uint8_t* __restrict__ flags, const T* __restrict__ s,
-                                                            T* __restrict__ q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    typedef typename VecT<T, V>::type vec;
-    typedef typename FlagT<V>::type fvec;
-    __shared__ T sdiag[8], sinv[8];
-    load_coef(sdiag, sinv, cf);
-    const int N = g.N;
-    const long sx = (long)N * N;
-    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
-    const int b = blockIdx.x;
-    const int tz = b % ntz, ty = (b / ntz) % nty, x = b / (ntz * nty);
-    const int y = ty * MY + wy, z0 = tz * MZV + lane * V;
-    const bool cv = y < N && z0 < N;
-    const long c0 = (long)x * sx + (long)min(y, N - 1) * N + min(z0, N - V);
-    auto active_bits = [](unsigned w) { return (w >> 1) & ((((w >> 2) & 0x07070707u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u; };
-    auto row = [&](long c, bool ok, vec& v, unsigned& a) {   // masked values of one row (ok is wave-uniform)
-        if (ok) {
-            const unsigned w = (unsigned)*reinterpret_cast<const fvec*>(flags + c);
-            const vec t = *reinterpret_cast<const vec*>(s + c);
-            a = cv ? active_bits(w) : 0u;
-#pragma unroll
-            for (int k = 0; k < V; ++k) v[k] = and_mask<T>(t[k], __builtin_amdgcn_sbfe((int)a, 8 * k, 1));
-        } else {
-            a = 0;
-            v = (vec)(T)0;
-        }
-    };
-    vec s0, xm, xp, ym, yp;
-    unsigned a0, au;
-    unsigned w0 = cv ? (unsigned)*reinterpret_cast<const fvec*>(flags + c0) : 0u;
-    row(c0, true, s0, a0);
-    row(c0 - sx, x > 0, xm, au);
-    row(c0 + sx, x < N - 1, xp, au);
-    row(c0 - N, y > 0 && y < N, ym, au);
-    row(c0 + N, y < N - 1, yp, au);
-    T left = dpp_wave_shr1<T>(s0[V - 1]), right = dpp_wave_shl1<T>(s0[0]);
-    if (ntz > 1) {   // a row wider than one wave: lanes 0 / 63 fetch the cell before / after the wave's range
-        const int rz = lane == 0 ? tz * MZV - 1 : tz * MZV + MZV;
-        T rim = 0;
-        if ((lane == 0 || lane == 63) && cv && rz >= 0 && rz < N) {
-            const long c = (long)x * sx + (long)y * N + rz;
-            const uint8_t f = flags[c];
-            rim = ((f & F_FLUID) && (f >> F_CNT_SHIFT)) ? s[c] : (T)0;
-        }
-        left = lane == 0 ? rim : left;
-        right = lane == 63 ? rim : right;
-    }
-    __syncthreads();   // coef table
-    vec out;
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const T zl = k ? s0[k > 0 ? k - 1 : 0] : left, zr = k < V - 1 ? s0[k < V - 1 ? k + 1 : 0] : right;
-        const T nb = xm[k] + xp[k] + ym[k] + yp[k] + zl + zr;
-        const T r = sdiag[__builtin_amdgcn_ubfe(w0, 8 * k + F_CNT_SHIFT, 3)] * s0[k] + cf.off * nb;
-        out[k] = and_mask<T>(r, __builtin_amdgcn_sbfe((int)a0, 8 * k, 1));
-    }
-    if (cv) __builtin_nontemporal_store(out, reinterpret_cast<vec*>(&q[c0]));
-}
-template <typename T, int MY>
-static void front_launch(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
-{
-    constexpr int V = 16 / (int)sizeof(T), MZV = 64 * V;
-    const int nty = (g.N + MY - 1) / MY, ntz = (g.N + MZV - 1) / MZV;
-    hipLaunchKernelGGL((k_stencil_front<T, MY>), dim3((unsigned)((long)nty * ntz * g.N)), dim3(MY * 64), 0, st, g, nty, ntz, flags, s, q, cf);
-}
-
-// ---- streaming probes (developer: FLUID_MARCH_VARIANT=20001 / 20002): what a plain copy of the same arrays reaches ----
-// 20001: q = s, 16 bytes per lane, non-temporal stores; 20002: q = active(flag) ? s : 0 (adds the 1-byte-per-cell flag stream).
-// They bound what the stencil sweep can reach from HBM on this part (tools/sweep.py ... hbm).
-template <typename T, bool FLAGS>
-__global__ __launch_bounds__(256) void k_stream_probe(long n16, const uint8_t* __restrict__ flags, const T* __restrict__ s, T* __restrict__ q)
-{
-    constexpr int V = 16 / (int)sizeof(T);
-    typedef typename VecT<T, V>::type vec;
-    typedef typename FlagT<V>::type fvec;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
-        vec v = reinterpret_cast<const vec*>(s)[i];
-        if (FLAGS) {
-            const fvec f = reinterpret_cast<const fvec*>(flags)[i];
-#pragma unroll
-            for (int c = 0; c < V; ++c) {
-                const uint8_t fc = (uint8_t)(f >> (8 * c));
-                v[c] = ((fc & F_FLUID) && (fc >> F_CNT_SHIFT)) ? v[c] : (T)0;
-            }
-        }
-        __builtin_nontemporal_store(v, reinterpret_cast<vec*>(q) + i);
-    }
-}
-
-// variant = MY*100 + MD of the one-cell-per-lane march, 10000 + ... of the 16-bytes-per-lane march, 30000 + R*100 + MD of the
-// barrier-free rows form, 40000 / 60000 + MY*100 + MD of the lean march along x / y, 20001 / 20002 / 5xxxx / 7xxxx: copy probes;
-// cxlen = planes per chunk.  0 = the measured best at 256^3 FROM HBM (tools/sweep.py 256 hbm ..., profiles/r03/stencil_sweep_hbm.txt):
-// the lean march along x, 4 rows + 2 rim waves per block, 2 planes in flight, chunks of 16 (float) / 32 (double) planes —
-// 4.4 TB/s (float) and 4.9 TB/s (double) where a copy of the same arrays with the flag stream reaches 5.8 / 5.9 TB/s.  Every
-// form of the march measured lands within 5 % of that — one cell or 16 bytes per lane, with or without the LDS plane and its
-// barrier, 70 or 15 instructions per cell, along x or along y (each wave one contiguous stream), and the march run as a plain
-// copy (no LDS, no arithmetic) as well: the gap to the linear copy is not in the kernel's arithmetic or synchronisation.
-template <typename T>
-void launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T* s, T* q, Coef<T> cf, int variant, int cxlen)
-{
-    constexpr int V = 16 / (int)sizeof(T);
-    const bool can_vec = g.N % V == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)q & 15) == 0;
-    if (variant >= 900000 && launch_stencil_dma<T>(st, g, flags, s, q, cf, variant - 900000, cxlen)) return;   // 900000 + D G NP RY: the LDS-DMA plane ring
-    if (variant >= 900000) { variant = 0; cxlen = 0; }
-    if (variant >= 80000 && can_vec) {   // 80000 + MY: the linear-front sweep, MY rows (waves) per block
-        switch (variant - 80000) {
-        case 2: front_launch<T, 2>(st, g, flags, s, q, cf); break;
-        case 4: front_launch<T, 4>(st, g, flags, s, q, cf); break;
-        case 8: front_launch<T, 8>(st, g, flags, s, q, cf); break;
-        default: front_launch<T, 16>(st, g, flags, s, q, cf); break;
-        }
-        return;
-    }
-    if (variant >= 60000 && can_vec) {   // 60000 + MY*100 + MD: the lean march along y (every wave one contiguous stream); 70000 + ...: as a copy (probe)
-        if (cxlen <= 0) cxlen = 32;
-        switch (variant - 60000) {
-        case 402: lean_launch<T, 4, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 403: lean_launch<T, 4, 3, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 404: lean_launch<T, 4, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 602: lean_launch<T, 6, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 604: lean_launch<T, 6, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 802: lean_launch<T, 8, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 804: lean_launch<T, 8, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 1402: lean_launch<T, 14, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 1404: lean_launch<T, 14, 4, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 408: lean_launch<T, 4, 8, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 416: lean_launch<T, 4, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 616: lean_launch<T, 6, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 808: lean_launch<T, 8, 8, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 816: lean_launch<T, 8, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 1416: lean_launch<T, 14, 16, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 10402: lean_launch<T, 4, 2, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 10804: lean_launch<T, 8, 4, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 10416: lean_launch<T, 4, 16, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 10816: lean_launch<T, 8, 16, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
-        default: lean_launch<T, 8, 2, 0, 1>(st, g, cxlen, flags, s, q, cf); break;
-        }
-        return;
-    }
-    if (variant >= 40000 && can_vec) {   // 40000 + MY*100 + MD: the lean LDS-plane march, MY rows (+ 2 rim waves), MD planes in flight
-        if (cxlen <= 0) cxlen = 32;
-        switch (variant - 40000) {
-        case 402: lean_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
-        case 403: lean_launch<T, 4, 3>(st, g, cxlen, flags, s, q, cf); break;
-        case 404: lean_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 408: lean_launch<T, 4, 8>(st, g, cxlen, flags, s, q, cf); break;
-        case 602: lean_launch<T, 6, 2>(st, g, cxlen, flags, s, q, cf); break;
-        case 604: lean_launch<T, 6, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 802: lean_launch<T, 8, 2>(st, g, cxlen, flags, s, q, cf); break;
-        case 808: lean_launch<T, 8, 8>(st, g, cxlen, flags, s, q, cf); break;
-        case 1408: lean_launch<T, 14, 8>(st, g, cxlen, flags, s, q, cf); break;
-        case 803: lean_launch<T, 8, 3>(st, g, cxlen, flags, s, q, cf); break;
-        case 804: lean_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 806: lean_launch<T, 8, 6>(st, g, cxlen, flags, s, q, cf); break;
-        case 1402: lean_launch<T, 14, 2>(st, g, cxlen, flags, s, q, cf); break;
-        case 1404: lean_launch<T, 14, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 10402: lean_launch<T, 4, 2, 1>(st, g, cxlen, flags, s, q, cf); break;   // probe: the march as a copy
-        case 10802: lean_launch<T, 8, 2, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 10804: lean_launch<T, 8, 4, 1>(st, g, cxlen, flags, s, q, cf); break;
-        default: lean_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
-        }
-        return;
-    }
-    if (variant >= 30000 && can_vec) {   // 30000 + R*100 + MD: independent waves, R rows each, MD planes in flight
-        if (cxlen <= 0) cxlen = 32;
-        switch (variant - 30000) {
-        case 101: rows_launch<T, 1, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 102: rows_launch<T, 1, 2>(st, g, cxlen, flags, s, q, cf); break;
-        case 103: rows_launch<T, 1, 3>(st, g, cxlen, flags, s, q, cf); break;
-        case 104: rows_launch<T, 1, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 201: rows_launch<T, 2, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 202: rows_launch<T, 2, 2>(st, g, cxlen, flags, s, q, cf); break;
-        case 203: rows_launch<T, 2, 3>(st, g, cxlen, flags, s, q, cf); break;
-        case 401: rows_launch<T, 4, 1>(st, g, cxlen, flags, s, q, cf); break;
-        case 402: rows_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
-        default: rows_launch<T, 1, 2>(st, g, cxlen, flags, s, q, cf); break;
-        }
-        return;
-    }
-    if (variant >= 20000 && can_vec) {
-        const long n16 = (long)g.cells() / V;
-        const int nb = cxlen > 0 ? cxlen * 256 : 2048;
-        if (variant == 20001) hipLaunchKernelGGL((k_stream_probe<T, false>), dim3(nb), dim3(256), 0, st, n16, flags, s, q);
-        else hipLaunchKernelGGL((k_stream_probe<T, true>), dim3(nb), dim3(256), 0, st, n16, flags, s, q);
-        return;
-    }
-    if (variant == 0 && can_vec) {
-        // measured from HBM at 256^3 (tools/stencil_hbm.py): 4 planes in flight, chunks of 32 (fp32) / 64 (fp64) planes
-        const int cx = (sizeof(T) == 4 ? 32 : 64) >> (g.N < 256 ? 1 : 0);
-        lean_launch<T, 4, 4>(st, g, cx, flags, s, q, cf);
-        return;
-    }
-    if (can_vec && variant >= 10000) {
-        const int v = variant >= 10000 ? variant - 10000 : 402;
-        if (cxlen <= 0) cxlen = 16;
-        switch (v) {
-        case 404: vec_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 408: vec_launch<T, 4, 8>(st, g, cxlen, flags, s, q, cf); break;
-        case 804: vec_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 808: vec_launch<T, 8, 8>(st, g, cxlen, flags, s, q, cf); break;
-        case 1604: vec_launch<T, 16, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 202: vec_launch<T, 2, 2>(st, g, cxlen, flags, s, q, cf); break;
-        case 204: vec_launch<T, 2, 4>(st, g, cxlen, flags, s, q, cf); break;
-        case 402: vec_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
-        default: vec_launch<T, 4, 2>(st, g, cxlen, flags, s, q, cf); break;
-        }
-        return;
-    }
-    if (cxlen <= 0) cxlen = 32;
-    switch (variant) {
-    case 804: march_launch<T, 8, 4>(st, g, cxlen, flags, s, q, cf); break;
-    case 808: march_launch<T, 8, 8>(st, g, cxlen, flags, s, q, cf); break;
-    case 1604: march_launch<T, 16, 4>(st, g, cxlen, flags, s, q, cf); break;
-    case 1608: march_launch<T, 16, 8>(st, g, cxlen, flags, s, q, cf); break;
-    case 404: march_launch<T, 4, 4>(st, g, cxlen, flags, s, q, cf); break;
-    case 408: march_launch<T, 4, 8>(st, g, cxlen, flags, s, q, cf); break;
-    default: march_launch<T, 16, 4>(st, g, cxlen, flags, s, q, cf); break;  // best of the sweep at 256^3 (profiles/r01/stencil_sweep.txt)
-    }
-}
-
 template <typename T>
 void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags, const T* s, T* q, Coef<T> cf)
 {
@@ -1721,14 +1043,15 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
     template void launch_pcg_xr_rows<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*, int,      \
                                         const double*, int, double*, double*, PcgState*, const int*, int);                               \
     template void launch_stencil_apply<T>(hipStream_t, Grid, Box, const uint8_t*, const T*, T*, Coef<T>);                              \
-    template void launch_stencil_march<T>(hipStream_t, Grid, const uint8_t*, const T*, T*, Coef<T>, int, int);                                   \
     template void launch_store_pressure<T>(hipStream_t, Grid, LBox, const uint8_t*, const T*, double*, double*, const PcgState*);      \
     template void launch_pcg_init_guess<T>(hipStream_t, Grid, LBox, const uint8_t*, const float*, const double*, const double*, double, double, T*, T*, Coef<T>, \
                                            double*, double*, PcgState*);                                                               \
     template void launch_pcg_sq_dist<T>(hipStream_t, LBox, const uint8_t*, const T*, const T*, T*, T*, Coef<T>, const double*, const double*, \
                                         const double*, double*, PcgState*, int, double, int);                                            \
     template void launch_pcg_xr_dist<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,          \
-                                        const double*, double*, double*, PcgState*);
+                                        const double*, double*, double*, PcgState*);                                                    \
+    template void launch_pcg_az_dist<T>(hipStream_t, LBox, const uint8_t*, const T*, T*, Coef<T>, double*, PcgState*);                  \
+    template void launch_pcg_cgear_upd<T>(hipStream_t, LBox, const uint8_t*, T*, T*, T*, T*, const T*, const T*, const double*, double*, int, double*, PcgState*, int, double);
 INST(double)
 INST(float)
 

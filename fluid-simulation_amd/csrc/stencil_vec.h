@@ -25,4 +25,17 @@ __device__ __forceinline__ T and_mask(T v, int m)
     else return __builtin_bit_cast(T, __builtin_bit_cast(long long, v) & (long long)m);   // m sign-extends
 }
 
+// static indices only: a runtime index into a by-value kernel argument would go through scratch
+template <typename T, typename C>
+__device__ __forceinline__ void load_coef(T* sdiag, T* sinv, const C& cf)
+{
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            sdiag[i] = cf.diag[i];
+            sinv[i] = cf.inv[i];
+        }
+    }
+}
+
 }  // namespace fl

@@ -360,12 +360,14 @@ def test_particles_roundtrip_order(fs):
     assert np.array_equal(p, pos) and np.array_equal(v, vel)
 
 
-@pytest.mark.parametrize("n", [64, 66, 200])
+@pytest.mark.parametrize("n", [64, 66, 96, 112, 200])
 def test_marching_stencil_forms_agree(fs, n, monkeypatch):
-    """The dense-sweep kernels of the stencil micro-benchmark: the scalar march, the 16-bytes-per-lane march (4 floats / 2
-    doubles per lane, z neighbours by wave shuffles) in several tile shapes, and the LDS-tiled kernel give the same bits, and so does
-    the barrier-free form in which every wave marches R rows of its own (n = 66: the float forms fall back to the scalar march, rows
-    are not 16-byte aligned)."""
+    """The dense-sweep kernels of the stencil micro-benchmark give the same bits as the LDS-tiled kernel: the LDS-DMA plane ring
+    (kernels_stencil.hip; the default where rows of flag bytes are made of 16-byte pieces: n = 64, 96, 112 — 96 and 112 have rows that
+    are no multiple of one DMA instruction's 1 KiB) with several ring depths, slab heights and chunk lengths (chunks that end in one or
+    two planes, slabs that overhang the grid), and the register-staged lean march in several tile shapes (the fallback: n = 66, 200; the
+    float form at n = 66 has rows that are not 16-byte aligned and takes the tiled kernel).  Holes inside the water, garbage in s
+    outside the unknowns."""
     F = fs.FIELD
     for prec in ("fp64", "fp32"):
         sim = fs.FluidSim(n=n, precision=prec)
@@ -380,12 +382,12 @@ def test_marching_stencil_forms_agree(fs, n, monkeypatch):
         sim.stencil_apply(reps=1, box=2)
         want = sim.field(F.Q)
         assert np.abs(want).max() > 0
-        for variant, cx in (("10000", "16"), ("10404", "8"), ("11604", "32"), ("10202", "5"), ("1604", "32"), ("804", "7"),
-                            ("30102", "32"), ("30103", "7"), ("30202", "16"), ("30401", "9"), ("40402", "16"), ("40804", "32"), ("41402", "5"), ("40603", "9"), ("60402", "32"), ("60804", "7"), ("61402", "256"), ("80004", "1"), ("80016", "1"),
-                            ("0", "0")):   # 3xxxx: independent waves, R rows each
+        for variant, cx in (("40402", "16"), ("40804", "32"), ("41402", "5"), ("40404", "9"),
+                            ("900000", "0"), ("920004", "7"), ("940008", "33"), ("930016", "5"), ("960005", "31"), ("930008", str(n)),
+                            ("0", "0")):   # 4xxxx: lean march MY*100 + MD; 9D00RY: the LDS-DMA ring, D planes in flight, RY rows per block
             monkeypatch.setenv("FLUID_MARCH_VARIANT", variant)
             monkeypatch.setenv("FLUID_MARCH_CX", cx)
-            sim.upload_field(F.Q if False else F.SEARCH, s)
+            sim.upload_field(F.SEARCH, s)
             sim.stencil_apply(reps=1, box=0)
             got = sim.field(F.Q)
             assert np.array_equal(got, want), (prec, variant, cx)

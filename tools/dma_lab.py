@@ -2,7 +2,7 @@
 """Developer sweep of the LDS-DMA plane-ring stencil (kernels_stencil.hip): python tools/dma_lab.py [check] [n]
 Checks the form bit for bit against the tiled kernel at a few sizes, then times it from HBM (launches rotating over > 1 GiB of
 separate operand sets) next to the register-staged default and the copy probe.
-variant = 900000 + D*10000 + G*1000 + NP*100 + RY ; cx = cxlen + 1000*nt + 10000*rot + 100000*mode"""
+variant = 900000 + D*10000 + RY ; cx = planes per chunk (0: N/8 + 1)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,7 +41,7 @@ def check():
             os.environ.pop("FLUID_MARCH_VARIANT", None)
             sim.stencil_apply(reps=1, box=2)
             want = sim.field(F.Q)
-            for var, cx in ((936208, 31000), (926204, 11000), (933208, 1000 + 7), (936408, 50000), (934208, 21000 + 5), (946208, 91000), (936216, 31000), (936208, 31003)):
+            for var, cx in ((900000, 0), (920004, 7), (940008, 33), (930016, 5), (960005, 31), (930008, 32), (40404, 9)):
                 sim.upload_field(F.Q, np.zeros_like(want)) if False else None
                 run(sim, var, cx)
                 got = sim.field(F.Q)
@@ -56,13 +56,14 @@ def sweep(n):
     for prec, T in (("fp64", 8), ("fp32", 4)):
         sim = setup(n, prec, False)
         algo = n ** 3 * (2 * T + 1)
-        rows = [(0, 0), (20002, 4)]
+        rows = [(0, 0), (20002, 4), (40404, 64 if prec == "fp64" else 32)]
         if len(sys.argv) > 2:
             rows = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]
         else:
-            for rot in (0, 1, 3):
-                for ry in (4, 8):
-                    rows.append((936200 + ry, 1000 + rot * 10000))
+            for d in (2, 3, 4):
+                for cx in (32, 33, 34):
+                    rows.append((900008 + d * 10000, cx))
+            rows += [(930004, 33), (930016, 33)]
         for var, cx in rows:
             ms = run(sim, var, cx, hbm=True)
             print(prec, var, cx, f"{ms*1e3:.1f} us {algo/ms/1e6:.0f} GB/s  {algo/ms/1e6/8000:.3f}", flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The HBM-proof dense stencil sweep alone, for profiling: python tools/stencil_hbm.py <prec> <variant> <cx> [n] [reps]
-(variant / cx as FLUID_MARCH_VARIANT / FLUID_MARCH_CX: 0 0 = the library's default form)."""
+(variant / cx as FLUID_MARCH_VARIANT / FLUID_MARCH_CX (launch_stencil_march, kernels_stencil.hip): 0 0 = the default)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
