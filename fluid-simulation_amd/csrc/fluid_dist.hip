@@ -118,6 +118,10 @@ struct DistState {
     double rb_ratio = 2.0;
     int n_rebalanced = 0;
     int n_rebalance_refused = 0;     // re-balances every rank gave up together (some rank had no room for a second window)
+    // form of the PCG recurrence in the decomposed solve (FLUID_DIST_CG=cg|cgear): 0 = the loop of ConjugateGradient.h as the one-GPU solve
+    // runs it (two scalar all-reduces per iteration), 1 = Chronopoulos-Gear (one); gcg = {gamma, alpha} of the last two bodies (device)
+    int cg_form = 1;
+    double* gcg = nullptr;
     // test hooks, read once in fluid_create_dist: the rank whose growth (route_round) / second window (dist_rebalance) is refused; -1 = none
     int fail_grow_rank = -1, fail_rebuild_rank = -1;
     int* rb_buf = nullptr;            // device: 3 N axis histograms + one count per rank
@@ -272,6 +276,7 @@ int halo_exchange1(fluid_sim* s, HaloPlan& p, int elem, void* a)
 
 int comm_allreduce(fluid_sim* s, void* buf, long count, int dtype, int op)
 {
+    if (s->ds->comm.size == 1) return FLUID_OK;   // one rank: the buffer already holds the result (no call with nobody to talk to)
     COMMCHK(s->ds->comm.allreduce(s->ds->comm.ctx, buf, (int64_t)count, dtype, op, (void*)s->st));
     return FLUID_OK;
 }
@@ -285,6 +290,7 @@ int comm_allreduce(fluid_sim* s, void* buf, long count, int dtype, int op)
 int dist_agree(fluid_sim* s, int local_rc)
 {
     DistState* d = s->ds;
+    if (d->comm.size == 1) return local_rc;
     int* flag = d->h_cnt + 96;
     *flag = local_rc ? 1 : 0;
     hipError_t e = hipMemcpyAsync(d->d_cnt + 96, flag, sizeof(int), hipMemcpyHostToDevice, s->st);
@@ -307,6 +313,11 @@ int route_round(fluid_sim* s)
     DistState* d = s->ds;
     const Grid g = s->g;
     int rc;
+    {   // a block without neighbours (one rank) has nobody to hand particles to or to copy ghosts for
+        bool any = false;
+        for (int dd = 0; dd < 27; ++dd) any = any || (dd != 13 && d->nbr[dd] >= 0);
+        if (!any) return FLUID_OK;
+    }
     HIPCHK(hipMemsetAsync(d->d_cnt, 0, 64 * sizeof(int), s->st));
     launch_route(s->st, g, d->ob, s->np, s->pa.shifted(s->p_off), d->d_cnt, nullptr, 0);
     HIPCHK(hipGetLastError());
@@ -413,10 +424,12 @@ int dist_particles(fluid_sim* s)
             v[3 + a] = h.bbox_max[a] < 0 ? 0x7fffffff : -(h.bbox_max[a] + o[a]);
         }
         v[6] = -h.max_cell;
-        HIPCHK(hipMemcpyAsync(d->d_cnt + 64, v, 7 * sizeof(int), hipMemcpyHostToDevice, s->st));
-        if ((rc = comm_allreduce(s, d->d_cnt + 64, 7, FLUID_DT_I32, FLUID_OP_MIN))) return rc;
-        HIPCHK(hipMemcpyAsync(v, d->d_cnt + 64, 7 * sizeof(int), hipMemcpyDeviceToHost, s->st));
-        HIPCHK(hipStreamSynchronize(s->st));
+        if (d->comm.size > 1) {
+            HIPCHK(hipMemcpyAsync(d->d_cnt + 64, v, 7 * sizeof(int), hipMemcpyHostToDevice, s->st));
+            if ((rc = comm_allreduce(s, d->d_cnt + 64, 7, FLUID_DT_I32, FLUID_OP_MIN))) return rc;
+            HIPCHK(hipMemcpyAsync(v, d->d_cnt + 64, 7 * sizeof(int), hipMemcpyDeviceToHost, s->st));
+            HIPCHK(hipStreamSynchronize(s->st));
+        }
         s->max_cell = -v[6];
         const int N = g.N;
         if (v[0] == 0x7fffffff) {
@@ -905,9 +918,28 @@ int dist_solve(fluid_sim* s)
             // the residual's halo: exchanged on the second stream behind the interior tiles of the level-0 down leg (every rank takes
             // the same branch: the switch is a parameter of the run, and a rank without a level-0 domain has an empty plan)
             const bool ovl = mg && d->overlap && d->lv[0].plan.n > 0 && !ib_empty(d->lv[0].dom);
+            const bool cgear = mg && d->cg_form == 1;
             if (ovl) rc = halo_exchange_begin(s, d->lv[0].plan, sizeof(T), R);
             else rc = halo_exchange1(s, d->lv[0].plan, sizeof(T), R);
             if (rc) return rc;
+            if (cgear) {
+                // Chronopoulos-Gear: z = M^-1 r, w = A z, then ONE all-reduce of {|r|^2 of the previous body (|b|^2 before the first),
+                // gamma = r.z, delta = w.z (, |r0|^2 of a solve started from a guess)} and one fused update of s, q = A s, x, r
+                if (s->mg_fp32) rc = dist_vcycle_t<float>(s, R, Z, s->mg_part, ovl);
+                else rc = dist_vcycle_t<double>(s, R, Z, s->mg_part, ovl);
+                if (rc) return rc;
+                T* Wv = Sx[1];
+                int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
+                launch_pcg_az_dist<T>(s->st, L, cnt, Z, Wv, cf, s->part_pq, s->ps);
+                prof_end(s, FLUID_PROF_PCG_SQ, tok);
+                const bool g0 = it == 0 && guess;
+                launch_sum4(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->mg_part, n_rz, s->part_pq, nsq, s->part_rz[1], g0 ? nxr : 0, d->gstage[cur]);
+                if ((rc = comm_allreduce(s, d->gstage[cur], g0 ? 4 : 3, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+                tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
+                launch_pcg_cgear_upd<T>(s->st, L, cnt, X, R, Sx[0], Q, Z, Wv, d->gstage[cur], d->gcg, cur, s->part_rr, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol);
+                prof_end(s, FLUID_PROF_PCG_XR, tok);
+                continue;
+            }
             // gstage[cur] = {|r|^2 of the previous body (|b|^2 before the first), r.z of this one}
             if (mg) {
                 if (s->mg_fp32) rc = dist_vcycle_t<float>(s, R, Z, s->mg_part, ovl);
@@ -1298,7 +1330,7 @@ void fl::dist_destroy(fluid_sim* s)
 {
     DistState* d = s->ds;
     if (!d) return;
-    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq, d->tl_int, d->tl_bnd, d->rb_buf};
+    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq, d->gcg, d->tl_int, d->tl_bnd, d->rb_buf};
     for (void* p : ptrs) if (p) hipFree(p);
     if (d->st2) { hipStreamSynchronize(d->st2); hipStreamDestroy(d->st2); }
     if (d->ev_pack) hipEventDestroy(d->ev_pack);
@@ -1355,6 +1387,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
     if (d->split_force < 0 || d->split_force > 2) d->split_force = 0;
     if (const char* e = getenv("FLUID_DIST_OVERLAP")) d->overlap = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DIST_REBALANCE")) d->rb_every = std::max(0, atoi(e));
+    if (const char* e = getenv("FLUID_DIST_CG")) d->cg_form = !strcmp(e, "cg") ? 0 : 1;
     if (const char* e = getenv("FLUID_DIST_FAIL_GROW")) d->fail_grow_rank = atoi(e);         // test hooks (tests/test_gpu_dist.py)
     if (const char* e = getenv("FLUID_DIST_FAIL_REBUILD")) d->fail_rebuild_rank = atoi(e);
     if (const char* e = getenv("FLUID_DIST_GATHER")) d->split_exchange_force = !strcmp(e, "exchange") ? 1 : (!strcmp(e, "allreduce") ? 0 : -1);
@@ -1381,7 +1414,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
     s->dist = true;
     s->ds = d;
     auto bail = [&](const std::string& m) { fluid_destroy(s); *out = nullptr; return fail(FLUID_ERR_HIP, m); };
-    if (dalloc(&d->gstage[0], (size_t)4) != hipSuccess || dalloc(&d->gstage[1], (size_t)4) != hipSuccess || dalloc(&d->gpq, (size_t)1) != hipSuccess ||
+    if (dalloc(&d->gstage[0], (size_t)4) != hipSuccess || dalloc(&d->gstage[1], (size_t)4) != hipSuccess || dalloc(&d->gpq, (size_t)1) != hipSuccess || dalloc(&d->gcg, (size_t)4) != hipSuccess ||
         dalloc(&d->d_cnt, (size_t)128) != hipSuccess || dalloc(&d->cnt_pcg, s->lmax + 64) != hipSuccess ||
         hipHostMalloc((void**)&d->h_cnt, 128 * sizeof(int)) != hipSuccess)
         return bail("alloc of the decomposition's scratch failed");
