@@ -104,7 +104,7 @@ struct StepState {
     int n_drop;               // closed pockets of the pressure system found this step (kernels_droplets.hip); may exceed the buffer's capacity
     int n_tl_mg, n_tl_sq;     // active tiles of the level-0 V-cycle legs / of SQ and XR (mostly-air boxes)
     int n_rows, n_l1_old;     // z rows of 32 cells that hold an unknown (XR's list); unknowns of level 1 as the re-discretised cycle types it ...
-    int n_l1_gal, pad3_;      // ... and as aggregation does (any child): their ratio says how much of the pool the coarse levels lose (kernels_gal.hip)
+    int n_l1_gal, n_drop_fail;   // ... and as aggregation does (any child); droplets whose own CG did not reach the tolerance this step (k_drop_solve)
     unsigned long long max_speed_bits;  // max |v_p| as non-negative double bits
     double dt;                // fluid.cc:1367 / 992-999
     double err_num;           // |b-b2|^2
@@ -313,9 +313,9 @@ void launch_row_list(hipStream_t st, LBox L, const uint8_t* cnt, int* flags, int
 // closed pockets of the pressure system (kernels_droplets.hip): found and taken out of cnt once per step, solved once per pass
 constexpr int DROP_CAP = 65536;   // components the buffers hold (64 cells each); the ones beyond stay in the global solve
 constexpr int DROP_NCTR = 64;     // ... in as many ranges, each with a counter of its own
-void launch_drop_find(hipStream_t st, LBox L, uint8_t* cnt, int* ctr, int* pre, int* total, int* comp_n, int* comp_cells);
+void launch_drop_find(hipStream_t st, LBox L, uint8_t* cnt, int* ctr, int* pre, int* total, int* comp_n, int* comp_cells, const Box* own = nullptr);   // own (local-box coordinates): a claimed pocket lies wholly inside (decomposed run: the owned cells)
 void launch_drop_solve(hipStream_t st, Grid g, LBox L, int n_comp, const int* pre, const int* comp_n, const int* comp_cells, const uint8_t* flags,
-                       const float* b, Coef<double> cf, double tol, double* pressure, double* keep);
+                       const float* b, Coef<double> cf, double tol, double* pressure, double* keep, int* n_fail = nullptr);   // n_fail += droplets whose CG stopped short of the tolerance
 template <typename T>
 void launch_pcg_xr_rows(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                         int n_rz, const double* part_pq, int n_pq, double* part_rr, double* part_rz_next, PcgState* ps, const int* rlist, int nrows);

@@ -986,7 +986,7 @@ static int solve_mg(fluid_sim* s)
     // the new solution goes into the buffer of the older guess, which then becomes the latest
     launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, s->warm ? s->p_guess2 : nullptr, s->ps);
     launch_drop_solve(s->st, g, L, s->n_drop, s->drop_ctr + 64 * DROP_NCTR, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol,
-                      s->pressure, s->warm ? s->p_guess2 : nullptr);
+                      s->pressure, s->warm ? s->p_guess2 : nullptr, &s->ss->n_drop_fail);
     if (s->warm) s->rotate_guess();
     s->have_guess = s->warm;
     HIPCHK(hipGetLastError());
@@ -1178,7 +1178,7 @@ static int solve_impl(fluid_sim* s)
     }
     launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure);
     launch_drop_solve(s->st, g, L, s->n_drop, s->drop_ctr + 64 * DROP_NCTR, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol,
-                      s->pressure, nullptr);
+                      s->pressure, nullptr, &s->ss->n_drop_fail);
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;
@@ -1220,6 +1220,7 @@ int fl::phase_pressure_pass(fluid_sim* s, double* error)
         launch_err_norm(s->st, s->g, s->Rb, s->flags, s->diver, s->diver2, s->part_err, s->ss);
         HIPCHK(hipGetLastError());
         if ((rc = read_ss(s))) return rc;
+        if (s->h_ss->n_drop_fail > 0) s->stats.paths |= FLUID_PATH_DROPLETS_SHORT;   // a pocket solved apart stopped short of the tolerance: reported, not hidden
         err = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);  // fluid.cc:1483
     }
     s->stats.error = err;

@@ -122,6 +122,8 @@ struct DistState {
     // runs it (two scalar all-reduces per iteration), 1 = Chronopoulos-Gear (one); gcg = {gamma, alpha} of the last two bodies (device)
     int cg_form = 1;
     double* gcg = nullptr;
+    // the previous step's GLOBAL active box was mostly air (every rank the same): this step looks for closed pockets (droplets)
+    bool airy_prev = false, drops_step = false;
     // test hooks, read once in fluid_create_dist: the rank whose growth (route_round) / second window (dist_rebalance) is refused; -1 = none
     int fail_grow_rank = -1, fail_rebuild_rank = -1;
     int* rb_buf = nullptr;            // device: 3 N axis histograms + one count per rank
@@ -593,6 +595,9 @@ struct GDom {
     int lo[3], dim[3];
 };
 
+template <typename V>
+MgCoef<V> coef_as(const fluid_sim* s, int level);
+
 int dist_mg_setup(fluid_sim* s)
 {
     DistState* d = s->ds;
@@ -731,6 +736,27 @@ int dist_mg_setup(fluid_sim* s)
         const IBox o = d->lv[0].own;
         Box ownL = ib_empty(o) ? Box{0, 0, 0, -1, -1, -1}
                                : Box{o.lo[0] - org0[0], o.lo[1] - org0[1], o.lo[2] - org0[2], o.hi[0] - 1 - org0[0], o.hi[1] - 1 - org0[1], o.hi[2] - 1 - org0[2]};
+        // Closed pockets of the pressure system (kernels_droplets.hip) leave the global solve here too: every rank searches its
+        // local box and claims the pockets that lie wholly in its OWNED cells (their pressure is written by that one owner; a pocket
+        // across a cut stays in the global solve), clears their count bytes, and the count bytes' halo then comes from the owners — so
+        // both sides of a cut build cnt_pcg, the cell types and the coarse levels on the same system.  Whether a step searches is
+        // decided from global numbers (the previous step's box was mostly air), so every rank takes part in the exchange or none does.
+        s->n_drop = 0;
+        d->drops_step = s->drops_on && use_mg(s) && (d->airy_prev || s->lists_force == 1);
+        if (d->drops_step) {
+            if (!s->drop_cells) {
+                HIPCHK(hipMalloc((void**)&s->drop_ctr, (size_t)(64 * DROP_NCTR + DROP_NCTR + 1) * sizeof(int)));
+                HIPCHK(hipMalloc((void**)&s->drop_n, (size_t)DROP_CAP * sizeof(int)));
+                HIPCHK(hipMalloc((void**)&s->drop_cells, (size_t)DROP_CAP * 64 * sizeof(int)));
+            }
+            HIPCHK(hipMemsetAsync(&s->ss->n_drop, 0, sizeof(int), s->st));
+            if (!ib_empty(o)) launch_drop_find(s->st, s->L, s->cntL, s->drop_ctr, s->drop_ctr + 64 * DROP_NCTR, &s->ss->n_drop, s->drop_n, s->drop_cells, &ownL);
+            HIPCHK(hipGetLastError());
+            if ((rc = halo_exchange1(s, d->lv[0].plan, 1, s->cntL))) return rc;
+            if ((rc = read_ss(s))) return rc;
+            s->n_drop = ib_empty(o) ? 0 : std::min(s->h_ss->n_drop, DROP_CAP);
+            if (s->n_drop > 0) s->stats.paths |= FLUID_PATH_DROPLETS;
+        }
         launch_cnt_pcg(s->st, s->L, ownL, s->cntL, d->cnt_pcg);
     }
     if (!ib_empty(d->lv[0].dom))
@@ -770,6 +796,77 @@ int dist_mg_setup(fluid_sim* s)
         }
         HIPCHK(hipGetLastError());
     }
+    // ---- Galerkin coarse levels by aggregation (kernels_gal.hip) in a mostly-air box, like the one-GPU solve ------------------
+    // With split = 1 every level below level 0 is replicated, so only level 1's coefficients need the blocks: each rank forms
+    // them for the coarse cells under its owned fine cells (the children and their face neighbours lie inside its halo: cuts are
+    // multiples of 4) and the owners' values are gathered like the level's right-hand side, once per step; the levels below are
+    // coarsened identically everywhere.  Every input of the decision is a global number: the same cycle on every rank.
+    s->gal = false;
+    s->gal_eligible = false;
+    {
+        int lc = 1;
+        while (lc < nl - 1 && !gal_fits_coarsest(s->mgl[lc])) ++lc;
+        const double c0 = (double)gd[0].dim[0] * gd[0].dim[1] * gd[0].dim[2];
+        const bool airy = (double)s->stats.num_active < 0.45 * c0 && c0 > 1500000.0;
+        if (!(s->gal_mode && s->mg_fp32 && split == 1 && lc >= 2 && gal_fits_coarsest(s->mgl[lc]) && (airy || s->gal_mode >= 2))) {
+            s->gal_it[0] = s->gal_it[1] = -1;
+            return FLUID_OK;
+        }
+        s->gal_eligible = true;
+        bool use = s->gal_mode >= 2;
+        if (s->gal_mode == 1) {
+            if (s->gal_it[0] < 0) use = false;
+            else if (s->gal_it[1] < 0) use = true;
+            else {
+                use = s->gal_it[1] < s->gal_it[0];
+                if (++s->gal_since_probe >= 32) { use = !use; s->gal_since_probe = 0; }
+            }
+        }
+        if (!use) return FLUID_OK;
+        size_t total_g = 0, off[fluid_sim::MG_MAXL][6];
+        for (int l = 1; l <= lc; ++l)
+            for (int q = 0; q < 6; ++q) {
+                off[l][q] = total_g;
+                total_g += (q < 5 ? ((q < 4 ? sizeof(float) : 1) * (s->mgl[l].cells + 64) + 255) / 256 * 256 : ((size_t)gal_tile_count(s->mgl[l]) + 255) / 256 * 256);
+            }
+        if (total_g > s->gal_slab_cap) {
+            if (s->gal_slab) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->gal_slab); s->gal_slab = nullptr; }
+            HIPCHK(hipMalloc((void**)&s->gal_slab, total_g + total_g / 4));
+            s->gal_slab_cap = total_g + total_g / 4;
+        }
+        HIPCHK(hipMemsetAsync(s->gal_slab, 0, total_g, s->st));
+        for (int l = 1; l <= lc; ++l) {
+            for (int q = 0; q < 4; ++q) s->gal_c[l][q] = (float*)(s->gal_slab + off[l][q]);
+            s->gal_cnt[l] = (uint8_t*)(s->gal_slab + off[l][4]);
+            s->gal_tfl[l] = (uint8_t*)(s->gal_slab + off[l][5]);
+        }
+        DLevel& F0 = d->lv[0];
+        if (!ib_empty(F0.dom)) {
+            const int off1[3] = {(F0.dom.lo[0] >> 1) - gd[1].lo[0], (F0.dom.lo[1] >> 1) - gd[1].lo[1], (F0.dom.lo[2] >> 1) - gd[1].lo[2]};
+            launch_gal_level1(s->st, F0.m, s->cntL, coef_as<float>(s, 0), coarse_view(s->mgl[1], off1), s->gal_c[1][0], s->gal_c[1][1], s->gal_c[1][2], s->gal_c[1][3],
+                              s->gal_cnt[1]);
+            HIPCHK(hipGetLastError());
+        }
+        for (int q = 0; q < 5; ++q) {   // the owners' coarse cells to everyone
+            void* arr = q < 4 ? (void*)s->gal_c[1][q] : (void*)s->gal_cnt[1];
+            if (d->split_exchange) {
+                if ((rc = halo_exchange1(s, d->plan_split, q < 4 ? 4 : 1, arr))) return rc;
+            } else {
+                if (q < 4) launch_mask_outside<float>(s->st, s->mgl[1], to_box(own_l(1, me), gd[1].lo), (float*)arr);
+                else launch_mask_outside<uint8_t>(s->st, s->mgl[1], to_box(own_l(1, me), gd[1].lo), (uint8_t*)arr);
+                HIPCHK(hipGetLastError());
+                if ((rc = comm_allreduce(s, arr, (long)s->mgl[1].cells, q < 4 ? FLUID_DT_F32 : FLUID_DT_U8, FLUID_OP_SUM))) return rc;
+            }
+        }
+        for (int l = 2; l <= lc; ++l)
+            launch_gal_coarsen(s->st, s->mgl[l - 1], s->gal_c[l - 1][0], s->gal_c[l - 1][1], s->gal_c[l - 1][2], s->gal_c[l - 1][3], s->gal_cnt[l - 1], s->mgl[l],
+                               s->gal_c[l][0], s->gal_c[l][1], s->gal_c[l][2], s->gal_c[l][3], s->gal_cnt[l]);
+        for (int l = 1; l < lc; ++l) launch_gal_tile_flags(s->st, s->mgl[l], s->gal_cnt[l], s->gal_tfl[l]);
+        HIPCHK(hipGetLastError());
+        s->gal = true;
+        s->gal_lc = lc;
+        s->gal_dt = s->dt;
+    }
     return FLUID_OK;
 }
 
@@ -804,6 +901,55 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz,
         else for (int a = 0; a < 3; ++a) off[a] = (Lf.dom.lo[a] >> 1) - (d->dom0.lo[a] >> (l + 1));
         return coarse_view(l + 1 < split ? d->lv[l + 1].m : s->mgl[l + 1], off);
     };
+    if (s->gal && sizeof(V) == 4) {
+        // Galerkin coarse levels (split = 1): level 0 by the same legs with its own coefficients — the down leg also forms the coarse
+        // right-hand side (the sum of its residual over each coarse cell's children: no halo), the up leg takes the parent's value —,
+        // the gathered level 1 and everything below by the kernels of kernels_gal.hip, identically on every rank
+        typedef float G;
+        auto GU = [&](int l) { return (G*)s->mg_u[l]; };
+        auto GW = [&](int l) { return (G*)s->mg_v[l]; };
+        auto GF = [&](int l) { return (G*)s->mg_f[l]; };
+        auto C = [&](int l, int q) { return (const float*)s->gal_c[l][q]; };
+        const int lc = s->gal_lc;
+        DLevel& L = d->lv[0];
+        const MLevel mc = ib_empty(L.dom) ? s->mgl[1] : under(0);
+        if (!ib_empty(L.dom)) {
+            if (halo_pending) {
+                if (d->n_int) launch_mg_down<G, double>(s->st, L.m, L.cnt, rhs0, GU(0), (G*)s->mg_r[0], mc, nullptr, GF(1), coef_as<G>(s, 0), ps, d->tl_int, d->n_int, true);
+                if ((rc = halo_exchange_end(s, L.plan, sizeof(double)))) return rc;
+                if (d->n_bnd) launch_mg_down<G, double>(s->st, L.m, L.cnt, rhs0, GU(0), (G*)s->mg_r[0], mc, nullptr, GF(1), coef_as<G>(s, 0), ps, d->tl_bnd, d->n_bnd, true);
+            } else {
+                launch_mg_down<G, double>(s->st, L.m, L.cnt, rhs0, GU(0), (G*)s->mg_r[0], mc, nullptr, GF(1), coef_as<G>(s, 0), ps, nullptr, 0, true);
+            }
+            HIPCHK(hipGetLastError());
+        } else if (halo_pending) {
+            if ((rc = halo_exchange_end(s, L.plan, sizeof(double)))) return rc;
+        }
+        if (d->split_exchange) {
+            if ((rc = halo_exchange1(s, d->plan_split, sizeof(G), GF(1)))) return rc;
+        } else {
+            int lo[3];
+            for (int a = 0; a < 3; ++a) lo[a] = d->dom0.lo[a] >> 1;
+            IBox gb;
+            for (int a = 0; a < 3; ++a) { gb.lo[a] = lo[a]; gb.hi[a] = lo[a] + (a == 0 ? s->mgl[1].dx : (a == 1 ? s->mgl[1].dy : s->mgl[1].dz)); }
+            const IBox o = ib_isect(block_level(d, d->comm.rank, 1, s->g.N), gb);
+            launch_mask_outside<G>(s->st, s->mgl[1], to_box(o, lo), GF(1));
+            HIPCHK(hipGetLastError());
+            if ((rc = comm_allreduce(s, GF(1), (long)s->mgl[1].cells, FLUID_DT_F32, FLUID_OP_SUM))) return rc;
+        }
+        for (int l = 1; l < lc; ++l) launch_gal_down(s->st, s->mgl[l], s->gal_tfl[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), GF(l), GU(l), s->mgl[l + 1], GF(l + 1), ps);
+        launch_gal_coarsest(s->st, s->mgl[lc], C(lc, 0), C(lc, 1), C(lc, 2), C(lc, 3), GF(lc), GU(lc), s->gal_sweeps, ps);
+        for (int l = lc - 1; l >= 1; --l)
+            launch_gal_up(s->st, s->mgl[l], s->gal_tfl[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), GF(l), GU(l), GW(l), s->mgl[l + 1], l + 1 == lc ? GU(l + 1) : GW(l + 1),
+                          (float)s->gal_wc, ps);
+        if (!ib_empty(L.dom)) {
+            const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)ib_cells(L.dom));
+            launch_mg_up<G, double, double>(s->st, L.m, L.cnt, rhs0, (const G*)GU(0), z0, mc, GW(1), coef_as<G>(s, 0), part_rz, ps, s->gal_wc, nullptr, 0, d->cnt_pcg, 1);
+            prof_end(s, FLUID_PROF_MG_UP0, tok);
+        }
+        HIPCHK(hipGetLastError());
+        return FLUID_OK;
+    }
     // ---- down: levels on block + halo ----
     for (int l = 0; l < split; ++l) {
         DLevel& L = d->lv[l];
@@ -974,6 +1120,8 @@ int dist_solve(fluid_sim* s)
     const double rr = s->h_ps->rr;
     if (!s->h_ps->done) iters = (int)max_it;
     launch_store_pressure<T>(s->st, g, L, cnt, X, s->pressure, mg && s->warm ? s->p_guess2 : nullptr, s->ps);
+    launch_drop_solve(s->st, g, L, s->n_drop, s->drop_ctr + 64 * DROP_NCTR, s->drop_n, s->drop_cells, s->flags, s->diver, make_coef<double>(s), tol, s->pressure,
+                      mg && s->warm ? s->p_guess2 : nullptr, &s->ss->n_drop_fail);
     if (mg && s->warm) s->rotate_guess();   // (the pressure halo exchange that follows carries the new p_guess)
     s->have_guess = mg && s->warm;
     HIPCHK(hipGetLastError());
@@ -981,6 +1129,8 @@ int dist_solve(fluid_sim* s)
     s->stats.cg_iters_last = iters;
     s->stats.cg_iters += iters;
     s->mg_last_iters_k[pclass] = iters;
+    if (s->gal) s->stats.paths |= FLUID_PATH_MG_GALERKIN;
+    if (s->gal_eligible && s->stats.outer_passes == 0) s->gal_it[s->gal ? 1 : 0] = iters;   // the first pass of the step: what the two cycles are compared by
     s->stats.relres = s->h_ps->bb > 0 ? std::sqrt(rr / s->h_ps->bb) : 0.0;
     if (s->h_ps->breakdown) return fail(FLUID_ERR_SOLVER, "PCG breakdown: s.As <= 0 or NaN");
     return FLUID_OK;
@@ -1047,11 +1197,13 @@ int dist_step_decomposed(fluid_sim* s, fluid_step_stats_t* stats)
         s->last_num_active = s->stats.num_active;
     }
     // ---- local solver layout, multigrid hierarchy ----
+    const bool airy_now = any && (double)s->stats.num_active < 0.45 * (double)ib_cells(d->Rg) && ib_cells(d->Rg) > 1500000;
     if (any) {
         if ((rc = dist_mg_setup(s))) return rc;
         const size_t lb = (s->L.cells() + 2 * (size_t)s->L.Lz) * solver_elem(s);
         HIPCHK(zero_search(s, lb));
     }
+    d->airy_prev = airy_now;
     s->have_p2g = s->have_flags = true;
     // ---- pressure do..while (:1457-1484) ----
     double error = NAN;
@@ -1084,6 +1236,7 @@ int dist_step_decomposed(fluid_sim* s, fluid_step_stats_t* stats)
             HIPCHK(hipGetLastError());
             if ((rc = comm_allreduce(s, &s->ss->err_num, 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
             if ((rc = read_ss(s))) return rc;
+            if (s->h_ss->n_drop_fail > 0) s->stats.paths |= FLUID_PATH_DROPLETS_SHORT;
             error = std::sqrt(s->h_ss->err_num) / std::sqrt(s->h_ss->err_den);
         }
         s->stats.error = error;

@@ -35,10 +35,12 @@ __device__ __forceinline__ double wsum_d(double v)   // every lane gets the tota
 // Slots: the buffers hold DROP_CAP components in DROP_NCTR ranges of DROP_CAP / DROP_NCTR, each filled through a counter of its own
 // (a block adds its claims to counter blockIdx % DROP_NCTR with ONE atomic: ten thousand returning atomics on a single
 // address cost more than the whole search).  The counters lie 256 bytes apart.
-__global__ __launch_bounds__(512) void k_drop_find(LBox L, const uint8_t* __restrict__ cnt, int ncx, int ncy, int ncz,
+// own: the cells (local-box coordinates, inclusive) a claimed component must lie in — the whole box on one GPU; the rank's OWNED cells in a
+// decomposed run (a pocket that straddles a cut stays in the global solve; the pressure of a claimed one is written by its one owner)
+__global__ __launch_bounds__(512) void k_drop_find(LBox L, Box own, const uint8_t* __restrict__ cnt, int ncx, int ncy, int ncz,
                                                    int* __restrict__ ctr, int* __restrict__ comp_n, int* __restrict__ comp_cells)
 {
-    __shared__ int s_claims, s_base, s_nu;
+    __shared__ int s_claims, s_base, s_nu, s_wclaims[8];
     __shared__ uint16_t ulist[DCELLS];   // the unknowns of the window: the sweeps visit these only
     constexpr unsigned AIR = 0xFFFFu, NEW = 0xFFFEu;   // not an unknown / an unknown the search has not reached
     __shared__ uint16_t lab[DCELLS], lab2[DCELLS];
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(512) void k_drop_find(LBox L, const uint8_t* __rest
         if (l >= NEW) continue;
         const int wi = w >> 8, wj = (w >> 4) & 15, wk = w & 15;
         bool b = wi == 0 || wi == DW - 1 || wj == 0 || wj == DW - 1 || wk == 0 || wk == DW - 1 || (unsigned)w < l;
+        b = b || i0 + wi < own.x0 || i0 + wi > own.x1 || j0 + wj < own.y0 || j0 + wj > own.y1 || k0 + wk < own.z0 || k0 + wk > own.z1;
         if (!b) {
             const unsigned n0 = lab[w - 1], n1 = lab[w + 1], n2 = lab[w - DW], n3 = lab[w + DW], n4 = lab[w - DW * DW], n5 = lab[w + DW * DW];
             b = (n0 != AIR && n0 != l) || (n1 != AIR && n1 != l) || (n2 != AIR && n2 != l) || (n3 != AIR && n3 != l) ||
@@ -163,16 +166,26 @@ __global__ __launch_bounds__(512) void k_drop_find(LBox L, const uint8_t* __rest
         atomicAdd(&meta[core_of(l)], 1);
     }
     __syncthreads();
-    if (tid == 0) s_claims = 0;
-    __syncthreads();
     int my_root = -1, my_n = 0, my_local = 0;   // thread = core cell: a root if it kept its own label
     {
         const int w = ((DA + ci) * DW + DA + cj) * DW + DA + ck;
         if (lab[w] == (unsigned)w) {
             const int n = meta[tid];
             meta[tid] = 0;
-            if (!bad[tid] && n <= 64) { my_root = tid; my_n = n; my_local = atomicAdd(&s_claims, 1); }
+            if (!bad[tid] && n <= 64) { my_root = tid; my_n = n; }
         }
+    }
+    {   // the claims of a block are numbered in the order of their core cells (not in the order atomics arrive): when a range of the
+        // buffers overflows, the same roots of the block are dropped in every run
+        const unsigned long long bal = __ballot(my_root >= 0);
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane == 0) s_wclaims[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { before += q < wv ? s_wclaims[q] : 0; all += s_wclaims[q]; }
+        my_local = before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (tid == 0) s_claims = all;
     }
     __syncthreads();
     constexpr int RANGE = DROP_CAP / DROP_NCTR;
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(256) void k_drop_clear(const int* __restrict__ ctr,
 // one wave per droplet
 __global__ __launch_bounds__(256) void k_drop_solve(Grid g, LBox L, int n_comp, const int* __restrict__ pre, const int* __restrict__ comp_n, const int* __restrict__ comp_cells,
                                                     const uint8_t* __restrict__ flags, const float* __restrict__ b, Coef<double> cf, double tol,
-                                                    double* __restrict__ pressure, double* __restrict__ keep)
+                                                    double* __restrict__ pressure, double* __restrict__ keep, int* __restrict__ n_fail)
 {
     __shared__ int skey[4][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -302,21 +315,24 @@ __global__ __launch_bounds__(256) void k_drop_solve(Grid g, LBox L, int n_comp, 
         pressure[c] = x;
         if (keep) keep[c] = x;
     }
+    // a droplet that left the loop by its iteration cap or a breakdown, not by the stopping rule: counted, fluid_step reports it
+    if (lane == 0 && bb > 0 && !(rr <= thr) && n_fail) atomicAdd(n_fail, 1);
 }
 
 // cells: 64 ints per component; blocks of 8^3 over the interior of the local box.  ctr: 64 * DROP_NCTR ints; pre: DROP_NCTR + 1 ints
-void launch_drop_find(hipStream_t st, LBox L, uint8_t* cnt, int* ctr, int* pre, int* total, int* comp_n, int* comp_cells)
+void launch_drop_find(hipStream_t st, LBox L, uint8_t* cnt, int* ctr, int* pre, int* total, int* comp_n, int* comp_cells, const Box* own)
 {
+    const Box all{0, 0, 0, L.Lx - 1, L.Ly - 1, L.Lz - 1};
     const int ncx = (L.nx + DC - 1) / DC, ncy = (L.ny + DC - 1) / DC, ncz = (L.nz + DC - 1) / DC;
     hipMemsetAsync(ctr, 0, (size_t)64 * DROP_NCTR * sizeof(int), st);
-    hipLaunchKernelGGL(k_drop_find, dim3((unsigned)(ncx * ncy * ncz)), dim3(512), 0, st, L, cnt, ncx, ncy, ncz, ctr, comp_n, comp_cells);
+    hipLaunchKernelGGL(k_drop_find, dim3((unsigned)(ncx * ncy * ncz)), dim3(512), 0, st, L, own ? *own : all, cnt, ncx, ncy, ncz, ctr, comp_n, comp_cells);
     hipLaunchKernelGGL(k_drop_clear, dim3((unsigned)((size_t)DROP_CAP * 64 / 256)), dim3(256), 0, st, ctr, comp_n, comp_cells, cnt, pre, total);
 }
 void launch_drop_solve(hipStream_t st, Grid g, LBox L, int n_comp, const int* pre, const int* comp_n, const int* comp_cells, const uint8_t* flags,
-                       const float* b, Coef<double> cf, double tol, double* pressure, double* keep)
+                       const float* b, Coef<double> cf, double tol, double* pressure, double* keep, int* n_fail)
 {
     if (n_comp <= 0) return;
-    hipLaunchKernelGGL(k_drop_solve, dim3((unsigned)((n_comp + 3) / 4)), dim3(256), 0, st, g, L, n_comp, pre, comp_n, comp_cells, flags, b, cf, tol, pressure, keep);
+    hipLaunchKernelGGL(k_drop_solve, dim3((unsigned)((n_comp + 3) / 4)), dim3(256), 0, st, g, L, n_comp, pre, comp_n, comp_cells, flags, b, cf, tol, pressure, keep, n_fail);
 }
 
 }  // namespace fl

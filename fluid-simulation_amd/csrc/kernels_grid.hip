@@ -513,6 +513,7 @@ __global__ void k_zero_step_state(StepState* ss, int N)
     ss->bbox_max[0] = ss->bbox_max[1] = ss->bbox_max[2] = -1;
     ss->num_active = 0;
     ss->n_out = 0;
+    ss->n_drop_fail = 0;
     ss->max_speed_bits = 0ull;
     ss->err_num = 0;
     ss->err_den = 0;

@@ -122,6 +122,7 @@ typedef struct fluid_step_stats {
 #define FLUID_PATH_MG_COARSE 16       /* the V-cycle's coarse levels ran as one persistent launch (FLUID_MG_COARSE=1|2; off by default) */
 #define FLUID_PATH_MG_GALERKIN 128   /* the V-cycle's coarse levels were Galerkin operators by aggregation (mostly-air box whose re-discretised levels lose much of the pool) */
 #define FLUID_PATH_DROPLETS 64        /* closed pockets of <= 64 unknowns (airborne droplets) were solved apart from the global system   */
+#define FLUID_PATH_DROPLETS_SHORT 256 /* ... and at least one of them left its own CG by the iteration cap or a breakdown, not by the stopping rule (relres above cg_tol there) */
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 /* Reference defaults (N=121, g=(0,-10,0), dx=1, rho=1, max_dt=0.1, outer_tol=0.1,

@@ -346,6 +346,53 @@ def test_baseline_multi_gpu_configs_on_blocks(fs, n, ppc):
     assert a <= 1.2 * b, (a, b)
 
 
+def _pool_with_spray(fs, n, rng):
+    """A shallow pool wall to wall, and closed pockets above it: single cells and pairs, some of them lying across the cut planes of a
+    2 x 2 x 2 decomposition (those must stay in the global solve), none touching another."""
+    lo, hi = fs.grid_bounds(n)
+    w0, w1 = lo + 2, hi - 2
+    def fill(cells, ppc):
+        cells = np.asarray(cells, dtype=np.float64).reshape(-1, 3)
+        return np.repeat(cells, ppc, axis=0) + rng.uniform(-0.3, 0.3, size=(len(cells) * ppc, 3))
+    pool = np.stack(np.meshgrid(np.arange(w0, w1 + 1), np.arange(w0, w0 + 5), np.arange(w0, w1 + 1), indexing="ij"), -1).reshape(-1, 3)
+    parts = [fill(pool, 2)]
+    drops = []
+    for x in range(w0 + 3, w1 - 3, 6):
+        for y in range(w0 + 12, w1 - 3, 7):
+            for z in range(w0 + 3, w1 - 3, 6):
+                drops.append((x, y, z))
+                if (x + y + z) % 3 == 0:
+                    drops.append((x + 1, y, z))            # a two-cell pocket; x = -1 gives one across the x cut
+    drops += [(-1, 10, 5), (0, 10, 5), (7, -1, -9), (7, 0, -9), (11, 13, -1), (11, 13, 0)]   # pockets across each cut plane (cells -1 | 0)
+    parts.append(fill(sorted(set(drops)), 3))
+    return np.concatenate(parts)
+
+
+def test_decomposed_with_droplets_and_galerkin_levels(fs, monkeypatch):
+    """Round 3's solver pieces in the decomposed step: closed pockets are found per rank (owned cells only: a pocket across a cut stays in
+    the global solve), leave the system on both sides of every cut (count-byte halo from the owners) and are solved by their owner; the
+    coarse levels are Galerkin operators by aggregation, level 1's coefficients gathered from the owners.  Forced on at test size
+    (FLUID_TILE_LISTS=1, FLUID_MG_GALERKIN=2); against one GPU with the same pieces on and with them off: same unknown numbering, same
+    pressure, iteration counts within 10 %."""
+    n, steps = 64, 3
+    pos = _pool_with_spray(fs, n, np.random.default_rng(11))
+    plain = single(fs, n, pos, None, steps)
+    monkeypatch.setenv("FLUID_TILE_LISTS", "1")
+    monkeypatch.setenv("FLUID_MG_GALERKIN", "2")
+    monkeypatch.setenv("FLUID_DROPLETS_MIN", "0")        # (one GPU: search in every step, also while few pockets are found)
+    ref = single(fs, n, pos, None, steps)
+    assert all(s["paths"] & 64 for s in ref["st"]) and all(s["paths"] & 128 for s in ref["st"]), [s["paths"] for s in ref["st"]]
+    d = run_blocks(fs, (2, 2, 2), n, pos, None, steps, "decomposed", uniform=True)
+    compare(d, ref, len(pos), "droplets + galerkin", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
+    assert rel_l2(d["pressure"], plain["pressure"]) < 1e-7
+    assert all(s["paths"] & 128 for s in d["st"])                                   # Galerkin levels on every rank
+    assert sum(1 for st in d["all_st"] if st[0]["paths"] & 64) >= 4                  # the ranks above the pool found pockets
+    assert not any(s["paths"] & 256 for st in d["all_st"] for s in st)               # every pocket's own CG met the stopping rule
+    a, b = sum(s["cg_iters"] for s in d["st"]), sum(s["cg_iters"] for s in ref["st"])
+    print(f"droplets + galerkin: iterations decomposed {a} one GPU {b} (plain cycle, droplets in: {sum(s['cg_iters'] for s in plain['st'])})")
+    assert abs(a - b) <= 0.1 * b + 2 * steps
+
+
 def test_decomposed_through_the_splash(fs):
     """2 x 2 x 2 blocks, 160 free-running steps: the cube falls across the cut planes, hits the floor, splashes into all eight
     blocks (migration in every direction, ghosts at edges and corners, blocks whose share grows several-fold: buffers grow on
