@@ -621,7 +621,34 @@ int dist_mg_setup(fluid_sim* s)
     // levels held on block + halo: 0 .. split-1.  Level 1 is gathered (split = 1) while it is small: one all-reduce of
     // the level instead of two halo exchanges per iteration, at the price of every rank sweeping all of it.
     const long l1 = (long)gd[1].dim[0] * gd[1].dim[1] * gd[1].dim[2];
-    int split = d->split_force ? d->split_force : (l1 <= 300000 ? 1 : 2);
+    // Galerkin coarse levels by aggregation (kernels_gal.hip) in a mostly-air box, like the one-GPU solve: decided first, from global
+    // numbers only (every rank the same cycle) — the aggregated levels run replicated, so a step that takes them gathers level 1
+    // (split = 1) whatever its size.
+    s->gal = false;
+    s->gal_eligible = false;
+    bool want_gal = false;
+    int gal_lc = 1;
+    {
+        while (gal_lc < nl - 1 && !gal_fits_coarsest(level_layout(gd[gal_lc].dim[0], gd[gal_lc].dim[1], gd[gal_lc].dim[2]))) ++gal_lc;
+        const double c0 = (double)gd[0].dim[0] * gd[0].dim[1] * gd[0].dim[2];
+        const bool airy = (double)s->stats.num_active < 0.45 * c0 && c0 > 1500000.0;
+        if (s->gal_mode && s->mg_fp32 && use_mg(s) && d->split_force != 2 && gal_lc >= 2 && gal_lc < nl &&
+            gal_fits_coarsest(level_layout(gd[gal_lc].dim[0], gd[gal_lc].dim[1], gd[gal_lc].dim[2])) && (airy || s->gal_mode >= 2)) {
+            s->gal_eligible = true;
+            want_gal = s->gal_mode >= 2;
+            if (s->gal_mode == 1) {
+                if (s->gal_it[0] < 0) want_gal = false;
+                else if (s->gal_it[1] < 0) want_gal = true;
+                else {
+                    want_gal = s->gal_it[1] < s->gal_it[0];
+                    if (++s->gal_since_probe >= 32) { want_gal = !want_gal; s->gal_since_probe = 0; }
+                }
+            }
+        } else {
+            s->gal_it[0] = s->gal_it[1] = -1;   // (measured again when the box is mostly air again)
+        }
+    }
+    int split = d->split_force ? d->split_force : (want_gal || l1 <= 300000 ? 1 : 2);
     if (split > nl - 1) split = nl - 1;
     if (split < 1) split = 1;
     d->split = split;
@@ -796,33 +823,13 @@ int dist_mg_setup(fluid_sim* s)
         }
         HIPCHK(hipGetLastError());
     }
-    // ---- Galerkin coarse levels by aggregation (kernels_gal.hip) in a mostly-air box, like the one-GPU solve ------------------
+    // ---- the Galerkin levels' coefficients ------------------------------------------------------------------------------------
     // With split = 1 every level below level 0 is replicated, so only level 1's coefficients need the blocks: each rank forms
     // them for the coarse cells under its owned fine cells (the children and their face neighbours lie inside its halo: cuts are
     // multiples of 4) and the owners' values are gathered like the level's right-hand side, once per step; the levels below are
-    // coarsened identically everywhere.  Every input of the decision is a global number: the same cycle on every rank.
-    s->gal = false;
-    s->gal_eligible = false;
-    {
-        int lc = 1;
-        while (lc < nl - 1 && !gal_fits_coarsest(s->mgl[lc])) ++lc;
-        const double c0 = (double)gd[0].dim[0] * gd[0].dim[1] * gd[0].dim[2];
-        const bool airy = (double)s->stats.num_active < 0.45 * c0 && c0 > 1500000.0;
-        if (!(s->gal_mode && s->mg_fp32 && split == 1 && lc >= 2 && gal_fits_coarsest(s->mgl[lc]) && (airy || s->gal_mode >= 2))) {
-            s->gal_it[0] = s->gal_it[1] = -1;
-            return FLUID_OK;
-        }
-        s->gal_eligible = true;
-        bool use = s->gal_mode >= 2;
-        if (s->gal_mode == 1) {
-            if (s->gal_it[0] < 0) use = false;
-            else if (s->gal_it[1] < 0) use = true;
-            else {
-                use = s->gal_it[1] < s->gal_it[0];
-                if (++s->gal_since_probe >= 32) { use = !use; s->gal_since_probe = 0; }
-            }
-        }
-        if (!use) return FLUID_OK;
+    // coarsened identically everywhere.
+    if (want_gal && split == 1) {
+        const int lc = gal_lc;
         size_t total_g = 0, off[fluid_sim::MG_MAXL][6];
         for (int l = 1; l <= lc; ++l)
             for (int q = 0; q < 6; ++q) {

@@ -39,9 +39,20 @@ ref.upload_particles(pos)
 rs = []
 for _ in range(steps):
     t1 = time.perf_counter(); s = ref.step(); rs.append((time.perf_counter() - t1, s))
-for i in range(steps):
-    a, b = res[0][0][i], rs[i]
-    print(f"  step {i}: blocks {a[0]*1e3:8.2f} ms  iters {a[1]['cg_iters']:4d} passes {a[1]['outer_passes']}  unknowns {a[1]['num_active']}   |  one GPU {b[0]*1e3:6.2f} ms iters {b[1]['cg_iters']:4d} passes {b[1]['outer_passes']} unknowns {b[1]['num_active']}")
+if steps <= 20:
+    for i in range(steps):
+        a, b = res[0][0][i], rs[i]
+        print(f"  step {i}: blocks {a[0]*1e3:8.2f} ms  iters {a[1]['cg_iters']:4d} passes {a[1]['outer_passes']}  unknowns {a[1]['num_active']}   |  one GPU {b[0]*1e3:6.2f} ms iters {b[1]['cg_iters']:4d} passes {b[1]['outer_passes']} unknowns {b[1]['num_active']}")
+else:   # a long run: sums per 100 steps (the two runs part ways in the splash: chaotic, compare totals)
+    for i0 in range(0, steps, 100):
+        A = [x[1] for x in res[0][0][i0:i0 + 100]]; B = [x[1] for x in rs[i0:i0 + 100]]
+        gal = lambda S: sum(1 for s in S if s["paths"] & 128)
+        drp = lambda R: sum(1 for s in R if s["paths"] & 64)
+        print(f"  steps {i0:3d}-{i0 + len(A) - 1:3d}: blocks iters {sum(s['cg_iters'] for s in A):6d} passes {sum(s['outer_passes'] for s in A):4d} galerkin steps {gal(A):3d} "
+              f"droplet steps (any rank) {sum(1 for k in range(len(A)) if any(r[0][i0 + k][1]['paths'] & 64 for r in res)):3d}  |  one GPU iters {sum(s['cg_iters'] for s in B):6d} "
+              f"passes {sum(s['outer_passes'] for s in B):4d} galerkin steps {gal(B):3d} droplet steps {drp(B):3d}")
+    ta, tb = sum(x[1]['cg_iters'] for x in res[0][0]), sum(x[1]['cg_iters'] for x in rs)
+    print(f"  total iterations: blocks {ta}  one GPU {tb}  ratio {ta / tb:.3f}")
 ids = np.concatenate([r[3] for r in res]); o = np.argsort(ids)
 P = np.concatenate([r[1] for r in res])[o]; V = np.concatenate([r[2] for r in res])[o]
 p, v = ref.download_particles()
