@@ -92,7 +92,7 @@ def usable_cores():
 
 def pmc_traffic(kernel, n, ppc):
     """HBM/fabric bytes per launch measured by separate rocprofv3 --pmc passes of this workload (see the file's "method")."""
-    tj = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r03", "r02")) if os.path.exists(q)), None)
+    tj = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r04", "r03", "r02")) if os.path.exists(q)), None)
     if n != 256 or ppc != 8 or tj is None:
         return None
     table = json.load(open(tj))
@@ -105,6 +105,24 @@ def pmc_traffic(kernel, n, ppc):
             return None
         kernel = cand[0]
     return table[kernel].get("bytes_per_launch")
+
+
+def mpm_pmc_traffic():
+    """Fabric bytes per operator application of the scaled snow cone (k_mpm_apply_particles + k_mpm_apply_cells), from the newest
+    profiles/r0N/mpm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/mpm_run.py 63 24 64; FETCH_SIZE doubled)."""
+    for r in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", r, "mpm_pmc.txt")
+        if not os.path.exists(path):
+            continue
+        tot, seen = 0.0, set()
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 3 and f[0] in ("k_mpm_apply_particles", "k_mpm_apply_cells") and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                tot += float(f[2]) * 1e6
+                seen.add((f[0], f[1]))
+        if len(seen) >= 2:
+            return tot, f"profiles/{r}/mpm_pmc.txt ({', '.join(sorted(a + ' ' + b for a, b in seen))})"
+    return None, None
 
 
 def stencil_microbench(fs, n, device):
@@ -519,7 +537,7 @@ def main():
                 us = d["apply_kernel_us"]
                 d["roofline"] = {"kernel": "k_mpm_apply_particles + k_mpm_apply_gather (one application of the matrix-free operator; time = HIP events around both)",
                                  "bound": "fp64-valu", "achieved": flops / (us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / (us * 1e-6) / 78.6e12,
-                                 "traffic": None,
+                                 "traffic": mpm_pmc_traffic()[0] if B == 63 else None, "traffic_source": mpm_pmc_traffic()[1] if B == 63 else None,
                                  "l2_bytes_per_application": 104.0 * 8 * sim.num_particles + 428.0 * sim.num_particles,
                                  "l2_rate_TBs": (104.0 * 8 + 428.0) * sim.num_particles / (us * 1e-6) / 1e12,
                                  "note": "latency-bound: ~1300 fp64 operations per particle in dependent chains at 2 waves per SIMD (154 VGPRs), then a node gather "

@@ -131,7 +131,7 @@ SYMBOLS = [
     ("mpm_step_advance", C.c_int, [_P, C.POINTER(MpmStepStats)]),
     ("mpm_download_particles", C.c_int, [_P, C.c_int32, _P]),
     ("mpm_download_field", C.c_int, [_P, C.c_int32, _P]),
-    ("mpm_download_system", C.c_int, [_P, _P, _P]),
+    ("mpm_download_system", C.c_int, [_P, _P, _P, C.c_int64]),
     ("mpm_apply_matrix", C.c_int, [_P, _P, _P]),
     ("mpm_eval", C.c_int, [C.c_int32, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P]),
     ("mpm_scene_cone", C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint32, _P]),

@@ -243,7 +243,9 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, 
 void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                       float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,
-                      const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss);
+                      const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss, int* items = nullptr, long n_particles = 0);
+// items != nullptr: over a device-built work list (2 + 2 * g2p_max_items ints) instead of one block per tile: empty tiles cost nothing, piles are split
+long g2p_max_items(Box pb, long n_particles);
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,
                 const double* pcy, const double* pcz, double blend, StepState* ss);
 void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss);
@@ -358,11 +360,6 @@ constexpr int MG_TAIL_MAX = 4;          // levels the single-block tail kernel c
 constexpr size_t MG_TAIL_LDS = 144 * 1024;  // dynamic LDS the tail kernel may use (160 KB per CU on gfx950): levels whose u, v, f + counts fit go into the tail
 size_t mg_tail_lds_bytes(int nl, const MLevel* lv, size_t elem);
 int mg_up_blocks(const MLevel& m);
-// XR of a PCG iteration + the level-0 down leg of the next V-cycle in one launch (kernels_mg.hip, k_mg_down_xr): mg_up_blocks(m) blocks
-// and |r|^2 partials; r_out != r_in
-template <typename T>
-void launch_mg_down_xr(hipStream_t st, MLevel m, const uint8_t* cnt, const double* r_in, double* r_out, const double* q, double* x, const double* s_vec,
-                       T* u, T* r0, MgCoef<T> cf, PcgState* ps, const double* part_rz_cur, int n_rz, const double* part_pq, int n_pq, double* part_rr);
 // T = the V-cycle's arithmetic/storage type, F / O = element types of a level's rhs / result (double at level 0)
 template <typename T, typename F>
 void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T* u, T* r, MLevel mc, const uint8_t* cnt_c, T* fc, MgCoef<T> cf,
@@ -394,31 +391,5 @@ void launch_compact_flags(hipStream_t st, const uint8_t* flags, int n, int* list
 template <typename T>
 void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8_t* const* cnt, T* u0, const T* off, int sweeps, const PcgState* ps,
                     double wc);
-
-// the coarse levels of the cycle as one persistent launch (k_mg_coarse, float cycle only)
-constexpr int MGC_MAXL = 8;                  // = fluid_sim::MG_MAXL
-constexpr int MGC_MAXPH = 10;                // phases: restrict, down per level (<= 4 levels), tail, up per level
-constexpr int MGC_SLOT = 32 * (MGC_MAXPH + 1);   // ints per counter slot: ticket word + one word per phase, each on its own 128-byte line
-constexpr size_t MGC_SYNC_BYTES = 2 * MGC_SLOT * sizeof(int);
-template <typename T>
-struct MgCoarseArgs {
-    int nl, first, tail;        // levels of the hierarchy; the launch runs [first, tail) as legs and [tail, nl) as the tail
-    bool restrict0;             // first phase: f[first] = restriction of r_prev (the residual of level first-1, from an earlier launch)
-    MLevel m[MGC_MAXL];
-    uint8_t* cnt[MGC_MAXL];
-    T *u[MGC_MAXL], *w[MGC_MAXL], *f[MGC_MAXL];
-    const T* r_prev;
-    MgCoef<T> cf[MGC_MAXL];
-    T off[MGC_MAXL];            // off-diagonals of the tail levels
-    double wc[MGC_MAXL], wc_tail;
-    int sweeps;
-};
-size_t mg_coarse_desc_bytes();
-template <typename T>
-void launch_mg_coarse_store(hipStream_t st, const MgCoarseArgs<T>& a, void* desc, int* sync, long long* dbg, int max_blocks, int tpt, int* nblocks, size_t* lds);
-int mg_coarse_ntasks_max();   // tasks the developer trace buffer holds
-template <typename T>
-void launch_mg_coarse(hipStream_t st, const void* desc, int nblocks, size_t lds, int gen, const PcgState* ps, bool prefetch);
-int mg_coarse_max_levels();   // leg levels one launch can hold
 
 }  // namespace fl

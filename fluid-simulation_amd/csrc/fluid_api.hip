@@ -168,24 +168,12 @@ int fluid_destroy(fluid_sim_t* s)
     if (!s) return FLUID_OK;
     if (s->st) hipStreamSynchronize(s->st);
     if (s->ds) dist_destroy(s);
-    if (s->mgc_dbg) {
-        // developer trace of the persistent coarse-level launch: {ticket taken, phase wait over, body done, stores drained} per task, 10 ns ticks
-        if (const char* path = getenv("FLUID_MGC_TRACE")) {
-            std::vector<long long> h((size_t)4 * mg_coarse_ntasks_max());
-            if (hipMemcpy(h.data(), s->mgc_dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
-                if (FILE* f = fopen(path, "w")) {
-                    for (size_t t = 0; t < h.size() / 4 && h[4 * t]; ++t) fprintf(f, "%zu %lld %lld %lld %lld\n", t, h[4 * t], h[4 * t + 1], h[4 * t + 2], h[4 * t + 3]);
-                    fclose(f);
-                }
-            }
-        }
-    }
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->R2, s->gal_slab};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->g2p_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->gal_slab};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -235,24 +223,12 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     s->mg_fp32 = p->mg_precision == FLUID_MG_FP32;
     s->warm = p->solve_start == FLUID_START_WARM;
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments): they override the params
-    if (const char* e = getenv("FLUID_MG_FP64")) s->mg_fp32 = atoi(e) == 0;
-    if (const char* e = getenv("FLUID_WARM_START")) s->warm = atoi(e) != 0;
     if (const char* e = getenv("FLUID_TILE_LISTS")) s->lists_force = atoi(e) != 0;
     if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
-    if (const char* e = getenv("FLUID_MG_WC")) sscanf(e, "%lf,%lf,%lf,%lf", &s->mg_wc[0], &s->mg_wc[1], &s->mg_wc[2], &s->mg_wc[3]);
-    if (const char* e = getenv("FLUID_XR_ROWS")) s->rows_on = atoi(e) != 0;
-    if (const char* e = getenv("FLUID_XR_FUSE")) s->xr_fuse = atoi(e) != 0;
     if (const char* e = getenv("FLUID_MG_GALERKIN")) s->gal_mode = atoi(e);
-    if (const char* e = getenv("FLUID_MG_GALERKIN_WC")) s->gal_wc = atof(e);
-    if (const char* e = getenv("FLUID_MG_GALERKIN_SWEEPS")) s->gal_sweeps = atoi(e);
     if (const char* e = getenv("FLUID_DROPLETS")) s->drops_on = atoi(e) != 0;
     if (const char* e = getenv("FLUID_ROW_SWEEPS")) s->row_sweeps = atoi(e) != 0;
     if (const char* e = getenv("FLUID_DROPLETS_MIN")) s->drop_min = atoi(e);
-    if (const char* e = getenv("FLUID_MG_COARSE")) s->mgc_mode = atoi(e);
-    if (const char* e = getenv("FLUID_MG_COARSE_BLOCKS")) s->mgc_max_blocks = std::max(1, atoi(e));
-    if (const char* e = getenv("FLUID_MG_COARSE_CELLS")) s->mgc_max_cells = atol(e);
-    if (const char* e = getenv("FLUID_MG_COARSE_TPT")) s->mgc_tpt = atoi(e);
-    if (const char* e = getenv("FLUID_MG_COARSE_PREFETCH")) s->mgc_prefetch = atoi(e) != 0;
     *out = nullptr;
     auto bail = [&](int rc) { fluid_destroy(s); return rc; };
 #define A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(FLUID_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
@@ -285,8 +261,6 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     A(dalloc(&s->ps, (size_t)1)); A(dalloc(&s->ss, (size_t)1));
     A(dalloc(&s->cell_count, n + 4)); A(dalloc(&s->cell_start, n + 4));
     A(dalloc(&s->d_small, (size_t)32));
-    A(dalloc((char**)&s->mgc_desc, mg_coarse_desc_bytes())); A(dalloc((char**)&s->mgc_sync, MGC_SYNC_BYTES));
-    if (getenv("FLUID_MGC_TRACE")) A(dalloc(&s->mgc_dbg, (size_t)4 * mg_coarse_ntasks_max()));
     A(hipHostMalloc((void**)&s->h_small, 32 * sizeof(int)));
     A(hipHostMalloc((void**)&s->h_ps, 2 * sizeof(PcgState)));
     A(hipEventCreateWithFlags(&s->ev_poll[0], hipEventDisableTiming));
@@ -649,17 +623,6 @@ static int mg_setup(fluid_sim* s)
     }
     s->Zmg = s->mg_slab + o_z;
     HIPCHK(hipMemsetAsync(s->mg_slab, 0, total, s->st));
-    // which levels run inside the persistent coarse-level launch: from the first level of <= mgc_max_cells cells on (bigger
-    // levels are real work for the whole chip and keep their own launches)
-    {
-        auto cells = [&](int l) { return (long)s->mgl[l].dx * s->mgl[l].dy * s->mgl[l].dz; };
-        int first = 1;
-        while (first < tail && (cells(first) > s->mgc_max_cells || tail - first > mg_coarse_max_levels())) ++first;
-        const bool fold0 = cells(0) <= 200000;   // level 0 restricts inside its down kernel (mg_vcycle_t)
-        s->mgc_first = first;
-        s->mgc_restrict0 = s->mgc_mode >= 2 && first == 1 && !fold0;
-        s->mgc_on = s->mgc_mode >= 1 && s->mg_fp32 && !s->dist && cells(first) <= s->mgc_max_cells && (first < tail || s->mgc_restrict0);
-    }
     launch_mg_type0(s->st, s->g, s->L, s->mgl[0], s->flags, s->cntL, s->mg_typ[0]);
     for (int l = 1; l < nl; ++l) launch_mg_coarsen(s->st, s->mgl[l - 1], s->mg_typ[l - 1], s->mgl[l], s->mg_typ[l], s->mg_cnt[l]);
     { int rcg = gal_build(s); if (rcg) return rcg; }
@@ -709,7 +672,7 @@ static int gal_build(fluid_sim* s)
     const int nl = s->mg_nl;
     int lc = 1;
     while (lc < nl - 1 && !gal_fits_coarsest(s->mgl[lc])) ++lc;
-    if (!(s->gal_mode && s->lists_on && s->mg_fp32 && !s->dist && !s->mgc_on && (long)s->mgl[0].dx * s->mgl[0].dy * s->mgl[0].dz > 200000 &&
+    if (!(s->gal_mode && s->lists_on && s->mg_fp32 && !s->dist && (long)s->mgl[0].dx * s->mgl[0].dy * s->mgl[0].dz > 200000 &&
           gal_fits_coarsest(s->mgl[lc]) && lc >= 2)) {
         s->gal_it[0] = s->gal_it[1] = -1;   // (measured again when the box is mostly air again)
         return FLUID_OK;
@@ -758,29 +721,6 @@ static int gal_build(fluid_sim* s)
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
-// descriptor of the persistent coarse-level launch for this solve (stream-ordered; the coefficients follow dt)
-static int mg_coarse_prepare(fluid_sim* s)
-{
-    if (!s->mgc_on) return FLUID_OK;
-    typedef float V;
-    MgCoarseArgs<V> a;
-    a.nl = s->mg_nl; a.first = s->mgc_first; a.tail = s->mg_tail; a.restrict0 = s->mgc_restrict0;
-    for (int l = 0; l < MGC_MAXL; ++l) {
-        const int q = l < a.nl ? l : a.nl - 1;
-        a.m[l] = s->mgl[q]; a.cnt[l] = s->mg_cnt[q];
-        a.u[l] = (V*)s->mg_u[q]; a.w[l] = (V*)s->mg_v[q]; a.f[l] = (V*)s->mg_f[q];
-        a.cf[l] = mg_coef_as<V>(s, q);
-        a.off[l] = (V)mg_coef(s, q).off;
-        a.wc[l] = s->mg_wc[q == 1 ? 1 : 2];
-    }
-    a.r_prev = (const V*)s->mg_r[a.first - 1];
-    a.wc_tail = s->mg_wc[3];
-    a.sweeps = s->mg_csweeps;
-    launch_mg_coarse_store<V>(s->st, a, s->mgc_desc, s->mgc_sync, s->mgc_dbg, s->mgc_max_blocks, s->mgc_tpt, &s->mgc_blocks, &s->mgc_lds);
-    HIPCHK(hipGetLastError());
-    return FLUID_OK;
-}
-
 // The cycle with Galerkin coarse levels (kernels_gal.hip): level 0 by the kernels of kernels_mg.hip (its own coefficients; the up leg
 // takes the parent's value as the correction), levels 1 .. gal_lc - 1 by k_gal_down / k_gal_up, the coarsest by one block.
 static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
@@ -809,7 +749,7 @@ static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, double* z0, double* p
 }
 
 template <typename V>
-static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, bool down0_done = false)
+static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
     const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
@@ -817,30 +757,23 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     auto W = [&](int l) { return (V*)s->mg_v[l]; };
     auto F = [&](int l) { return (V*)s->mg_f[l]; };
     auto R = [&](int l) { return (V*)s->mg_r[l]; };
-    // the levels from `coarse` on run inside ONE persistent launch (float cycle; kernels_mg.hip, k_mg_coarse), the others leg by leg
-    const bool pc = s->mgc_on && sizeof(V) == 4;
-    const int coarse = pc ? s->mgc_first : tail;
-    for (int l = 0; l < coarse; ++l) {
+    for (int l = 0; l < tail; ++l) {
         const MLevel& m = s->mgl[l];
         // restriction inside the down kernel (halo 3): not at a big level 0, where 5x halo reads cost more than a launch
         const bool fold = l > 0 || (long)m.dx * m.dy * m.dz <= 200000;
         V* fc = fold ? F(l + 1) : nullptr;
         const uint8_t* cc = fold ? s->mg_cnt[l + 1] : nullptr;
         const bool lst = s->lists_on && !fold;
-        if (l == 0 && down0_done) { /* the fused XR of the iteration before has run this leg (k_mg_down_xr) */ }
-        else if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
+        if (l == 0) launch_mg_down<V, double>(s->st, m, s->cntL, rhs0, U(0), R(0), s->mgl[1], cc, fc, mg_coef_as<V>(s, 0), ps, lst ? s->tl_mg : nullptr, s->n_tl_mg);
         else launch_mg_down<V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), U(l), R(l), s->mgl[l + 1], cc, fc, mg_coef_as<V>(s, l), ps);
-        if (!fold && !(pc && s->mgc_restrict0)) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
+        if (!fold) launch_mg_restrict<V>(s->st, m, (const V*)R(l), s->mgl[l + 1], s->mg_cnt[l + 1], F(l + 1), ps);
     }
-    if (pc) {
-        s->stats.paths |= FLUID_PATH_MG_COARSE;
-        launch_mg_coarse<float>(s->st, s->mgc_desc, s->mgc_blocks, s->mgc_lds, (int)(s->mgc_gen++ & 1), ps, s->mgc_prefetch);
-    } else {
+    {
         V off[fluid_sim::MG_MAXL];
         for (int l = tail; l < nl; ++l) off[l] = (V)mg_coef(s, l).off;
         launch_mg_tail<V>(s->st, nl - tail, (const V*)F(tail), s->mgl + tail, s->mg_cnt + tail, U(tail), off + tail, s->mg_csweeps, ps, s->mg_wc[3]);
     }
-    for (int l = coarse - 1; l >= 0; --l) {
+    for (int l = tail - 1; l >= 0; --l) {
         const MLevel& m = s->mgl[l];
         const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);  // out != u: neighbouring tiles still read u
         if (l == 0) {
@@ -855,10 +788,10 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
-static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, bool down0_done = false)
+static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
 {
     if (s->gal && s->lists_on) return mg_vcycle_gal(s, rhs0, z0, part_rz);
-    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz, down0_done) : mg_vcycle_t<double>(s, rhs0, z0, part_rz, down0_done);
+    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz) : mg_vcycle_t<double>(s, rhs0, z0, part_rz);
 }
 
 // PCG loop of ConjugateGradient.h:28-90 with z = V-cycle(r); same start, stopping rule and cap as solve_impl.
@@ -868,7 +801,7 @@ static int solve_mg(fluid_sim* s)
     const Grid g = s->g;
     const LBox L = s->L;
     T* X = (T*)s->X;
-    T* R = (T*)s->R;   // (the fused form below alternates between R and a second array)
+    T* R = (T*)s->R;
     T* Q = (T*)s->Q;
     T* Sx[2] = {(T*)s->S[0], (T*)s->S[1]};
     T* Z = (T*)s->Zmg;  // z lives in its own level-0 array: the V-cycle uses mg_u[0]/mg_v[0]/mg_r[0] as scratch and writes z last
@@ -889,24 +822,12 @@ static int solve_mg(fluid_sim* s)
     const bool fold = n_rz_raw > 1024;
     const int n_rz = fold ? 1 : n_rz_raw;
     int rc;
-    // XR and the level-0 down leg of the next V-cycle as one launch (k_mg_down_xr): dense level 0 with its own restriction launch
-    // (not the small boxes whose down leg restricts itself), one |r|^2 partial per tile (at most 1024 of them)
-    const MLevel& m0 = s->mgl[0];
-    const int n_tiles0 = mg_up_blocks(m0);
-    const bool fuse = s->xr_fuse && !lists && !s->mgc_on && (long)m0.dx * m0.dy * m0.dz > 200000 && n_tiles0 <= 1024 && s->mg_nl >= 2;
-    if (fuse && !s->R2) HIPCHK(hipMalloc((void**)&s->R2, s->lmax * sizeof(double)));
-    T* Rb[2] = {R, fuse ? (T*)s->R2 : R};
-    int rp = 0;                 // Rb[rp] holds the current residual
-    bool down0_done = false;    // the level-0 down leg of the next V-cycle has already run (inside the fused launch)
-    const int n_xr = fuse ? n_tiles0 : n_list;   // |r|^2 partials of an XR launch after the first iteration (dense unfused: launch_pcg_sq's default)
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
-    if ((rc = mg_coarse_prepare(s))) return rc;
     if (s->gal && s->gal_dt != s->dt) {   // dt changed since the coefficients were built (phase API): same decision, new coefficients
         const int keep = s->gal_mode; s->gal_mode = 2; rc = gal_build(s); s->gal_mode = keep;
         if (rc) return rc;
     }
     if (s->gal) s->stats.paths |= FLUID_PATH_MG_GALERKIN;
-    if (fuse) HIPCHK(hipMemsetAsync(s->R2, 0, (s->L.cells() + 2 * (size_t)s->L.Lz) * sizeof(double), s->st));   // zeros off the unknowns, like R
     // Start: x = 0 like the reference's cg.solve(b) — or, by default, the previous solve's pressure (Eigen's solveWithGuess
     // form of the same loop: r0 = b - A x0, same threshold tol^2 |b|^2).  The converged p does not depend on the start
     // beyond the tolerance; a settled pool needs far fewer iterations.  r0.r0 partials travel in part_rz[1] (unused by body 0).
@@ -927,7 +848,7 @@ static int solve_mg(fluid_sim* s)
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = mg_vcycle(s, Rb[rp], Z, fold ? s->mg_part : s->part_rz[cur], down0_done))) return rc;
+            if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur]))) return rc;
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
             if (lists)
@@ -936,19 +857,10 @@ static int solve_mg(fluid_sim* s)
                                       s->n_tl_sq);
             else
                 launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
-                                 s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse, fuse && it > 0 ? n_xr : -1);
+                                 s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-            if (fuse) {
-                if (s->mg_fp32)
-                    launch_mg_down_xr<float>(s->st, m0, cnt, Rb[rp], Rb[rp ^ 1], Q, X, Sx[cur], (float*)s->mg_u[0], (float*)s->mg_r[0], mg_coef_as<float>(s, 0),
-                                             s->ps, s->part_rz[cur], n_rz, s->part_pq, pcg_sq_blocks(L), s->part_rr);
-                else
-                    launch_mg_down_xr<double>(s->st, m0, cnt, Rb[rp], Rb[rp ^ 1], Q, X, Sx[cur], (double*)s->mg_u[0], (double*)s->mg_r[0],
-                                              mg_coef_as<double>(s, 0), s->ps, s->part_rz[cur], n_rz, s->part_pq, pcg_sq_blocks(L), s->part_rr);
-                rp ^= 1;
-                down0_done = true;
-            } else if (rows)
+            if (rows)
                 launch_pcg_xr_rows<T>(s->st, L, cnt, X, R, Sx[cur], Q, cf, s->part_rz[cur], n_rz, s->part_pq, pcg_list_blocks(s->n_tl_sq), s->part_rr,
                                       s->part_err, s->ps, s->row_list, s->n_rows);
             else if (lists)
@@ -967,8 +879,7 @@ static int solve_mg(fluid_sim* s)
                 launch_pcg_sq_list<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, n_list, s->part_rz[prv], s->part_rz[prv], s->part_pq,
                                       s->ps, 0, tol, n_rz, 1, s->tl_sq, s->n_tl_sq);
             else
-                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1, 0,
-                                 fuse ? n_xr : -1);
+                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1, 0);
         }
         HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
         HIPCHK(hipStreamSynchronize(s->st));
@@ -1249,12 +1160,22 @@ static int phase_flip_advect(fluid_sim* s)
     if (rcp) return rcp;
     if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    if (s->sorted && s->p_off == 0 && (double)s->np >= 4.0 * (double)s->Pb.cells()) {
-        // sorted by base cell and not moved since, and the bounding box is densely filled (the falling cube: 8 per cell;
-        // the splash: 0.7 per cell with up to 10^4 in one — there one block per tile is badly balanced and the
-        // thread-per-particle kernel is 2.8x faster): gather through LDS tiles; the off-grid bucket (the array's tail)
-        // only has its speeds counted
-        launch_g2p_tiled(s->st, s->g, s->Pb, s->pa, s->cell_start, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
+    if (s->sorted && s->p_off == 0 && !box_empty(s->Pb)) {
+        // sorted by base cell and not moved since: gather through LDS tiles.  Where the bounding box is densely filled (the falling cube:
+        // 8 per cell) one block per tile; else (the splash: 0.7 per cell with up to 10^4 in one) over a device-built work list — no block
+        // for an empty tile, a pile split over many (the thread-per-particle kernel with its 81 divergent loads per particle served here
+        // before: 336 us at step 445 of the 256^3 drop).  The off-grid bucket (the array's tail) only has its speeds counted.
+        int* items = nullptr;
+        if ((double)s->np < 4.0 * (double)s->Pb.cells()) {
+            const size_t need = 2 + 2 * (size_t)g2p_max_items(s->Pb, s->np);
+            if (need > s->g2p_items_cap) {
+                if (s->g2p_items) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->g2p_items); s->g2p_items = nullptr; }
+                HIPCHK(hipMalloc((void**)&s->g2p_items, (need + need / 4) * sizeof(int)));
+                s->g2p_items_cap = need + need / 4;
+            }
+            items = s->g2p_items;
+        }
+        launch_g2p_tiled(s->st, s->g, s->Pb, s->pa, s->cell_start, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss, items, s->np);
         if (s->n_out > 0)
             launch_g2p(s->st, s->g, s->n_out, s->pa.shifted(s->np - s->n_out), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
     } else {

@@ -895,54 +895,7 @@ __global__ __launch_bounds__(256) void k_mg_tile_flags(MLevel m, const uint8_t* 
     if (threadIdx.x == 0) flags[tile] = any != 0;
 }
 
-// XR of one PCG iteration and the level-0 down leg of the NEXT V-cycle as one launch (dense level 0 of at most 1024 tiles; the
-// tile lists, the row list and the decomposed solve keep the two launches).  XR is a stream over x, r, s, q that ends in a grid-wide
-// dependency (the next kernel reads r with a halo), the down leg a tile kernel that begins by loading r with a halo: fused, the leg
-// forms r' = r - alpha q wherever it would have loaded r — on its halo too, recomputed like everything else there — and the thread that
-// forms a tile cell's residual also stores r' and x' = x + alpha s for it and adds r'^2 to the tile's partial.  r' goes into a SECOND
-// array (neighbouring tiles still read r on their halos); the solve swaps the two after every iteration.  One launch less per
-// iteration and r read once; the values are those of the two launches, the |r|^2 partials are per tile instead of per XR block.
-template <typename T>
-__global__ __launch_bounds__(256) void k_mg_down_xr(MLevel m, const uint8_t* __restrict__ cnt, const double* __restrict__ r_in, double* __restrict__ r_out,
-                                                    const double* __restrict__ qv, double* __restrict__ x, const double* __restrict__ sv,
-                                                    T* __restrict__ u, T* __restrict__ r0, MgCoef<T> cf, PcgState* ps, int gx, int gy,
-                                                    const double* __restrict__ part_rz_cur, int n_rz, const double* __restrict__ part_pq, int n_pq,
-                                                    double* __restrict__ part_rr)
-{
-    __shared__ __attribute__((aligned(16))) char lds[DownTile<T, MG_TX, MG_TY, MG_TZ, false>::bytes];
-    __shared__ T sd[8], si[8];
-    __shared__ double red[16];
-    __shared__ int s_done;
-    if (threadIdx.x == 0) s_done = ps->done;   // one read per block, broadcast: block 0 of this launch may set it while we start
-    __syncthreads();
-    if (s_done) return;
-    double rz, pq, d3;
-    block_sum3(part_rz_cur, n_rz, part_pq, n_pq, part_pq, 0, red, rz, pq, d3);
-    if (!(pq > 0) || !(rz == rz)) {  // not SPD / NaN: stop instead of spreading NaNs (as k_pcg_xr_l)
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ps->breakdown = 1; ps->done = 1; }
-        return;
-    }
-    const double alpha = rz / pq;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const MLevel none{};
-    double arr = 0;
-    auto rnew = [&](size_t q) { return r_in[q] - alpha * qv[q]; };   // (-ffp-contract=off: the same two operations as k_pcg_xr_l)
-    mg_down_body_fn<T, double, MG_TX, MG_TY, MG_TZ, false, IoPlain, 1>(
-        m, cnt, u, r0, none, nullptr, nullptr, &cf, cf.off, tile, gx, gy, true, (int)threadIdx.x, lds, sd, si, 0, rnew, [&](size_t q) {
-            const double rn = rnew(q);
-            r_out[q] = rn;
-            x[q] = x[q] + alpha * sv[q];
-            arr += rn * rn;
-        });
-    arr = block_sum<double, 4>(arr, red);
-    if (threadIdx.x == 0) part_rr[blockIdx.x] = arr;
-}
-
-static inline bool mg_ng4()   // FLUID_MG_NG4=0: every leg one thread group per tile (developer switch for A/B runs)
-{
-    static const int on = [] { const char* e = getenv("FLUID_MG_NG4"); return e ? atoi(e) : 1; }();
-    return on != 0;
-}
+static inline bool mg_ng4() { return true; }   // a tile of a small level is worked by four thread groups
 static inline dim3 mg_tiles(const MLevel& m, int tx, int ty, int tz)
 {
     return dim3((unsigned)((m.dz + tz - 1) / tz), (unsigned)((m.dy + ty - 1) / ty), (unsigned)((m.dx + tx - 1) / tx));
@@ -977,19 +930,6 @@ void launch_mg_down(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, T*
     }
 }
 // XR + the level-0 down leg (k_mg_down_xr): mg_up_blocks(m) blocks, as many |r|^2 partials
-template <typename T>
-void launch_mg_down_xr(hipStream_t st, MLevel m, const uint8_t* cnt, const double* r_in, double* r_out, const double* q, double* x, const double* s_vec,
-                       T* u, T* r0, MgCoef<T> cf, PcgState* ps, const double* part_rz_cur, int n_rz, const double* part_pq, int n_pq, double* part_rr)
-{
-    const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
-    hipLaunchKernelGGL((k_mg_down_xr<T>), dim3(g.x * g.y * g.z), dim3(256), 0, st, m, cnt, r_in, r_out, q, x, s_vec, u, r0, cf, ps, (int)g.x, (int)g.y,
-                       part_rz_cur, n_rz, part_pq, n_pq, part_rr);
-}
-template void launch_mg_down_xr<float>(hipStream_t, MLevel, const uint8_t*, const double*, double*, const double*, double*, const double*, float*, float*,
-                                       MgCoef<float>, PcgState*, const double*, int, const double*, int, double*);
-template void launch_mg_down_xr<double>(hipStream_t, MLevel, const uint8_t*, const double*, double*, const double*, double*, const double*, double*, double*,
-                                        MgCoef<double>, PcgState*, const double*, int, const double*, int, double*);
-// prolongation + both post-sweeps (+ partials of f.out, mg_up_blocks(m) of them)
 template <typename T, typename F, typename O>
 void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, const T* u, O* out, MLevel mc, const T* ec, MgCoef<T> cf,
                   double* part_dot, const PcgState* ps, double wc, const int* tlist, int nlist, const uint8_t* own, int pconst)
@@ -1073,220 +1013,6 @@ void launch_mg_tail(hipStream_t st, int nl, const T* f0, const MLevel* lv, uint8
     }
     hipLaunchKernelGGL((k_mg_tail<T>), dim3(1), dim3(1024), (size_t)a.lds_bytes, st, a, ps);
 }
-
-// ---- the coarse levels of the cycle as ONE persistent launch ----------------------------------------------------------
-// At bench size the levels under level 0 hold <= 91 k cells: each of their legs (restrict, down, down, tail, up, up) was a
-// launch of 5-10 us that computes for a fraction of that — 41 of the 86 us of a PCG iteration (profiles/r02).  k_mg_coarse
-// runs them as PHASES of one launch: 1024-thread workgroups (a 256-thread leg tile by the first four waves, or the whole
-// tail by all sixteen) pull TASKS (a leg tile / 1024 restriction cells / the tail) from one ticket counter, in phase
-// order; a task of phase p starts once the done-counter of phase p-1 has reached that phase's task count.
-//   * hand-off between workgroups: every array a later phase reads is written with sc1 (write-through) stores and read
-//     with sc1 loads (IoSc1); after its stores a workgroup drains them (s_waitcnt vmcnt(0) in every wave, barrier) and ONE
-//     lane adds 1 to the phase counter (agent-scope atomic); the consumer's lane 0 polls that counter with sc1 loads and
-//     the workgroup passes a barrier before its first load.  No L2 write-back / invalidate fence anywhere (a device-scope
-//     __threadfence per workgroup is what made the earlier grid-barrier attempt lose), and nothing depends on
-//     where a workgroup runs.
-//   * progress: tickets are handed out in task order, a workgroup only ever waits for tasks with smaller tickets, and
-//     those are held by workgroups that are running — so the launch finishes with any number >= 1 of resident
-//     workgroups, and every workgroup leaves as soon as the tickets run out (each prefetches one ticket ahead; that
-//     changes nothing in the argument).
-//   * the counters live in two slots used by alternate launches (`gen`): workgroup 0 clears the slot of the NEXT launch,
-//     which nobody touches during this one, also when the solve is already done and everybody leaves at once.
-// Same arithmetic, cell for cell, as the separate launches (the legs are the same device functions).
-enum { MGC_RESTRICT = 0, MGC_DOWN = 1, MGC_TAIL = 2, MGC_UP = 3 };
-// everything a task of one phase needs, in one record: a task reads it with ONE batch of scalar loads once its ticket has
-// told it the phase (chains of dependent descriptor reads — phase table -> level -> level record -> pointers — cost a
-// task more than its arithmetic)
-template <typename T>
-struct MgcPhase {
-    int kind, level, ntasks, first;   // first = ticket of its first task
-    int gx, gy, ntiles, need;         // need = tasks of the phase before (what its counter must reach)
-    MLevel m, mc;                     // the level and the one under it (RESTRICT: the finer level and the level)
-    const uint8_t *cnt, *cnt_c;
-    const T *f, *u, *ec;              // rhs, (UP) pre-smoothed u and the coarse correction; RESTRICT: f = the finer level's residual
-    T* out;                           // DOWN: u; UP: the corrected, post-smoothed result; RESTRICT: this level's rhs
-    T* fc;                            // DOWN: rhs of the level under it
-    T diag[7], inv[7], off, wc;
-};
-template <typename T>
-struct MgCoarseDesc {
-    int nphase, ntasks, tpt, pad;
-    MgcPhase<T> ph[MGC_MAXPH];
-    MgTail<T> tail;
-    int* sync;
-    long long* dbg;   // developer trace (FLUID_MGC_TRACE): 4 wall-clock stamps per task of the last launch, else nullptr
-};
-size_t mg_coarse_desc_bytes() { return sizeof(MgCoarseDesc<double>) > sizeof(MgCoarseDesc<float>) ? sizeof(MgCoarseDesc<double>) : sizeof(MgCoarseDesc<float>); }
-int mg_coarse_max_levels() { return (MGC_MAXPH - 2) / 2; }
-
-constexpr int MGC_RX = 8, MGC_RY = 8, MGC_RZ = 8;     // down tiles (restriction folded in)
-constexpr int MGC_TX = 8, MGC_TY = 8, MGC_TZ = 16;    // up tiles
-template <typename T>
-constexpr int mgc_leg_bytes()
-{
-    return DownTile<T, MGC_RX, MGC_RY, MGC_RZ, true>::bytes > UpTile<T, MGC_TX, MGC_TY, MGC_TZ>::bytes ? DownTile<T, MGC_RX, MGC_RY, MGC_RZ, true>::bytes
-                                                                                                        : UpTile<T, MGC_TX, MGC_TY, MGC_TZ>::bytes;
-}
-
-template <typename T, bool PREFETCH>
-__global__ __launch_bounds__(1024) void k_mg_coarse(const MgCoarseDesc<T>* __restrict__ D, int gen, const PcgState* ps)
-{
-    extern __shared__ double mgc_lds[];
-    __shared__ T tsd[MG_TAIL_MAX][8], tsi[MG_TAIL_MAX][8];
-    __shared__ T sd[8], si[8];
-    __shared__ int s_task;
-    const int tid0 = threadIdx.x;
-    int* const sync = D->sync;
-    int* const slot = sync + (gen & 1) * MGC_SLOT;
-    if (blockIdx.x == 0 && tid0 <= MGC_MAXPH) sync[((gen + 1) & 1) * MGC_SLOT + 32 * tid0] = 0;
-    if (ps && ps->done) return;
-    int nxt = 0, cur = -1;
-    if (tid0 == 0) nxt = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int ntasks = D->ntasks, tpt = D->tpt;
-    long long* const dbg = D->dbg;
-    int first[MGC_MAXPH];   // ticket ranges of the phases, in scalar registers for the whole launch (unused ones: INT_MAX)
-#pragma unroll
-    for (int i = 0; i < MGC_MAXPH; ++i) first[i] = D->ph[i].first;
-    for (;;) {
-        if (tid0 == 0) s_task = nxt;
-        __syncthreads();
-        const int t = __builtin_amdgcn_readfirstlane(s_task);   // wave-uniform by construction: everything read from the descriptor stays scalar
-        if (t >= ntasks) break;
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));   // opaque per task: the legs' thread -> cell arithmetic stays inside their branches (hoisted out of the loop it spills)
-        // the next ticket: asked for now (its answer is not needed before the next round) or, without PREFETCH, when this task is
-        // done — a prefetched ticket is one a faster workgroup cannot take (measured: half the workgroups ran two tiles of the
-        // first phase each while the others sat on tickets of later phases)
-        if (PREFETCH && tid == 0) nxt = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (dbg && tid == 0) dbg[4 * t] = wall_clock64();
-        int p = 0;
-#pragma unroll
-        for (int i = 1; i < MGC_MAXPH; ++i) p += t >= first[i];
-        const MgcPhase<T>& P = D->ph[p];
-        const int kind = P.kind, local = t - P.first;
-        if (p != cur) {
-            // the phase before must be complete: lane 0 polls, the barrier holds everybody's loads back
-            if (tid == 0 && p > 0) {
-                const int need = P.need;
-                while (__hip_atomic_load(slot + 32 * p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
-            }
-            if (tid < 7 && (kind == MGC_DOWN || kind == MGC_UP)) {
-                sd[tid] = P.diag[tid];
-                si[tid] = P.inv[tid];
-            }
-            __syncthreads();
-            cur = p;
-        }
-        if (dbg && tid == 0) dbg[4 * t + 1] = wall_clock64();
-        if (kind == MGC_RESTRICT) {
-            d_restrict<T, IoSc1>(P.m, P.f, P.mc, P.cnt_c, P.out, (long)local * 1024 + tid);
-        } else if (kind == MGC_TAIL) {
-            mg_tail_body<T, IoSc1>(D->tail, mgc_lds, tsd, tsi, tid);
-        } else {
-            // `tpt` tiles per task, one per group of 4 waves.  The legs are LDS-bound: four tiles side by side on a CU run
-            // each at a quarter of the speed, so by default a task is ONE tile and waves 4-15 only keep the barriers company
-            // (both legs pass exactly three)
-            const int grp = __builtin_amdgcn_readfirstlane(tid >> 8), col = tid & 255, ntiles = P.ntiles;
-            int tile = local * tpt + grp;
-            const bool live = tile < ntiles;
-            tile = live ? tile : ntiles - 1;
-            char* lds = (char*)mgc_lds + grp * mgc_leg_bytes<T>();
-            if (grp >= tpt) {
-                __syncthreads();
-                __syncthreads();
-                __syncthreads();
-            } else if (kind == MGC_DOWN)
-                mg_down_body<T, T, MGC_RX, MGC_RY, MGC_RZ, true, IoSc1>(P.m, P.cnt, P.f, P.out, (T*)nullptr, P.mc, P.cnt_c, P.fc, nullptr, P.off, tile, P.gx,
-                                                                        P.gy, live, col, lds, sd, si);
-            else
-                mg_up_body<T, T, T, MGC_TX, MGC_TY, MGC_TZ, IoSc1>(P.m, P.cnt, P.f, P.u, P.out, P.mc, P.ec, nullptr, P.off, nullptr, tile, P.gx, P.gy, P.wc,
-                                                                   nullptr, live, col, lds, sd, si, nullptr);
-        }
-        // publish: every wave's stores have left, then one add to the phase's counter
-        if (dbg && tid == 0) dbg[4 * t + 2] = wall_clock64();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (dbg && tid == 0) dbg[4 * t + 3] = wall_clock64();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(slot + 32 * (p + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!PREFETCH) nxt = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-int mg_coarse_ntasks_max() { return 4096; }
-
-template <typename T>
-__global__ void k_mgc_store(MgCoarseDesc<T> d, MgCoarseDesc<T>* dst)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = d;
-}
-
-// Phases and tasks of the launch for levels [a.first, a.tail) + the tail; the descriptor goes to `desc` (device) by a
-// one-thread kernel on the stream (constant for a solve: the coefficients follow dt).  Returns workgroups and LDS bytes.
-template <typename T>
-void launch_mg_coarse_store(hipStream_t st, const MgCoarseArgs<T>& a, void* desc, int* sync, long long* dbg, int max_blocks, int tpt, int* nblocks, size_t* lds)
-{
-    static_assert(sizeof(MgCoarseDesc<T>) <= 4096, "the descriptor travels as a kernel argument");
-    tpt = tpt >= 4 ? 4 : (tpt >= 2 ? 2 : 1);
-    MgCoarseDesc<T> d;
-    std::memset((void*)&d, 0, sizeof d);
-    int np = 0, tk = 0, most = 1;
-    auto add = [&](int kind, int level, int ntasks, int gx, int gy, int ntiles) -> MgcPhase<T>& {
-        MgcPhase<T>& q = d.ph[np];
-        q.kind = kind; q.level = level; q.ntasks = ntasks; q.first = tk; q.gx = gx; q.gy = gy; q.ntiles = ntiles;
-        q.need = np ? d.ph[np - 1].ntasks : 0;
-        for (int k = 0; k < 7; ++k) { q.diag[k] = a.cf[level].diag[k]; q.inv[k] = a.cf[level].inv[k]; }
-        q.off = a.cf[level].off; q.wc = (T)a.wc[level];
-        ++np;
-        tk += ntasks;
-        if (ntasks > most) most = ntasks;
-        return q;
-    };
-    if (a.restrict0) {
-        const MLevel& mc = a.m[a.first];
-        MgcPhase<T>& q = add(MGC_RESTRICT, a.first, (int)(((long)mc.dx * mc.dy * mc.dz + 1023) / 1024), 0, 0, 0);
-        q.m = a.m[a.first - 1]; q.mc = mc; q.f = a.r_prev; q.cnt_c = a.cnt[a.first]; q.out = a.f[a.first];
-    }
-    for (int l = a.first; l < a.tail; ++l) {
-        const dim3 g = mg_tiles(a.m[l], MGC_RX, MGC_RY, MGC_RZ);
-        const int nt = (int)(g.x * g.y * g.z);
-        MgcPhase<T>& q = add(MGC_DOWN, l, (nt + tpt - 1) / tpt, (int)g.x, (int)g.y, nt);
-        q.m = a.m[l]; q.mc = a.m[l + 1]; q.cnt = a.cnt[l]; q.cnt_c = a.cnt[l + 1]; q.f = a.f[l]; q.out = a.u[l]; q.fc = a.f[l + 1];
-    }
-    add(MGC_TAIL, a.tail, 1, 0, 0, 0);
-    for (int l = a.tail - 1; l >= a.first; --l) {
-        const dim3 g = mg_tiles(a.m[l], MGC_TX, MGC_TY, MGC_TZ);
-        const int nt = (int)(g.x * g.y * g.z);
-        MgcPhase<T>& q = add(MGC_UP, l, (nt + tpt - 1) / tpt, (int)g.x, (int)g.y, nt);
-        q.m = a.m[l]; q.mc = a.m[l + 1]; q.cnt = a.cnt[l]; q.f = a.f[l]; q.u = a.u[l]; q.out = a.w[l];
-        q.ec = l + 1 == a.tail ? a.u[l + 1] : a.w[l + 1];   // out != u: neighbouring tiles still read u
-    }
-    for (int i = np; i < MGC_MAXPH; ++i) d.ph[i].first = 0x7fffffff;
-    d.nphase = np; d.ntasks = tk; d.tpt = tpt;
-    d.tail = make_mg_tail<T>(a.nl - a.tail, (const T*)a.f[a.tail], a.m + a.tail, a.cnt + a.tail, a.u[a.tail], a.off + a.tail, a.sweeps, a.wc_tail);
-    d.sync = sync;
-    d.dbg = tk <= mg_coarse_ntasks_max() ? dbg : nullptr;
-    hipLaunchKernelGGL((k_mgc_store<T>), dim3(1), dim3(64), 0, st, d, (MgCoarseDesc<T>*)desc);
-    *nblocks = most < max_blocks ? most : max_blocks;
-    const size_t legs = a.first < a.tail ? tpt * (size_t)mgc_leg_bytes<T>() : 0;
-    *lds = legs > (size_t)d.tail.lds_bytes ? legs : (size_t)d.tail.lds_bytes;
-}
-template <typename T>
-void launch_mg_coarse(hipStream_t st, const void* desc, int nblocks, size_t lds, int gen, const PcgState* ps, bool prefetch)
-{
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_mg_coarse<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_TAIL_LDS);
-        hipFuncSetAttribute((const void*)k_mg_coarse<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_TAIL_LDS);
-        attr_set = true;
-    }
-    if (prefetch) hipLaunchKernelGGL((k_mg_coarse<T, true>), dim3(nblocks), dim3(1024), lds, st, (const MgCoarseDesc<T>*)desc, gen, ps);
-    else hipLaunchKernelGGL((k_mg_coarse<T, false>), dim3(nblocks), dim3(1024), lds, st, (const MgCoarseDesc<T>*)desc, gen, ps);
-}
-template void launch_mg_coarse_store<float>(hipStream_t, const MgCoarseArgs<float>&, void*, int*, long long*, int, int, int*, size_t*);
-
-template void launch_mg_coarse<float>(hipStream_t, const void*, int, size_t, int, const PcgState*, bool);
 
 #define INSTMG(T)                                                                                                                        \
     template void launch_mg_down<T, T>(hipStream_t, MLevel, const uint8_t*, const T*, T*, T*, MLevel, const uint8_t*, T*, MgCoef<T>, const PcgState*, \

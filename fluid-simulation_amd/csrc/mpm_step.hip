@@ -1707,9 +1707,12 @@ int mpm_download_field(mpm_sim_t* s, int32_t field, void* out)
     return 0;
 }
 
-int mpm_download_system(mpm_sim_t* s, double* b, double* x)
+int mpm_download_system(mpm_sim_t* s, double* b, double* x, int64_t count)
 {
     if (!s) return fluid_fail(FLUID_ERR_ARG, "mpm_download_system: null handle");
+    if (count != 3 * (int64_t)s->num_active)
+        return fluid_fail(FLUID_ERR_ARG, "mpm_download_system: the buffers hold " + std::to_string(count) + " doubles, the last solve's system has " +
+                                             std::to_string(3 * (int64_t)s->num_active));
     const size_t bytes = sizeof(double) * 3 * (size_t)s->num_active;
     if (b && bytes) HIPCHK(hipMemcpyAsync(b, s->b, bytes, hipMemcpyDeviceToHost, s->st));
     if (x && bytes) HIPCHK(hipMemcpyAsync(x, s->x, bytes, hipMemcpyDeviceToHost, s->st));

@@ -38,7 +38,7 @@ struct fluid_sim {
     float *container = nullptr, *rhs = nullptr, *diver = nullptr, *diver2 = nullptr;
     double *u = nullptr, *v = nullptr, *w = nullptr, *ub = nullptr, *vb = nullptr, *wb = nullptr;
     double *dcx = nullptr, *dcy = nullptr, *dcz = nullptr, *pressure = nullptr;
-    double* p_guess = nullptr;    // last solved pressure, never cleared: the multigrid PCG starts from it (FLUID_WARM_START=0: from 0 like the reference)
+    double* p_guess = nullptr;    // last solved pressure, never cleared: the multigrid PCG starts from it (solve_start = FLUID_START_ZERO: from 0 like the reference)
     bool warm = true, have_guess = false;
     // Passes of one step's do..while solve the SAME matrix for right-hand sides b_{k+1} = (1 - f) b_k + c (f = update_frac: the partial
     // velocity update takes f of the pressure gradient out of the divergence, c = what gravity puts back, the same in every pass), so
@@ -88,6 +88,8 @@ struct fluid_sim {
     size_t p2g_part_cap = 0;
     int* p2g_items = nullptr;    // k_p2g_rows' work list (count + int4 items), grown on demand; the count is 0 between launches
     size_t p2g_items_cap = 0;
+    int* g2p_items = nullptr;    // k_g2p_tiled's work list in unevenly filled boxes (count, pad, then (tile, chunk) pairs), grown on demand
+    size_t g2p_items_cap = 0;
     int max_cell = 0;            // most particles in one cell after the last sort (all ranks' cells when distributed)
     // mostly-air box (splash, settled pool): level-0 legs, SQ and XR run over compacted lists of the tiles that hold an unknown
     uint8_t* tl_flags = nullptr;  // per-tile flags (both tile shapes, one after the other)
@@ -97,10 +99,7 @@ struct fluid_sim {
     int *row_flags = nullptr, *row_pos = nullptr, *row_list = nullptr;   // XR's list of non-empty z rows (32 cells), built with the tile lists
     size_t row_cap = 0;
     int n_rows = 0;
-    bool rows_on = true;          // FLUID_XR_ROWS=0: XR over the SQ tile list as before
-    bool xr_fuse = false;         // FLUID_XR_FUSE=1: XR and the level-0 down leg of the next V-cycle as ONE launch (k_mg_down_xr; dense level 0 only).
-                                  // Measured at 256^3: 2.947 ms/step against 2.895 for the two launches (the leg reads r AND q with its halo) - off
-    double* R2 = nullptr;         // the second residual array of the fused form (lmax doubles, allocated when first needed)
+    bool rows_on = true;          // XR over the z rows that hold an unknown (finer than the SQ tile list)
     // closed pockets (airborne droplets) of the pressure system, solved on their own (kernels_droplets.hip; FLUID_DROPLETS=0: off)
     bool drops_on = true;
     bool row_sweeps = true;       // FLUID_ROW_SWEEPS=0: the per-step box sweeps keep their cell-per-thread forms (kernels_grid.hip, k_*4)
@@ -147,7 +146,7 @@ struct fluid_sim {
     bool gal = false;             // ... and in use this step (set by mg_setup)
     int gal_lc = 0;               // the coarsest level of the Galerkin cycle (one block)
     double gal_dt = 0;            // dt the coefficients were built with
-    double gal_wc = 1.8;          // over-correction of the piecewise-constant prolongation (FLUID_MG_GALERKIN_WC)
+    double gal_wc = 1.8;          // over-correction of the piecewise-constant prolongation 
     int gal_sweeps = 3;           // red-black sweeps, each direction, on the coarsest level (2 ... 16: the same iteration counts)
     char* gal_slab = nullptr;     // per level 1..gal_lc: gd, gx, gy, gz (float) and the unknown flags
     size_t gal_slab_cap = 0;
@@ -155,22 +154,9 @@ struct fluid_sim {
     uint8_t* gal_cnt[MG_MAXL] = {};
     uint8_t* gal_tfl[MG_MAXL] = {};   // per leg tile: holds an unknown
     char *mg_u[MG_MAXL] = {}, *mg_v[MG_MAXL] = {}, *mg_f[MG_MAXL] = {}, *mg_r[MG_MAXL] = {};  // per level: u, ping-pong, rhs, residual (float or double)
-    double mg_wc[4] = {1.25, 1.1, 1.0, 1.0};   // weight of the coarse correction at level 0 / level 1 / deeper kernel levels / inside the tail (FLUID_MG_WC=a,b,c,d)
-    bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (FLUID_MG_FP64=1: double)
+    double mg_wc[4] = {1.25, 1.1, 1.0, 1.0};   // weight of the coarse correction at level 0 / level 1 / deeper kernel levels / inside the tail 
+    bool mg_fp32 = true;           // the V-cycle computes and stores in float inside the double PCG (mg_precision = FLUID_MG_FP64: double)
     double* mg_part = nullptr;    // per-block partials of r.z when a level-0 launch has more blocks than the PCG kernels re-sum
-    // the coarse levels of the cycle as one persistent launch (k_mg_coarse): levels [mgc_first, mg_tail) + the tail, optionally
-    // starting with the restriction of level 0's residual.  FLUID_MG_COARSE=0 (separate launches, the default: measured faster) |
-    // 1 (legs + tail) | 2 (+ restriction)
-    int mgc_mode = 0, mgc_max_blocks = 256, mgc_tpt = 1;   // FLUID_MG_COARSE_BLOCKS, FLUID_MG_COARSE_TPT (leg tiles per task: 1, 2, 4)
-    long mgc_max_cells = 150000;            // a level with more cells keeps its own launches (FLUID_MG_COARSE_CELLS)
-    void* mgc_desc = nullptr;     // device: MgCoarseDesc, rewritten at the start of every solve (the coefficients follow dt)
-    int* mgc_sync = nullptr;      // device: two counter slots, used by alternate launches
-    long long* mgc_dbg = nullptr; // device: per-task clock stamps of the last launch (FLUID_MGC_TRACE=file: written out by fluid_destroy)
-    unsigned mgc_gen = 0;         // launches so far (its parity picks the slot)
-    bool mgc_prefetch = false;    // FLUID_MG_COARSE_PREFETCH=1: every workgroup asks for its next ticket before it runs the current one
-    bool mgc_on = false, mgc_restrict0 = false;   // this step's plan (mg_setup)
-    int mgc_first = 0, mgc_blocks = 0;
-    size_t mgc_lds = 0;
     char* mg_slab = nullptr;      // one allocation behind every mg_* array and Zmg (re-carved each step)
     size_t mg_slab_cap = 0;
     // multi-GPU (3-D block decomposition, fluid_dist.hip)

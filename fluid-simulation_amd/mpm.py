@@ -129,14 +129,14 @@ class MpmSim:
 
     def system(self, num_active=None):
         """Right-hand side and solution of the last solve (3 doubles per unknown).  The buffers are sized by the handle's own
-        unknown count; an explicit `num_active` must agree with it (mpm_download_system copies 3 * its count doubles)."""
+        unknown count; an explicit `num_active` must agree with it (mpm_download_system checks the count it is given against its own)."""
         mine = int(lib.mpm_num_active(self._h))   # the handle's own count sizes the buffers
         if num_active is not None and num_active != mine:
             raise ValueError(f"system(): the last solve had {mine} unknowns, not {num_active}")
         num_active = mine
         b = np.empty(3 * num_active, np.float64)
         x = np.empty(3 * num_active, np.float64)
-        check(lib.mpm_download_system(self._h, _ptr(b), _ptr(x)))
+        check(lib.mpm_download_system(self._h, _ptr(b), _ptr(x), 3 * num_active))
         return b, x
 
     def apply_matrix(self, v):

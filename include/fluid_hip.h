@@ -119,7 +119,6 @@ typedef struct fluid_step_stats {
 #define FLUID_PATH_DIST_DECOMPOSED 4  /* multi-GPU: window arrays, domain-decomposed PCG with the globally coupled V-cycle  */
 #define FLUID_PATH_DIST_REPLICATED 8  /* multi-GPU: particles sharded, pressure block replicated on every rank              */
 #define FLUID_PATH_DIST_REBALANCED 32 /* multi-GPU: the cut planes were moved at the end of this step (the window changed)      */
-#define FLUID_PATH_MG_COARSE 16       /* the V-cycle's coarse levels ran as one persistent launch (FLUID_MG_COARSE=1|2; off by default) */
 #define FLUID_PATH_MG_GALERKIN 128   /* the V-cycle's coarse levels were Galerkin operators by aggregation (mostly-air box whose re-discretised levels lose much of the pool) */
 #define FLUID_PATH_DROPLETS 64        /* closed pockets of <= 64 unknowns (airborne droplets) were solved apart from the global system   */
 #define FLUID_PATH_DROPLETS_SHORT 256 /* ... and at least one of them left its own CG by the iteration cap or a breakdown, not by the stopping rule (relres above cg_tol there) */

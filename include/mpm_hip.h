@@ -114,11 +114,13 @@ int mpm_step_advance(mpm_sim_t* s, mpm_step_stats_t* stats);
 int mpm_download_particles(mpm_sim_t* s, int32_t what, double* out);
 int mpm_download_field(mpm_sim_t* s, int32_t field, void* out);
 
-/* Unknowns of the last mpm_step_solve: mpm_download_system copies 3 x this many doubles into each buffer. */
+/* Unknowns of the last mpm_step_solve. */
 int32_t mpm_num_active(const mpm_sim_t* s);
 /* The linear system of the last step as the reference assembles it (mpm.cc:370-444): right-hand side b and solution x,
- * 3 * num_active doubles each (unknown k holds 3k..3k+2). */
-int mpm_download_system(mpm_sim_t* s, double* b, double* x);
+ * 3 * num_active doubles each (unknown k holds 3k..3k+2).  `count` = the doubles each buffer holds: it must be exactly
+ * 3 * mpm_num_active(s) (FLUID_ERR_ARG otherwise, nothing is written) — a caller that sized its buffers for another step's
+ * system cannot be overrun. */
+int mpm_download_system(mpm_sim_t* s, double* b, double* x, int64_t count);
 /* y = A v (or A^T v when transpose_system = 1) for the step's matrix A = I + beta dt^2 M (mpm.cc:418-441), applied matrix-free by the solver's own
  * kernel; v and y hold 3 * num_active doubles.  Only between mpm_step_solve and mpm_step_advance (afterwards the particles
  * have moved).  For tests: column k of A is mpm_apply_matrix(e_k). */

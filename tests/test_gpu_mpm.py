@@ -6,6 +6,8 @@ Bars: unknown numbering and num_active bit-exact; the float32 node mass within t
 relative at 400 particles per voxel, <= 2e-7 at 8); every fp64 field and particle array <= 1e-4 relative L2 (north_star's
 float tolerance) — the measured margins are orders of magnitude inside and asserted much tighter below.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -86,6 +88,11 @@ def test_solution_solves_the_programs_system(fs, mo):
         np.add.at(A, (rows, cols), vals)
         Aop = A.T if transposed else A
         bg, xg = sim.system(sg["num_active"])
+        # a caller whose buffers were sized for another system is refused before anything is written (mpm_download_system's count)
+        guard = np.full(n, 7.0)
+        assert fs.lib.mpm_download_system(sim._h, guard.ctypes.data_as(ctypes.c_void_p), guard.ctypes.data_as(ctypes.c_void_p), n - 3) == 1 and (guard == 7.0).all()   # FLUID_ERR_ARG
+        with pytest.raises(ValueError):
+            sim.system(sg["num_active"] + 1)
         # the node masses carry the float32 accumulation-order noise (~1e-7) into b = v + dt f / m and into A
         assert rel_l2(bg, b) < 2e-6
         assert rel_l2(xg, x) < 2e-6

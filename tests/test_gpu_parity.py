@@ -643,29 +643,6 @@ def test_forms_switch_by_themselves(fs, monkeypatch):
     assert rel_l2(pra, prb) < 1e-6 and rel_l2(pa, pb) < 1e-9 and rel_l2(va, vb) < 1e-6
 
 
-def test_fused_xr_and_down_leg_give_the_same_solve(fs, monkeypatch):
-    """k_mg_down_xr (kernels_mg.hip): XR of an iteration and the level-0 down leg of the next V-cycle in one launch (a dense level 0
-    with more than 200 k cells: the 64^3 box of the 176^3 drop).  x and r get the values of the two launches; only the |r|^2
-    partials are summed per tile instead of per XR block, so the iteration counts may differ by one now and then.  (Off by default:
-    it measured 2 % slower than the two launches at 256^3)"""
-    n = 176
-    outs = []
-    for env in ({"FLUID_XR_FUSE": "0"}, {"FLUID_XR_FUSE": "1"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        sim = fs.FluidSim(n=n); sim.upload_particles(fs.water_cube_drop(n, 4, seed=3))
-        st = [sim.step() for _ in range(3)]
-        p, v = sim.download_particles()
-        outs.append((st, p, v, sim.field(fs.FIELD.PRESSURE)))
-        sim.close()
-        for k in env:
-            monkeypatch.delenv(k)
-    (sa, pa, va, pra), (sb, pb, vb, prb) = outs
-    assert [s["outer_passes"] for s in sa] == [s["outer_passes"] for s in sb]
-    assert all(abs(a["cg_iters"] - b["cg_iters"]) <= a["outer_passes"] for a, b in zip(sa, sb))
-    assert rel_l2(pra, prb) < 1e-12 and rel_l2(pa, pb) < 1e-13 and rel_l2(va, vb) < 1e-11
-
-
 def _pool_and_spray(fs, n, rng, depth=8, ndrops=300):
     """A shallow pool over the whole floor and `ndrops` airborne clusters of a dozen particles within one cell's reach:
     each cluster marks a pocket of 8-27 fluid cells with nothing but air around it."""
@@ -821,32 +798,6 @@ def test_droplets_on_solids_and_walls(fs, oracle, monkeypatch):
     assert np.array_equal(sim2.field(fs.FIELD.PRESSURE), sim.field(fs.FIELD.PRESSURE))
     p2, v2 = sim2.download_particles()
     assert np.array_equal(p, p2) and np.array_equal(v, v2)
-
-
-@pytest.mark.parametrize("mode,tpt", [("1", "1"), ("2", "1"), ("2", "4")])
-def test_persistent_coarse_launch_is_bit_identical(fs, mode, tpt, monkeypatch):
-    """The V-cycle's coarse levels as ONE persistent launch (k_mg_coarse: phases handed from workgroup to workgroup through
-    sc1 stores / loads and agent-scope counters, FLUID_MG_COARSE) run the same device functions as the separate launches:
-    iteration counts equal and every array bit for bit, over several steps and solves (the counter slots alternate)."""
-    n = 96   # box 33^3 -> levels 35, 18, 9, 5: a folded level 0, one leg level, a two-level tail; 176: an unfolded level 0 (box 64^3), so mode 2 restricts inside the launch
-    outs = []
-    for env in ({"FLUID_MG_COARSE": "0"}, {"FLUID_MG_COARSE": mode, "FLUID_MG_COARSE_TPT": tpt}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        res = []
-        for nn in (n, 176):
-            sim = fs.FluidSim(n=nn); sim.upload_particles(fs.water_cube_drop(nn, 4, seed=3))
-            st = [sim.step() for _ in range(3)]
-            p, v = sim.download_particles()
-            res.append((st, p, v, sim.field(fs.FIELD.PRESSURE)))
-            sim.close()
-        outs.append(res)
-        for k in env:
-            monkeypatch.delenv(k)
-    for (sa, pa, va, pra), (sb, pb, vb, prb) in zip(*outs):
-        assert all(s["paths"] & 16 == 0 for s in sa) and all(s["paths"] & 16 for s in sb)
-        assert [s["cg_iters"] for s in sa] == [s["cg_iters"] for s in sb]
-        assert np.array_equal(pra, prb) and np.array_equal(pa, pb) and np.array_equal(va, vb)
 
 
 @pytest.mark.parametrize("n,ppc", [(24, 4), (40, 2)])
