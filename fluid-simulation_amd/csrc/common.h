@@ -243,9 +243,7 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, 
 void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                       float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,
-                      const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss, int* items = nullptr, long n_particles = 0);
-// items != nullptr: over a device-built work list (2 + 2 * g2p_max_items ints) instead of one block per tile: empty tiles cost nothing, piles are split
-long g2p_max_items(Box pb, long n_particles);
+                      const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss);
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,
                 const double* pcy, const double* pcz, double blend, StepState* ss);
 void launch_advect(hipStream_t st, Grid g, long n, Particles p, const uint8_t* flags, double max_dt, double dx, StepState* ss);

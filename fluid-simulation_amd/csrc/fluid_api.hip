@@ -173,7 +173,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->g2p_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->gal_slab};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->gal_slab};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -1160,22 +1160,13 @@ static int phase_flip_advect(fluid_sim* s)
     if (rcp) return rcp;
     if (!box_empty(s->Rb)) launch_flip_delta(s->st, s->g, s->Rb, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz);
     int tok = prof_begin(s, FLUID_PROF_G2P, (double)s->np);
-    if (s->sorted && s->p_off == 0 && !box_empty(s->Pb)) {
-        // sorted by base cell and not moved since: gather through LDS tiles.  Where the bounding box is densely filled (the falling cube:
-        // 8 per cell) one block per tile; else (the splash: 0.7 per cell with up to 10^4 in one) over a device-built work list — no block
-        // for an empty tile, a pile split over many (the thread-per-particle kernel with its 81 divergent loads per particle served here
-        // before: 336 us at step 445 of the 256^3 drop).  The off-grid bucket (the array's tail) only has its speeds counted.
-        int* items = nullptr;
-        if ((double)s->np < 4.0 * (double)s->Pb.cells()) {
-            const size_t need = 2 + 2 * (size_t)g2p_max_items(s->Pb, s->np);
-            if (need > s->g2p_items_cap) {
-                if (s->g2p_items) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->g2p_items); s->g2p_items = nullptr; }
-                HIPCHK(hipMalloc((void**)&s->g2p_items, (need + need / 4) * sizeof(int)));
-                s->g2p_items_cap = need + need / 4;
-            }
-            items = s->g2p_items;
-        }
-        launch_g2p_tiled(s->st, s->g, s->Pb, s->pa, s->cell_start, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss, items, s->np);
+    if (s->sorted && s->p_off == 0 && (double)s->np >= 4.0 * (double)s->Pb.cells()) {
+        // sorted by base cell and not moved since, and the bounding box is densely filled (the falling cube: 8 per cell;
+        // the splash: 0.7 per cell with up to 10^4 in one — there one block per tile is badly balanced and the
+        // thread-per-particle kernel is faster; round 4 tried the dense tiles over a device-built work list with the spray
+        // particle by particle: 357 / 407 us at steps 195 / 445 of the 256^3 drop against ~340 for this kernel alone, dropped,
+        // profiles/r04/NOTES.md): gather through LDS tiles; the off-grid bucket (the array's tail) only has its speeds counted
+        launch_g2p_tiled(s->st, s->g, s->Pb, s->pa, s->cell_start, s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
         if (s->n_out > 0)
             launch_g2p(s->st, s->g, s->n_out, s->pa.shifted(s->np - s->n_out), s->dcx, s->dcy, s->dcz, s->pcx, s->pcy, s->pcz, s->prm.flip_blend, s->ss);
     } else {

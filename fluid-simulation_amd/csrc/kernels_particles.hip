@@ -5,7 +5,6 @@
 // the transfer is a GATHER per cell over the 27 neighbouring cell lists: no atomics on the
 // fields, and the summation order is a pure function of the input (bitwise reproducible).
 #include "common.h"
-#include <algorithm>
 
 namespace fl {
 
@@ -720,35 +719,11 @@ __global__ __launch_bounds__(256) void k_g2p(Grid g, long n, Particles p, const 
 // texture addresser (0.29 ms at 256^3 for k_g2p, the gathers of neighbouring particles hitting the same lines).
 // Particles whose base cell is off the grid (last bucket) change nothing but their speed counts: k_g2p on that range.
 constexpr int G2P_TX = 4, G2P_TY = 4, G2P_TZ = 30;
-// items (mostly empty or unevenly filled boxes: the splash, the settled pool with its piles): a device-built work list instead of one block
-// per tile — items[0] = count, then (tile, chunk) pairs: an empty tile gets no item (nothing staged for it), a tile with more than
-// G2P_CHUNK particles gets one item per G2P_CHUNK of its particle list, so the block that meets a pile of 10^5 particles is many blocks.
-constexpr int G2P_CHUNK = 2048;
-__global__ __launch_bounds__(256) void k_g2p_items(Grid g, Box pb, const int* __restrict__ cell_start, int ntiles, int* __restrict__ items)
-{
-    const int tile = blockIdx.x * 256 + threadIdx.x;
-    if (tile >= ntiles) return;
-    const int nty = (pb.ny() + G2P_TY - 1) / G2P_TY, ntz = (pb.nz() + G2P_TZ - 1) / G2P_TZ;
-    const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
-    const int x0 = pb.x0 + tx * G2P_TX, y0 = pb.y0 + ty * G2P_TY, z0 = pb.z0 + tz * G2P_TZ;
-    const int z1 = z0 + G2P_TZ - 1 < pb.z1 ? z0 + G2P_TZ - 1 : pb.z1;
-    int n = 0;
-    for (int r = 0; r < G2P_TX * G2P_TY; ++r) {
-        const int cx = x0 + r / G2P_TY, cy = y0 + r % G2P_TY;
-        if (cx <= pb.x1 && cy <= pb.y1) n += cell_start[g.idx(cx, cy, z1) + 1] - cell_start[g.idx(cx, cy, z0)];
-    }
-    if (n == 0) return;
-    const int nch = (n + G2P_CHUNK - 1) / G2P_CHUNK;
-    const int base = atomicAdd(items, nch);   // (the order of the items reaches nothing: every particle is updated on its own)
-    for (int c = 0; c < nch; ++c) reinterpret_cast<int2*>(items + 2)[base + c] = make_int2(tile, c);
-}
-
 template <bool PIC>
 __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, const int* __restrict__ cell_start,
                                                    const double* __restrict__ dcx, const double* __restrict__ dcy,
                                                    const double* __restrict__ dcz, const double* __restrict__ pcx,
-                                                   const double* __restrict__ pcy, const double* __restrict__ pcz, double blend, StepState* ss,
-                                                   const int* __restrict__ items)
+                                                   const double* __restrict__ pcy, const double* __restrict__ pcz, double blend, StepState* ss)
 {
     constexpr int LX = G2P_TX + 2, LY = G2P_TY + 2, LZ = G2P_TZ + 2, LN = LX * LY * LZ, NROW = G2P_TX * G2P_TY;
     __shared__ double sf[PIC ? 6 : 3][LN];
@@ -756,14 +731,7 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
     __shared__ double sm[4];
     const int tid = threadIdx.x;
     const int nty = (pb.ny() + G2P_TY - 1) / G2P_TY, ntz = (pb.nz() + G2P_TZ - 1) / G2P_TZ;
-    int tile = blockIdx.x, lo = 0, hi = 0x7fffffff;   // [lo, hi): this block's part of the tile's particle list (rows one after the other)
-    if (items) {
-        if ((int)blockIdx.x >= items[0]) return;
-        const int2 it = reinterpret_cast<const int2*>(items + 2)[blockIdx.x];
-        tile = it.x;
-        lo = it.y * G2P_CHUNK;
-        hi = lo + G2P_CHUNK;
-    }
+    const int tile = blockIdx.x;
     const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
     const int x0 = pb.x0 + tx * G2P_TX, y0 = pb.y0 + ty * G2P_TY, z0 = pb.z0 + tz * G2P_TZ;
     const int z1 = z0 + G2P_TZ - 1 < pb.z1 ? z0 + G2P_TZ - 1 : pb.z1;
@@ -794,12 +762,8 @@ __global__ __launch_bounds__(256) void k_g2p_tiled(Grid g, Box pb, Particles p, 
     __syncthreads();
     const int wlo = g.lo + 2, whi = g.hi - 2;
     double len = 0;
-    int seen = 0;   // particles of the rows before this one
     for (int row = 0; row < NROW; ++row) {
-        const int a0 = srow[row][0], b0 = srow[row][1];
-        // the part of this row inside [lo, hi) of the tile's list
-        const int a = a0 + max(lo - seen, 0), b = min(b0, a0 + max(hi - seen, 0));
-        seen += b0 - a0;
+        const int a = srow[row][0], b = srow[row][1];
         for (int i = a + tid; i < b; i += 256) {
             const double cx = p.px[i], cy = p.py[i], cz = p.pz[i];
             const int fcx = (int)round(cx), fcy = (int)round(cy), fcz = (int)round(cz);
@@ -1042,23 +1006,12 @@ void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double
 }
 // pb = bounding box of the particles' base cells (after the sort, positions untouched since)
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,
-                      const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss, int* items, long n_particles)
+                      const double* pcx, const double* pcy, const double* pcz, double blend, StepState* ss)
 {
     if (pb.cells() <= 0) return;
     const unsigned nt = (unsigned)(((pb.nx() + G2P_TX - 1) / G2P_TX) * ((pb.ny() + G2P_TY - 1) / G2P_TY) * ((pb.nz() + G2P_TZ - 1) / G2P_TZ));
-    unsigned nb = nt;
-    if (items) {   // work list: at most one item per non-empty tile + one per G2P_CHUNK particles (blocks beyond the count leave at once)
-        hipMemsetAsync(items, 0, sizeof(int), st);
-        hipLaunchKernelGGL(k_g2p_items, dim3((nt + 255) / 256), dim3(256), 0, st, g, pb, cell_start, (int)nt, items);
-        nb = (unsigned)std::min<long>((long)nt + n_particles / G2P_CHUNK + 1, g2p_max_items(pb, n_particles));
-    }
-    if (pcx) hipLaunchKernelGGL(k_g2p_tiled<true>, dim3(nb), dim3(256), 0, st, g, pb, p, cell_start, dcx, dcy, dcz, pcx, pcy, pcz, blend, ss, (const int*)items);
-    else hipLaunchKernelGGL(k_g2p_tiled<false>, dim3(nb), dim3(256), 0, st, g, pb, p, cell_start, dcx, dcy, dcz, pcx, pcy, pcz, blend, ss, (const int*)items);
-}
-long g2p_max_items(Box pb, long n_particles)
-{
-    const long nt = (long)((pb.nx() + G2P_TX - 1) / G2P_TX) * ((pb.ny() + G2P_TY - 1) / G2P_TY) * ((pb.nz() + G2P_TZ - 1) / G2P_TZ);
-    return nt + n_particles / G2P_CHUNK + 1;
+    if (pcx) hipLaunchKernelGGL(k_g2p_tiled<true>, dim3(nt), dim3(256), 0, st, g, pb, p, cell_start, dcx, dcy, dcz, pcx, pcy, pcz, blend, ss);
+    else hipLaunchKernelGGL(k_g2p_tiled<false>, dim3(nt), dim3(256), 0, st, g, pb, p, cell_start, dcx, dcy, dcz, pcx, pcy, pcz, blend, ss);
 }
 void launch_g2p(hipStream_t st, Grid g, long n, Particles p, const double* dcx, const double* dcy, const double* dcz, const double* pcx,
                 const double* pcy, const double* pcz, double blend, StepState* ss)

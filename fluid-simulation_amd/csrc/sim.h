@@ -88,8 +88,6 @@ struct fluid_sim {
     size_t p2g_part_cap = 0;
     int* p2g_items = nullptr;    // k_p2g_rows' work list (count + int4 items), grown on demand; the count is 0 between launches
     size_t p2g_items_cap = 0;
-    int* g2p_items = nullptr;    // k_g2p_tiled's work list in unevenly filled boxes (count, pad, then (tile, chunk) pairs), grown on demand
-    size_t g2p_items_cap = 0;
     int max_cell = 0;            // most particles in one cell after the last sort (all ranks' cells when distributed)
     // mostly-air box (splash, settled pool): level-0 legs, SQ and XR run over compacted lists of the tiles that hold an unknown
     uint8_t* tl_flags = nullptr;  // per-tile flags (both tile shapes, one after the other)
