@@ -104,6 +104,7 @@ struct StepState {
     int n_drop;               // closed pockets of the pressure system found this step (kernels_droplets.hip); may exceed the buffer's capacity
     int n_tl_mg, n_tl_sq;     // active tiles of the level-0 V-cycle legs / of SQ and XR (mostly-air boxes)
     int n_rows, n_l1_old;     // z rows of 32 cells that hold an unknown (XR's list); unknowns of level 1 as the re-discretised cycle types it ...
+    int n_tl_int, n_tl_bnd;   // decomposed run: active level-0 down-leg tiles that read no received cell / that do
     int n_l1_gal, n_drop_fail;   // ... and as aggregation does (any child); droplets whose own CG did not reach the tolerance this step (k_drop_solve)
     unsigned long long max_speed_bits;  // max |v_p| as non-negative double bits
     double dt;                // fluid.cc:1367 / 992-999
@@ -329,7 +330,8 @@ void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int n
 void launch_sum4(hipStream_t st, const double* a, int na, const double* b, int nb, const double* c, int nc, const double* e, int ne, double* out);
 // Chronopoulos-Gear form of the decomposed PCG (one all-reduce per iteration): w = A z + partials of z.w; the fused update
 template <typename T>
-void launch_pcg_az_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* z, T* w, Coef<T> cf, double* part_zw, PcgState* ps);
+void launch_pcg_az_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* z, T* w, Coef<T> cf, double* part_zw, PcgState* ps, const int* tlist = nullptr,
+                        int nlist = 0);   // tlist: over the listed SQ tiles only, pcg_list_blocks(nlist) partials
 template <typename T>
 void launch_pcg_cgear_upd(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, T* s, T* q, const T* z, const T* w, const double* g, double* cg, int cur,
                           double* part_rr, PcgState* ps, int first, double tol);

@@ -40,6 +40,7 @@ template <typename T>
 void launch_mask_outside(hipStream_t st, MLevel m, Box own, T* a);
 void launch_mg_type_local(hipStream_t st, Grid g, MLevel m, int w0, int w1, int w2, const uint8_t* flags, const uint8_t* cnt, uint8_t* typ);
 void launch_copy_vel_before(hipStream_t st, Grid g, Box box, const double* u, const double* v, const double* w, double* ub, double* vb, double* wb);
+void launch_split_flags(hipStream_t st, const uint8_t* act, const uint8_t* cls, int n, uint8_t* fi, uint8_t* fb);
 void launch_pack_box_own(hipStream_t st, Grid g, Box box, Box own, const float* container, const double* u, const double* v, const double* w, double* buf);
 
 }  // namespace fl

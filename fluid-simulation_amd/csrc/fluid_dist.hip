@@ -136,6 +136,8 @@ struct DistState {
     size_t tl_cap = 0;
     int n_int = 0, n_bnd = 0;
     std::vector<int> h_tl;            // host copy behind the (stream-ordered) upload
+    uint8_t* tl_cls = nullptr;        // per level-0 leg tile: 1 = reads a received cell (the class the two lists above are cut by)
+    std::vector<uint8_t> h_cls;
 };
 
 namespace {
@@ -694,6 +696,7 @@ int dist_mg_setup(fluid_sim* s)
         constexpr int TX = 8, TY = 8, TZ = 16, H = 2;   // = MG_TX, MG_TY, MG_TZ of kernels_mg.hip
         const int gx = (m0.dz + TZ - 1) / TZ, gy = (m0.dy + TY - 1) / TY, gz = (m0.dx + TX - 1) / TX, nt = gx * gy * gz;
         d->h_tl.assign((size_t)2 * nt, 0);
+        d->h_cls.assign((size_t)nt, 0);
         int* li = d->h_tl.data();
         int* lb = li + nt;
         for (int t = 0; t < nt; ++t) {
@@ -706,13 +709,15 @@ int dist_mg_setup(fluid_sim* s)
                 for (int a = 0; a < 3; ++a) hit = hit && lo[a] < hp.rcv.lo[k][a] + hp.rcv.n[k][a] && hi[a] > hp.rcv.lo[k][a];
                 touches = hit;
             }
+            d->h_cls[t] = touches;
             if (touches) lb[d->n_bnd++] = t; else li[d->n_int++] = t;
         }
         if ((size_t)nt > d->tl_cap) {
-            if (d->tl_int) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->tl_int); hipFree(d->tl_bnd); d->tl_int = d->tl_bnd = nullptr; }
+            if (d->tl_int) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(d->tl_int); hipFree(d->tl_bnd); hipFree(d->tl_cls); d->tl_int = d->tl_bnd = nullptr; d->tl_cls = nullptr; }
             d->tl_cap = (size_t)nt + nt / 4 + 64;
             HIPCHK(hipMalloc((void**)&d->tl_int, d->tl_cap * sizeof(int)));
             HIPCHK(hipMalloc((void**)&d->tl_bnd, d->tl_cap * sizeof(int)));
+            HIPCHK(hipMalloc((void**)&d->tl_cls, d->tl_cap));
         }
         if (d->n_int) HIPCHK(hipMemcpyAsync(d->tl_int, li, d->n_int * sizeof(int), hipMemcpyHostToDevice, s->st));
         if (d->n_bnd) HIPCHK(hipMemcpyAsync(d->tl_bnd, lb, d->n_bnd * sizeof(int), hipMemcpyHostToDevice, s->st));
@@ -785,6 +790,46 @@ int dist_mg_setup(fluid_sim* s)
             if (s->n_drop > 0) s->stats.paths |= FLUID_PATH_DROPLETS;
         }
         launch_cnt_pcg(s->st, s->L, ownL, s->cntL, d->cnt_pcg);
+        // Mostly-air box (global numbers of the previous step; or pinned): the level-0 legs and the w = A z sweep of this rank run over the
+        // lists of their tiles that hold an unknown, like the one-GPU solve's; the down leg's two lists (tiles that read no received cell /
+        // tiles that do: the residual's halo exchange flies behind the first) are cut from the active tiles.  Rank-local: every launch
+        // shape and partial count that follows from them stays inside the rank.
+        s->lists_on = false;
+        const bool want_lists = use_mg(s) && !ib_empty(o) && s->lists_force != 0 && (d->airy_prev || s->lists_force == 1);
+        if (want_lists) {
+            const MLevel m0 = d->lv[0].m;
+            const int n_mg = mg_up_blocks(m0), n_sq = sq_tile_count(s->L);
+            const size_t need = (size_t)3 * n_mg + n_sq;
+            if (need > s->tl_cap) {
+                HIPCHK(hipStreamSynchronize(s->st));
+                hipFree(s->tl_flags); hipFree(s->tl_mg); hipFree(s->tl_sq);
+                s->tl_flags = nullptr; s->tl_mg = s->tl_sq = nullptr;
+                const size_t cap = need + need / 4;
+                HIPCHK(hipMalloc((void**)&s->tl_flags, cap));
+                HIPCHK(hipMalloc((void**)&s->tl_mg, cap * sizeof(int)));
+                HIPCHK(hipMalloc((void**)&s->tl_sq, cap * sizeof(int)));
+                s->tl_cap = cap;
+            }
+            const bool split = d->n_int + d->n_bnd == n_mg && d->tl_cls;   // the overlap's two lists exist for this step
+            uint8_t *act = s->tl_flags, *fi = act + n_mg, *fb = fi + n_mg, *fsq = fb + n_mg;
+            launch_mg_tile_flags(s->st, m0, s->cntL, act);
+            launch_compact_flags(s->st, act, n_mg, s->tl_mg, &s->ss->n_tl_mg);
+            if (split) {
+                HIPCHK(hipMemcpyAsync(d->tl_cls, d->h_cls.data(), (size_t)n_mg, hipMemcpyHostToDevice, s->st));
+                launch_split_flags(s->st, act, d->tl_cls, n_mg, fi, fb);
+                launch_compact_flags(s->st, fi, n_mg, d->tl_int, &s->ss->n_tl_int);
+                launch_compact_flags(s->st, fb, n_mg, d->tl_bnd, &s->ss->n_tl_bnd);
+            }
+            launch_sq_tile_flags(s->st, s->L, d->cnt_pcg, fsq);
+            launch_compact_flags(s->st, fsq, n_sq, s->tl_sq, &s->ss->n_tl_sq);
+            HIPCHK(hipGetLastError());
+            if ((rc = read_ss(s))) return rc;
+            s->n_tl_mg = s->h_ss->n_tl_mg; s->n_tl_sq = s->h_ss->n_tl_sq;
+            if (split) { d->n_int = s->h_ss->n_tl_int; d->n_bnd = s->h_ss->n_tl_bnd; }
+            s->lists_on = s->n_tl_mg > 0 && s->n_tl_sq > 0;
+            if (s->lists_on) s->stats.paths |= FLUID_PATH_TILE_LISTS;
+            else if (split) { d->n_int = d->n_bnd = 0; }   // (nothing to sweep on this rank)
+        }
     }
     if (!ib_empty(d->lv[0].dom))
         launch_mg_type_local(s->st, g, d->lv[0].m, d->lv[0].dom.lo[0] - g.ox, d->lv[0].dom.lo[1] - g.oy, d->lv[0].dom.lo[2] - g.oz, s->flags, s->cntL,
@@ -926,7 +971,8 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz,
                 if ((rc = halo_exchange_end(s, L.plan, sizeof(double)))) return rc;
                 if (d->n_bnd) launch_mg_down<G, double>(s->st, L.m, L.cnt, rhs0, GU(0), (G*)s->mg_r[0], mc, nullptr, GF(1), coef_as<G>(s, 0), ps, d->tl_bnd, d->n_bnd, true);
             } else {
-                launch_mg_down<G, double>(s->st, L.m, L.cnt, rhs0, GU(0), (G*)s->mg_r[0], mc, nullptr, GF(1), coef_as<G>(s, 0), ps, nullptr, 0, true);
+                launch_mg_down<G, double>(s->st, L.m, L.cnt, rhs0, GU(0), (G*)s->mg_r[0], mc, nullptr, GF(1), coef_as<G>(s, 0), ps, s->lists_on ? s->tl_mg : nullptr,
+                                          s->n_tl_mg, true);
             }
             HIPCHK(hipGetLastError());
         } else if (halo_pending) {
@@ -951,7 +997,8 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz,
                           (float)s->gal_wc, ps);
         if (!ib_empty(L.dom)) {
             const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)ib_cells(L.dom));
-            launch_mg_up<G, double, double>(s->st, L.m, L.cnt, rhs0, (const G*)GU(0), z0, mc, GW(1), coef_as<G>(s, 0), part_rz, ps, s->gal_wc, nullptr, 0, d->cnt_pcg, 1);
+            launch_mg_up<G, double, double>(s->st, L.m, L.cnt, rhs0, (const G*)GU(0), z0, mc, GW(1), coef_as<G>(s, 0), part_rz, ps, s->gal_wc, s->lists_on ? s->tl_mg : nullptr,
+                                            s->n_tl_mg, d->cnt_pcg, 1);
             prof_end(s, FLUID_PROF_MG_UP0, tok);
         }
         HIPCHK(hipGetLastError());
@@ -970,7 +1017,7 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz,
                     if ((rc = halo_exchange_end(s, L.plan, sizeof(double)))) return rc;
                     if (d->n_bnd) launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps, d->tl_bnd, d->n_bnd);
                 } else {
-                    launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps);
+                    launch_mg_down<V, double>(s->st, L.m, L.cnt, rhs0, U(0), R(0), mc, nullptr, nullptr, coef_as<V>(s, 0), ps, s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg);
                 }
                 launch_mg_restrict<V>(s->st, L.m, (const V*)R(0), mc, cc, F(1), ps);
             } else {
@@ -1019,8 +1066,8 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz,
             const MLevel mc = under(l);
             if (l == 0) {
                 const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)ib_cells(L.dom));
-                launch_mg_up<V, double, double>(s->st, L.m, L.cnt, rhs0, (const V*)U(0), z0, mc, ec, coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0], nullptr, 0,
-                                                d->cnt_pcg);
+                launch_mg_up<V, double, double>(s->st, L.m, L.cnt, rhs0, (const V*)U(0), z0, mc, ec, coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0],
+                                                s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg, d->cnt_pcg);
                 prof_end(s, FLUID_PROF_MG_UP0, tok);
             } else {
                 launch_mg_up<V, V, V>(s->st, L.m, L.cnt, (const V*)F(l), (const V*)U(l), W(l), mc, ec, coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
@@ -1048,8 +1095,9 @@ int dist_solve(fluid_sim* s)
     const bool mg = use_mg(s);
     long max_it = s->prm.cg_max_iters > 0 ? s->prm.cg_max_iters : 2 * (long)s->stats.num_active;
     if (max_it < 1) max_it = 1;
-    const int nxr = pcg_xr_blocks(L), nsq = pcg_sq_blocks(L);
-    const int n_rz = ib_empty(d->lv[0].dom) ? 0 : mg_up_blocks(d->lv[0].m);
+    const bool lists = mg && s->lists_on;
+    const int nxr = pcg_xr_blocks(L), nsq = lists && d->cg_form == 1 ? pcg_list_blocks(s->n_tl_sq) : pcg_sq_blocks(L);
+    const int n_rz = ib_empty(d->lv[0].dom) ? 0 : (lists ? s->n_tl_mg : mg_up_blocks(d->lv[0].m));
     const double cells = (double)ib_cells(d->lv[0].own);
     int rc;
     int tsolve = prof_begin(s, FLUID_PROF_SOLVE, cells);
@@ -1083,7 +1131,7 @@ int dist_solve(fluid_sim* s)
                 if (rc) return rc;
                 T* Wv = Sx[1];
                 int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-                launch_pcg_az_dist<T>(s->st, L, cnt, Z, Wv, cf, s->part_pq, s->ps);
+                launch_pcg_az_dist<T>(s->st, L, cnt, Z, Wv, cf, s->part_pq, s->ps, lists ? s->tl_sq : nullptr, s->n_tl_sq);
                 prof_end(s, FLUID_PROF_PCG_SQ, tok);
                 const bool g0 = it == 0 && guess;
                 launch_sum4(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->mg_part, n_rz, s->part_pq, nsq, s->part_rz[1], g0 ? nxr : 0, d->gstage[cur]);
@@ -1490,7 +1538,7 @@ void fl::dist_destroy(fluid_sim* s)
 {
     DistState* d = s->ds;
     if (!d) return;
-    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq, d->gcg, d->tl_int, d->tl_bnd, d->rb_buf};
+    void* ptrs[] = {d->hs, d->hr, d->mig_s, d->mig_r, d->d_cnt, d->repl_buf, d->rows, d->row_starts, d->cnt_pcg, d->gstage[0], d->gstage[1], d->gpq, d->gcg, d->tl_int, d->tl_bnd, d->tl_cls, d->rb_buf};
     for (void* p : ptrs) if (p) hipFree(p);
     if (d->st2) { hipStreamSynchronize(d->st2); hipStreamDestroy(d->st2); }
     if (d->ev_pack) hipEventDestroy(d->ev_pack);

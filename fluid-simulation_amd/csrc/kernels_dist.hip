@@ -322,4 +322,20 @@ void launch_pack_box_own(hipStream_t st, Grid g, Box box, Box own, const float* 
     if (box.cells() > 0) hipLaunchKernelGGL(k_pack_box_own, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, own, container, u, v, w, buf);
 }
 
+// Active-tile lists of a decomposed rank's level-0 down leg: act[t] = tile t holds an unknown, cls[t] = 1 where the tile reads a cell the
+// residual's halo exchange writes: fi = active tiles that can be swept while the exchange is in flight, fb = the active ones that cannot
+__global__ __launch_bounds__(256) void k_split_flags(const uint8_t* __restrict__ act, const uint8_t* __restrict__ cls, int n, uint8_t* __restrict__ fi,
+                                                     uint8_t* __restrict__ fb)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint8_t a = act[t], c = cls[t];
+    fi[t] = a && !c;
+    fb[t] = a && c;
+}
+void launch_split_flags(hipStream_t st, const uint8_t* act, const uint8_t* cls, int n, uint8_t* fi, uint8_t* fb)
+{
+    if (n > 0) hipLaunchKernelGGL(k_split_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, act, cls, n, fi, fb);
+}
+
 }  // namespace fl

@@ -839,10 +839,10 @@ void launch_sum4(hipStream_t st, const double* a, int na, const double* b, int n
 }
 // Chronopoulos-Gear form (decomposed solve): w = A z on the owned cells + pcg_sq_blocks(L) partials of z.w ...
 template <typename T>
-void launch_pcg_az_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* z, T* w, Coef<T> cf, double* part_zw, PcgState* ps)
+void launch_pcg_az_dist(hipStream_t st, LBox L, const uint8_t* cnt, const T* z, T* w, Coef<T> cf, double* part_zw, PcgState* ps, const int* tlist, int nlist)
 {
-    hipLaunchKernelGGL((k_pcg_sq_l<T, true, true>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, z, (const T*)nullptr, (T*)nullptr, w, cf, (const double*)nullptr,
-                       (const double*)nullptr, (const double*)nullptr, part_zw, 1, ps, 1, 0.0, 1, 1, 0, (const int*)nullptr, 0);
+    hipLaunchKernelGGL((k_pcg_sq_l<T, true, true>), dim3(tlist ? pcg_list_blocks(nlist) : pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, z, (const T*)nullptr,
+                       (T*)nullptr, w, cf, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_zw, 1, ps, 1, 0.0, 1, 1, 0, tlist, nlist);
 }
 // ... and the rest of the body from the all-reduced scalars g; writes pcg_xr_blocks(L) partials of |r|^2
 template <typename T>
@@ -1050,7 +1050,7 @@ void launch_stencil_apply(hipStream_t st, Grid g, Box box, const uint8_t* flags,
                                         const double*, double*, PcgState*, int, double, int);                                            \
     template void launch_pcg_xr_dist<T>(hipStream_t, LBox, const uint8_t*, T*, T*, const T*, const T*, Coef<T>, const double*,          \
                                         const double*, double*, double*, PcgState*);                                                    \
-    template void launch_pcg_az_dist<T>(hipStream_t, LBox, const uint8_t*, const T*, T*, Coef<T>, double*, PcgState*);                  \
+    template void launch_pcg_az_dist<T>(hipStream_t, LBox, const uint8_t*, const T*, T*, Coef<T>, double*, PcgState*, const int*, int);  \
     template void launch_pcg_cgear_upd<T>(hipStream_t, LBox, const uint8_t*, T*, T*, T*, T*, const T*, const T*, const double*, double*, int, double*, PcgState*, int, double);
 INST(double)
 INST(float)

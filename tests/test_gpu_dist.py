@@ -371,7 +371,8 @@ def _pool_with_spray(fs, n, rng):
 def test_decomposed_with_droplets_and_galerkin_levels(fs, monkeypatch):
     """Round 3's solver pieces in the decomposed step: closed pockets are found per rank (owned cells only: a pocket across a cut stays in
     the global solve), leave the system on both sides of every cut (count-byte halo from the owners) and are solved by their owner; the
-    coarse levels are Galerkin operators by aggregation, level 1's coefficients gathered from the owners.  Forced on at test size
+    coarse levels are Galerkin operators by aggregation, level 1's coefficients gathered from the owners; the level-0 legs and the w = A z
+    sweep run over each rank's own lists of active tiles (the down leg's interior / boundary lists cut from them).  Forced on at test size
     (FLUID_TILE_LISTS=1, FLUID_MG_GALERKIN=2); against one GPU with the same pieces on and with them off: same unknown numbering, same
     pressure, iteration counts within 10 %."""
     n, steps = 64, 3
@@ -386,6 +387,7 @@ def test_decomposed_with_droplets_and_galerkin_levels(fs, monkeypatch):
     compare(d, ref, len(pos), "droplets + galerkin", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
     assert rel_l2(d["pressure"], plain["pressure"]) < 1e-7
     assert all(s["paths"] & 128 for s in d["st"])                                   # Galerkin levels on every rank
+    assert sum(1 for st in d["all_st"] if all(s["paths"] & 2 for s in st)) >= 4    # active-tile lists on the ranks that hold unknowns
     assert sum(1 for st in d["all_st"] if st[0]["paths"] & 64) >= 4                  # the ranks above the pool found pockets
     assert not any(s["paths"] & 256 for st in d["all_st"] for s in st)               # every pocket's own CG met the stopping rule
     a, b = sum(s["cg_iters"] for s in d["st"]), sum(s["cg_iters"] for s in ref["st"])
@@ -393,11 +395,15 @@ def test_decomposed_with_droplets_and_galerkin_levels(fs, monkeypatch):
     assert abs(a - b) <= 0.1 * b + 2 * steps
 
 
-def test_decomposed_through_the_splash(fs):
+@pytest.mark.parametrize("lists", [False, True])
+def test_decomposed_through_the_splash(fs, lists, monkeypatch):
     """2 x 2 x 2 blocks, 160 free-running steps: the cube falls across the cut planes, hits the floor, splashes into all eight
     blocks (migration in every direction, ghosts at edges and corners, blocks whose share grows several-fold: buffers grow on
     demand).  No particle is lost or duplicated, every solve converges, and the run stays on the one-GPU trajectory for as
     long as two float-identical-to-rounding runs can (the first steps exactly in the integers)."""
+    if lists:   # the mostly-air forms pinned on at test size: active-tile lists and (decomposed: per rank) the droplet search
+        monkeypatch.setenv("FLUID_TILE_LISTS", "1")
+        monkeypatch.setenv("FLUID_DROPLETS_MIN", "0")
     n, ppc, steps = 48, 4, 160
     pos, _ = scene(fs, n, ppc)
     pos = pos + np.array([3.0, 6.0, -2.0])       # off-centre: unequal blocks
