@@ -130,6 +130,7 @@ struct DistState {
     std::vector<uint8_t> solid_global;   // what fluid_set_solid was given (empty: the default shell): a new window needs it again
     // overlap of the residual's halo exchange with the interior tiles of the level-0 down leg (FLUID_DIST_OVERLAP=0: off)
     bool overlap = true;
+    int overlap_checked = 0;          // 0: not yet; 1: the overlapped exchange delivered the serial one's bytes on every rank; 2: it did not (overlap switched off)
     hipStream_t st2 = nullptr;        // the exchange runs here while the solver's stream sweeps the tiles that read no halo cell
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
     int *tl_int = nullptr, *tl_bnd = nullptr;   // level-0 down-leg tiles (k_mg_down numbering): those that read no received cell / the others
@@ -1109,6 +1110,31 @@ int dist_solve(fluid_sim* s)
     s->start_guess(g1, g2, gca, gcb);
     if (guess) launch_pcg_init_guess<T>(s->st, g, L, cnt, s->diver, g1, g2, gca, gcb, X, R, cf, s->part_bb, s->part_rz[1], s->ps);
     else launch_pcg_init<T>(s->st, g, L, cnt, s->diver, X, R, cf, s->part_bb, s->part_rz[0], s->ps);
+    // Once per handle, with real peers: the residual's halo exchanged serially on the solver's stream and then again the overlapped way
+    // (pack on the solver's stream, transfer and unpack on the second) must deliver the same bytes on every rank — one communicator is
+    // driven from two streams there.  If any rank sees a difference every rank switches the overlap off (MAX all-reduce of the verdict).
+    if (mg && d->overlap && !d->overlap_checked && d->comm.size > 1) {
+        HaloPlan& hp = d->lv[0].plan;
+        const size_t nb = hp.n ? (size_t)hp.rtotal * sizeof(T) : 0;
+        std::vector<unsigned char> a(nb), b(nb);
+        if ((rc = halo_exchange1(s, hp, sizeof(T), R))) return rc;
+        if (nb) HIPCHK(hipMemcpyAsync(a.data(), d->hr, nb, hipMemcpyDeviceToHost, s->st));
+        if (nb) HIPCHK(hipMemsetAsync(d->hr, 0xFF, nb, s->st));
+        if (hp.n && !ib_empty(d->lv[0].dom)) {
+            if ((rc = halo_exchange_begin(s, hp, sizeof(T), R))) return rc;
+            if ((rc = halo_exchange_end(s, hp, sizeof(T)))) return rc;
+        } else if ((rc = halo_exchange1(s, hp, sizeof(T), R))) return rc;
+        if (nb) HIPCHK(hipMemcpyAsync(b.data(), d->hr, nb, hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        int* flag = d->h_cnt + 97;
+        *flag = nb && memcmp(a.data(), b.data(), nb) != 0 ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(d->d_cnt + 97, flag, sizeof(int), hipMemcpyHostToDevice, s->st));
+        if ((rc = comm_allreduce(s, d->d_cnt + 97, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
+        HIPCHK(hipMemcpyAsync(flag, d->d_cnt + 97, sizeof(int), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        d->overlap_checked = *flag ? 2 : 1;
+        if (*flag) d->overlap = false;
+    }
     long it = 0;
     const int pclass = s->pass_class();
     long batch = s->mg_last_iters_k[pclass] > 5 ? s->mg_last_iters_k[pclass] : 8;   // identical on every rank
@@ -1766,6 +1792,15 @@ int fluid_dist_set_rebalance(fluid_sim_t* s, int32_t every, double ratio)
     if (!s || !s->ds || every < 0 || !(ratio >= 1.0)) return fail(FLUID_ERR_ARG, "not a decomposed handle, or bad every / ratio");
     s->ds->rb_every = every;
     s->ds->rb_ratio = ratio;
+    return FLUID_OK;
+}
+
+int fluid_dist_get_info(fluid_sim_t* s, int32_t* overlap, int32_t* cg_form, int32_t* n_refused)
+{
+    if (!s || !s->ds) return fail(FLUID_ERR_ARG, "fluid_dist_get_info: not a decomposed handle");
+    if (overlap) *overlap = s->ds->overlap_checked;
+    if (cg_form) *cg_form = s->ds->cg_form;
+    if (n_refused) *n_refused = s->ds->n_rebalance_refused;
     return FLUID_OK;
 }
 

@@ -38,6 +38,8 @@ lib.fluid_create_dist.argtypes = [C.POINTER(Params), C.POINTER(FluidComm), C.POI
 lib.fluid_dist_set_rebalance.restype = C.c_int
 lib.fluid_dist_set_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_double]
 lib.fluid_dist_get_cuts.restype = C.c_int
+lib.fluid_dist_get_info.restype = C.c_int
+lib.fluid_dist_get_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 lib.fluid_dist_get_cuts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 lib.fluid_local_comm_create.restype = C.c_int
 lib.fluid_local_comm_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FluidComm)]
@@ -325,6 +327,12 @@ class DistFluidSim(FluidSim):
         nr = C.c_int32()
         check(lib.fluid_dist_get_cuts(self._h, arr[0], arr[1], arr[2], C.byref(nr)))
         return [list(c) for c in arr], nr.value
+
+    def info(self):
+        """{'overlap': 0 unchecked | 1 verified and in use | 2 failed its check and off, 'cg_form': 0 cg | 1 cgear, 'rebalances_refused': n}"""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.fluid_dist_get_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"overlap": a.value, "cg_form": b.value, "rebalances_refused": c.value}
 
     def _check(self, rc):
         if rc != 0 and getattr(self.comm, "error", None) is not None:

@@ -190,7 +190,8 @@ int fluid_upload_field(fluid_sim_t* s, int field, const void* src, size_t bytes)
  * call of extrapolate, at the end of P2Gtransfer (fluid.cc:1147), is commented out and resample is never called — so fluid_step
  * does not run them; they are here for a caller that wants the reference's code path with them switched on.  Single GPU.
  * fluid_extrapolate: call after fluid_p2g; fills FLUID_FIELD_VEL (and VEL_BEFORE) of every cell inside W that P2G left without
- * a velocity with the average of its defined 26-neighbours, layer by layer; n_layers (may be NULL) = passes run.
+ * a velocity with the average of its defined 26-neighbours, layer by layer; n_layers (may be NULL) = passes RUN — the "anything new"
+ * counter is read back every 8 passes, so this is the number of layers that filled a cell rounded up to a multiple of 8.
  * fluid_resample: at most per_cell particles per base cell, in upload-index order; the others are parked at
  * (hi + 40, hi + 40, hi + 40) (the reference's (100, 100, 100)); only cells with x < hi - 10 (its `rx < 50`). */
 int fluid_extrapolate(fluid_sim_t* s, int32_t* n_layers);
@@ -330,6 +331,11 @@ int fluid_partition_blocks(int32_t n, int64_t np, const double* pos, const int32
  * FLUID_PATH_DIST_REBALANCED.  fluid_dist_get_cuts: the current planes (dims[a] + 1 values per axis) and how often they moved. */
 int fluid_dist_set_rebalance(fluid_sim_t* s, int32_t every, double ratio);
 int fluid_dist_get_cuts(fluid_sim_t* s, int32_t* cuts_x, int32_t* cuts_y, int32_t* cuts_z, int32_t* n_rebalanced);
+/* What a decomposed handle decided about itself (any pointer may be NULL): overlap = 0 not checked yet (no solve with peers so far),
+ * 1 the residual's overlapped halo exchange (second stream) delivered the serial exchange's bytes on every rank and is in use,
+ * 2 it did not on some rank and is switched off everywhere; cg_form = 0 two scalar all-reduces per PCG iteration, 1 Chronopoulos-Gear
+ * (one); n_refused = re-balances every rank gave up together because some rank could not build its second window. */
+int fluid_dist_get_info(fluid_sim_t* s, int32_t* overlap, int32_t* cg_form, int32_t* n_refused);
 
 /* ---- OpenVDB file output (replaces file2.write(grids2) / file.write(grids), fluid.cc:1503-1504,1508) ----
  * Dense float32 N^3 arrays (z fastest, cell (0,0,0) = index coordinate (lo,lo,lo), lo = -(N/2)) written as unnamed

@@ -46,7 +46,7 @@ def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, solid=None, re
         st = [sim.step() for _ in range(steps)]
         p, v, ids = sim.download_local()
         return dict(st=st, p=p, v=v, ids=ids, idx=sim.field(F.INDICES), cont=sim.field(F.CONTAINER), pres=sim.field(F.PRESSURE),
-                    vel=sim.field(F.VEL), cuts=sim.cuts, moved=sim.n_rebalanced)
+                    vel=sim.field(F.VEL), cuts=sim.cuts, moved=sim.n_rebalanced, info=sim.info())
 
     try:
         res = grp.run(work)
@@ -59,7 +59,7 @@ def run_blocks(fs, dims, n, pos, vel, steps, mode, uniform=False, solid=None, re
     o = np.argsort(ids)
     out = dict(ids=ids[o], pos=np.concatenate([r["p"] for r in res])[o], vel=np.concatenate([r["v"] for r in res])[o],
                st=res[0]["st"], all_st=[r["st"] for r in res], cuts=res[0]["cuts"], counts=[len(r["ids"]) for r in res],
-               moved=[r["moved"] for r in res], all_cuts=[r["cuts"] for r in res])
+               moved=[r["moved"] for r in res], all_cuts=[r["cuts"] for r in res], info=[r["info"] for r in res])
     for k, key in (("indices", "idx"), ("container", "cont"), ("pressure", "pres"), ("velgrid", "vel")):
         out[k] = fd.assemble(n, sims, [r[key] for r in res])
     return out
@@ -260,6 +260,8 @@ def test_one_allreduce_per_iteration_gives_the_same_solve(fs, shape, monkeypatch
         out[form] = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed", uniform=True)
         compare(out[form], ref, len(pos), f"{shape} {form}", tol_p=1e-8, tol_v=1e-6, tol_pr=1e-7)
         assert all(s["relres"] < 2.3e-16 for s in out[form]["st"]), [s["relres"] for s in out[form]["st"]]
+        assert all(i["cg_form"] == (form == "cgear") for i in out[form]["info"])
+        assert all(i["overlap"] == 1 for i in out[form]["info"])      # the overlapped halo exchange passed its one-time check against the serial one on every rank
     a, b = sum(s["cg_iters"] for s in out["cg"]["st"]), sum(s["cg_iters"] for s in out["cgear"]["st"])
     print(f"{shape}: iterations cg {a} cgear {b}")
     assert b <= 1.1 * a + steps
@@ -277,6 +279,7 @@ def test_a_rank_that_cannot_build_its_new_window_keeps_every_rank_on_the_old_pla
     ref = single(fs, n, pos, vel, steps)
     d = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed", uniform=True, rebalance=(3, 1.1))
     assert d["moved"] == [0] * 8                                  # every attempt was given up, on every rank
+    assert len({i["rebalances_refused"] for i in d["info"]}) == 1 and d["info"][0]["rebalances_refused"] >= 1
     assert all(c == d["all_cuts"][0] for c in d["all_cuts"])
     monkeypatch.delenv("FLUID_DIST_FAIL_REBUILD")
     plain = run_blocks(fs, (2, 2, 2), n, pos, vel, steps, "decomposed", uniform=True)
