@@ -1675,7 +1675,10 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
                 return bail("replicated mode: gather buffer");
         } else {
             stage = std::max((size_t)48 * shell(1), (size_t)8 * shell(HALO_W));   // six doubles, 1 wide; one double, HALO_W wide
-            const long lsplit = std::max(300000L, (N / 4 + 2) * (N / 4 + 2) * (N / 4 + 2));   // the gathered level (level 1 while small, else level 2)
+            // the gathered level: level 1 while small, else level 2 — but a step that takes the Galerkin coarse levels gathers level 1
+            // whatever its size (dist_mg_setup), so with them enabled the whole of level 1 is provided for
+            const bool gal_possible = s->gal_mode != 0 && s->mg_fp32 && use_mg(s);
+            const long lsplit = gal_possible ? (N / 2 + 2) * (N / 2 + 2) * (N / 2 + 2) : std::max(300000L, (N / 4 + 2) * (N / 4 + 2) * (N / 4 + 2));
             stage = std::max(stage, (size_t)8 * lsplit);
             d->rows_cap = (size_t)N * N * d->dims[2] + 1024;
             if (hipMalloc((void**)&d->rows, d->rows_cap * sizeof(int)) != hipSuccess || hipMalloc((void**)&d->row_starts, d->rows_cap * sizeof(int)) != hipSuccess)
@@ -1686,6 +1689,28 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
             const size_t cap = (size_t)((double)(s->lmax + 4096) * 1.2 * (2 + 4 * es)) + 8 * (s->lmax + 4096) + (size_t)lsplit * 2 * (2 + 4 * es) + (1 << 20);
             if (hipMalloc((void**)&s->mg_slab, cap) != hipSuccess) return bail("multigrid slab");
             s->mg_slab_cap = cap;
+            // ... and what round 4 added to the decomposed solve, for the same reason (no allocation inside a step): the Galerkin levels'
+            // coefficients (4 floats + a count byte per cell of the replicated levels + their tile flags), the droplet buffers, the
+            // active-tile lists of the level-0 legs (8 x 8 x 16 cells a tile) and of the A z sweep (4 x 8 x 32)
+            if (gal_possible) {
+                s->gal_slab_cap = (size_t)lsplit * 20 + (1 << 20);
+                if (hipMalloc((void**)&s->gal_slab, s->gal_slab_cap) != hipSuccess) return bail("Galerkin coefficient slab");
+            }
+            if (s->drops_on && use_mg(s)) {
+                if (hipMalloc((void**)&s->drop_ctr, (size_t)(64 * DROP_NCTR + DROP_NCTR + 1) * sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&s->drop_n, (size_t)DROP_CAP * sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&s->drop_cells, (size_t)DROP_CAP * 64 * sizeof(int)) != hipSuccess)
+                    return bail("droplet buffers");
+            }
+            {
+                const size_t ntile = s->lmax / 256 + 8192;   // generous: partial tiles along every edge of the local box
+                s->tl_cap = 4 * ntile;
+                d->tl_cap = ntile;
+                if (hipMalloc((void**)&s->tl_flags, s->tl_cap) != hipSuccess || hipMalloc((void**)&s->tl_mg, s->tl_cap * sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&s->tl_sq, s->tl_cap * sizeof(int)) != hipSuccess || hipMalloc((void**)&d->tl_int, d->tl_cap * sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&d->tl_bnd, d->tl_cap * sizeof(int)) != hipSuccess || hipMalloc((void**)&d->tl_cls, d->tl_cap) != hipSuccess)
+                    return bail("tile lists");
+            }
         }
         if (ensure_stage(s, stage + 4096, stage + 4096)) return bail("halo staging buffers");
         const Box ownW = to_box(IBox{{d->ob.lo[0], d->ob.lo[1], d->ob.lo[2]}, {d->ob.hi[0], d->ob.hi[1], d->ob.hi[2]}}, (const int[3]){g.ox, g.oy, g.oz});
