@@ -57,6 +57,11 @@ struct MpmState {
     int cg_iters;                    // Eigen's `i` (ConjugateGradient.h:70-88)
     int num_touched;                 // nodes within one cell of a particle (the nodes the transfer and the force gather visit)
     int num_cells;                   // non-empty cells
+    // "the solve ends with this iteration" as k_mpm_cg_xrp (one launch for the residual update AND the convergence test) records it: slot =
+    // parity of the NEXT iteration, value = ((launch + 1) << 2) | status, so that a block of the launch that writes it can tell its own mark
+    // from an earlier launch's (a block that started late would otherwise skip its share of the last update of x); every later kernel
+    // treats a set slot like cg_done, the host folds the status into cg_done
+    int pend[2];
     int pad_;
     unsigned long long max_speed_bits, max_grad_bits, max_fp_bits, max_fe_bits, max_coeff_bits;
     double dt;
@@ -64,6 +69,8 @@ struct MpmState {
     double rho2[2];                  // <r,r>_w of the current / next iteration (slot = iteration parity)
     double max_force[3], max_mi;
 };
+
+__device__ __forceinline__ int solve_over(const MpmState* st) { return st->cg_done | st->pend[0] | st->pend[1]; }
 
 struct Part {   // SoA, stride = capacity
     double *pos, *vel, *FE, *FP, *gradV, *volume;
@@ -384,7 +391,7 @@ __global__ void __launch_bounds__(256) k_mpm_gather(MGrid G, Part P, const int* 
 {
     constexpr int NQ = MODE == 0 ? 4 : 3;
     __shared__ double sh[NQ][4];
-    if (MODE == 2 && in_solve && st->cg_done) return;   // speculative launches past convergence do nothing
+    if (MODE == 2 && in_solve && solve_over(st)) return;   // speculative launches past convergence do nothing
     const int nn = *n_list;
     const long C = G.cells();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -462,7 +469,7 @@ __global__ void __launch_bounds__(512) k_mpm_apply_cells(MGrid G, Part P, const 
                                                          const int* __restrict__ clist, const MpmState* st, int in_solve, double* __restrict__ part)
 {
     __shared__ double sp[22][CELL_CHUNK];   // 0-8 A_p F_p^T, 9 scale, 10-15 s2 (x0 x1 y0 y1 z0 z1), 16-21 grad
-    if (in_solve && st->cg_done) return;
+    if (in_solve && solve_over(st)) return;
     const int nc = st->num_cells;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ca = wv >> 2, cb = (wv >> 1) & 1, cc = wv & 1;   // this wave's corner: node = cell - 1 + (ca, cb, cc)
@@ -878,7 +885,7 @@ __global__ void k_mpm_maxforce_final(MGrid G, MpmState* st, const float* __restr
 __global__ void __launch_bounds__(128) k_mpm_apply_particles(MGrid G, long n, Part P, const int* __restrict__ indices, const double* __restrict__ invm,
                                                              const MpmState* st, double beta, int transposed, int in_solve, const double* __restrict__ v)
 {
-    if (in_solve && st->cg_done) return;   // speculative launches past convergence do nothing
+    if (in_solve && solve_over(st)) return;   // speculative launches past convergence do nothing
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
@@ -969,6 +976,7 @@ __global__ void k_mpm_cg_start(int nparts, const double* __restrict__ part1, con
     if (threadIdx.x) return;
     st->bb = a, st->rho2[0] = b, st->rr = a;
     st->cg_done = (a == 0) ? 1 : 0;   // b = 0 => x = 0 (IterativeSolverBase / ConjugateGradient.h:44-50)
+    st->pend[0] = st->pend[1] = 0;
 }
 // r = p = b, x = 0, y(=Ap) = p; partials of |b|^2 and <b,b>_w
 __global__ void k_mpm_cg_init(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
@@ -993,7 +1001,7 @@ __global__ void k_mpm_cg_pq(MGrid G, const int* __restrict__ active_cell, const 
                             const double* __restrict__ p, double* __restrict__ q, double* pa, double* pb, const int* __restrict__ cidx,
                             const double* __restrict__ apart, const double* __restrict__ invm)
 {
-    const long n3 = st->cg_done ? 0 : 3L * st->num_active;
+    const long n3 = solve_over(st) ? 0 : 3L * st->num_active;
     double d = 0;
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
         const double qk = apply_combine_one(G, active_cell, cidx, apart, invm, transposed, p, k);
@@ -1049,6 +1057,55 @@ __global__ void k_mpm_cg_p(MpmState* st, int par, double tol, long max_iters, co
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
         const double v = r[k] + beta * p[k];
         p[k] = v, q[k] = v;
+    }
+}
+// k_mpm_cg_xr and k_mpm_cg_p as ONE launch for small systems (the reference's scene has 39 values, the scaled cone 9 906): the vector
+// is short enough for EVERY block to form the whole new residual's two norms itself — the same order in every block, so all of them
+// take the same decisions — instead of handing partials to a third launch; a block then writes only its own share of x, r, p.  The new
+// residual goes into a second buffer (other blocks still read the old one in their reduction).
+constexpr long MPM_XRP_MAX = 2048;   // (9 906 values, the scaled cone: 64 blocks each reducing the whole vector cost more than the launch they save: solve 2.0 -> 2.7 ms)
+__global__ void k_mpm_cg_xrp(const int* __restrict__ active_cell, MpmState* st, const float* __restrict__ container, int transposed, int par, double tol,
+                             long max_iters, long launch, const double* __restrict__ part_pq, double* __restrict__ x, const double* __restrict__ r, double* __restrict__ r_new,
+                             double* __restrict__ p, const double* __restrict__ q)
+{
+    __shared__ int s_done;
+    __shared__ double sh[2][4];
+    if (threadIdx.x == 0) {
+        const int mine = (int)((launch + 1) << 2), a0 = st->pend[0], a1 = st->pend[1];   // a mark of THIS launch (block 0 may be ahead of us) does not count
+        s_done = st->cg_done | ((a0 & ~3) != mine ? a0 : 0) | ((a1 & ~3) != mine ? a1 : 0);
+    }
+    __syncthreads();
+    if (s_done) return;
+    const double pq = block_total(part_pq, RED_BLOCKS);
+    if (!(pq > 0) || !isfinite(pq)) {   // breakdown: leave x as it is (every block sees the same value)
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->pq = pq, st->cg_done = 2;
+        return;
+    }
+    const long n3 = 3L * st->num_active;
+    const double alpha = st->rho2[par] / pq;
+    double a = 0, d = 0;
+    for (long k = threadIdx.x; k < n3; k += blockDim.x) {
+        const double rv = r[k] - alpha * q[k];
+        a += rv * rv, d += dot_weight(container[active_cell[k / 3]], transposed) * rv * rv;
+    }
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o), d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = a, sh[1][threadIdx.x >> 6] = d;
+    __syncthreads();
+    double rr = 0, rho_new = 0;
+    for (int k = 0; k < (int)blockDim.x / 64; ++k) rr += sh[0][k], rho_new += sh[1][k];
+    const bool conv = rr < tol * tol * st->bb;
+    const double beta = rho_new / st->rho2[par];
+    __syncthreads();   // every thread has read the state before block 0 changes it
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->pq = pq, st->rr = rr, st->rho2[par ^ 1] = rho_new;
+        if (conv) st->pend[par ^ 1] = (int)((launch + 1) << 2) | 1;                 // Eigen leaves the loop before counting the iteration
+        else if (++st->cg_iters >= max_iters) st->pend[par ^ 1] = (int)((launch + 1) << 2) | 3;
+    }
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
+        const double pk = p[k], rv = r[k] - alpha * q[k];
+        x[k] += alpha * pk;
+        r_new[k] = rv;
+        if (!conv) p[k] = rv + beta * pk;
     }
 }
 __global__ void k_mpm_copy(long n, const double* __restrict__ a, double* __restrict__ b)
@@ -1254,6 +1311,7 @@ struct mpm_sim {
     int *cell_count = nullptr, *cell_start = nullptr, *key = nullptr, *rank = nullptr, *order = nullptr, *order2 = nullptr, *rank2 = nullptr;   // counting sort by base cell
     int *tflag = nullptr, *tidx = nullptr, *tlist = nullptr;   // nodes within one cell of a particle: flags, scratch numbering, list
     double *b = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *part = nullptr;
+    double* r2 = nullptr;   // the residual's second buffer (k_mpm_cg_xrp writes the new residual beside the one other blocks still read)
     double* invm = nullptr;       // 1 / node mass per unknown
     double* apart = nullptr;      // the operator's partial node sums (32 x 3 per unknown), grown with the unknown count
     size_t apart_cap = 0;
@@ -1339,6 +1397,7 @@ int read_state(mpm_sim* s)
 {
     HIPCHK(hipMemcpyAsync(s->h_state, s->state, sizeof(MpmState), hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
+    if (!s->h_state->cg_done) s->h_state->cg_done = std::max(s->h_state->pend[0] & 3, s->h_state->pend[1] & 3);   // (k_mpm_cg_xrp's end-of-solve slots)
     return 0;
 }
 
@@ -1382,7 +1441,7 @@ int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
          dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C + 1) || dalloc(&s->tflag, C) || dalloc(&s->tidx, C) || dalloc(&s->tlist, C) || dalloc(&s->cflag, C) || dalloc(&s->cidx, C) || dalloc(&s->clist, C) || dalloc(&s->part, 4 * RED_BLOCKS) || dalloc(&s->state, 1);
     // unknowns live inside the walls only: (2W+1)^3 at most
     const long maxu = (long)(2 * prm->W + 1) * (2 * prm->W + 1) * (2 * prm->W + 1);
-    rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu) || dalloc(&s->invm, maxu);
+    rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->r2, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu) || dalloc(&s->invm, maxu);
     if (!rc && hipHostMalloc((void**)&s->h_state, sizeof(MpmState)) != hipSuccess) rc = FLUID_ERR_HIP;
     for (int k = 0; k < 8 && !rc; ++k)
         if (hipEventCreate(&s->ev[k]) != hipSuccess) rc = FLUID_ERR_HIP;
@@ -1407,7 +1466,7 @@ int mpm_destroy(mpm_sim_t* s)
     if (!s) return 0;
     free_particles(s);
     void* a[] = {s->solid, s->container, s->output, s->massd, s->vel, s->velb, s->forces, s->flag, s->indices, s->active_cell, s->sums,
-                 s->part, s->state, s->b, s->x, s->r, s->p, s->q, s->stage, s->cell_count, s->cell_start, s->invm, s->tflag, s->tidx, s->tlist, s->apart, s->cflag, s->cidx, s->clist};
+                 s->part, s->state, s->b, s->x, s->r, s->r2, s->p, s->q, s->stage, s->cell_count, s->cell_start, s->invm, s->tflag, s->tidx, s->tlist, s->apart, s->cflag, s->cidx, s->clist};
     for (void* p : a)
         if (p) (void)hipFree(p);
     if (s->h_state) (void)hipHostFree(s->h_state);
@@ -1585,9 +1644,15 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
             if (timed) HIPCHK(hipEventRecord(s->ev[7], st));
             double *pa = s->part, *pb = s->part + RED_BLOCKS, *pc = s->part + 2 * RED_BLOCKS, *pd = s->part + 3 * RED_BLOCKS;
             k_mpm_cg_pq<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, pr.transpose_system, s->p, s->q, pa, pb, s->cidx, s->apart, s->invm);
-            k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, (int)(launched & 1), pb, s->x, s->r, s->p,
-                                                    s->q, pc, pd);
-            k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, (int)(launched & 1), pr.cg_tol, max_iters, pc, pd, s->r, s->p, s->q);
+            if (3L * s->num_active <= MPM_XRP_MAX) {
+                double *rc_ = (launched & 1) ? s->r2 : s->r, *rn_ = (launched & 1) ? s->r : s->r2;
+                k_mpm_cg_xrp<<<64, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, (int)(launched & 1), pr.cg_tol, max_iters, launched, pb, s->x, rc_, rn_,
+                                                 s->p, s->q);
+            } else {
+                k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, (int)(launched & 1), pb, s->x, s->r, s->p,
+                                                        s->q, pc, pd);
+                k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, (int)(launched & 1), pr.cg_tol, max_iters, pc, pd, s->r, s->p, s->q);
+            }
             ++launched;
         }
         HIPCHK(hipGetLastError());
