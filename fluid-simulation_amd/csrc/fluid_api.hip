@@ -1392,13 +1392,13 @@ static int stencil_run(fluid_sim* s, int reps, int box_mode, int nsets, void* co
         const void* S = nsets > 1 ? sets[i % nsets][0] : s->S[0];
         void* Q = nsets > 1 ? sets[i % nsets][1] : s->Q;
         const uint8_t* fl = nsets > 1 ? (const uint8_t*)sets[i % nsets][2] : s->flags;
-        // box_mode 0: dense sweep (LDS-DMA plane ring / lean march; grids under 192^3 cannot fill 256 CUs with whole-plane chunks -> tiled);
+        // box_mode 0: dense sweep (LDS-DMA plane ring from 192^3 on, the lean march below; under 64^3 the tiled kernel);
         // 1: active box, tiled kernel; 2: dense sweep, tiled kernel
         if (s->prm.precision == FLUID_PRECISION_FP32) {
-            if (!(box_mode == 0 && (N >= 192 || mv) && launch_stencil_march<float>(s->st, s->g, fl, (const float*)S, (float*)Q, make_coef<float>(s), mv, mc)))
+            if (!(box_mode == 0 && (N >= 64 || mv) && launch_stencil_march<float>(s->st, s->g, fl, (const float*)S, (float*)Q, make_coef<float>(s), mv, mc)))
                 launch_stencil_apply<float>(s->st, s->g, box, fl, (const float*)S, (float*)Q, make_coef<float>(s));
         } else {
-            if (!(box_mode == 0 && (N >= 192 || mv) && launch_stencil_march<double>(s->st, s->g, fl, (const double*)S, (double*)Q, make_coef<double>(s), mv, mc)))
+            if (!(box_mode == 0 && (N >= 64 || mv) && launch_stencil_march<double>(s->st, s->g, fl, (const double*)S, (double*)Q, make_coef<double>(s), mv, mc)))
                 launch_stencil_apply<double>(s->st, s->g, box, fl, (const double*)S, (double*)Q, make_coef<double>(s));
         }
     }

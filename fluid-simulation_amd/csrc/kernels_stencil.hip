@@ -487,6 +487,13 @@ bool launch_stencil_march(hipStream_t st, Grid g, const uint8_t* flags, const T*
         }
         return true;
     }
+    if (variant == 0 && g.N < 192) {
+        // small grids (the metric's 128^3: 19 / 36 MB per set, a launch of ~10 us): 8 chunks of N / 8 planes of the lean march fill the
+        // chip with short blocks — 10.4 us (fp64) / 8.9 us (fp32) at 128^3 against 20.8 / 12.4 for the tiled kernel and 16-17 / 11-12 for
+        // the plane ring, whose blocks march too few planes there to pay for their prologue (profiles/r04/NOTES.md)
+        lean_launch<T, 4, 4>(st, g, g.N / 8 > 8 ? g.N / 8 : 8, flags, s, q, cf);
+        return true;
+    }
     // the LDS-DMA plane ring: measured defaults at 256^3 from HBM (tools/dma_lab.py, profiles/r04/stencil_sweep_hbm.txt):
     // double: 8 loader waves (3 instructions each per plane) + 8 consumer waves with two pieces per lane; float: 4 + 8 with one
     // (planes in flight: 2 for double, 3 for float — 0.699 / 0.697 of the 8 TB/s peak; 3 / 2: 0.693 / 0.679)
