@@ -74,8 +74,8 @@ __device__ __forceinline__ int solve_over(const MpmState* st) { return st->cg_do
 
 struct Part {   // SoA, stride = capacity
     double *pos, *vel, *FE, *FP, *gradV, *volume;
-    // per-step cache for the operator: R, inverse of getDelR's 3x3 matrix, cofactor matrix, F^T applied later
-    double *R, *Minv, *cof, *coef;   // coef: mu_p, lambda_p, J
+    // per-step cache for the operator: R, inverse of getDelR's 3x3 matrix (the cofactor matrix is formed again from F where it is used)
+    double *R, *Minv, *coef;         // coef: mu_p, lambda_p, J
     double* node9;                   // 10 doubles per particle for the node gathers: the stress (forces) / A_p F_p^T (operator) + its scale
     double* wfac;                    // 12 doubles per particle, once per step: s2 and grad factors (deformHeader.h:99-101) of the nodes base-1, base per axis
     long cap;
@@ -225,7 +225,7 @@ __device__ void svd3(const double* F, double* U, double* s, double* V)
 
 // ---- constitutive pieces shared by the step kernels and by mpm_eval (the known-answer hook) ----
 struct Setup {          // per particle, once per step
-    double R[9], S[9], Minv[9], cof[9], sigma[9], mu, lambda, J;
+    double R[9], S[9], Minv[9], sigma[9], mu, lambda, J;
 };
 // getR / getS (deformHeader.h:22-36), getSigma (:273-307), and what getdPsydx2 recomputes for every node pair (:253-263):
 // the hardened coefficients, J, the cofactor matrix (getJFmt, :227-239) and the inverse of getDelR's 3x3 matrix (:139-142)
@@ -257,39 +257,48 @@ __device__ __forceinline__ void particle_setup(const double* F, const double* FP
     const double dm = mat_det(m);
 #pragma unroll
     for (int k = 0; k < 9; ++k) o.Minv[k] = dm != 0 ? mi[k] / dm : 0.0;
-    cofactor(F, o.cof);
 }
 // Ap = d2Psi/dF2 : dF (dPsydFdF, deformHeader.h:241-249, for a general dF): 2 mu dF - 2 mu dR + lambda cof (cof : dF) + lambda (J - 1) dcof,
 // dR from getDelR (:133-147), dcof = the derivative of the cofactor matrix along dF (what getdJF / doubleDot42 tabulate, :148-212)
-__device__ __forceinline__ void hessian_apply(const double* F, const double* R, const double* Mi, const double* cf, double mu, double lambda, double J,
-                                              const double* dF, double* Ap)
+// The four terms are formed and added one after the other (same left-to-right order as :248), each from the inputs it alone needs, so
+// that R / Minv and cof need not be live together; cof is cofactor(F) again, the expression of the reference's setup.
+__device__ __forceinline__ void hessian_apply(const double* F, const double* R, const double* Mi, double mu, double lambda, double J, const double* dF,
+                                              double* Ap)
 {
-    double RtdF[9];
     {
-        const double Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
-        mat_mul(Rt, dF, RtdF);
-    }
-    const double rhs01 = RtdF[1] - RtdF[3], rhs02 = RtdF[2] - RtdF[6], rhs12 = RtdF[5] - RtdF[7];   // R^T dF - dF^T R
-    const double x0 = Mi[0] * rhs01 + Mi[1] * rhs02 + Mi[2] * rhs12;
-    const double x1 = Mi[3] * rhs01 + Mi[4] * rhs02 + Mi[5] * rhs12;
-    const double x2 = Mi[6] * rhs01 + Mi[7] * rhs02 + Mi[8] * rhs12;
-    const double rdr[9] = {0, x0, x1, -1 * x0, 0, x2, -1 * x1, -1 * x2, 0};
-    double dR[9];
-    mat_mul(R, rdr, dR);
-    double dd = 0;
+        double RtdF[9];
+        {
+            const double Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+            mat_mul(Rt, dF, RtdF);
+        }
+        const double rhs01 = RtdF[1] - RtdF[3], rhs02 = RtdF[2] - RtdF[6], rhs12 = RtdF[5] - RtdF[7];   // R^T dF - dF^T R
+        const double x0 = Mi[0] * rhs01 + Mi[1] * rhs02 + Mi[2] * rhs12;
+        const double x1 = Mi[3] * rhs01 + Mi[4] * rhs02 + Mi[5] * rhs12;
+        const double x2 = Mi[6] * rhs01 + Mi[7] * rhs02 + Mi[8] * rhs12;
+        const double rdr[9] = {0, x0, x1, -1 * x0, 0, x2, -1 * x1, -1 * x2, 0};
+        double dR[9];
+        mat_mul(R, rdr, dR);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dd += cf[k] * dF[k];
-    double dcf[9];
+        for (int k = 0; k < 9; ++k) Ap[k] = 2 * mu * dF[k] - 2 * mu * dR[k];
+    }
+    {
+        double cf[9];
+        cofactor(F, cf);
+        double dd = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dd += cf[k] * dF[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ap[k] += lambda * cf[k] * dd;
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-            dcf[3 * r + c] = dF[3 * r1 + c1] * F[3 * r2 + c2] + F[3 * r1 + c1] * dF[3 * r2 + c2] - dF[3 * r1 + c2] * F[3 * r2 + c1] -
-                             F[3 * r1 + c2] * dF[3 * r2 + c1];
+            const double dcf = dF[3 * r1 + c1] * F[3 * r2 + c2] + F[3 * r1 + c1] * dF[3 * r2 + c2] - dF[3 * r1 + c2] * F[3 * r2 + c1] -
+                               F[3 * r1 + c2] * dF[3 * r2 + c1];
+            Ap[3 * r + c] += lambda * (J - 1) * dcf;   // deformHeader.h:248
         }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Ap[k] = 2 * mu * dF[k] - 2 * mu * dR[k] + lambda * cf[k] * dd + lambda * (J - 1) * dcf[k];   // deformHeader.h:248
 }
 // the singular-value clamp of updateDeformationGradient, mpm.cc:543-555
 __device__ __forceinline__ void clamp_update(const double* tFE, const double* FP, double minv, double maxv, double* nFE, double* nFP)
@@ -332,7 +341,7 @@ __global__ void k_mpm_eval(int what, long n, const double* __restrict__ a, const
         Setup st;
         particle_setup(A, I, 0.0, 0.0, 0.0, st);
         double Ap[9];
-        hessian_apply(A, st.R, st.Minv, st.cof, p1, p0, st.J, B, Ap);
+        hessian_apply(A, st.R, st.Minv, p1, p0, st.J, B, Ap);
 #pragma unroll
         for (int k = 0; k < 9; ++k) out0[9 * i + k] = Ap[k];
     } else if (what == MPM_EVAL_CLAMP) {     // a = tFE, b = FP, p0 = minv, p1 = maxv
@@ -458,58 +467,110 @@ __global__ void __launch_bounds__(256) k_mpm_gather(MGrid G, Part P, const int* 
     }
 }
 // The operator's node sums run once per CG iteration.  A particle of base cell f carries gradient weight on the nodes f-1 and f of
-// every axis only (k_mpm_gather), so a CELL's particles feed exactly its 8 corner nodes f - 1 + (a, b, c): one workgroup per
-// non-empty cell stages the cell's list (position, A_p F_p^T, scale: 13 doubles per particle, read ONCE) in LDS, and wave s of its
-// 8 waves sums the contributions to corner s over the list — lanes stride it, add in list order, fold in a fixed order.  The 8 x 3
-// partial sums of a cell go to part[compact cell index]; a node's value is the sum over its 8 cells, taken in a fixed order by the
-// kernel that consumes it (k_mpm_cg_pq, k_mpm_apply_combine).  (A first gather form had one wave per (node, cell): every particle was
-// then read 8 times from L2 — 59 us per application on the 219 k particle cone against 27 us for the whole per-particle kernel.)
-constexpr int CELL_CHUNK = 256;   // particles staged per pass (45 KB of LDS)
-__global__ void __launch_bounds__(512) k_mpm_apply_cells(MGrid G, Part P, const int* __restrict__ cell_start, const int* __restrict__ cell_count,
-                                                         const int* __restrict__ clist, const MpmState* st, int in_solve, double* __restrict__ part)
+// every axis only (k_mpm_gather), so a CELL's particles feed exactly its 8 corner nodes f - 1 + (a, b, c).  One WAVE per non-empty
+// cell, lane = particle: a lane reads its particle once (position factors, A_p F_p^T, scale: 22 doubles, coalesced, one round trip
+// for the whole cell), forms the 8 x 3 contributions and the wave folds them by a halving butterfly (lane bits 5, 4, 3 against the
+// corner bits: 12 + 6 + 3 exchanges, then 9 over the low bits) — fixed order, no LDS, no barrier.  A cell above CELL_HEAVY
+// particles is shared by the four waves of its block (their sums folded through LDS in wave order).  The 8 x 3 partial sums of a
+// cell go to part[compact cell index]; a node's value is the sum over its 8 cells, taken in a fixed order by the kernel that
+// consumes it (k_mpm_cg_pq, k_mpm_apply_combine).
+// (Earlier forms: one wave per (node, cell), every particle read 8 times from L2 — 59 us per application on the 219 k particle cone;
+// one 512-thread block per cell staging its list through LDS, wave = corner — 21.8 us, three blocks per CU; one wave per cell with
+// lane = (slot, corner) striding the list — 23.7 us: a memory round trip per eight particles.)
+constexpr int CELL_HEAVY = 128;
+constexpr int CELL_WAVES = 4;
+__global__ void __launch_bounds__(64 * CELL_WAVES) k_mpm_apply_cells(MGrid G, Part P, const int* __restrict__ cell_start, const int* __restrict__ cell_count,
+                                                                     const int* __restrict__ clist, const MpmState* st, int in_solve, int coop, double* __restrict__ part)
 {
-    __shared__ double sp[22][CELL_CHUNK];   // 0-8 A_p F_p^T, 9 scale, 10-15 s2 (x0 x1 y0 y1 z0 z1), 16-21 grad
+    __shared__ double sh[CELL_WAVES][8][3];
     if (in_solve && solve_over(st)) return;
     const int nc = st->num_cells;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ca = wv >> 2, cb = (wv >> 1) & 1, cc = wv & 1;   // this wave's corner: node = cell - 1 + (ca, cb, cc)
-    for (int b = blockIdx.x; b < nc; b += gridDim.x) {
-        const long c = clist[b];
+    // the sums of one cell over its particles first + lane, first + lane + stride, ...: afterwards every lane holds the three
+    // components of corner (lane >> 3) (bit 5 = a, bit 4 = b, bit 3 = c of node = cell - 1 + (a, b, c))
+    auto cell_sum = [&](long c, int first, int stride, double* out) {
         const int fz = (int)(c % G.N) - G.B, fy = (int)((c / G.N) % G.N) - G.B, fx = (int)(c / ((long)G.N * G.N)) - G.B;
-        const bool node_ok = G.in(fx - 1 + ca, fy - 1 + cb, fz - 1 + cc);
         const int cnt = cell_count[c];
         const long j0 = cell_start[c];
-        double acc[3] = {0, 0, 0};
-        for (int base = 0; base < cnt; base += CELL_CHUNK) {
-            const int m = cnt - base < CELL_CHUNK ? cnt - base : CELL_CHUNK;
-            __syncthreads();   // the previous pass has been consumed
-            if ((int)threadIdx.x < m) {   // thread i stages particle i: 22 loads in flight together, each coalesced across the threads
-                const long j = j0 + base + threadIdx.x;
+        double acc[24];
 #pragma unroll
-                for (int k = 0; k < 10; ++k) sp[k][threadIdx.x] = ld(P.node9, P.cap, k, j);
+        for (int k = 0; k < 24; ++k) acc[k] = 0;
+        for (int i = first + lane; i < cnt; i += stride) {
+            const long j = j0 + i;
+            double w[12], m[9];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) sp[10 + k][threadIdx.x] = ld(P.wfac, P.cap, k, j);
+            for (int k = 0; k < 12; ++k) w[k] = ld(P.wfac, P.cap, k, j);   // s2 (x0 x1 y0 y1 z0 z1), grad (same order)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m[k] = ld(P.node9, P.cap, k, j);
+            const double sc = ld(P.node9, P.cap, 9, j);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int ca = s >> 2, cb = (s >> 1) & 1, cc = s & 1;
+                const double s2x = w[ca], s2y = w[2 + cb], s2z = w[4 + cc], gx = w[6 + ca], gy = w[8 + cb], gz = w[10 + cc];
+                const double g[3] = {-1 * gx * s2y * s2z, -1 * s2x * gy * s2z, -1 * s2x * s2y * gz};   // getGradW, deformHeader.h:99-103
+#pragma unroll
+                for (int r = 0; r < 3; ++r) acc[3 * s + r] += sc * (m[3 * r] * g[0] + m[3 * r + 1] * g[1] + m[3 * r + 2] * g[2]);
             }
-            __syncthreads();
-            if (node_ok) {
-                for (int i = lane; i < m; i += 64) {
-                    const double s2x = sp[10 + ca][i], s2y = sp[12 + cb][i], s2z = sp[14 + cc][i];
-                    const double gx = sp[16 + ca][i], gy = sp[18 + cb][i], gz = sp[20 + cc][i];
-                    const double g[3] = {-1 * gx * s2y * s2z, -1 * s2x * gy * s2z, -1 * s2x * s2y * gz};   // getGradW, deformHeader.h:99-103
-                    const double sc = sp[9][i];
+        }
+        // halve: a lane keeps the corners whose bit matches its lane bit and takes the partner's sums for them
+        double h12[12], h6[6];
+        const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) acc[r] += sc * (sp[3 * r][i] * g[0] + sp[3 * r + 1][i] * g[1] + sp[3 * r + 2][i] * g[2]);
+        for (int k = 0; k < 12; ++k) {
+            const double keep = b5 ? acc[12 + k] : acc[k], send = b5 ? acc[k] : acc[12 + k];
+            h12[k] = keep + __shfl_xor(send, 32);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double keep = b4 ? h12[6 + k] : h12[k], send = b4 ? h12[k] : h12[6 + k];
+            h6[k] = keep + __shfl_xor(send, 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double keep = b3 ? h6[3 + k] : h6[k], send = b3 ? h6[k] : h6[3 + k];
+            double v = keep + __shfl_xor(send, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            out[k] = v;
+        }
+        // a corner node outside the grid takes nothing (the reference's loops stop at the grid's edge)
+        const int s = lane >> 3;
+        if (!G.in(fx - 1 + (s >> 2), fy - 1 + ((s >> 1) & 1), fz - 1 + (s & 1))) out[0] = out[1] = out[2] = 0;
+    };
+    // coop (the host's choice when the average cell is heavy: few cells, e.g. the reference's scene of 16 cells x 390): a block per cell
+    const int cpb = coop ? 1 : CELL_WAVES;
+    for (int base = blockIdx.x * cpb; base < nc; base += gridDim.x * cpb) {
+        if (!coop) {
+            const int b = base + wv;
+            const long c = b < nc ? clist[b] : 0;
+            const bool heavy = b < nc && cell_count[c] > CELL_HEAVY;
+            if (b < nc && !heavy) {
+                double v[3];
+                cell_sum(c, 0, 64, v);
+                if ((lane & 7) == 0) {
+                    double* o = part + (long)b * 24 + 3 * (lane >> 3);
+                    o[0] = v[0], o[1] = v[1], o[2] = v[2];
                 }
             }
+            if (!__syncthreads_or(heavy)) continue;
         }
+        for (int w = 0; w < cpb && base + w < nc; ++w) {   // block-uniform
+            const long cw = clist[base + w];
+            if (!coop && cell_count[cw] <= CELL_HEAVY) continue;
+            double v[3];
+            cell_sum(cw, wv * 64, 64 * CELL_WAVES, v);
+            if ((lane & 7) == 0) sh[wv][lane >> 3][0] = v[0], sh[wv][lane >> 3][1] = v[1], sh[wv][lane >> 3][2] = v[2];
+            __syncthreads();
+            if (threadIdx.x < 24) {
+                const int cr = threadIdx.x / 3, r = threadIdx.x % 3;
+                double t = sh[0][cr][r];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            double v = acc[r];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            acc[r] = v;
+                for (int k = 1; k < CELL_WAVES; ++k) t += sh[k][cr][r];
+                part[(long)(base + w) * 24 + threadIdx.x] = t;
+            }
+            __syncthreads();
         }
-        if (lane < 3) part[(long)b * 24 + 3 * wv + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
     }
 }
 // value of unknown q, component r: v + (mass factor) x the partial sums of the 8 cells around the node, cells in a fixed order
@@ -796,7 +857,6 @@ __global__ void __launch_bounds__(128) k_mpm_forces(MGrid G, long n, Part P, dou
     for (int k = 0; k < 9; ++k) {
         stv(P.R, P.cap, k, i, su.R[k]);
         stv(P.Minv, P.cap, k, i, su.Minv[k]);
-        stv(P.cof, P.cap, k, i, su.cof[k]);
         stv(P.node9, P.cap, k, i, su.sigma[k]);
     }
     stv(P.coef, P.cap, 0, i, su.mu), stv(P.coef, P.cap, 1, i, su.lambda), stv(P.coef, P.cap, 2, i, su.J);
@@ -882,55 +942,58 @@ __global__ void k_mpm_maxforce_final(MGrid G, MpmState* st, const float* __restr
 // Two launches per application: per PARTICLE the gather of G = sum_j v_j (x) grad w_j from the unknown vector, one application of
 // the energy Hessian and A_p F_p^T (k_mpm_apply_particles, below); per unknown NODE the sum over the particles around it
 // (k_mpm_gather<2>).  v, y: 3 * num_active doubles in unknown order.
-__global__ void __launch_bounds__(128) k_mpm_apply_particles(MGrid G, long n, Part P, const int* __restrict__ indices, const double* __restrict__ invm,
-                                                             const MpmState* st, double beta, int transposed, int in_solve, const double* __restrict__ v)
+__global__ void __launch_bounds__(128) k_mpm_apply_particles(MGrid G, long n, Part P, const MpmState* st, double beta, int in_solve, const double* __restrict__ vd)
 {
     if (in_solve && solve_over(st)) return;   // speculative launches past convergence do nothing
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double p[3] = {ld(P.pos, P.cap, 0, i), ld(P.pos, P.cap, 1, i), ld(P.pos, P.cap, 2, i)};
-    Nbh nb;
-    neighbourhood(G, p, nb, true);
-    // G = sum_j v_j (x) grad w_j over the unknown nodes, one x-plane of 9 nodes at a time (node -> unknown number -> value: the 9
-    // numbers of a plane are fetched together, then their values); the x factors are picked by selects so that the plane loop
-    // stays rolled without indexing registers dynamically
-    double Gm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-    for (int a = 0; a < 3; ++a) {
-        const double s2x = a == 0 ? nb.s2[0][0] : (a == 1 ? nb.s2[0][1] : nb.s2[0][2]);
-        const double gx = a == 0 ? nb.g[0][0] : (a == 1 ? nb.g[0][1] : nb.g[0][2]);
-        const int cx = nb.lo[0] + a;
-        int kk[9];
+    // G = sum_j v_j (x) grad w_j over the unknown nodes: of a particle's 27 nodes only the eight base - 1, base per axis carry gradient
+    // weight (the third node's factors are exactly 0, see k_mpm_forces), and their factors are in wfac since the forces pass — no
+    // spline is evaluated here.  The operand comes as a NODE-indexed array (vd: 3 x cells, the mass factor of the transposed system
+    // already applied, 0 on every node that is not an unknown — written by the kernel that made the vector, k_mpm_spread /
+    // k_mpm_cg_init / k_mpm_cg_p / k_mpm_cg_xrp): 24 independent loads at fixed offsets from the particle's corner node instead of
+    // node -> unknown number -> value.  Nodes in the order of the reference's loops (x outermost).
+    int f[3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+    for (int a = 0; a < 3; ++a) f[a] = (int)round(ld(P.pos, P.cap, a, i));
+    double w[12];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int cy = nb.lo[1] + b, cz = nb.lo[2] + c;
-                const bool in = cx <= nb.hi[0] && cy <= nb.hi[1] && cz <= nb.hi[2];
-                kk[3 * b + c] = in ? indices[G.at(cx, cy, cz)] : -1;
-            }
+    for (int k = 0; k < 12; ++k) w[k] = ld(P.wfac, P.cap, k, i);   // s2 (x0 x1 y0 y1 z0 z1), grad (same order)
+    const long C = G.cells();
+    double vv[24];
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+    for (int s = 0; s < 8; ++s) {
+        const int cx = f[0] - 1 + (s >> 2), cy = f[1] - 1 + ((s >> 1) & 1), cz = f[2] - 1 + (s & 1);
+        // a node beyond the grid's edge reads node 0 and is multiplied away (a select would let the compiler put the loads behind branches)
+        const bool in = G.in(cx, cy, cz);
+        const long k = in ? G.at(cx, cy, cz) : 0;
+        const double keep = in ? 1.0 : 0.0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int k = kk[3 * b + c];
-                const long kq = k >= 0 ? k : 0;
-                const double g[3] = {-1 * gx * nb.s2[1][b] * nb.s2[2][c], -1 * s2x * nb.g[1][b] * nb.s2[2][c], -1 * s2x * nb.s2[1][b] * nb.g[2][c]};
-                // transposed system (what the reference's Eigen solves, see mpm_hip.h): K D^-1 v — the mass divides the input
-                const double wj = k < 0 ? 0.0 : (transposed ? invm[kq] : 1.0);
-                const double vx = wj * v[3 * kq], vy = wj * v[3 * kq + 1], vz = wj * v[3 * kq + 2];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) Gm[d] += vx * g[d], Gm[3 + d] += vy * g[d], Gm[6 + d] += vz * g[d];
-            }
+        for (int d = 0; d < 3; ++d) vv[3 * s + d] = keep * vd[d * C + k];
     }
-    double F[9], R[9], Mi[9], cf[9];
+    double Gm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) F[k] = ld(P.FE, P.cap, k, i), R[k] = ld(P.R, P.cap, k, i), Mi[k] = ld(P.Minv, P.cap, k, i), cf[k] = ld(P.cof, P.cap, k, i);
-    const double mu = ld(P.coef, P.cap, 0, i), lambda = ld(P.coef, P.cap, 1, i), J = ld(P.coef, P.cap, 2, i);
+    for (int s = 0; s < 8; ++s) {
+        const int ca = s >> 2, cb = (s >> 1) & 1, cc = s & 1;
+        const double g[3] = {-1 * w[6 + ca] * w[2 + cb] * w[4 + cc], -1 * w[ca] * w[8 + cb] * w[4 + cc], -1 * w[ca] * w[2 + cb] * w[10 + cc]};
+        const double vx = vv[3 * s], vy = vv[3 * s + 1], vz = vv[3 * s + 2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) Gm[d] += vx * g[d], Gm[3 + d] += vy * g[d], Gm[6 + d] += vz * g[d];
+    }
+    double F[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) F[k] = ld(P.FE, P.cap, k, i);
     double dF[9];
     mat_mul(Gm, F, dF);                         // rows of getDelFE (deformHeader.h:107-132), summed over nodes and directions
+    double R[9], Mi[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = ld(P.R, P.cap, k, i);
+    // Minv = cof(m) / det(m) of a symmetric m is symmetric to the bit (the mirrored cofactor is the same two products): six loads
+    Mi[0] = ld(P.Minv, P.cap, 0, i), Mi[1] = ld(P.Minv, P.cap, 1, i), Mi[2] = ld(P.Minv, P.cap, 2, i), Mi[4] = ld(P.Minv, P.cap, 4, i);
+    Mi[5] = ld(P.Minv, P.cap, 5, i), Mi[8] = ld(P.Minv, P.cap, 8, i), Mi[3] = Mi[1], Mi[6] = Mi[2], Mi[7] = Mi[5];
+    const double mu = ld(P.coef, P.cap, 0, i), lambda = ld(P.coef, P.cap, 1, i), J = ld(P.coef, P.cap, 2, i);
     double Ap[9];
-    hessian_apply(F, R, Mi, cf, mu, lambda, J, dF, Ap);
+    hessian_apply(F, R, Mi, mu, lambda, J, dF, Ap);
     double ApFt[9];
     mat_mul_bt(Ap, F, ApFt);                    // A_p F^T
 #pragma unroll
@@ -941,6 +1004,19 @@ __global__ void __launch_bounds__(128) k_mpm_apply_particles(MGrid G, long n, Pa
 
 // ---- CG vector kernels (3 * num_active doubles, weighted dots) ----
 // A = I + c D^-1 K is self-adjoint in <u, v> = u^T D v, its transpose I + c K D^-1 in u^T D^-1 v
+// the operator's operand by node (k_mpm_apply_particles): vd[d * C + node] = (mass factor) * v[3 q + d] for unknown q at that node
+struct Dense {
+    double* vd;
+    const double* invm;
+    long C;
+    int transposed;
+    // transposed system (what the reference's Eigen solves, see mpm_hip.h): K D^-1 v — the mass divides the input
+    __device__ __forceinline__ void put(const int* __restrict__ active_cell, long k, double v) const
+    {
+        const long q = k / 3;
+        vd[(k - 3 * q) * C + active_cell[q]] = (transposed ? invm[q] : 1.0) * v;
+    }
+};
 __device__ __forceinline__ double dot_weight(float mass, int transposed) { return transposed ? 1.0 / (double)mass : (double)mass; }
 constexpr int RED_BLOCKS = 256;
 __device__ __forceinline__ void block_sum2(double a, double b, double* pa, double* pb)
@@ -981,13 +1057,14 @@ __global__ void k_mpm_cg_start(int nparts, const double* __restrict__ part1, con
 // r = p = b, x = 0, y(=Ap) = p; partials of |b|^2 and <b,b>_w
 __global__ void k_mpm_cg_init(const int* __restrict__ active_cell, const MpmState* st, const float* __restrict__ container, int transposed,
                               const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
-                              double* __restrict__ q, double* pa, double* pb)
+                              double* __restrict__ q, double* pa, double* pb, Dense dn)
 {
     const long n3 = 3L * st->num_active;
     double a = 0, d = 0;
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
         const double v = b[k], m = dot_weight(container[active_cell[k / 3]], transposed);
         x[k] = 0, r[k] = v, p[k] = v, q[k] = v;
+        dn.put(active_cell, k, v);
         a += v * v, d += m * v * v;
     }
     block_sum2(a, d, pa, pb);
@@ -1038,7 +1115,7 @@ __global__ void k_mpm_cg_xr(const int* __restrict__ active_cell, MpmState* st, c
 }
 // convergence test (ConjugateGradient.h:76-79), then p = r + beta p and q = p (the identity part of the next product)
 __global__ void k_mpm_cg_p(MpmState* st, int par, double tol, long max_iters, const double* __restrict__ part_rr, const double* __restrict__ part_rho,
-                           const double* __restrict__ r, double* __restrict__ p, double* __restrict__ q)
+                           const double* __restrict__ r, double* __restrict__ p, double* __restrict__ q, const int* __restrict__ active_cell, Dense dn)
 {
     __shared__ int s_done;
     if (threadIdx.x == 0) s_done = st->cg_done;
@@ -1057,6 +1134,7 @@ __global__ void k_mpm_cg_p(MpmState* st, int par, double tol, long max_iters, co
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
         const double v = r[k] + beta * p[k];
         p[k] = v, q[k] = v;
+        dn.put(active_cell, k, v);
     }
 }
 // k_mpm_cg_xr and k_mpm_cg_p as ONE launch for small systems (the reference's scene has 39 values, the scaled cone 9 906): the vector
@@ -1066,7 +1144,7 @@ __global__ void k_mpm_cg_p(MpmState* st, int par, double tol, long max_iters, co
 constexpr long MPM_XRP_MAX = 2048;   // (9 906 values, the scaled cone: 64 blocks each reducing the whole vector cost more than the launch they save: solve 2.0 -> 2.7 ms)
 __global__ void k_mpm_cg_xrp(const int* __restrict__ active_cell, MpmState* st, const float* __restrict__ container, int transposed, int par, double tol,
                              long max_iters, long launch, const double* __restrict__ part_pq, double* __restrict__ x, const double* __restrict__ r, double* __restrict__ r_new,
-                             double* __restrict__ p, const double* __restrict__ q)
+                             double* __restrict__ p, const double* __restrict__ q, Dense dn)
 {
     __shared__ int s_done;
     __shared__ double sh[2][4];
@@ -1105,7 +1183,20 @@ __global__ void k_mpm_cg_xrp(const int* __restrict__ active_cell, MpmState* st, 
         const double pk = p[k], rv = r[k] - alpha * q[k];
         x[k] += alpha * pk;
         r_new[k] = rv;
-        if (!conv) p[k] = rv + beta * pk;
+        if (!conv) {
+            const double v = rv + beta * pk;
+            p[k] = v;
+            dn.put(active_cell, k, v);
+        }
+    }
+}
+// the operand of one application outside a solve (mpm_apply_matrix) / the operand's nodes back to 0 once the unknowns are done with
+__global__ void k_mpm_spread(const MpmState* st, const int* __restrict__ active_cell, const double* __restrict__ v, Dense dn, int clear)
+{
+    const long n3 = 3L * st->num_active;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
+        if (clear) dn.vd[(k % 3) * dn.C + active_cell[k / 3]] = 0;
+        else dn.put(active_cell, k, v[k]);
     }
 }
 __global__ void k_mpm_copy(long n, const double* __restrict__ a, double* __restrict__ b)
@@ -1313,6 +1404,7 @@ struct mpm_sim {
     double *b = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *part = nullptr;
     double* r2 = nullptr;   // the residual's second buffer (k_mpm_cg_xrp writes the new residual beside the one other blocks still read)
     double* invm = nullptr;       // 1 / node mass per unknown
+    double* vdense = nullptr;     // the operator's operand by node (3 x cells, 0 off the unknowns), see Dense
     double* apart = nullptr;      // the operator's partial node sums (32 x 3 per unknown), grown with the unknown count
     size_t apart_cap = 0;
     int *cflag = nullptr, *cidx = nullptr, *clist = nullptr;   // non-empty cells: flags, compact index per cell (-1: empty), list
@@ -1354,7 +1446,7 @@ void free_particles(mpm_sim* s)
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.cof, &s->P.coef, &s->P.node9, &s->P.wfac,
+    double** a[] = {&s->P.pos, &s->P.vel, &s->P.FE, &s->P.FP, &s->P.gradV, &s->P.volume, &s->P.R, &s->P.Minv, &s->P.coef, &s->P.node9, &s->P.wfac,
                     &s->P2.pos, &s->P2.vel, &s->P2.FE, &s->P2.FP, &s->P2.volume};
     for (auto p : a) {
         if (*p) (void)hipFree(*p);
@@ -1368,7 +1460,7 @@ int alloc_particles(mpm_sim* s, long cap)
     s->P.cap = s->P2.cap = cap;
     if (dalloc(&s->P.pos, 3 * cap) || dalloc(&s->P.vel, 3 * cap) || dalloc(&s->P.FE, 9 * cap) || dalloc(&s->P.FP, 9 * cap) ||
         dalloc(&s->P.gradV, 9 * cap) || dalloc(&s->P.volume, cap) || dalloc(&s->P.R, 9 * cap) || dalloc(&s->P.Minv, 9 * cap) ||
-        dalloc(&s->P.cof, 9 * cap) || dalloc(&s->P.coef, 3 * cap) || dalloc(&s->P.node9, 10 * cap) || dalloc(&s->P.wfac, 12 * cap) || dalloc(&s->key, cap) || dalloc(&s->rank, cap) ||
+        dalloc(&s->P.coef, 3 * cap) || dalloc(&s->P.node9, 10 * cap) || dalloc(&s->P.wfac, 12 * cap) || dalloc(&s->key, cap) || dalloc(&s->rank, cap) ||
         dalloc(&s->order, cap) || dalloc(&s->order2, cap) || dalloc(&s->rank2, cap) ||
         dalloc(&s->pid, cap) || dalloc(&s->pid2, cap) || dalloc(&s->P2.pos, 3 * cap) || dalloc(&s->P2.vel, 3 * cap) || dalloc(&s->P2.FE, 9 * cap) ||
         dalloc(&s->P2.FP, 9 * cap) || dalloc(&s->P2.volume, cap))
@@ -1381,9 +1473,15 @@ int alloc_particles(mpm_sim* s, long cap)
 int apply_operator(mpm_sim* s, int in_solve)
 {
     if (s->n) {
-        k_mpm_apply_particles<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, s->indices, s->invm, s->state, s->prm.beta, s->prm.transpose_system, in_solve, s->p);
-        k_mpm_apply_cells<<<(unsigned)std::min<long>(std::max<long>(s->num_cells, 1), 4096), 512, 0, s->st>>>(s->G, s->P, s->cell_start, s->cell_count, s->clist, s->state,
-                                                                                                           in_solve, s->apart);
+        const Dense dn{s->vdense, s->invm, s->C, s->prm.transpose_system};
+        const unsigned ub = blocks_for(3L * std::max(s->num_active, 1), 256);
+        if (!in_solve) k_mpm_spread<<<ub, 256, 0, s->st>>>(s->state, s->active_cell, s->p, dn, 0);
+        k_mpm_apply_particles<<<blocks_for(s->n, 128), 128, 0, s->st>>>(s->G, s->n, s->P, s->state, s->prm.beta, in_solve, s->vdense);
+        if (!in_solve) k_mpm_spread<<<ub, 256, 0, s->st>>>(s->state, s->active_cell, s->p, dn, 1);
+        const int coop = s->n > (long)std::max(s->num_cells, 1) * CELL_HEAVY;
+        const long cblocks = coop ? s->num_cells : (s->num_cells + CELL_WAVES - 1) / CELL_WAVES;
+        k_mpm_apply_cells<<<(unsigned)std::min<long>(std::max<long>(cblocks, 1), 8192), 64 * CELL_WAVES, 0, s->st>>>(s->G, s->P, s->cell_start, s->cell_count, s->clist,
+                                                                                                                   s->state, in_solve, coop, s->apart);
         // inside a solve the next kernel (k_mpm_cg_pq) forms q from the partial sums itself
         if (!in_solve)
             k_mpm_apply_combine<<<blocks_for(3L * std::max(s->num_active, 1), 256), 256, 0, s->st>>>(s->G, s->state, s->active_cell, s->cidx, s->apart, s->invm,
@@ -1441,7 +1539,7 @@ int mpm_create(const mpm_params_t* prm, mpm_sim_t** out)
          dalloc(&s->sums, nb) || dalloc(&s->cell_count, C) || dalloc(&s->cell_start, C + 1) || dalloc(&s->tflag, C) || dalloc(&s->tidx, C) || dalloc(&s->tlist, C) || dalloc(&s->cflag, C) || dalloc(&s->cidx, C) || dalloc(&s->clist, C) || dalloc(&s->part, 4 * RED_BLOCKS) || dalloc(&s->state, 1);
     // unknowns live inside the walls only: (2W+1)^3 at most
     const long maxu = (long)(2 * prm->W + 1) * (2 * prm->W + 1) * (2 * prm->W + 1);
-    rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->r2, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu) || dalloc(&s->invm, maxu);
+    rc = rc || dalloc(&s->b, 3 * maxu) || dalloc(&s->x, 3 * maxu) || dalloc(&s->r, 3 * maxu) || dalloc(&s->r2, 3 * maxu) || dalloc(&s->p, 3 * maxu) || dalloc(&s->q, 3 * maxu) || dalloc(&s->invm, maxu) || dalloc(&s->vdense, 3 * C);
     if (!rc && hipHostMalloc((void**)&s->h_state, sizeof(MpmState)) != hipSuccess) rc = FLUID_ERR_HIP;
     for (int k = 0; k < 8 && !rc; ++k)
         if (hipEventCreate(&s->ev[k]) != hipSuccess) rc = FLUID_ERR_HIP;
@@ -1466,7 +1564,7 @@ int mpm_destroy(mpm_sim_t* s)
     if (!s) return 0;
     free_particles(s);
     void* a[] = {s->solid, s->container, s->output, s->massd, s->vel, s->velb, s->forces, s->flag, s->indices, s->active_cell, s->sums,
-                 s->part, s->state, s->b, s->x, s->r, s->r2, s->p, s->q, s->stage, s->cell_count, s->cell_start, s->invm, s->tflag, s->tidx, s->tlist, s->apart, s->cflag, s->cidx, s->clist};
+                 s->part, s->state, s->b, s->x, s->r, s->r2, s->p, s->q, s->stage, s->cell_count, s->cell_start, s->invm, s->tflag, s->tidx, s->tlist, s->apart, s->cflag, s->cidx, s->clist, s->vdense};
     for (void* p : a)
         if (p) (void)hipFree(p);
     if (s->h_state) (void)hipHostFree(s->h_state);
@@ -1614,7 +1712,8 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
                                           s->b, s->invm, s->part, &s->state->max_coeff_bits);
     k_mpm_maxforce_cell<<<RED_BLOCKS, 256, 0, st>>>(G, s->active_cell, s->state, s->container, s->forces);
     k_mpm_maxforce_final<<<1, 1, 0, st>>>(G, s->state, s->container, s->forces);
-    k_mpm_cg_init<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->b, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS);
+    k_mpm_cg_init<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, s->b, s->x, s->r, s->p, s->q, s->part, s->part + RED_BLOCKS,
+                                          Dense{s->vdense, s->invm, s->C, pr.transpose_system});
     k_mpm_cg_start<<<1, 256, 0, st>>>(RED_BLOCKS, s->part, s->part + RED_BLOCKS, s->state);
     HIPCHK(hipGetLastError());
     if (read_state(s)) return FLUID_ERR_HIP;
@@ -1636,6 +1735,7 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
     // first batch: what the previous step's solve needed (counts change slowly from step to step), then two at a time
     long batch = s->last_iters > 0 ? s->last_iters + 1 : 4;
     long launched = 0;
+    const Dense dn{s->vdense, s->invm, s->C, pr.transpose_system};
     while (!s->h_state->cg_done) {
         for (long it = 0; it < batch; ++it) {
             const bool timed = it == 0;
@@ -1647,11 +1747,11 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
             if (3L * s->num_active <= MPM_XRP_MAX) {
                 double *rc_ = (launched & 1) ? s->r2 : s->r, *rn_ = (launched & 1) ? s->r : s->r2;
                 k_mpm_cg_xrp<<<64, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, (int)(launched & 1), pr.cg_tol, max_iters, launched, pb, s->x, rc_, rn_,
-                                                 s->p, s->q);
+                                                 s->p, s->q, dn);
             } else {
                 k_mpm_cg_xr<<<RED_BLOCKS, 256, 0, st>>>(s->active_cell, s->state, s->container, pr.transpose_system, (int)(launched & 1), pb, s->x, s->r, s->p,
                                                         s->q, pc, pd);
-                k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, (int)(launched & 1), pr.cg_tol, max_iters, pc, pd, s->r, s->p, s->q);
+                k_mpm_cg_p<<<RED_BLOCKS, 256, 0, st>>>(s->state, (int)(launched & 1), pr.cg_tol, max_iters, pc, pd, s->r, s->p, s->q, s->active_cell, dn);
             }
             ++launched;
         }
@@ -1661,6 +1761,8 @@ int mpm_step_solve(mpm_sim_t* s, mpm_step_stats_t* out)
         if (hipEventElapsedTime(&ms, s->ev[6], s->ev[7]) == hipSuccess) ms_apply += ms, ++n_apply;
         batch = 2;
     }
+    // the operand's nodes back to 0: the next step's unknowns are other nodes
+    k_mpm_spread<<<blocks_for(3L * std::max(s->num_active, 1), 256), 256, 0, st>>>(s->state, s->active_cell, s->p, dn, 1);
     const int iters = s->h_state->cg_iters;
     s->last_iters = iters;
     const double cg_error = s->h_state->bb > 0 ? std::sqrt(s->h_state->rr / s->h_state->bb) : 0.0;
