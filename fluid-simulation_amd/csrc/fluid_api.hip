@@ -681,14 +681,16 @@ static int gal_build(fluid_sim* s)
     // against 31 at step 445 of the 256^3 drop, 61 against 72 (three passes) at step 210 — and loses on dense or flat water (30 against 21
     // in free fall, +8 % on a flat slab); the share of level-1 cells the re-discretised rule keeps does not separate the splash (0.80) from the
     // slab (0.8).  Both cycles give the same pressure, so the step simply measures: the first-pass iteration count of each is kept, the
-    // better one is used, and the other is looked at again every 32nd step.
+    // cheaper one (count x cost per iteration) is used, and the other is looked at again every 32nd step.
     s->gal_eligible = true;
     bool use = s->gal_mode >= 2;
     if (s->gal_mode == 1) {
         if (s->gal_it[0] < 0) use = false;
         else if (s->gal_it[1] < 0) use = true;
         else {
-            use = s->gal_it[1] < s->gal_it[0];
+            // counts weighted by the measured cost of an iteration (175 us against 170 at step 445, 512-thread k_gal_* legs + a one-block coarsest
+            // level against the tail kernel: +3..5 %, profiles/r03/NOTES.md) — a fixed weight, not a timer: the choice stays a function of the state
+            use = 21 * s->gal_it[1] < 20 * s->gal_it[0];
             if (++s->gal_since_probe >= 32) { use = !use; s->gal_since_probe = 0; }
         }
     }

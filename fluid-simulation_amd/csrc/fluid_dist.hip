@@ -643,7 +643,7 @@ int dist_mg_setup(fluid_sim* s)
                 if (s->gal_it[0] < 0) want_gal = false;
                 else if (s->gal_it[1] < 0) want_gal = true;
                 else {
-                    want_gal = s->gal_it[1] < s->gal_it[0];
+                    want_gal = 21 * s->gal_it[1] < 20 * s->gal_it[0];   // counts x the measured cost of an iteration, as on one GPU (gal_build)
                     if (++s->gal_since_probe >= 32) { want_gal = !want_gal; s->gal_since_probe = 0; }
                 }
             }
