@@ -297,6 +297,9 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
 template <typename T>
 void launch_pcg_xr(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* part_rz_cur,
                    const double* part_pq, double* part_rr, double* part_rz_next, PcgState* ps, int n_rz = -1, int sparse = 0);
+void launch_pcg_sq_zf(hipStream_t st, LBox L, const uint8_t* cnt, const float* z, const double* s_in, double* s_out, double* q, Coef<double> cf,
+                      const double* part_rr, int n_prev, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
+                      double tol, int n_rz, int sparse, const int* tlist, int nlist);   // z = the float cycle's result, kept float (tlist: listed tiles only)
 // the same two over a list of active SQ tiles (mostly-air box).  n_prev = partials of the previous launch in part_rr (the init
 // kernel's pcg_xr_blocks(L) for the first body, pcg_list_blocks(nlist) afterwards); both write pcg_list_blocks(nlist) partials
 int pcg_list_blocks(int nlist);

@@ -725,7 +725,7 @@ static int gal_build(fluid_sim* s)
 }
 // The cycle with Galerkin coarse levels (kernels_gal.hip): level 0 by the kernels of kernels_mg.hip (its own coefficients; the up leg
 // takes the parent's value as the correction), levels 1 .. gal_lc - 1 by k_gal_down / k_gal_up, the coarsest by one block.
-static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, float* z0, double* part_rz)
 {
     typedef float V;
     const PcgState* ps = s->ps;
@@ -743,15 +743,16 @@ static int mg_vcycle_gal(fluid_sim* s, const double* rhs0, double* z0, double* p
         launch_gal_up(s->st, s->mgl[l], s->gal_tfl[l], C(l, 0), C(l, 1), C(l, 2), C(l, 3), F(l), U(l), W(l), s->mgl[l + 1], l + 1 == lc ? U(l + 1) : W(l + 1),
                       (float)s->gal_wc, ps);
     const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)s->Rb.cells());
-    launch_mg_up<V, double, double>(s->st, m0, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], W(1), mg_coef_as<V>(s, 0), part_rz, ps, s->gal_wc, s->tl_mg, s->n_tl_mg,
-                                    nullptr, 1);
+    launch_mg_up<V, double, float>(s->st, m0, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], W(1), mg_coef_as<V>(s, 0), part_rz, ps, s->gal_wc, s->tl_mg, s->n_tl_mg,
+                                   nullptr, 1);
     prof_end(s, FLUID_PROF_MG_UP0, tok);
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
 
+// z0: the result in the cycle's own type — a float cycle's z stays float in memory (k_pcg_sq_l converts, exactly)
 template <typename V>
-static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+static int mg_vcycle_t(fluid_sim* s, const double* rhs0, V* z0, double* part_rz)
 {
     const int nl = s->mg_nl, tail = s->mg_tail;
     const PcgState* ps = s->ps;
@@ -780,8 +781,8 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
         const V* ec = l + 1 == tail ? U(l + 1) : W(l + 1);  // out != u: neighbouring tiles still read u
         if (l == 0) {
             const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)s->Rb.cells());
-            launch_mg_up<V, double, double>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0],
-                                            s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg);
+            launch_mg_up<V, double, V>(s->st, m, s->cntL, rhs0, (const V*)U(0), z0, s->mgl[1], ec, mg_coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0],
+                                       s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg);
             prof_end(s, FLUID_PROF_MG_UP0, tok);
         } else {
             launch_mg_up<V, V, V>(s->st, m, s->mg_cnt[l], (const V*)F(l), (const V*)U(l), W(l), s->mgl[l + 1], ec, mg_coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
@@ -790,10 +791,10 @@ static int mg_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* par
     HIPCHK(hipGetLastError());
     return FLUID_OK;
 }
-static int mg_vcycle(fluid_sim* s, const double* rhs0, double* z0, double* part_rz)
+static int mg_vcycle(fluid_sim* s, const double* rhs0, void* z0, double* part_rz)
 {
-    if (s->gal && s->lists_on) return mg_vcycle_gal(s, rhs0, z0, part_rz);
-    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, z0, part_rz) : mg_vcycle_t<double>(s, rhs0, z0, part_rz);
+    if (s->gal && s->lists_on) return mg_vcycle_gal(s, rhs0, (float*)z0, part_rz);
+    return s->mg_fp32 ? mg_vcycle_t<float>(s, rhs0, (float*)z0, part_rz) : mg_vcycle_t<double>(s, rhs0, (double*)z0, part_rz);
 }
 
 // PCG loop of ConjugateGradient.h:28-90 with z = V-cycle(r); same start, stopping rule and cap as solve_impl.
@@ -847,19 +848,26 @@ static int solve_mg(fluid_sim* s)
     const int pclass = s->pass_class();
     long batch = s->mg_last_iters_k[pclass] > 5 ? s->mg_last_iters_k[pclass] + 1 : 4;
     bool done = false;
+    // SQ of one body: s' = z + beta s into Sx[cur], q = A s'.  z is in the cycle's own type (float by default)
+    const bool zf = s->mg_fp32 || (s->gal && s->lists_on);
+    auto sq = [&](int cur, const double* part_rr, int n_prev, const double* rz_new, const double* rz_old, int first, int sp) {
+        const int prv = cur ^ 1;
+        if (zf)
+            launch_pcg_sq_zf(s->st, L, cnt, (const float*)s->Zmg, Sx[prv], Sx[cur], Q, cf, part_rr, n_prev, rz_new, rz_old, s->part_pq, s->ps, first, tol, n_rz, sp,
+                             lists ? s->tl_sq : nullptr, s->n_tl_sq);
+        else if (lists)
+            launch_pcg_sq_list<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, part_rr, n_prev, rz_new, rz_old, s->part_pq, s->ps, first, tol, n_rz, 1, s->tl_sq, s->n_tl_sq);
+        else
+            launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, part_rr, rz_new, rz_old, s->part_pq, s->ps, first, tol, n_rz, 1, sp, n_prev);
+    };
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if ((rc = mg_vcycle(s, R, Z, fold ? s->mg_part : s->part_rz[cur]))) return rc;
+            if ((rc = mg_vcycle(s, R, s->Zmg, fold ? s->mg_part : s->part_rz[cur]))) return rc;
             if (fold) launch_sum2(s->st, s->mg_part, n_rz_raw, s->mg_part, 0, s->part_rz[cur], nullptr);
             int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-            if (lists)
-                launch_pcg_sq_list<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, it == 0 ? n_init : n_list,
-                                      s->part_rz[cur], s->part_rz[prv], s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, s->tl_sq,
-                                      s->n_tl_sq);
-            else
-                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, it == 0 ? s->part_bb : s->part_rr, s->part_rz[cur], s->part_rz[prv],
-                                 s->part_pq, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol, n_rz, 1, sparse);
+            sq(cur, it == 0 ? s->part_bb : s->part_rr, it == 0 ? n_init : (lists ? n_list : n_init), s->part_rz[cur], s->part_rz[prv], it == 0 ? (guess ? 2 : 1) : 0,
+               sparse);
             prof_end(s, FLUID_PROF_PCG_SQ, tok);
             tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
             if (rows)
@@ -877,11 +885,7 @@ static int solve_mg(fluid_sim* s)
             // the break test of the last body sits at the head of the next SQ launch: a head-only launch (its s'/q are
             // overwritten by the real launch of that iteration if the solve goes on; the counter is put back below)
             const int cur = (int)(it & 1), prv = cur ^ 1;
-            if (lists)
-                launch_pcg_sq_list<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, n_list, s->part_rz[prv], s->part_rz[prv], s->part_pq,
-                                      s->ps, 0, tol, n_rz, 1, s->tl_sq, s->n_tl_sq);
-            else
-                launch_pcg_sq<T>(s->st, L, cnt, Z, Sx[prv], Sx[cur], Q, cf, s->part_rr, s->part_rz[prv], s->part_rz[prv], s->part_pq, s->ps, 0, tol, n_rz, 1, 0);
+            sq(cur, s->part_rr, lists ? n_list : n_init, s->part_rz[prv], s->part_rz[prv], 0, 0);
         }
         HIPCHK(hipMemcpyAsync(&s->h_ps[0], s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
         HIPCHK(hipStreamSynchronize(s->st));

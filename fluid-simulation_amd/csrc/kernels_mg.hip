@@ -580,8 +580,8 @@ __device__ __forceinline__ void mg_up_body(const MLevel& m, const uint8_t* __res
     }
 }
 
-template <typename T, typename F, typename O, int TX, int TY, int TZ, int NG = 1>
-__global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
+template <typename T, typename F, typename O, int TX, int TY, int TZ>
+__global__ __launch_bounds__(256, 5) void k_mg_up(MLevel m, const uint8_t* __restrict__ cnt, const F* __restrict__ f, const T* __restrict__ u,
                                                                       O* __restrict__ out, MLevel mc, const T* __restrict__ ec, MgCoef<T> cf,
                                                                       double* __restrict__ part_dot, const PcgState* ps, int gx, int gy, T wc,
                                                                       const int* __restrict__ tlist, const uint8_t* __restrict__ own, int pconst)
@@ -591,8 +591,8 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void k_mg_up(MLevel m, c
     __shared__ double red[4];
     if (ps && ps->done) return;
     const int tile = tlist ? tlist[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);  // see k_mg_down
-    mg_up_body<T, F, O, TX, TY, TZ, IoPlain, NG>(m, cnt, f, u, out, mc, ec, &cf, cf.off, part_dot, tile, gx, gy, wc, own, true, NG > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x,
-                                                 lds, sd, si, red, NG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0, pconst != 0);
+    mg_up_body<T, F, O, TX, TY, TZ, IoPlain, 1>(m, cnt, f, u, out, mc, ec, &cf, cf.off, part_dot, tile, gx, gy, wc, own, true, (int)threadIdx.x, lds, sd, si, red, 0,
+                                                pconst != 0);
 }
 
 // ---- restriction of the level-0 residual (its down kernel has no room for a halo of 3) -----------------
@@ -936,13 +936,8 @@ void launch_mg_up(hipStream_t st, MLevel m, const uint8_t* cnt, const F* f, cons
 {
     const dim3 g = mg_tiles(m, MG_TX, MG_TY, MG_TZ);
     if (!tlist && g.x * g.y * g.z == 0) return;   // an empty local level (decomposed run: a block outside the active box)
-    // (measured at 256^3: the four-group form takes the down legs of levels 1-2 from 6.33 to 5.72 us and the up legs from 5.93 to 6.13 —
-    // a leg is ~3 us of launch and drain + ~2 us of load latency, the arithmetic was never the long part — so only the down leg uses it)
-    if (false && !tlist && !part_dot && !own && sizeof(F) == sizeof(T) && sizeof(O) == sizeof(T) && g.x * g.y * g.z <= MG_FEW_TILES && mg_ng4()) {
-        hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ, 4>), dim3(g.x * g.y * g.z), dim3(1024), 0, st, m, cnt, f, u, out, mc, ec, cf, part_dot, ps,
-                           (int)g.x, (int)g.y, (T)wc, tlist, own, pconst);
-        return;
-    }
+    // (a four-group form like the down leg's was measured at 256^3: up legs of levels 1-2 5.93 -> 6.13 us — a leg is ~3 us of launch and drain +
+    // ~2 us of load latency, the arithmetic was never the long part — so only the down leg has one)
     hipLaunchKernelGGL((k_mg_up<T, F, O, MG_TX, MG_TY, MG_TZ>), dim3(tlist ? (unsigned)nlist : g.x * g.y * g.z), dim3(256), 0, st, m, cnt, f, u, out, mc,
                        ec, cf, part_dot, ps, (int)g.x, (int)g.y, (T)wc, tlist, own, pconst);
 }
@@ -1027,6 +1022,8 @@ INSTMG(float)
 template void launch_mg_down<float, double>(hipStream_t, MLevel, const uint8_t*, const double*, float*, float*, MLevel, const uint8_t*, float*,
                                             MgCoef<float>, const PcgState*, const int*, int, bool);
 template void launch_mg_up<float, double, double>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, double*, MLevel, const float*,
+                                                  MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*, int);
+template void launch_mg_up<float, double, float>(hipStream_t, MLevel, const uint8_t*, const double*, const float*, float*, MLevel, const float*,
                                                   MgCoef<float>, double*, const PcgState*, double, const int*, int, const uint8_t*, int);
 
 }  // namespace fl

@@ -212,8 +212,10 @@ __device__ __forceinline__ bool pcg_head(const double* __restrict__ part_rr, con
 // of halo cells next to the owned ones (z and s are valid there, so s' is formed there too and no exchange of s' is
 // needed) and is 0 beyond; q and the partial s'.q are formed on the owned cells only.  The scalars are single
 // all-reduced values (n_prev = n_rz = 1).
-template <typename T, bool DIST, bool AZ = false>
-__global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restrict__ cnt, const T* __restrict__ r,
+// ZT: element type of `r` — the float cycle's z stays float in memory (4 bytes less written by the up leg and read here per cell; the
+// conversion is exact, so nothing else changes)
+template <typename T, bool DIST, bool AZ = false, typename ZT = T>
+__global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restrict__ cnt, const ZT* __restrict__ r,
                                                   const T* __restrict__ s_in, T* __restrict__ s_out, T* __restrict__ q, Coef<T> cf,
                                                   const double* __restrict__ part_rr, const double* __restrict__ part_rz_new,
                                                   const double* __restrict__ part_rz_old, double* __restrict__ part_pq, int n_prev,
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
     int nxt = entry(lidx + (int)gridDim.x);
     // ---- issue the first tile's loads -------------------------------------------------------
     uint8_t fc[TX + 2], fy = 0, fz = 0;
-    T rv[TX + 2], sv[TX + 2], ry = 0, sy = 0, rz = 0, sz = 0;
+    ZT rv[TX + 2], ry = 0, rz = 0;
+    T sv[TX + 2], sy = 0, sz = 0;
     long c0 = 0;
     auto issue = [&](int tl, bool counts, bool values) {
         const int tz = tl % ntz, ty = (tl / ntz) % nty, tx = tl / (ntz * nty);
@@ -300,16 +303,16 @@ __global__ __launch_bounds__(256) void k_pcg_sq_l(LBox L, const uint8_t* __restr
         // ---- combine -> LDS ---------------------------------------------------------------------
         T val[TX + 2];
 #pragma unroll
-        for (int m = 0; m < TX + 2; ++m) val[m] = fc[m] ? (zmode ? rv[m] : rv[m] * sinv[DIST ? fc[m] & 7 : fc[m]]) + beta * sv[m] : (T)0;
+        for (int m = 0; m < TX + 2; ++m) val[m] = fc[m] ? (zmode ? (T)rv[m] : (T)rv[m] * sinv[DIST ? fc[m] & 7 : fc[m]]) + beta * sv[m] : (T)0;
 #pragma unroll
         for (int lx = 0; lx < TX; ++lx) sT[(lx * PY + ly + 1) * PZ + kz + 1] = val[lx + 1];
         {
             const int pl = tid >> 6, side = (tid >> 5) & 1;
-            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = fy ? (zmode ? ry : ry * sinv[DIST ? fy & 7 : fy]) + beta * sy : (T)0;
+            sT[(pl * PY + (side ? TY + 1 : 0)) * PZ + kz + 1] = fy ? (zmode ? (T)ry : (T)ry * sinv[DIST ? fy & 7 : fy]) + beta * sy : (T)0;
         }
         if (tid < 64) {
             const int lx = tid >> 4, l2 = (tid >> 1) & 7, side = tid & 1;
-            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = fz ? (zmode ? rz : rz * sinv[DIST ? fz & 7 : fz]) + beta * sz : (T)0;
+            sT[(lx * PY + l2 + 1) * PZ + (side ? TZ + 1 : 0)] = fz ? (zmode ? (T)rz : (T)rz * sinv[DIST ? fz & 7 : fz]) + beta * sz : (T)0;
         }
         __syncthreads();
         const long cc = c0;
@@ -816,6 +819,14 @@ void launch_pcg_sq(hipStream_t st, LBox L, const uint8_t* cnt, const T* r, const
     const int nx = pcg_xr_blocks(L);
     hipLaunchKernelGGL((k_pcg_sq_l<T, false>), dim3(pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, r, s_in, s_out, q, cf, part_rr,
                        part_rz_new, part_rz_old, part_pq, n_prev < 0 ? nx : n_prev, ps, first, tol, n_rz < 0 ? nx : n_rz, zmode, sparse, (const int*)nullptr, 0);
+}
+// the same with z = M^-1 r as the float cycle left it (zmode; tlist = nullptr: every tile)
+void launch_pcg_sq_zf(hipStream_t st, LBox L, const uint8_t* cnt, const float* z, const double* s_in, double* s_out, double* q, Coef<double> cf,
+                      const double* part_rr, int n_prev, const double* part_rz_new, const double* part_rz_old, double* part_pq, PcgState* ps, int first,
+                      double tol, int n_rz, int sparse, const int* tlist, int nlist)
+{
+    hipLaunchKernelGGL((k_pcg_sq_l<double, false, false, float>), dim3(tlist ? pcg_list_blocks(nlist) : pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, z, s_in, s_out, q,
+                       cf, part_rr, part_rz_new, part_rz_old, part_pq, n_prev, ps, first, tol, n_rz, 1, tlist ? 0 : sparse, tlist, nlist);
 }
 // decomposed run: g_* = single all-reduced scalars; cnt carries the ring bit (k_cnt_pcg); writes pcg_sq_blocks(L) partials of s'.q
 template <typename T>
