@@ -240,7 +240,8 @@ void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride)
 long p2g_max_items(Box box);
 constexpr int P2G_PILED = 256;   // a cell with more particles: the particles have piled up (walls, floor), P2G takes the tile form
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
-                double* part, int* items, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
+                double* part, int* items, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb, int2* crowd_list = nullptr,
+                Particles park = Particles{});
 void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                       float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb);
 void launch_g2p_tiled(hipStream_t st, Grid g, Box pb, Particles p, const int* cell_start, const double* dcx, const double* dcy, const double* dcz,

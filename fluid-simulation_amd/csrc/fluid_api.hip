@@ -173,7 +173,7 @@ int fluid_destroy(fluid_sim_t* s)
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
                     s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
-                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->gal_slab};
+                    s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->p2g_crowd, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->gal_slab};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->h_ps) hipHostFree(s->h_ps);
     for (int i = 0; i < 2; ++i) if (s->ev_poll[i]) hipEventDestroy(s->ev_poll[i]);
@@ -224,7 +224,7 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
     s->warm = p->solve_start == FLUID_START_WARM;
     if (const char* e = getenv("FLUID_MG_CSWEEPS")) s->mg_csweeps = atoi(e);       // developer knobs (tools/, experiments): they override the params
     if (const char* e = getenv("FLUID_TILE_LISTS")) s->lists_force = atoi(e) != 0;
-    if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : 0);
+    if (const char* e = getenv("FLUID_P2G_FORM")) s->p2g_force = !strcmp(e, "rows") ? 1 : (!strcmp(e, "tiles") ? 2 : (!strcmp(e, "crowd") ? 3 : 0));
     if (const char* e = getenv("FLUID_MG_GALERKIN")) s->gal_mode = atoi(e);
     if (const char* e = getenv("FLUID_DROPLETS")) s->drops_on = atoi(e) != 0;
     if (const char* e = getenv("FLUID_ROW_SWEEPS")) s->row_sweeps = atoi(e) != 0;
@@ -490,10 +490,22 @@ int fl::run_p2g(fluid_sim* s, const Box& box)
     const long ref_cells = s->p2g_ref_cells > 0 ? s->p2g_ref_cells : s->Rb.cells();
     const bool airy = s->last_num_active > 0 && (double)s->last_num_active < 0.3 * (double)ref_cells;
     const bool huge = (size_t)12 * sizeof(double) * (size_t)box.cells() > ((size_t)16 << 30);  // the row form's partials: 96 B per box cell
-    if (s->p2g_force ? s->p2g_force == 2 : (s->max_cell > P2G_PILED || airy || huge)) {
+    const bool piled = s->max_cell > P2G_PILED || airy;
+    if (s->p2g_force ? s->p2g_force == 2 : huge) {
         s->stats.paths |= FLUID_PATH_P2G_TILES;
         launch_p2g_tiles(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->container, s->u, s->v, s->w, s->ub, s->vb, s->wb);
         return FLUID_OK;
+    }
+    // piled particles, mostly-air box: the crowded cells on the matrix cores first (k_p2g_crowd_sum), the rows walk the rest
+    const bool crowd = s->p2g_force ? s->p2g_force == 3 : piled;
+    if (crowd) {
+        s->stats.paths |= FLUID_PATH_P2G_CROWD;
+        const size_t nl = (size_t)s->cap / 16 + 64;   // pieces <= particles / 18
+        if (nl > s->p2g_crowd_cap) {
+            if (s->p2g_crowd) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->p2g_crowd); s->p2g_crowd = nullptr; }
+            HIPCHK(hipMalloc((void**)&s->p2g_crowd, nl * sizeof(int2)));
+            s->p2g_crowd_cap = nl;
+        }
     }
     const size_t need = (size_t)12 * box.cells();
     if (need > s->p2g_part_cap) {
@@ -509,7 +521,7 @@ int fl::run_p2g(fluid_sim* s, const Box& box)
         s->p2g_items_cap = ni + ni / 4;
     }
     launch_p2g(s->st, s->g, box, s->pa, s->pw, s->cap, s->cell_start, s->flags, s->p2g_part, s->p2g_items, s->container, s->u, s->v, s->w, s->ub,
-               s->vb, s->wb);
+               s->vb, s->wb, crowd ? s->p2g_crowd : nullptr, s->pb);
     return FLUID_OK;
 }
 

@@ -262,14 +262,20 @@ constexpr int P2G_SEG = P2G_CH / 8 + 1;
 __device__ __forceinline__ int p2g_slot(int k) { return (k & 7) * P2G_SEG + (k >> 3); }
 constexpr int P2G_LDS = 8 * P2G_SEG;
 constexpr int P2G_HEAVY = 48;  // a longer per-lane window is swept by the whole wave
+constexpr int P2G_CROWD = 18;  // CROWD form: cells of this many particles or more are summed by k_p2g_crowd_sum (18 slots per piece x 6 arrays = 108 sums)
+constexpr int P2G_PIECE = 512; // ... in pieces of this many particles, one wave each
 constexpr int P2G_BUDGET = 8192;  // particles per work item and z piece before a y segment is cut further (a regular 256^3 segment: ~6500)
 constexpr int P2G_ZT = 62;     // most target cells a wave takes (lanes 0 and 63 are sources only); the launcher splits nz evenly
 
 // part: [3 source x-planes][4: weight, u, v, w][cells of box].  VEC: the weight and velocity arrays are 16 B aligned with an
 // even stride (the launcher checks), so two particles are staged per lane and load
-template <bool VEC>
+// CROWD (piled particles, mostly-air boxes): the sums of every cell of P2G_CROWD or more particles have been formed by k_p2g_crowd_sum and
+// are parked in `crowd` (six arrays, see there); such a cell is not walked here — its lane adds the 36 parked values of its target plane —
+// and a chunk that holds particles of such cells only is not staged.
+template <bool VEC, bool CROWD>
 __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
-                                                          const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt, const int* __restrict__ items)
+                                                          const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt, const int* __restrict__ items,
+                                                          Particles crowd)
 {
     __shared__ double sr[12][P2G_LDS];   // wx0..2, wy0..2, wz0..2, vx, vy, vz
     const int tid = threadIdx.x, e = tid >> 6, lane = tid & 63;
@@ -310,9 +316,15 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
                 ca = cell_start[r0];
                 cz = cell_start[r0 + 1];
             }
+            const int ca_all = ca, n_all = cz - ca;
+            if (CROWD && n_all >= P2G_CROWD) cz = ca;   // not walked: its sums are parked
             for (int cb = VEC ? (jb & ~1) : jb; cb < je; cb += P2G_CH) {
                 const int ce = cb + P2G_CH < je ? cb + P2G_CH : je;
-                __syncthreads();  // the previous chunk has been consumed
+                if (CROWD) {
+                    // (also the barrier that frees the staged chunk before) a chunk without a particle that anyone walks is not staged
+                    if (!__syncthreads_or((ca > cb ? ca : cb) < (cz < ce ? cz : ce))) continue;
+                } else
+                    __syncthreads();  // the previous chunk has been consumed
                 if (VEC) {
                     // 16 B accesses from an even index; the odd particle before jb / after je - 1 is staged but never read
                     for (int j = cb + 2 * tid; j < ce; j += 2 * P2G_THREADS) {
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
                 // whole wave: such cells are swept by all 64 lanes together and wave-reduced (fixed order).
                 int lo = ca > cb ? ca : cb, hi = cz < ce ? cz : ce;
                 if (hi < lo) hi = lo;
-                const bool heavy = hi - lo > P2G_HEAVY;
+                const bool heavy = !CROWD && hi - lo > P2G_HEAVY;   // (CROWD: a walked cell has at most 17 particles)
                 if (!heavy) {
                     for (int j = lo; j < hi; ++j) {
                         const int k = p2g_slot(j - cb);
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
                         }
                     }
                 }
-                unsigned long long hm = __ballot(heavy);
+                unsigned long long hm = CROWD ? 0ull : __ballot(heavy);
                 while (hm) {
                     const int L = __ffsll((long long)hm) - 1;
                     hm &= hm - 1;
@@ -390,6 +402,26 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
                     }
                 }
             }
+            if (CROWD) {
+                // parked value (x offset e, target y a, target z d, value q) of a cell whose first particle is ca: linear index
+                // ((3 e + a) * 12 + 4 d + q) over six arrays of 18 values per 512-particle piece, pieces added in order
+                const double* c0 = e == 0 ? crowd.px : (e == 1 ? crowd.pz : crowd.vy);
+                const double* c1 = e == 0 ? crowd.py : (e == 1 ? crowd.vx : crowd.vz);
+                if (n_all >= P2G_CROWD) {
+                    for (int at = ca_all; at < ca_all + n_all; at += P2G_PIECE) {
+                        const long o18 = ca_all + 18L * ((at - ca_all) / P2G_PIECE);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int Lr = a * 12 + d * 4 + q;
+                                    T[a][d][q] += (Lr < 18 ? c0 : c1)[o18 + Lr % 18];
+                                }
+                    }
+                }
+            }
         }
         // target zc collects: source zc-1 reaches it with its z index 2, zc with 1, zc+1 with 0 (d = target - source + 1)
 #pragma unroll
@@ -409,6 +441,123 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
         for (int q = 0; q < 4; ++q) { C[0][q] = C[1][q]; C[1][q] = C[2][q]; C[2][q] = 0; }
     }
     }  // items
+}
+
+// ---- crowded cells on the matrix cores (piled particles, mostly-air boxes) --------------------------------------------------
+// After the splash a third of the particles sit in cells of 18 .. 10^4 (step 445 of the 256^3 drop: 46 k cells above 17 hold 41 % of
+// the particles); walking them lane by lane, or wave by wave, is what made P2G 1.1 - 1.5 ms there.  What any target can want from a
+// source cell is 27 x 4 sums over its particles — a contraction with the particles on k: an fp64 MFMA (v_mfma_f64_16x16x4_f64) with
+// A = 9 rows (x offset, y offset: sx * sy) x 4 particles, B = 4 particles x 12 columns (z offset, value: sz, sz * v) gives all 108 in
+// its 16 x 16 result; a wave takes a piece of <= 512 particles of one cell (its particles staged 64 at a time, lane = particle, then
+// 16 steps of four).  The 108 sums of piece j of a cell are parked in the slots ca + 18 j .. + 17 of the six arrays of the OTHER
+// particle buffer (free between the reorder pass and the next sort; a cell of >= 18 particles owns at least that many slots): linear
+// index (3 dx + dy) * 12 + 4 dz + value, 18 to an array, so the row kernel's wave for x offset e finds its 36 values in arrays 2e, 2e + 1.
+// Every sum is a fixed function of the cell's sorted particle list (steps of four from the cell's first particle, pieces in order).
+// (The weight keeps the reference's association (sx*sy)*sz; a velocity sum is (sx*sy)*(sz*v) where the walk forms ((sx*sy)*sz)*v.)
+constexpr int PC_WAVES = 4;
+typedef double pc_d4 __attribute__((ext_vector_type(4)));
+// list: one entry per piece of every cell of >= P2G_CROWD particles in box — (first particle of the piece, piece << 9 | particles in it - 1);
+// count[0] = entries (zero on entry).  A thread looks at four cells along z; one returning atomic per block of 1024 cells.
+__global__ __launch_bounds__(256) void k_p2g_crowd_list(Grid g, Box box, const int* __restrict__ cell_start, int2* __restrict__ list, int* __restrict__ count)
+{
+    __shared__ int s_w[4], s_base;
+    const int nz = box.nz(), ny = box.ny(), nz4 = (nz + 3) / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int first[5] = {0, 0, 0, 0, 0};
+    int pieces = 0;
+    if (i < (long)box.nx() * ny * nz4) {
+        const int z = 4 * (int)(i % nz4), y = (int)((i / nz4) % ny), x = (int)(i / ((long)nz4 * ny));
+        const int* cs = cell_start + g.idx(box.x0 + x, box.y0 + y, box.z0 + z);
+        const int m = nz - z < 4 ? nz - z : 4;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) first[k] = cs[k <= m ? k : m];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = first[k + 1] - first[k];
+            pieces += n >= P2G_CROWD ? (n + P2G_PIECE - 1) / P2G_PIECE : 0;
+        }
+    }
+    // exclusive prefix over the block (the order of the list does not reach the sums)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = pieces;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        s_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (!pieces) return;
+    int at = s_base + inc - pieces;
+    for (int w = 0; w < wv; ++w) at += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = first[k + 1] - first[k];
+        if (n < P2G_CROWD) continue;
+        for (int j = 0; j * P2G_PIECE < n; ++j) {
+            const int len = n - j * P2G_PIECE < P2G_PIECE ? n - j * P2G_PIECE : P2G_PIECE;
+            list[at++] = make_int2(first[k] + j * P2G_PIECE, (j << 9) | (len - 1));
+        }
+    }
+}
+__global__ __launch_bounds__(64 * PC_WAVES) void k_p2g_crowd_sum(Particles p, const double* __restrict__ pw, long wstride,
+                                                                const int2* __restrict__ list, int* __restrict__ count, Particles park)
+{
+    __shared__ double sw[PC_WAVES][12][64];   // wx0..2, wy0..2, wz0..2, vx, vy, vz of the 64 staged particles of each wave
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 15, gq = lane >> 4;
+    const int total = count[0];
+    double(*my)[64] = sw[wv];
+    // as A: row n = (x offset, y offset); as B: column n = (z offset, value)
+    const double* ax = my[n < 9 ? n / 3 : 0];
+    const double* ay = my[3 + (n < 9 ? n % 3 : 0)];
+    const double* bz = my[6 + (n < 12 ? n >> 2 : 0)];
+    const double* bv = my[8 + ((n & 3) ? (n & 3) : 1)];
+    for (int ent = blockIdx.x * PC_WAVES + wv; ent < total; ent += gridDim.x * PC_WAVES) {
+        const int2 en = list[ent];
+        const int piece = en.y >> 9, lo = en.x, hi = lo + (en.y & 511) + 1, ca = lo - P2G_PIECE * piece;
+        pc_d4 D = {0, 0, 0, 0};
+        for (int b = lo; b < hi; b += 64) {
+            const int j = b + lane;
+            const bool ok = j < hi;
+            double v[12];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = ok ? pw[q * wstride + j] : 0.0;
+            v[9] = ok ? p.vx[j] : 0.0, v[10] = ok ? p.vy[j] : 0.0, v[11] = ok ? p.vz[j] : 0.0;
+            __builtin_amdgcn_wave_barrier();   // (the wave's own LDS rows: every lane has read the batch before)
+#pragma unroll
+            for (int q = 0; q < 12; ++q) my[q][lane] = v[q];
+            __builtin_amdgcn_wave_barrier();
+            const int nb = hi - b < 64 ? hi - b : 64;
+#pragma unroll 4
+            for (int s4 = 0; s4 < 16; ++s4) {
+                if (4 * s4 >= nb) break;   // wave-uniform; a slot past the piece holds zeros
+                const int k = 4 * s4 + gq;
+                const double A = n < 9 ? ax[k] * ay[k] : 0.0;
+                const double zw = bz[k], zv = zw * bv[k];
+                const double B = n < 12 ? ((n & 3) ? zv : zw) : 0.0;
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, D, 0, 0, 0);
+            }
+        }
+        // D: column n, rows gq + 4 i in register i: linear index row * 12 + n
+        if (n < 12) {
+            const long o18 = ca + 18L * piece;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int row = gq + 4 * i;
+                if (row < 9) {
+                    const int L = row * 12 + n, arr = L / 18;
+                    double* dst = arr == 0 ? park.px : (arr == 1 ? park.py : (arr == 2 ? park.pz : (arr == 3 ? park.vx : (arr == 4 ? park.vy : park.vz))));
+                    dst[o18 + L % 18] = D[i];
+                }
+            }
+        }
+    }
 }
 
 // The work list of k_p2g_rows.  A regular cut (x-plane) x (nseg equal y segments) x (z piece) would hand every row of a
@@ -447,7 +596,7 @@ __global__ __launch_bounds__(256) void k_p2g_combine(Grid g, Box box, const doub
                                                      int* __restrict__ items)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) items[0] = 0;  // k_p2g_rows is done with the work list: empty for the next k_p2g_items
+    if (i == 0) items[0] = items[1] = 0;  // k_p2g_rows is done with the work list (and with the crowded cells' list, counted in items[1]): empty for the next launch
     if (i >= cells) return;
     const int nz = box.nz(), ny = box.ny();
     const int z = (int)(i % nz), y = (int)((i / nz) % ny), x = (int)(i / ((long)nz * ny));
@@ -983,8 +1132,11 @@ long p2g_max_items(Box box)
 }
 // pw: the particles' axis weights (launch_reorder / launch_weights); part: 12 doubles per cell of box; items: work list,
 // 4 + 4 * p2g_max_items(box) ints, items[0] == 0 on entry and on exit
+// crowd_list != nullptr (piled particles, mostly-air box): the cells of >= P2G_CROWD particles are summed on the matrix cores first
+// (list of at least n_particles / 16 + 64 int2, `park` = the other particle buffer), the rows walk the rest
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
-                double* part, int* items, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
+                double* part, int* items, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb, int2* crowd_list,
+                Particles park)
 {
     int ntz, zt, nseg;
     p2g_cut(box, ntz, zt, nseg);
@@ -993,8 +1145,17 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, 
     const unsigned nt = (unsigned)((box.nx() + 2) * nseg * ntz);  // the regular cut fills the chip; further items are taken in a grid-stride loop
     hipLaunchKernelGGL(k_p2g_items, dim3(nblk((long)(box.nx() + 2) * nseg)), dim3(256), 0, st, g, box, cell_start, nseg, ntz, budget, items);
     const bool vec = ((((uintptr_t)pw | (uintptr_t)p.vx | (uintptr_t)p.vy | (uintptr_t)p.vz) & 15) == 0) && (wstride & 1) == 0;
-    if (vec) hipLaunchKernelGGL(k_p2g_rows<true>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items);
-    else hipLaunchKernelGGL(k_p2g_rows<false>, dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items);
+    if (crowd_list) {
+        // the source cells of box: one cell further on every side (a decomposed run holds particles there)
+        Box sb = box;
+        sb.x0 = sb.x0 > 0 ? sb.x0 - 1 : 0, sb.y0 = sb.y0 > 0 ? sb.y0 - 1 : 0, sb.z0 = sb.z0 > 0 ? sb.z0 - 1 : 0;
+        sb.x1 = sb.x1 < g.nx - 1 ? sb.x1 + 1 : g.nx - 1, sb.y1 = sb.y1 < g.ny - 1 ? sb.y1 + 1 : g.ny - 1, sb.z1 = sb.z1 < g.nz - 1 ? sb.z1 + 1 : g.nz - 1;
+        hipLaunchKernelGGL(k_p2g_crowd_list, dim3(nblk((long)sb.nx() * sb.ny() * ((sb.nz() + 3) / 4))), dim3(256), 0, st, g, sb, cell_start, crowd_list, items + 1);
+        hipLaunchKernelGGL(k_p2g_crowd_sum, dim3(2048), dim3(64 * PC_WAVES), 0, st, p, pw, wstride, crowd_list, items + 1, park);
+        if (vec) hipLaunchKernelGGL((k_p2g_rows<true, true>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
+        else hipLaunchKernelGGL((k_p2g_rows<false, true>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
+    } else if (vec) hipLaunchKernelGGL((k_p2g_rows<true, false>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
+    else hipLaunchKernelGGL((k_p2g_rows<false, false>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
     hipLaunchKernelGGL(k_p2g_combine, dim3(nblk(cells)), dim3(256), 0, st, g, box, part, cells, flags, container, u, v, w, ub, vb, wb, items);
 }
 void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,

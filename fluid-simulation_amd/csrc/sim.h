@@ -86,6 +86,8 @@ struct fluid_sim {
     double* pw = nullptr;  // 9 axis weights per particle, SoA with stride cap
     double* p2g_part = nullptr;  // k_p2g_rows' three x-plane partials: 12 doubles per cell of the P2G box (grown on demand)
     size_t p2g_part_cap = 0;
+    int2* p2g_crowd = nullptr;   // (cell, piece) list of k_p2g_crowd_sum, grown on demand; its count is p2g_items[1]
+    size_t p2g_crowd_cap = 0;
     int* p2g_items = nullptr;    // k_p2g_rows' work list (count + int4 items), grown on demand; the count is 0 between launches
     size_t p2g_items_cap = 0;
     int max_cell = 0;            // most particles in one cell after the last sort (all ranks' cells when distributed)

@@ -114,7 +114,8 @@ typedef struct fluid_step_stats {
     int32_t box_hi[3];
     int32_t paths;            /* kernel forms this step took: FLUID_PATH_* bits                  */
 } fluid_step_stats_t;
-#define FLUID_PATH_P2G_TILES 1   /* particle -> grid in its 2 x 2-column tile form (piled particles, mostly empty box) */
+#define FLUID_PATH_P2G_TILES 1   /* particle -> grid in its 2 x 2-column tile form (a box whose row partials would not fit) */
+#define FLUID_PATH_P2G_CROWD 16  /* particle -> grid with the cells of >= 18 particles summed on the matrix cores first (piled particles, mostly empty box) */
 #define FLUID_PATH_TILE_LISTS 2  /* level-0 solver kernels over the lists of tiles that hold an unknown (mostly-air box) */
 #define FLUID_PATH_DIST_DECOMPOSED 4  /* multi-GPU: window arrays, domain-decomposed PCG with the globally coupled V-cycle  */
 #define FLUID_PATH_DIST_REPLICATED 8  /* multi-GPU: particles sharded, pressure block replicated on every rank              */

@@ -54,11 +54,11 @@ def test_p2g_and_flags(fs, oracle, n, ppc):
 
 @pytest.mark.parametrize("n,ppc", [(32, 8), (33, 3)])
 def test_p2g_forms_agree(fs, oracle, n, ppc, monkeypatch):
-    """The two particle -> grid kernels (row-marching for evenly filled water, 2 x 2 tiles once particles pile up; the
-    host switches by the fullest cell) form the same sums in a different association: both against the oracle, and
-    against each other."""
+    """The particle -> grid forms (row-marching for evenly filled water; the same with the cells of 18 or more particles summed on
+    the matrix cores first once particles pile up — the host switches by the fullest cell; 2 x 2 tiles for boxes whose partial
+    sums would not fit) form the same sums in a different association: all against the oracle, and against each other."""
     out = {}
-    for form in ("rows", "tiles"):
+    for form in ("rows", "tiles", "crowd"):
         monkeypatch.setenv("FLUID_P2G_FORM", form)
         sim, orc, pos = make_pair(fs, oracle, n, ppc, vel_scale=1.0)
         sim.p2g(); sim.flags_index()
@@ -68,17 +68,19 @@ def test_p2g_forms_agree(fs, oracle, n, ppc, monkeypatch):
         assert rel_l2(out[form][0], orc.field(0)) < TOL_W
         assert rel_l2(out[form][1], orc.field(2)) < 1e-6
         sim.close()
-    assert np.array_equal(out["rows"][0] > 0, out["tiles"][0] > 0)
-    assert rel_l2(out["rows"][0], out["tiles"][0]) < TOL_W
-    # the velocity is divided by the float32 weight sum, whose rounding sequence is the form's: 6e-8, the bar of the oracle
-    assert rel_l2(out["rows"][1], out["tiles"][1]) < 1e-6
+    for other in ("tiles", "crowd"):
+        assert np.array_equal(out["rows"][0] > 0, out[other][0] > 0)
+        assert rel_l2(out["rows"][0], out[other][0]) < TOL_W
+        # the velocity is divided by the float32 weight sum, whose rounding sequence is the form's: 6e-8, the bar of the oracle
+        assert rel_l2(out["rows"][1], out[other][1]) < 1e-6
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_p2g_forms_agree_on_piles(fs, oracle, seed, monkeypatch):
     """Random piles of 60 .. 12000 particles per cell on a thin background, some against the walls: the wave-swept heavy
     cells, rows longer than a staged chunk and the work list's cut of crowded planes (more than 8192 particles in a plane
-    segment) in the row-marching form, against the tile form and the oracle."""
+    segment) in the row-marching form, the crowded cells' sums on the matrix cores (pieces of 512 particles, steps of four), against
+    the tile form and the oracle."""
     n = 24
     rng = np.random.default_rng(100 + seed)
     lo, hi = fs.grid_bounds(n)
@@ -94,7 +96,7 @@ def test_p2g_forms_agree_on_piles(fs, oracle, seed, monkeypatch):
     vel = rng.standard_normal(pos.shape)
     orc = oracle.Oracle(n=n); orc.set_particles(pos, vel); orc.p2g(); orc.flags_index()
     out = {}
-    for form in ("rows", "tiles"):
+    for form in ("rows", "tiles", "crowd"):
         monkeypatch.setenv("FLUID_P2G_FORM", form)
         sim = fs.FluidSim(n=n); sim.upload_particles(pos, vel)
         sim.p2g(); sim.flags_index()
@@ -105,8 +107,9 @@ def test_p2g_forms_agree_on_piles(fs, oracle, seed, monkeypatch):
         assert rel_l2(out[form][0], orc.field(0)) < 1e-5
         assert rel_l2(out[form][1], orc.field(2)) < 1e-5
         sim.close()
-    assert rel_l2(out["rows"][0], out["tiles"][0]) < 1e-5
-    assert rel_l2(out["rows"][1], out["tiles"][1]) < 1e-5
+    for other in ("tiles", "crowd"):
+        assert rel_l2(out["rows"][0], out[other][0]) < 1e-5
+        assert rel_l2(out["rows"][1], out[other][1]) < 1e-5
 
 
 def orc_adiag_counts(orc):
@@ -636,7 +639,7 @@ def test_forms_switch_by_themselves(fs, monkeypatch):
     sb, pb, vb, prb = run({"FLUID_TILE_LISTS": "0", "FLUID_P2G_FORM": "rows"})
     assert sa[0]["paths"] & 2 == 0                      # no hint yet in the first step
     assert all(s["paths"] & 2 for s in sa[1:])          # active-tile lists from then on
-    assert all(s["paths"] & 1 for s in sa[1:])          # and P2G in its tile form (mostly empty box)
+    assert all(s["paths"] & 16 for s in sa[1:])         # and P2G with the crowded cells on the matrix cores (mostly empty box)
     assert all(s["paths"] == 0 for s in sb)
     assert [s["num_active"] for s in sa] == [s["num_active"] for s in sb]
     assert [s["outer_passes"] for s in sa] == [s["outer_passes"] for s in sb]
