@@ -238,6 +238,7 @@ void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, cons
 void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst, double* w = nullptr, long wstride = 0);
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
 long p2g_max_items(Box box);
+size_t p2g_part_doubles(Box box);   // size of launch_p2g's `part`
 constexpr int P2G_PILED = 256;   // a cell with more particles: the particles have piled up (walls, floor), P2G takes the tile form
 void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                 double* part, int* items, float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb, int2* crowd_list = nullptr,

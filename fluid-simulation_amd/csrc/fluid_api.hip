@@ -507,7 +507,7 @@ int fl::run_p2g(fluid_sim* s, const Box& box)
             s->p2g_crowd_cap = nl;
         }
     }
-    const size_t need = (size_t)12 * box.cells();
+    const size_t need = p2g_part_doubles(box);
     if (need > s->p2g_part_cap) {
         if (s->p2g_part) { HIPCHK(hipStreamSynchronize(s->st)); hipFree(s->p2g_part); s->p2g_part = nullptr; }
         HIPCHK(hipMalloc((void**)&s->p2g_part, (need + need / 4) * sizeof(double)));

@@ -1714,7 +1714,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
         }
         if (ensure_stage(s, stage + 4096, stage + 4096)) return bail("halo staging buffers");
         const Box ownW = to_box(IBox{{d->ob.lo[0], d->ob.lo[1], d->ob.lo[2]}, {d->ob.hi[0], d->ob.hi[1], d->ob.hi[2]}}, (const int[3]){g.ox, g.oy, g.oz});
-        const size_t need = (size_t)12 * ownW.cells(), ni = 4 + 4 * (size_t)p2g_max_items(ownW);
+        const size_t need = p2g_part_doubles(ownW), ni = 4 + 4 * (size_t)p2g_max_items(ownW);
         if (hipMalloc((void**)&s->p2g_part, need * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->p2g_items, ni * sizeof(int)) != hipSuccess ||
             hipMemset(s->p2g_items, 0, 4 * sizeof(int)) != hipSuccess)
             return bail("P2G partials / work list");

@@ -275,7 +275,7 @@ constexpr int P2G_ZT = 62;     // most target cells a wave takes (lanes 0 and 63
 template <bool VEC, bool CROWD>
 __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Particles p, const double* __restrict__ pw, long wstride,
                                                           const int* __restrict__ cell_start, double* __restrict__ part, long cells, int zt, const int* __restrict__ items,
-                                                          Particles crowd)
+                                                          Particles crowd, uint8_t* __restrict__ colflag, int ntz)
 {
     __shared__ double sr[12][P2G_LDS];   // wx0..2, wy0..2, wz0..2, vx, vy, vz
     const int tid = threadIdx.x, e = tid >> 6, lane = tid & 63;
@@ -296,7 +296,20 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) C[a][q] = 0;
+    // the particle ranges of the item's rows, 64 rows at a time (lane = row): after the splash more than half of the row pieces are
+    // empty, and an empty row must not cost a trip to memory
+    int pjb = 0, pje = 0;
+    uint8_t* const cflag = colflag + ((long)(2 - e) * box.nx() + (X - box.x0)) * box.ny() * ntz + wi.w;
     for (int ry = Y0 - 1; ry <= Y1 + 1; ++ry) {
+        const int ri = ry - (Y0 - 1);
+        if ((ri & 63) == 0) {
+            const int y = ry + lane;
+            pjb = pje = 0;
+            if (rowx && y >= 0 && y < g.ny && y <= Y1 + 1) {
+                pjb = cell_start[g.idx(rx, y, zlo)];
+                pje = cell_start[g.idx(rx, y, zhi) + 1];
+            }
+        }
         double T[3][3][4];  // this row's sums by target y (ry-1..ry+1), target z (zc-1..zc+1), value
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -304,11 +317,7 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
             for (int d = 0; d < 3; ++d)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) T[a][d][q] = 0;
-        int jb = 0, je = 0;
-        if (rowx && ry >= 0 && ry < g.ny) {
-            jb = cell_start[g.idx(rx, ry, zlo)];
-            je = cell_start[g.idx(rx, ry, zhi) + 1];
-        }
+        const int jb = __shfl(pjb, ri & 63, 64), je = __shfl(pje, ri & 63, 64);
         if (je > jb) {  // block-uniform
             int ca = 0, cz = 0;  // my source cell's particles in this row
             if (src) {
@@ -329,14 +338,18 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
                     // 16 B accesses from an even index; the odd particle before jb / after je - 1 is staged but never read
                     for (int j = cb + 2 * tid; j < ce; j += 2 * P2G_THREADS) {
                         const int k0 = p2g_slot(j - cb), k1 = p2g_slot(j + 1 - cb);
-                        double2 t[12];
+                        double2 t[6];   // (two batches of six arrays: the twelve at once are 48 registers the walk's 36 sums need)
 #pragma unroll
-                        for (int q = 0; q < 9; ++q) t[q] = *reinterpret_cast<const double2*>(pw + q * wstride + j);
-                        t[9] = *reinterpret_cast<const double2*>(p.vx + j);
-                        t[10] = *reinterpret_cast<const double2*>(p.vy + j);
-                        t[11] = *reinterpret_cast<const double2*>(p.vz + j);
+                        for (int q = 0; q < 6; ++q) t[q] = *reinterpret_cast<const double2*>(pw + q * wstride + j);
 #pragma unroll
-                        for (int q = 0; q < 12; ++q) { sr[q][k0] = t[q].x; sr[q][k1] = t[q].y; }
+                        for (int q = 0; q < 6; ++q) { sr[q][k0] = t[q].x; sr[q][k1] = t[q].y; }
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) t[q] = *reinterpret_cast<const double2*>(pw + (6 + q) * wstride + j);
+                        t[3] = *reinterpret_cast<const double2*>(p.vx + j);
+                        t[4] = *reinterpret_cast<const double2*>(p.vy + j);
+                        t[5] = *reinterpret_cast<const double2*>(p.vz + j);
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) { sr[6 + q][k0] = t[q].x; sr[6 + q][k1] = t[q].y; }
                     }
                 } else {
                     for (int j = cb + tid; j < ce; j += P2G_THREADS) {
@@ -431,11 +444,16 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
                 const double below = __shfl_up(T[a][2][q], 1, 64), above = __shfl_down(T[a][0][q], 1, 64);
                 C[a][q] = ((C[a][q] + below) + T[a][1][q]) + above;
             }
-        // column ry-1 has met rows ry-2, ry-1, ry of this x-plane
-        if (ry - 1 >= Y0 && tgt) {
-            double* o = out + (long)(ry - 1 - box.y0) * box.nz();
+        // column ry-1 has met rows ry-2, ry-1, ry of this x-plane.  A column piece that received nothing (weight sums all zero) is only
+        // flagged: neither written here nor read by k_p2g_combine
+        if (ry - 1 >= Y0 && colx) {
+            const bool any = __any(tgt && C[0][0] != 0);
+            if (lane == 0) cflag[(long)(ry - 1 - box.y0) * ntz] = any;
+            if (any && tgt) {
+                double* o = out + (long)(ry - 1 - box.y0) * box.nz();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q * cells] = C[0][q];
+                for (int q = 0; q < 4; ++q) o[q * cells] = C[0][q];
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { C[0][q] = C[1][q]; C[1][q] = C[2][q]; C[2][q] = 0; }
@@ -593,7 +611,7 @@ __global__ __launch_bounds__(256) void k_p2g_combine(Grid g, Box box, const doub
                                                      const uint8_t* __restrict__ flags, float* __restrict__ container,
                                                      double* __restrict__ u, double* __restrict__ v, double* __restrict__ w,
                                                      double* __restrict__ ub, double* __restrict__ vb, double* __restrict__ wb,
-                                                     int* __restrict__ items)
+                                                     int* __restrict__ items, const uint8_t* __restrict__ colflag, int zt, int ntz)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i == 0) items[0] = items[1] = 0;  // k_p2g_rows is done with the work list (and with the crowded cells' list, counted in items[1]): empty for the next launch
@@ -604,8 +622,10 @@ __global__ __launch_bounds__(256) void k_p2g_combine(Grid g, Box box, const doub
     if (flags[c] & F_SOLID) return;  // solid cells receive nothing (:288,870): fields stay 0
     float wf = 0.0f;
     double s[3] = {0, 0, 0};
+    const uint8_t* cf = colflag + ((long)x * ny + y) * ntz + z / zt;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        if (!cf[(long)k * box.nx() * ny * ntz]) continue;   // nothing reached this column piece from that x-plane: its partial was not written
         const double* q = part + (long)k * 4 * cells + i;
         wf = (float)((double)wf + q[0]);
 #pragma unroll
@@ -1124,6 +1144,13 @@ static void p2g_cut(const Box& box, int& ntz, int& zt, int& nseg)
         if (best < 0 || cost < best) { best = cost; nseg = k; }
     }
 }
+// doubles of the row form's partial buffer over box: 12 per cell + the column-piece flags
+size_t p2g_part_doubles(Box box)
+{
+    int ntz, zt, nseg;
+    p2g_cut(box, ntz, zt, nseg);
+    return (size_t)12 * box.cells() + ((size_t)3 * box.nx() * box.ny() * ntz + 7) / 8 + 8;
+}
 long p2g_max_items(Box box)
 {
     int ntz, zt, nseg;
@@ -1145,6 +1172,7 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, 
     const unsigned nt = (unsigned)((box.nx() + 2) * nseg * ntz);  // the regular cut fills the chip; further items are taken in a grid-stride loop
     hipLaunchKernelGGL(k_p2g_items, dim3(nblk((long)(box.nx() + 2) * nseg)), dim3(256), 0, st, g, box, cell_start, nseg, ntz, budget, items);
     const bool vec = ((((uintptr_t)pw | (uintptr_t)p.vx | (uintptr_t)p.vy | (uintptr_t)p.vz) & 15) == 0) && (wstride & 1) == 0;
+    uint8_t* colflag = reinterpret_cast<uint8_t*>(part + 12 * cells);   // 3 x nx x ny x ntz bytes behind the partials (p2g_part_doubles)
     if (crowd_list) {
         // the source cells of box: one cell further on every side (a decomposed run holds particles there)
         Box sb = box;
@@ -1152,11 +1180,11 @@ void launch_p2g(hipStream_t st, Grid g, Box box, Particles p, const double* pw, 
         sb.x1 = sb.x1 < g.nx - 1 ? sb.x1 + 1 : g.nx - 1, sb.y1 = sb.y1 < g.ny - 1 ? sb.y1 + 1 : g.ny - 1, sb.z1 = sb.z1 < g.nz - 1 ? sb.z1 + 1 : g.nz - 1;
         hipLaunchKernelGGL(k_p2g_crowd_list, dim3(nblk((long)sb.nx() * sb.ny() * ((sb.nz() + 3) / 4))), dim3(256), 0, st, g, sb, cell_start, crowd_list, items + 1);
         hipLaunchKernelGGL(k_p2g_crowd_sum, dim3(2048), dim3(64 * PC_WAVES), 0, st, p, pw, wstride, crowd_list, items + 1, park);
-        if (vec) hipLaunchKernelGGL((k_p2g_rows<true, true>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
-        else hipLaunchKernelGGL((k_p2g_rows<false, true>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
-    } else if (vec) hipLaunchKernelGGL((k_p2g_rows<true, false>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
-    else hipLaunchKernelGGL((k_p2g_rows<false, false>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park);
-    hipLaunchKernelGGL(k_p2g_combine, dim3(nblk(cells)), dim3(256), 0, st, g, box, part, cells, flags, container, u, v, w, ub, vb, wb, items);
+        if (vec) hipLaunchKernelGGL((k_p2g_rows<true, true>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park, colflag, ntz);
+        else hipLaunchKernelGGL((k_p2g_rows<false, true>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park, colflag, ntz);
+    } else if (vec) hipLaunchKernelGGL((k_p2g_rows<true, false>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park, colflag, ntz);
+    else hipLaunchKernelGGL((k_p2g_rows<false, false>), dim3(nt), dim3(P2G_THREADS), 0, st, g, box, p, pw, wstride, cell_start, part, cells, zt, items, park, colflag, ntz);
+    hipLaunchKernelGGL(k_p2g_combine, dim3(nblk(cells)), dim3(256), 0, st, g, box, part, cells, flags, container, u, v, w, ub, vb, wb, items, colflag, zt, ntz);
 }
 void launch_p2g_tiles(hipStream_t st, Grid g, Box box, Particles p, const double* pw, long wstride, const int* cell_start, const uint8_t* flags,
                       float* container, double* u, double* v, double* w, double* ub, double* vb, double* wb)
