@@ -298,7 +298,8 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
         for (int q = 0; q < 4; ++q) C[a][q] = 0;
     // the particle ranges of the item's rows, 64 rows at a time (lane = row): after the splash more than half of the row pieces are
     // empty, and an empty row must not cost a trip to memory
-    int pjb = 0, pje = 0;
+    int pjb = 0, pje = 0, nca = 0, ncz = 0;
+    bool have = false;   // nca / ncz hold the row's cell range already
     uint8_t* const cflag = colflag + ((long)(2 - e) * box.nx() + (X - box.x0)) * box.ny() * ntz + wi.w;
     for (int ry = Y0 - 1; ry <= Y1 + 1; ++ry) {
         const int ri = ry - (Y0 - 1);
@@ -318,13 +319,25 @@ __global__ __launch_bounds__(P2G_THREADS, 3) void k_p2g_rows(Grid g, Box box, Pa
 #pragma unroll
                 for (int q = 0; q < 4; ++q) T[a][d][q] = 0;
         const int jb = __shfl(pjb, ri & 63, 64), je = __shfl(pje, ri & 63, 64);
-        if (je > jb) {  // block-uniform
-            int ca = 0, cz = 0;  // my source cell's particles in this row
+        // my source cell's particles in this row — fetched while the row before was worked on (a row piece after the splash holds a handful of
+        // particles: its visit is trips to memory, one fewer this way)
+        int ca = nca, cz = ncz;
+        if (je > jb && !have && src) {
+            const size_t r0 = g.idx(rx, ry, zc);
+            ca = cell_start[r0];
+            cz = cell_start[r0 + 1];
+        }
+        have = false;
+        if (((ri + 1) & 63) != 0 && ry < Y1 + 1 && __shfl(pje, (ri + 1) & 63, 64) > __shfl(pjb, (ri + 1) & 63, 64)) {
+            have = true;
+            nca = ncz = 0;
             if (src) {
-                const size_t r0 = g.idx(rx, ry, zc);
-                ca = cell_start[r0];
-                cz = cell_start[r0 + 1];
+                const size_t r1 = g.idx(rx, ry + 1, zc);
+                nca = cell_start[r1];
+                ncz = cell_start[r1 + 1];
             }
+        }
+        if (je > jb) {  // block-uniform
             const int ca_all = ca, n_all = cz - ca;
             if (CROWD && n_all >= P2G_CROWD) cz = ca;   // not walked: its sums are parked
             for (int cb = VEC ? (jb & ~1) : jb; cb < je; cb += P2G_CH) {
