@@ -493,13 +493,13 @@ def main():
             siml = fs.FluidSim(n=n, device=local_rank, cg_tol=a.cg_tol, flip_blend=a.flip_blend)
             siml.upload_particles(pos0)
             ts, its, passes, boxes, its_by_step = [], 0, 0, [], []
-            forms = {"p2g_tile_form": 0, "tile_lists": 0, "droplets_solved_apart": 0, "galerkin_coarse_levels": 0}   # steps that took each form (stats.paths bits 1, 2, 64, 128)
+            forms = {"p2g_tile_form": 0, "p2g_crowded_cells_on_mfma": 0, "tile_lists": 0, "droplets_solved_apart": 0, "galerkin_coarse_levels": 0}   # steps that took each form (stats.paths bits 1, 16, 2, 64, 128)
             for _ in range(a.long_steps):
                 c0 = time.perf_counter()
                 st = siml.step()
                 ts.append((time.perf_counter() - c0) * 1e3)
                 its += st["cg_iters"]; passes += st["outer_passes"]
-                forms["p2g_tile_form"] += bool(st["paths"] & 1); forms["tile_lists"] += bool(st["paths"] & 2); forms["droplets_solved_apart"] += bool(st["paths"] & 64); forms["galerkin_coarse_levels"] += bool(st["paths"] & 128)
+                forms["p2g_tile_form"] += bool(st["paths"] & 1); forms["p2g_crowded_cells_on_mfma"] += bool(st["paths"] & 16); forms["tile_lists"] += bool(st["paths"] & 2); forms["droplets_solved_apart"] += bool(st["paths"] & 64); forms["galerkin_coarse_levels"] += bool(st["paths"] & 128)
                 boxes.append((tuple(st["box_lo"]), tuple(st["box_hi"]))); its_by_step.append((st["cg_iters"], st["outer_passes"]))
             ts = np.array(ts)
             # phases of the run by the active box: free fall (the cube has not reached the floor: the box is still the cube's), splash (the box
@@ -533,21 +533,23 @@ def main():
                      "cg_iters_mean": float(np.mean([x["cg_iters"] for x in sts])), "cg_error_max": float(max(x["cg_error"] for x in sts)),
                      "phase_ms": {k[3:]: float(np.mean([x[k] for x in sts])) for k in ("ms_transfer", "ms_forces", "ms_solve", "ms_deform", "ms_advect")},
                      "apply_kernel_us": float(np.mean([x["ms_apply_avg"] for x in sts]) * 1e3)}
-                # One operator application = k_mpm_apply_particles (per particle: gather of G from the unknown vector, energy Hessian,
-                # A_p F_p^T: fp64 arithmetic) + k_mpm_apply_gather (per unknown node: the sum over the particles of the 8 cells that reach
-                # it).  Neither is an HBM kernel: the particle state (104 B read by the gather per particle visit, 8 visits per particle;
-                # 348 B read + 80 B written by the particle kernel) stays in L2 / Infinity Cache, so the honest roofline is the fp64
-                # VECTOR peak for the arithmetic and the aggregate L2 rate for the gather (MI355X guide: 78.6 TFLOP/s fp64 vector, 34.5 TB/s L2).
-                # flops per particle, counted from the source (27 nodes x (3 gradient components x 2 mul + 9 FMA-pairs) + Hessian + 3 3x3 products): ~1300
-                flops = 1300.0 * sim.num_particles
+                # One operator application = k_mpm_apply_particles (per particle: gather of G over its 8 weighted nodes from the node-indexed
+                # operand, energy Hessian, A_p F_p^T: 66 doubles read, 10 written) + k_mpm_apply_cells (per non-empty cell: the sums onto its 8
+                # corner nodes, 22 doubles read per particle).  Measured on the
+                # fabric: the PMC bytes of the two kernels (139 MB per application on the scaled cone) are 0.8 of these algorithmic bytes, so the operator
+                # streams the particle state once per application — bound by the memory side, priced against the HBM peak; the fp64 VECTOR peak
+                # (78.6 TFLOP/s) is given beside it.
+                # flops per particle, counted from the source (8 nodes x 24 + three 3x3 products + Hessian ~300 + 8 corners x 30): ~800
+                flops = 800.0 * sim.num_particles
                 us = d["apply_kernel_us"]
-                d["roofline"] = {"kernel": "k_mpm_apply_particles + k_mpm_apply_gather (one application of the matrix-free operator; time = HIP events around both)",
-                                 "bound": "fp64-valu", "achieved": flops / (us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / (us * 1e-6) / 78.6e12,
+                cache_bytes = (66.0 + 10.0 + 22.0) * 8 * sim.num_particles
+                d["roofline"] = {"kernel": "k_mpm_apply_particles + k_mpm_apply_cells (one application of the matrix-free operator; time = HIP events around both)",
+                                 "bound": "hbm", "achieved": cache_bytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cache_bytes / (us * 1e-6) / 8e12,
+                                 "fp64_TFLOPs": flops / (us * 1e-6) / 1e12, "fp64_frac_of_78.6": flops / (us * 1e-6) / 78.6e12,
                                  "traffic": mpm_pmc_traffic()[0] if B == 63 else None, "traffic_source": mpm_pmc_traffic()[1] if B == 63 else None,
-                                 "l2_bytes_per_application": 104.0 * 8 * sim.num_particles + 428.0 * sim.num_particles,
-                                 "l2_rate_TBs": (104.0 * 8 + 428.0) * sim.num_particles / (us * 1e-6) / 1e12,
-                                 "note": "latency-bound: ~1300 fp64 operations per particle in dependent chains at 2 waves per SIMD (154 VGPRs), then a node gather "
-                                         "whose waves make one round trip of 13 loads per particle; per-kernel times and the PMC traffic: profiles/r03/mpm_*; "
+                                 "algorithmic_bytes_per_application": cache_bytes,
+                                 "note": "98 doubles per particle and application (66 read + 10 written by the particle kernel, 22 read by the cell kernel); `traffic` = the fabric-side PMC bytes; the small "
+                                         "scene is pure launch latency; per-kernel times and the PMC traffic: profiles/r04/mpm_*; "
                                          "sums are gathers in a fixed order (no atomics): two runs give the same bits"}
                 sim.close()
                 return d, posm
