@@ -1137,7 +1137,12 @@ int dist_solve(fluid_sim* s)
     }
     long it = 0;
     const int pclass = s->pass_class();
-    long batch = s->mg_last_iters_k[pclass] > 5 ? s->mg_last_iters_k[pclass] : 8;   // identical on every rank
+    // Bodies launched before the first look at the device: what the class's previous solve needed (identical on every rank).  Eigen's count i
+    // means i + 1 bodies ran; the Chronopoulos-Gear loop polls with a test of its own (k_pcg_poll_stage) and needs no further body to
+    // notice the end, the standard loop notices it at the head of the next body.
+    const bool cgear_loop = mg && d->cg_form == 1;
+    long batch = s->mg_last_iters_k[pclass] > 5 ? s->mg_last_iters_k[pclass] + (cgear_loop ? 1 : 0) : 8;
+    int polls = 0;
     bool done = false;
     while (!done) {
         for (long k = 0; k < batch && it < max_it; ++k, ++it) {
@@ -1190,12 +1195,18 @@ int dist_solve(fluid_sim* s)
             prof_end(s, FLUID_PROF_PCG_XR, tok);
         }
         HIPCHK(hipGetLastError());
-        // the break test of the last body sits at the head of the next SQ launch; every rank must leave at the same iteration
-        if ((rc = comm_allreduce(s, &s->ps->done, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
+        if (cgear_loop) {
+            launch_pcg_poll_stage(s->st, s->part_rr, nxr, s->ps, d->gpq);
+            if ((rc = comm_allreduce(s, d->gpq, 2, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
+            launch_pcg_poll_test(s->st, d->gpq, s->ps);
+        } else {
+            // the break test of the last body sits at the head of the next SQ launch; every rank must leave at the same iteration
+            if ((rc = comm_allreduce(s, &s->ps->done, 1, FLUID_DT_I32, FLUID_OP_MAX))) return rc;
+        }
         HIPCHK(hipMemcpyAsync(s->h_ps, s->ps, sizeof(PcgState), hipMemcpyDeviceToHost, s->st));
         HIPCHK(hipStreamSynchronize(s->st));
         done = s->h_ps->done || it >= max_it;
-        batch = 2;
+        batch = cgear_loop && ++polls <= 2 ? 1 : 2;   // (a poll costs about what a body costs)
     }
     int iters = s->h_ps->iters;
     const double rr = s->h_ps->rr;
@@ -1648,7 +1659,7 @@ int fluid_create_dist(const fluid_params_t* p, const fluid_comm_t* comm, const f
     s->dist = true;
     s->ds = d;
     auto bail = [&](const std::string& m) { fluid_destroy(s); *out = nullptr; return fail(FLUID_ERR_HIP, m); };
-    if (dalloc(&d->gstage[0], (size_t)4) != hipSuccess || dalloc(&d->gstage[1], (size_t)4) != hipSuccess || dalloc(&d->gpq, (size_t)1) != hipSuccess || dalloc(&d->gcg, (size_t)4) != hipSuccess ||
+    if (dalloc(&d->gstage[0], (size_t)4) != hipSuccess || dalloc(&d->gstage[1], (size_t)4) != hipSuccess || dalloc(&d->gpq, (size_t)2) != hipSuccess || dalloc(&d->gcg, (size_t)4) != hipSuccess ||
         dalloc(&d->d_cnt, (size_t)128) != hipSuccess || dalloc(&d->cnt_pcg, s->lmax + 64) != hipSuccess ||
         hipHostMalloc((void**)&d->h_cnt, 128 * sizeof(int)) != hipSuccess)
         return bail("alloc of the decomposition's scratch failed");

@@ -464,6 +464,26 @@ __global__ __launch_bounds__(256) void k_pcg_cgear_upd(long n2, const uint8_t* _
     if (threadIdx.x == 0) part_rr[blockIdx.x] = arr;
 }
 
+// The convergence poll of the Chronopoulos-Gear loop (decomposed run).  A body learns the global |r|^2 of the body before it from its one
+// all-reduce, so a solve of n bodies would need an (n + 1)-th — a whole V-cycle — only to find out that it is over.  Instead, where the host
+// polls anyway: out = {this rank's sum of the last body's |r|^2 partials, done so far}, one all-reduce (SUM) of the two, then the test of
+// ConjugateGradient.h:76-79 on the global value — the same on every rank, and the same value the next body's head would have seen.
+__global__ __launch_bounds__(256) void k_pcg_poll_stage(const double* __restrict__ part_rr, int n, const PcgState* ps, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    double ra, rb, rc;
+    block_sum3(part_rr, n, part_rr, 0, part_rr, 0, red, ra, rb, rc);
+    if (threadIdx.x == 0) {
+        out[0] = ra;
+        out[1] = ps->done ? 1.0 : 0.0;
+    }
+}
+__global__ void k_pcg_poll_test(const double* __restrict__ g, PcgState* ps)
+{
+    if (g[1] > 0) ps->done = 1;   // some rank's body has ended the solve already (start test, breakdown, its own head)
+    else if (g[0] < ps->thr) { ps->rr = g[0]; ps->done = 1; }   // (iters: Eigen leaves the loop before counting the body)
+}
+
 // XR: alpha, x += alpha s, r -= alpha q, partial |r|^2 and r.(invdiag r)   (ConjugateGradient.h:70-74,79-81)
 // Flat stream over the local box, two cells (16 bytes) per lane per access, 4 accesses in flight.
 template <typename T, bool SPARSE>
@@ -862,6 +882,11 @@ void launch_pcg_cgear_upd(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r
 {
     hipLaunchKernelGGL((k_pcg_cgear_upd<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, z, w, g, cg, cur, part_rr, ps, first, tol);
 }
+void launch_pcg_poll_stage(hipStream_t st, const double* part_rr, int n, const PcgState* ps, double* out)
+{
+    hipLaunchKernelGGL(k_pcg_poll_stage, dim3(1), dim3(256), 0, st, part_rr, n, ps, out);
+}
+void launch_pcg_poll_test(hipStream_t st, const double* g, PcgState* ps) { hipLaunchKernelGGL(k_pcg_poll_test, dim3(1), dim3(1), 0, st, g, ps); }
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b)
 {
     hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, st, a, na, b, nb, out_a, out_b);
