@@ -112,6 +112,49 @@ def test_p2g_forms_agree_on_piles(fs, oracle, seed, monkeypatch):
         assert rel_l2(out["rows"][1], out[other][1]) < 1e-5
 
 
+def test_p2g_crowded_cells_at_the_thresholds(fs, oracle, monkeypatch):
+    """Cells of exactly 17 / 18 / 19 particles (walked / summed on the matrix cores), 63 / 64 / 65 (one staged batch / two),
+    511 / 512 / 513 and 1024 / 1025 (one, two, three pieces of a cell), alone, side by side along z (one wave's lanes), in a wall
+    corner and next to the walls, over a thin background: the crowded-cell form against the row form and the oracle, and the same
+    bits from two runs."""
+    n = 32
+    rng = np.random.default_rng(77)
+    lo, hi = fs.grid_bounds(n)
+    counts = (17, 18, 19, 63, 64, 65, 511, 512, 513, 1024, 1025)
+    parts = [fs.water_cube_drop(n, 1, seed=5)]
+    cells = []
+    for k, cnt in enumerate(counts):          # alone: cells two apart along z in one row, then scattered
+        cells.append(((lo + 5, lo + 6, lo + 4 + 2 * k), cnt))
+    for k, cnt in enumerate(counts):          # side by side along z, another row
+        cells.append(((lo + 9, lo + 9, lo + 4 + k), cnt))
+    cells += [((lo + 3, lo + 3, lo + 3), 600), ((hi - 3, hi - 3, hi - 3), 18), ((lo + 3, hi - 3, lo + 12), 513), ((hi - 3, lo + 3, hi - 3), 64)]
+    for c, cnt in cells:
+        parts.append(np.asarray(c, dtype=np.float64) + rng.uniform(-0.49, 0.49, size=(cnt, 3)))
+    pos = np.concatenate(parts)
+    pos = pos[rng.permutation(len(pos))]
+    vel = rng.standard_normal(pos.shape)
+    orc = oracle.Oracle(n=n); orc.set_particles(pos, vel); orc.p2g(); orc.flags_index()
+    F = fs.FIELD
+    out = {}
+    for form in ("rows", "crowd", "crowd"):
+        monkeypatch.setenv("FLUID_P2G_FORM", form)
+        sim = fs.FluidSim(n=n); sim.upload_particles(pos, vel)
+        sim.p2g(); sim.flags_index()
+        got = (sim.field(F.CONTAINER), sim.field(F.VEL), sim.field(F.INDICES))
+        assert bool(sim.stats()["paths"] & 16) == (form == "crowd")
+        sim.close()
+        assert np.array_equal(got[2], orc.field(4))
+        assert rel_l2(got[0], orc.field(0)) < 1e-5 and rel_l2(got[1], orc.field(2)) < 1e-5
+        if form in out:   # the second run of the crowded form: the same bits
+            assert np.array_equal(got[0], out[form][0]) and np.array_equal(got[1], out[form][1])
+        out[form] = got
+    assert rel_l2(out["rows"][0], out["crowd"][0]) < TOL_W
+    assert rel_l2(out["rows"][1], out["crowd"][1]) < 1e-6
+    # per cell, where the two forms differ at all it is float32 rounding of the weight sum
+    w0, w1 = out["rows"][0], out["crowd"][0]
+    assert np.max(np.abs(w0 - w1) / np.maximum(w0, 1e-30)) < 3e-7
+
+
 def orc_adiag_counts(orc):
     orc.rhs_div(); orc.build_matrix()
     ad = orc.field(10)
