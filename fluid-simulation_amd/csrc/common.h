@@ -237,6 +237,7 @@ void launch_bin_rank(hipStream_t st, long n_pos, long pos0, const int* key, cons
                      int* order2);
 void launch_reorder(hipStream_t st, long n, const int* order, Particles src, Particles dst, double* w = nullptr, long wstride = 0);
 void launch_weights(hipStream_t st, long n, Particles p, double* w, long stride);
+void launch_axpby_box(hipStream_t st, Grid g, Box box, double a, const double* x, double b, const double* y, double* out);   // out = a x + b y on box
 long p2g_max_items(Box box);
 size_t p2g_part_doubles(Box box);   // size of launch_p2g's `part`
 constexpr int P2G_PILED = 256;   // a cell with more particles: the particles have piled up (walls, floor), P2G takes the tile form

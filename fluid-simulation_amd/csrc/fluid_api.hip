@@ -171,7 +171,7 @@ int fluid_destroy(fluid_sim_t* s)
     prof_resolve(s);
     free_particles(s);
     void* ptrs[] = {s->solid, s->flags, s->container, s->rhs, s->diver, s->diver2, s->u, s->v, s->w, s->ub, s->vb, s->wb, s->dcx, s->dcy,
-                    s->dcz, s->pressure, s->p_guess, s->p_guess2, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
+                    s->dcz, s->pressure, s->p_guess, s->p_guess2, s->p_q, s->indices, s->scan_sums, s->ipart, s->R, s->S[0], s->Q, s->X, s->mg_slab, s->mg_part, s->cntL, s->part_bb, s->part_rr,
                     s->part_rz[0], s->part_rz[1], s->part_pq, s->part_err, s->ps, s->cell_count, s->cell_start, s->ss,
                     s->pcx, s->pcy, s->pcz, s->p2g_part, s->p2g_items, s->p2g_crowd, s->tl_flags, s->tl_mg, s->tl_sq, s->d_small, s->row_flags, s->row_pos, s->row_list, s->drop_n, s->drop_cells, s->drop_ctr, s->gal_slab};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -244,6 +244,7 @@ int fl::fluid_create_window(const fluid_params_t* p, const Grid& g, fluid_sim_t*
         A(dalloc(&s->p_guess, n)); A(dalloc(&s->p_guess2, n));
         if (hipMemset(s->p_guess, 0, n * sizeof(double)) != hipSuccess || hipMemset(s->p_guess2, 0, n * sizeof(double)) != hipSuccess) return bail(FLUID_ERR_HIP);
         if (const char* e = getenv("FLUID_EXTRAPOLATE")) s->extrapolate = atoi(e) != 0;
+        if (s->extrapolate) { A(dalloc(&s->p_q, n)); if (hipMemset(s->p_q, 0, n * sizeof(double)) != hipSuccess) return bail(FLUID_ERR_HIP); }
     }
     A(dalloc(&s->indices, n));
     A(dalloc(&s->scan_sums, (n + 2) / 2048 + 16));
@@ -918,6 +919,10 @@ static int solve_mg(fluid_sim* s)
                       s->pressure, s->warm ? s->p_guess2 : nullptr, &s->ss->n_drop_fail);
     if (s->warm) s->rotate_guess();
     s->have_guess = s->warm;
+    if (s->make_q()) {   // (one GPU and the replicated solve of a multi-GPU run; the decomposed step forms it after its halo exchange) q = p_1 - (1 - f) p_0 over the box, for the next steps' second passes (start_guess)
+        launch_axpby_box(s->st, g, s->Rb, 1.0, s->p_guess, -(1.0 - s->prm.update_frac), s->p_guess2, s->p_q);
+        s->q_step = s->step_counter;
+    }
     HIPCHK(hipGetLastError());
     prof_end(s, FLUID_PROF_SOLVE, tsolve);
     s->stats.cg_iters_last = iters;

@@ -1310,6 +1310,10 @@ int dist_step_decomposed(fluid_sim* s, fluid_step_stats_t* stats)
                 void* a[2] = {s->pressure, s->p_guess};   // (+ the next solve's starting guess: ring values from their owners)
                 if ((rc = halo_exchange(s, d->plan_f1, 8, s->have_guess ? 2 : 1, a))) return rc;
             }
+            if (s->make_q()) {   // (both guesses carry their owners' ring values: so does q, over the whole window)
+                launch_axpby_box(s->st, g, Box{0, 0, 0, g.nx - 1, g.ny - 1, g.nz - 1}, 1.0, s->p_guess, -(1.0 - s->prm.update_frac), s->p_guess2, s->p_q);
+                s->q_step = s->step_counter;
+            }
             const double dtp = dt * s->prm.update_frac, k = dtp / (s->prm.rho * s->prm.dx);
             if (!box_empty(d->Sr))
                 launch_vel_update(s->st, g, d->Sr, s->flags, s->pressure, s->u, s->v, s->w, k, s->prm.gravity[0] * dtp, s->prm.gravity[1] * dtp,

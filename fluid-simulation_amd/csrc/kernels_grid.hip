@@ -718,4 +718,20 @@ void launch_resample(hipStream_t st, Grid g, long n, Particles p, const int* cel
     if (n > 0) hipLaunchKernelGGL(k_resample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, n, p, cell_start, per_cell, xlim, far_, n_parked);
 }
 
+// out = a x + b y over the cells of box (dense layout)
+__global__ __launch_bounds__(256) void k_axpby_box(Grid g, Box box, double a, const double* __restrict__ x, double b, const double* __restrict__ y,
+                                                   double* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= box.cells()) return;
+    const int nz = box.nz(), ny = box.ny();
+    const size_t c = g.idx(box.x0 + (int)(i / ((long)nz * ny)), box.y0 + (int)((i / nz) % ny), box.z0 + (int)(i % nz));
+    out[c] = a * x[c] + b * y[c];
+}
+void launch_axpby_box(hipStream_t st, Grid g, Box box, double a, const double* x, double b, const double* y, double* out)
+{
+    if (box.cells() <= 0) return;
+    hipLaunchKernelGGL(k_axpby_box, dim3((unsigned)((box.cells() + 255) / 256)), dim3(256), 0, st, g, box, a, x, b, y, out);
+}
+
 }  // namespace fl
