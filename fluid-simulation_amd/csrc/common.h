@@ -333,6 +333,9 @@ template <typename T>
 void launch_pcg_xr_dist(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r, const T* s, const T* q, Coef<T> cf, const double* g_rz_cur,
                         const double* g_pq, double* part_rr, double* part_rz_next, PcgState* ps);
 void launch_sum2(hipStream_t st, const double* a, int na, const double* b, int nb, double* out_a, double* out_b);
+void launch_pcg_az_dist_zf(hipStream_t st, LBox L, const uint8_t* cnt, const float* z, double* w, Coef<double> cf, double* part_zw, PcgState* ps, const int* tlist, int nlist);
+void launch_pcg_cgear_upd_zf(hipStream_t st, LBox L, const uint8_t* cnt, double* x, double* r, double* s, double* q, const float* z, const double* w, const double* g,
+                             double* cg, int cur, double* part_rr, PcgState* ps, int first, double tol);
 void launch_pcg_poll_stage(hipStream_t st, const double* part_rr, int n, const PcgState* ps, double* out);   // out[2]: see k_pcg_poll_stage
 void launch_pcg_poll_test(hipStream_t st, const double* g, PcgState* ps);
 void launch_sum4(hipStream_t st, const double* a, int na, const double* b, int nb, const double* c, int nc, const double* e, int ne, double* out);

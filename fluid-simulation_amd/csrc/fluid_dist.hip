@@ -935,9 +935,11 @@ MgCoef<V> coef_as(const fluid_sim* s, int level)
 
 // z0 = M^-1 rhs0: the V(2,2) cycle of kernels_mg.hip over the decomposed hierarchy.  rhs0 (the PCG residual) must be
 // valid on the whole local level-0 domain (its halo exchanged by the caller); z0 is valid on the owned cells + 1 ring.
+// zf: z0 is a float array (the float cycle's result as it is: the Chronopoulos-Gear loop's kernels convert)
 template <typename V>
-int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz, bool halo_pending)
+int dist_vcycle_t(fluid_sim* s, const double* rhs0, void* z0v, double* part_rz, bool halo_pending, bool zf = false)
 {
+    double* const z0 = (double*)z0v;
     DistState* d = s->ds;
     const int nl = s->mg_nl, tail = s->mg_tail, split = d->split;
     const PcgState* ps = s->ps;
@@ -998,8 +1000,12 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz,
                           (float)s->gal_wc, ps);
         if (!ib_empty(L.dom)) {
             const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)ib_cells(L.dom));
-            launch_mg_up<G, double, double>(s->st, L.m, L.cnt, rhs0, (const G*)GU(0), z0, mc, GW(1), coef_as<G>(s, 0), part_rz, ps, s->gal_wc, s->lists_on ? s->tl_mg : nullptr,
-                                            s->n_tl_mg, d->cnt_pcg, 1);
+            if (zf)
+                launch_mg_up<G, double, float>(s->st, L.m, L.cnt, rhs0, (const G*)GU(0), (float*)z0v, mc, GW(1), coef_as<G>(s, 0), part_rz, ps, s->gal_wc,
+                                               s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg, d->cnt_pcg, 1);
+            else
+                launch_mg_up<G, double, double>(s->st, L.m, L.cnt, rhs0, (const G*)GU(0), z0, mc, GW(1), coef_as<G>(s, 0), part_rz, ps, s->gal_wc,
+                                                s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg, d->cnt_pcg, 1);
             prof_end(s, FLUID_PROF_MG_UP0, tok);
         }
         HIPCHK(hipGetLastError());
@@ -1067,8 +1073,14 @@ int dist_vcycle_t(fluid_sim* s, const double* rhs0, double* z0, double* part_rz,
             const MLevel mc = under(l);
             if (l == 0) {
                 const int tok = prof_begin(s, FLUID_PROF_MG_UP0, (double)ib_cells(L.dom));
-                launch_mg_up<V, double, double>(s->st, L.m, L.cnt, rhs0, (const V*)U(0), z0, mc, ec, coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0],
-                                                s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg, d->cnt_pcg);
+                if constexpr (std::is_same<V, float>::value) {
+                    if (zf)
+                        launch_mg_up<float, double, float>(s->st, L.m, L.cnt, rhs0, (const float*)U(0), (float*)z0v, mc, ec, coef_as<float>(s, 0), part_rz, ps, s->mg_wc[0],
+                                                           s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg, d->cnt_pcg);
+                }
+                if (!zf)
+                    launch_mg_up<V, double, double>(s->st, L.m, L.cnt, rhs0, (const V*)U(0), z0, mc, ec, coef_as<V>(s, 0), part_rz, ps, s->mg_wc[0],
+                                                    s->lists_on ? s->tl_mg : nullptr, s->n_tl_mg, d->cnt_pcg);
                 prof_end(s, FLUID_PROF_MG_UP0, tok);
             } else {
                 launch_mg_up<V, V, V>(s->st, L.m, L.cnt, (const V*)F(l), (const V*)U(l), W(l), mc, ec, coef_as<V>(s, l), nullptr, ps, s->mg_wc[l == 1 ? 1 : 2]);
@@ -1157,18 +1169,24 @@ int dist_solve(fluid_sim* s)
             if (cgear) {
                 // Chronopoulos-Gear: z = M^-1 r, w = A z, then ONE all-reduce of {|r|^2 of the previous body (|b|^2 before the first),
                 // gamma = r.z, delta = w.z (, |r0|^2 of a solve started from a guess)} and one fused update of s, q = A s, x, r
-                if (s->mg_fp32) rc = dist_vcycle_t<float>(s, R, Z, s->mg_part, ovl);
+                const bool zf = s->mg_fp32 && sizeof(T) == 8;   // z stays float in memory
+                if (s->mg_fp32) rc = dist_vcycle_t<float>(s, R, Z, s->mg_part, ovl, zf);
                 else rc = dist_vcycle_t<double>(s, R, Z, s->mg_part, ovl);
                 if (rc) return rc;
                 T* Wv = Sx[1];
                 int tok = prof_begin(s, FLUID_PROF_PCG_SQ, cells);
-                launch_pcg_az_dist<T>(s->st, L, cnt, Z, Wv, cf, s->part_pq, s->ps, lists ? s->tl_sq : nullptr, s->n_tl_sq);
+                if (zf) launch_pcg_az_dist_zf(s->st, L, cnt, (const float*)Z, (double*)Wv, make_coef<double>(s), s->part_pq, s->ps, lists ? s->tl_sq : nullptr, s->n_tl_sq);
+                else launch_pcg_az_dist<T>(s->st, L, cnt, Z, Wv, cf, s->part_pq, s->ps, lists ? s->tl_sq : nullptr, s->n_tl_sq);
                 prof_end(s, FLUID_PROF_PCG_SQ, tok);
                 const bool g0 = it == 0 && guess;
                 launch_sum4(s->st, it == 0 ? s->part_bb : s->part_rr, nxr, s->mg_part, n_rz, s->part_pq, nsq, s->part_rz[1], g0 ? nxr : 0, d->gstage[cur]);
                 if ((rc = comm_allreduce(s, d->gstage[cur], g0 ? 4 : 3, FLUID_DT_F64, FLUID_OP_SUM))) return rc;
                 tok = prof_begin(s, FLUID_PROF_PCG_XR, cells);
-                launch_pcg_cgear_upd<T>(s->st, L, cnt, X, R, Sx[0], Q, Z, Wv, d->gstage[cur], d->gcg, cur, s->part_rr, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol);
+                if (zf)
+                    launch_pcg_cgear_upd_zf(s->st, L, cnt, (double*)X, (double*)R, (double*)Sx[0], (double*)Q, (const float*)Z, (const double*)Wv, d->gstage[cur], d->gcg, cur,
+                                            s->part_rr, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol);
+                else
+                    launch_pcg_cgear_upd<T>(s->st, L, cnt, X, R, Sx[0], Q, Z, Wv, d->gstage[cur], d->gcg, cur, s->part_rr, s->ps, it == 0 ? (guess ? 2 : 1) : 0, tol);
                 prof_end(s, FLUID_PROF_PCG_XR, tok);
                 continue;
             }

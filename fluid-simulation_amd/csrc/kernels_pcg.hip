@@ -384,9 +384,9 @@ __global__ __launch_bounds__(256) void k_sum4(const double* __restrict__ a, int 
 //   s = z + beta s ; q = w + beta q  (= A s by recurrence) ; x += alpha s ; r -= alpha q ; partial |r|^2
 // on the owned unknowns (count byte non-zero, bit 7 clear).  Same start, stopping rule and iteration count as pcg_head
 // (ConjugateGradient.h:28-90); in exact arithmetic the same iterates.  cg = {gamma, alpha} of the last two bodies, by parity.
-template <typename T>
+template <typename T, typename ZT = T>
 __global__ __launch_bounds__(256) void k_pcg_cgear_upd(long n2, const uint8_t* __restrict__ cnt, T* __restrict__ x, T* __restrict__ r, T* __restrict__ s,
-                                                       T* __restrict__ q, const T* __restrict__ z, const T* __restrict__ w, const double* __restrict__ g,
+                                                       T* __restrict__ q, const ZT* __restrict__ z, const T* __restrict__ w, const double* __restrict__ g,
                                                        double* __restrict__ cg, int cur, double* __restrict__ part_rr, PcgState* ps, int first, double tol)
 {
     __shared__ double red[16];
@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void k_pcg_cgear_upd(long n2, const uint8_t* _
         ca = (ca & 0x80) ? 0 : ca;
         cb = (cb & 0x80) ? 0 : cb;
         if (!(ca | cb)) continue;
-        const V2 zv = ((const V2*)z)[i], wv = ((const V2*)w)[i];
+        const Vec2<ZT> zf = ((const Vec2<ZT>*)z)[i];   // (ZT = float: the float cycle's z as it left it, converted exactly)
+        const V2 zv = {(T)zf.a, (T)zf.b}, wv = ((const V2*)w)[i];
         V2 sv = ((V2*)s)[i], qv = ((V2*)q)[i], xv = ((V2*)x)[i], rv = ((V2*)r)[i];
         if (ca) {
             sv.a = zv.a + be * sv.a;
@@ -881,6 +882,17 @@ void launch_pcg_cgear_upd(hipStream_t st, LBox L, const uint8_t* cnt, T* x, T* r
                           double* part_rr, PcgState* ps, int first, double tol)
 {
     hipLaunchKernelGGL((k_pcg_cgear_upd<T>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, z, w, g, cg, cur, part_rr, ps, first, tol);
+}
+// the same two with z = M^-1 r kept float (the float cycle's result: 8 bytes per cell and body less)
+void launch_pcg_az_dist_zf(hipStream_t st, LBox L, const uint8_t* cnt, const float* z, double* w, Coef<double> cf, double* part_zw, PcgState* ps, const int* tlist, int nlist)
+{
+    hipLaunchKernelGGL((k_pcg_sq_l<double, true, true, float>), dim3(tlist ? pcg_list_blocks(nlist) : pcg_sq_blocks(L)), dim3(256), 0, st, L, cnt, z, (const double*)nullptr,
+                       (double*)nullptr, w, cf, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, part_zw, 1, ps, 1, 0.0, 1, 1, 0, tlist, nlist);
+}
+void launch_pcg_cgear_upd_zf(hipStream_t st, LBox L, const uint8_t* cnt, double* x, double* r, double* s, double* q, const float* z, const double* w, const double* g,
+                             double* cg, int cur, double* part_rr, PcgState* ps, int first, double tol)
+{
+    hipLaunchKernelGGL((k_pcg_cgear_upd<double, float>), dim3(pcg_xr_blocks(L)), dim3(256), 0, st, (long)(L.cells() / 2), cnt, x, r, s, q, z, w, g, cg, cur, part_rr, ps, first, tol);
 }
 void launch_pcg_poll_stage(hipStream_t st, const double* part_rr, int n, const PcgState* ps, double* out)
 {
